@@ -1,0 +1,236 @@
+/*
+ * mmloam_hip.h -- C-ABI of libmmloam_hip.so: the MI355X (gfx950) implementation of the mm-loam
+ * scan-registration hot path.
+ *
+ * The reference (TIERS/multi-modal-loam) has no plugin / FFI surface: the path sits behind two C++
+ * classes.  This header defines the boundary directly beneath them; every entry point cites the
+ * reference member it replaces (paths relative to /root/reference/mm-loam/).  The C++ adapter
+ * (multi-modal-loam_amd/host/mmloam_adapter.hpp) re-creates the reference's method signatures on
+ * top of these calls; INTEGRATION.md shows the binding a maintainer adds inside the catkin package.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes, the library owns the opaque
+ *     mml_ctx (device allocations, maps, one HIP stream).  One ctx per caller thread / per GPU.
+ *   - every function returns 0 on success, < 0 on error (mml_status); mml_last_error(ctx) gives
+ *     a message.  No exceptions cross the boundary.  There is NO CPU fallback: without a HIP
+ *     device mml_create fails with MML_ERR_NO_DEVICE.
+ *   - work is batched: a ctx holds `max_scans` scan slots; the reference's one-scan-at-a-time
+ *     use is slot 0, count 1.  Calls are stream-ordered on the ctx stream; functions that copy
+ *     results to host memory synchronise that stream before returning.
+ *   - matrices are row-major doubles; quaternions are (x, y, z, w).
+ */
+#ifndef MMLOAM_HIP_H
+#define MMLOAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MML_ABI_VERSION 1
+
+typedef enum {
+    MML_OK = 0,
+    MML_ERR_INVALID = -1,   /* bad argument (null, out of range, wrong state) */
+    MML_ERR_NO_DEVICE = -2, /* no HIP device / device index out of range */
+    MML_ERR_HIP = -3,       /* a HIP runtime call failed */
+    MML_ERR_CAPACITY = -4,  /* input exceeds a capacity fixed in mml_config */
+    MML_ERR_STATE = -5      /* call order violated (e.g. estimate before a map was set) */
+} mml_status;
+
+typedef struct mml_ctx mml_ctx;
+
+/* livox_ros_driver/CustomPoint as laid out by roscpp (20 bytes): pass msg->points.data(). */
+typedef struct {
+    uint32_t offset_time;
+    float x, y, z;
+    uint8_t reflectivity, tag, line, _pad;
+} mml_livox_point;
+
+typedef struct {
+    int max_scans;          /* scan slots (batch capacity) */
+    int max_velo_points;    /* per slot */
+    int max_livox_points;   /* per slot */
+    int n_rings;            /* VELO_N_SCANS, unionFeatureExtract.cpp:192 (16) */
+    float pitch0_deg;       /* -15: ring = int((pitch - pitch0) / pitch_step + 0.5), :1162 */
+    float pitch_step_deg;   /* 2 */
+    int n_livox_lines;      /* 6, unionFeatureExtract.cpp:906,959 */
+    float near_th, far_th;  /* near/far_points_threshold, mm_lio_full.launch:28-29 (2.0 / 50.0) */
+    float leaf_corner;      /* filter_parameter_corner, launch:43 (0.4), Estimator.cpp:78 */
+    float leaf_surf;        /* filter_parameter_surf,   launch:44 (0.2), Estimator.cpp:79 */
+    float cell_corner;      /* kNN grid cell edge for the corner map, metres (<=0: 2.5 * leaf) */
+    float cell_surf;        /* kNN grid cell edge for the surf map (<=0: 2.5 * leaf) */
+    int max_features;       /* per slot per kind after down-sampling (<=0: 8192) */
+    int max_map_points;     /* per map (<=0: 1<<21) */
+} mml_config;
+
+/* Fills the reference's shipped parameters (launch/mm_lio_full.launch) for `max_scans` slots. */
+void mml_config_default(mml_config* cfg, int max_scans);
+
+int mml_abi_version(void);
+int mml_create(const mml_config* cfg, int device, mml_ctx** out);
+void mml_destroy(mml_ctx* ctx);
+const char* mml_last_error(const mml_ctx* ctx);
+int mml_synchronize(mml_ctx* ctx);
+
+/* ---- input ------------------------------------------------------------------------------------
+ * Host -> device copy of one union_cloud message (union-cloud/msg/union_cloud.msg: velo_time_aligned
+ * as packed x,y,z,intensity floats, livox_time_aligned.points) into a slot.  Either part may be
+ * empty (n = 0).  Asynchronous on the ctx stream (the host buffers must stay valid until the next
+ * synchronising call). */
+int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo,
+                    const mml_livox_point* livox, int n_livox);
+
+/* ---- a1..a8: feature extraction -----------------------------------------------------------------
+ * feature_extraction::unionCloudHandler minus the PCL GICP refresh (unionFeatureExtract.cpp:266-321):
+ * getVeloFeature (:1113-1317) + getHoriFeature/getHoriFeatureExtract (:891-1035) with
+ * detectFeaturePoints (:341-844) per ring / line, label scatter, near/far crop.  Result per slot: the
+ * fused labelled cloud [velo_combine ; livox_combine] kept on the device (what PoseEstimation merges at
+ * unionPoseEstimation.cpp:746-757).  livox_extrinsic: optional row-major 4x4 float applied to the Livox
+ * part when livox_corner_num > 100 (:302-318); NULL = identity. */
+int mml_extract(mml_ctx* ctx, int first_slot, int count, const float* livox_extrinsic);
+
+typedef struct {
+    int n_points;       /* fused cloud size */
+    int n_velo;         /* leading points that came from the Velodyne */
+    int velo_corner_num, velo_surf_num;   /* union_cloud.msg:16-19, set at :1299-1300 */
+    int livox_corner_num, livox_surf_num; /* set at :939-940 */
+} mml_scan_info;
+int mml_scan_info_get(mml_ctx* ctx, int slot, mml_scan_info* info);
+/* Copies the fused labelled cloud of a slot to host (any pointer may be NULL).  Capacity must be
+ * >= n_points.  label: 0 none / 1 corner / 2 surf (normal_z); line: ring or Livox line (normal_y);
+ * reltime: normal_x.  xyzi: 4 floats per point. */
+int mml_scan_download(mml_ctx* ctx, int slot, float* xyzi, float* reltime, uint8_t* line, uint8_t* label,
+                      int capacity);
+
+/* Unit-level twin of feature_extraction::detectFeaturePoints (unionFeatureExtract.cpp:341-343) for one
+ * scan line: pts = n x (x,y,z,intensity) on the host; sharp / flat receive indices into the line
+ * (capacity n each); flags (optional, n ints) receives CloudFeatureFlag[]. */
+int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sharp, int* flat, int* n_flat,
+                    int* flags);
+
+/* ---- a9: RemoveLidarDistortion (unionPoseEstimation.cpp:402-421) ---------------------------------
+ * In place on the fused cloud of each slot.  dR: count x 9, dt: count x 3 (host). Sets reltime to 1. */
+int mml_undistort(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt);
+
+/* ---- a10: label split + pcl::VoxelGrid down-sample (Estimator.cpp:992-1026) ---------------------- */
+int mml_downsample(mml_ctx* ctx, int first_slot, int count);
+/* kind: 0 corner (laserCloudCornerStack), 1 surf (laserCloudSurfStack). xyz: 3 floats per feature. */
+int mml_features_download(mml_ctx* ctx, int slot, int kind, float* xyz, int capacity, int* n);
+/* Test hook: replace the down-sampled stack of a slot with caller-provided features. */
+int mml_features_upload(mml_ctx* ctx, int slot, int kind, const float* xyz, int n);
+
+/* ---- a13 map side: laserCloud{Corner,Surf}FromLocal (Estimator.cpp:1159-1167) --------------------
+ * Uploads a map cloud (3 floats per point) and builds the radix-sorted uniform grid that replaces
+ * pcl::KdTreeFLANN::setInputCloud.  kind: 0 corner, 1 surf. */
+int mml_map_set_local(mml_ctx* ctx, int kind, const float* xyz, int m);
+/* Exact 5-NN against a local map (twin of kdtree->nearestKSearch(p, 5, idx, d2), Estimator.cpp:284,704):
+ * q: nq x 3 host floats (already in the map frame); idx: nq x 5 (indices into the uploaded cloud,
+ * ascending d2, ties by lower index), d2: nq x 5 (float, ((dx*dx+dy*dy)+dz*dz)). max_d2: search bound
+ * (neighbours are exact for every query whose 5th distance is < max_d2; others report -1 / inf). */
+int mml_knn5(mml_ctx* ctx, int kind, const float* q, int nq, float max_d2, int* idx, float* d2);
+
+/* ---- a11..a16: association + model fit -------------------------------------------------------------
+ * Estimator::processPointToLine (Estimator.cpp:148-365) and processPointToPlanVec (:573-777) on the
+ * local maps for `count` slots.  T_wl: count x 16 (transformTobeMapped, :1268-1270).  Factors stay on
+ * the device. */
+typedef struct {
+    int n_line, n_plane;        /* factors produced (vLineFeatures / vPlanFeatures sizes) */
+    int n_line_used, n_plane_used; /* with |error| > 1e-5 (Estimator.cpp:1385,1396) */
+    double normal_gram[9];      /* sum of omega omega^T over plane factors */
+    double min_singular;        /* checkLocalizability (:536-565): sqrt(lambda_min(gram)), -1 if n_plane <= 10 */
+    int is_degenerate;          /* min_singular < 3.0 (:772-775) */
+} mml_assoc_stats;
+int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, double thres_dist,
+                  mml_assoc_stats* stats /* count entries, may be NULL */);
+
+/* Factor read-back for parity tests.  line: n x 10 doubles (pointOri, P1, P2, error) plus src feature
+ * index; plane: n x 10 doubles (pointOri, pointProj, omega, error). Capacity in factors. */
+int mml_factors_download(mml_ctx* ctx, int slot, int kind, double* out, int* src, int capacity, int* n);
+
+/* ---- a17..a20: residual + Jacobian + normal equations ------------------------------------------------
+ * Cost_NavState_IMU_Line / Cost_NavState_IMU_Plan_Vec (include/utils/ceresfunc.h:397-458, 517-570) with
+ * analytic Jacobians, Ceres' Huber correction and the J^T J / J^T r reduction for one slot at pose
+ * x = [t, phi].  T_bl: 16 doubles.  H: 36, g: 6, cost: 1 (host). */
+int mml_linearize(mml_ctx* ctx, int slot, const double* x, const double* T_bl, double plan_weight_tan,
+                  double huber_delta, double* H, double* g, double* cost);
+
+typedef struct {
+    int max_num_iterations;  /* Estimator.cpp:1428 (10) */
+    int fixed_iterations;    /* != 0: run exactly max_num_iterations, no convergence tests */
+    double huber_delta;      /* 0.1 / lidar_m in 1-frame mode (:1216-1222); <= 0: no loss */
+    double plan_weight_tan;  /* :1203 / :1206 */
+} mml_solve_opts;
+typedef struct {
+    int iterations, successful;
+    double initial_cost, final_cost;
+    int termination;         /* 0 max iterations, 1 gradient, 2 parameter, 3 function tolerance */
+} mml_solve_summary;
+/* ceres::Solve replacement (Estimator.cpp:1425-1432): trust-region dogleg on the device, one problem per
+ * window of `window` consecutive slots (window = 1: the reference's live 1-frame mode).  x: count x 6
+ * in/out; summaries: count / window entries (may be NULL); trace (may be NULL): per problem
+ * max_num_iterations x (6*window) doubles, x after every iteration. */
+int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double* T_bl,
+              const mml_solve_opts* opts, double* x, mml_solve_summary* summaries, double* trace);
+
+/* ---- a21: Estimator::Estimate, 1-frame mode (Estimator.cpp:1143-1581) -------------------------------
+ * Outer loop (re-associate with thres_dist 25 -> 10 -> 1, solve, convergence test) for `count` slots.
+ * P: count x 3, Q: count x 4 (body pose in/out), exTlb: 16.  Requires mml_downsample first. */
+typedef struct {
+    int outer_iterations;
+    int is_degenerate;
+    int n_corner_feat, n_surf_feat;
+} mml_estimate_info;
+int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, double* P, double* Q,
+                 int max_outer, int inner_iters, mml_estimate_info* info /* count entries or NULL */);
+
+/* ---- the benchmarked step ---------------------------------------------------------------------------
+ * One pass of the hot path over slots [first, first+count) with inputs already uploaded:
+ * extract -> undistort -> downsample -> associate (1 pass, thres_dist) -> `gn_iters` trust-region
+ * iterations (fixed count).  Everything stays on the device; poses: count x 6 ([t,phi], device-updated,
+ * copied back).  This is what bench.py times. */
+int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt,
+             const double* exTlb, double thres_dist, int gn_iters, double* x_inout);
+
+/* ---- multi-GPU window solve (one frame per GPU) ---------------------------------------
+ * Record layout of one frame's normal equations for the all-gather: 32 doubles =
+ * [H upper triangle row-major (21), g (6), cost (1), n_line_used, n_plane_used, 0, 0]. */
+#define MML_NEQ_RECORD_DOUBLES 32
+/* Writes the record of `slot` at pose x to a DEVICE buffer (32 doubles) -- e.g. a torch tensor's
+ * data_ptr() that is then passed to all_gather. Stream-ordered; call mml_synchronize before the collective. */
+int mml_linearize_record(mml_ctx* ctx, int slot, const double* x, const double* T_bl, double plan_weight_tan,
+                         double huber_delta, double* d_record);
+/* Host-side joint dogleg state machine over W gathered records (pure host code, no device needed):
+ * restates the same trust-region iteration as mml_solve for a block-diagonal window. */
+typedef struct mml_window_solver mml_window_solver;
+mml_window_solver* mml_window_solver_create(int W, const mml_solve_opts* opts);
+void mml_window_solver_destroy(mml_window_solver* s);
+/* Feed the records evaluated at the point last returned in x_eval (first call: the initial x).  On return
+ * x_eval holds the next point to linearise at; returns 1 when finished (x_eval = solution), 0 to continue,
+ * < 0 on error. */
+int mml_window_solver_step(mml_window_solver* s, const double* records /* W x 32 */, double* x_eval /* W x 6 */);
+int mml_window_solver_summary(const mml_window_solver* s, mml_solve_summary* out);
+
+/* ---- measurement hooks ----------------------------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the ctx stream. */
+#define MML_MAX_STAGES 32
+typedef struct {
+    int n_stages;
+    const char* name[MML_MAX_STAGES];
+    double total_ms[MML_MAX_STAGES];
+    long launches[MML_MAX_STAGES];
+} mml_profile;
+int mml_profile_enable(mml_ctx* ctx, int on);
+int mml_profile_reset(mml_ctx* ctx);
+int mml_profile_get(mml_ctx* ctx, mml_profile* out);
+/* Device facts for bench.py: name, CU count, total HBM bytes. */
+int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes);
+/* Device-to-device copy bandwidth probe (GB/s) over `bytes` bytes, `reps` repetitions (practical HBM roof). */
+int mml_copy_bandwidth(mml_ctx* ctx, size_t bytes, int reps, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMLOAM_HIP_H */

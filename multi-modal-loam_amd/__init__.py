@@ -1,0 +1,356 @@
+"""multi-modal-loam_amd -- MI355X-native scan-registration hot path of TIERS/multi-modal-loam.
+
+This package is a thin ctypes view of the C-ABI in include/mmloam_hip.h (libmmloam_hip.so, built from
+csrc/*.hip for gfx950).  It exists for the pytest harness, bench.py and Python users; the C++ adapter that
+mirrors the reference classes (feature_extraction / Estimator) is host/mmloam_adapter.hpp.
+
+There is no CPU fallback: importing works without a GPU (so the symbol-export test can run), but creating a
+Context without a HIP device raises MmlError(MML_ERR_NO_DEVICE).
+
+Import with importlib.import_module("multi-modal-loam_amd") (the directory name is not a Python identifier).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmloam_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmloam_hip.h")
+
+MML_OK, MML_ERR_INVALID, MML_ERR_NO_DEVICE, MML_ERR_HIP, MML_ERR_CAPACITY, MML_ERR_STATE = 0, -1, -2, -3, -4, -5
+NEQ_RECORD_DOUBLES = 32
+MAX_STAGES = 32
+
+LIVOX_DTYPE = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+                        ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1"), ("_pad", "u1")])
+
+
+class MmlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mmloam_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("max_scans", C.c_int), ("max_velo_points", C.c_int), ("max_livox_points", C.c_int),
+                ("n_rings", C.c_int), ("pitch0_deg", C.c_float), ("pitch_step_deg", C.c_float),
+                ("n_livox_lines", C.c_int), ("near_th", C.c_float), ("far_th", C.c_float),
+                ("leaf_corner", C.c_float), ("leaf_surf", C.c_float), ("cell_corner", C.c_float),
+                ("cell_surf", C.c_float), ("max_features", C.c_int), ("max_map_points", C.c_int)]
+
+
+class ScanInfo(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("n_velo", C.c_int), ("velo_corner_num", C.c_int), ("velo_surf_num", C.c_int),
+                ("livox_corner_num", C.c_int), ("livox_surf_num", C.c_int)]
+
+
+class AssocStats(C.Structure):
+    _fields_ = [("n_line", C.c_int), ("n_plane", C.c_int), ("n_line_used", C.c_int), ("n_plane_used", C.c_int),
+                ("normal_gram", C.c_double * 9), ("min_singular", C.c_double), ("is_degenerate", C.c_int)]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("fixed_iterations", C.c_int), ("huber_delta", C.c_double),
+                ("plan_weight_tan", C.c_double)]
+
+
+class SolveSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("successful", C.c_int), ("initial_cost", C.c_double),
+                ("final_cost", C.c_double), ("termination", C.c_int)]
+
+
+class EstimateInfo(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int), ("is_degenerate", C.c_int), ("n_corner_feat", C.c_int),
+                ("n_surf_feat", C.c_int)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("n_stages", C.c_int), ("name", C.c_char_p * MAX_STAGES), ("total_ms", C.c_double * MAX_STAGES),
+                ("launches", C.c_long * MAX_STAGES)]
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libmmloam_hip.so (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "-s", "clean"])
+    subprocess.check_call(["make", "-C", csrc, "-s", "-j8"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libmmloam_hip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MmlError(MML_ERR_STATE, "libmmloam_hip.so is missing: run __graft_entry__.build() "
+                                          "(or make -C multi-modal-loam_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.mml_last_error.restype = C.c_char_p
+        L.mml_last_error.argtypes = [C.c_void_p]
+        L.mml_window_solver_create.restype = C.c_void_p
+        L.mml_window_solver_create.argtypes = [C.c_int, C.POINTER(SolveOpts)]
+        L.mml_window_solver_destroy.argtypes = [C.c_void_p]
+        L.mml_window_solver_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mml_window_solver_summary.argtypes = [C.c_void_p, C.POINTER(SolveSummary)]
+        L.mml_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_config(max_scans=1, **over):
+    cfg = Config()
+    lib().mml_config_default(C.byref(cfg), C.c_int(max_scans))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """One mml_ctx: owns device buffers, maps and a HIP stream for `cfg.max_scans` scan slots."""
+
+    def __init__(self, cfg=None, device=0, **over):
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        self._h = C.c_void_p()
+        rc = lib().mml_create(C.byref(self.cfg), C.c_int(device), C.byref(self._h))
+        if rc != MML_OK:
+            raise MmlError(rc, "mml_create failed (no HIP device?)" if rc == MML_ERR_NO_DEVICE else "mml_create failed")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mml_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != MML_OK:
+            raise MmlError(rc, lib().mml_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._ck(lib().mml_synchronize(self._h))
+
+    # ---- input / feature extraction (feature_extraction::unionCloudHandler) ----
+    def scan_upload(self, slot, velo_xyzi, livox):
+        v = _f32(velo_xyzi).reshape(-1, 4) if velo_xyzi is not None else np.zeros((0, 4), np.float32)
+        l = np.ascontiguousarray(livox) if livox is not None else np.zeros(0, LIVOX_DTYPE)
+        assert l.dtype.itemsize == 20
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append((v, l))  # host buffers must outlive the async copy
+        self._ck(lib().mml_scan_upload(self._h, C.c_int(slot), _p(v), C.c_int(len(v)), _p(l), C.c_int(len(l))))
+        if len(self._keep) > 4 * self.cfg.max_scans:
+            self.synchronize()
+            self._keep = self._keep[-self.cfg.max_scans:]
+
+    def extract(self, first=0, count=1, livox_extrinsic=None):
+        e = _f32(livox_extrinsic).reshape(16) if livox_extrinsic is not None else None
+        self._ck(lib().mml_extract(self._h, C.c_int(first), C.c_int(count), _p(e)))
+
+    def scan_info(self, slot):
+        info = ScanInfo()
+        self._ck(lib().mml_scan_info_get(self._h, C.c_int(slot), C.byref(info)))
+        return info
+
+    def scan_download(self, slot):
+        info = self.scan_info(slot)
+        n = info.n_points
+        xyzi = np.zeros((max(n, 1), 4), np.float32)
+        rel = np.zeros(max(n, 1), np.float32)
+        line = np.zeros(max(n, 1), np.uint8)
+        label = np.zeros(max(n, 1), np.uint8)
+        self._ck(lib().mml_scan_download(self._h, C.c_int(slot), _p(xyzi), _p(rel), _p(line), _p(label), C.c_int(max(n, 1))))
+        return dict(xyzi=xyzi[:n], reltime=rel[:n], ring=line[:n].astype(np.int32), label=label[:n].astype(np.int32),
+                    info=info)
+
+    def detect_line(self, pts):
+        """Twin of feature_extraction::detectFeaturePoints: returns (sharp idx, flat idx, CloudFeatureFlag)."""
+        pts = _f32(pts).reshape(-1, 4)
+        n = len(pts)
+        sharp = np.zeros(max(n, 1), np.int32)
+        flat = np.zeros(max(n, 1), np.int32)
+        flags = np.zeros(max(n, 1), np.int32)
+        ns, nf = C.c_int(0), C.c_int(0)
+        self._ck(lib().mml_detect_line(self._h, _p(pts), C.c_int(n), _p(sharp), C.byref(ns), _p(flat), C.byref(nf),
+                                       _p(flags)))
+        return sharp[:ns.value].copy(), flat[:nf.value].copy(), flags[:n].copy()
+
+    # ---- RemoveLidarDistortion ----
+    def undistort(self, first, count, dR, dt):
+        dR = _f64(dR).reshape(count, 9)
+        dt = _f64(dt).reshape(count, 3)
+        self._ck(lib().mml_undistort(self._h, C.c_int(first), C.c_int(count), _p(dR), _p(dt)))
+
+    # ---- Estimator::EstimateLidarPose pieces ----
+    def downsample(self, first=0, count=1):
+        self._ck(lib().mml_downsample(self._h, C.c_int(first), C.c_int(count)))
+
+    def features_download(self, slot, kind):
+        n = C.c_int(0)
+        self._ck(lib().mml_features_download(self._h, C.c_int(slot), C.c_int(kind), None, C.c_int(0), C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        self._ck(lib().mml_features_download(self._h, C.c_int(slot), C.c_int(kind), _p(out), C.c_int(max(n.value, 1)),
+                                             C.byref(n)))
+        return out[:n.value]
+
+    def features_upload(self, slot, kind, xyz):
+        xyz = _f32(xyz).reshape(-1, 3)
+        self._ck(lib().mml_features_upload(self._h, C.c_int(slot), C.c_int(kind), _p(xyz), C.c_int(len(xyz))))
+
+    def map_set_local(self, kind, xyz):
+        xyz = _f32(xyz).reshape(-1, 3)
+        self._ck(lib().mml_map_set_local(self._h, C.c_int(kind), _p(xyz), C.c_int(len(xyz))))
+
+    def knn5(self, kind, q, max_d2=np.inf):
+        q = _f32(q).reshape(-1, 3)
+        idx = np.zeros((len(q), 5), np.int32)
+        d2 = np.zeros((len(q), 5), np.float32)
+        md = np.float32(min(max_d2, 3.0e38))
+        self._ck(lib().mml_knn5(self._h, C.c_int(kind), _p(q), C.c_int(len(q)), C.c_float(md), _p(idx), _p(d2)))
+        return idx, d2
+
+    def associate(self, first, count, T_wl, thres_dist):
+        T = _f64(T_wl).reshape(count, 16)
+        st = (AssocStats * count)()
+        self._ck(lib().mml_associate(self._h, C.c_int(first), C.c_int(count), _p(T), C.c_double(thres_dist), st))
+        return list(st)
+
+    def factors_download(self, slot, kind):
+        n = C.c_int(0)
+        self._ck(lib().mml_factors_download(self._h, C.c_int(slot), C.c_int(kind), None, None, C.c_int(0), C.byref(n)))
+        out = np.zeros((max(n.value, 1), 10))
+        src = np.zeros(max(n.value, 1), np.int32)
+        self._ck(lib().mml_factors_download(self._h, C.c_int(slot), C.c_int(kind), _p(out), _p(src),
+                                            C.c_int(max(n.value, 1)), C.byref(n)))
+        return out[:n.value], src[:n.value]
+
+    def linearize(self, slot, x, T_bl, w_tan=0.0, huber=0.1 / 1.5e-3):
+        H = np.zeros((6, 6))
+        g = np.zeros(6)
+        c = C.c_double(0)
+        self._ck(lib().mml_linearize(self._h, C.c_int(slot), _p(_f64(x)), _p(_f64(T_bl).reshape(16)), C.c_double(w_tan),
+                                     C.c_double(huber), _p(H), _p(g), C.byref(c)))
+        return H, g, c.value
+
+    def linearize_record(self, slot, x, T_bl, d_record_ptr, w_tan=0.0, huber=0.1 / 1.5e-3):
+        self._ck(lib().mml_linearize_record(self._h, C.c_int(slot), _p(_f64(x)), _p(_f64(T_bl).reshape(16)),
+                                            C.c_double(w_tan), C.c_double(huber), C.c_void_p(d_record_ptr)))
+
+    def solve(self, first, count, x, T_bl, window=1, max_iters=10, fixed=False, huber=0.1 / 1.5e-3, w_tan=0.0,
+              trace=False):
+        x = _f64(x).reshape(count, 6).copy()
+        opts = SolveOpts(max_iters, 1 if fixed else 0, huber, w_tan)
+        nprob = count // window
+        summ = (SolveSummary * nprob)()
+        tr = np.zeros((nprob, max_iters, 6 * window)) if trace else None
+        self._ck(lib().mml_solve(self._h, C.c_int(first), C.c_int(count), C.c_int(window), _p(_f64(T_bl).reshape(16)),
+                                 C.byref(opts), _p(x), summ, _p(tr)))
+        return x, list(summ), tr
+
+    def estimate(self, first, count, exTlb, P, Q, max_outer=5, inner_iters=10):
+        P = _f64(P).reshape(count, 3).copy()
+        Q = _f64(Q).reshape(count, 4).copy()
+        info = (EstimateInfo * count)()
+        self._ck(lib().mml_estimate(self._h, C.c_int(first), C.c_int(count), _p(_f64(exTlb).reshape(16)), _p(P), _p(Q),
+                                    C.c_int(max_outer), C.c_int(inner_iters), info))
+        return P, Q, list(info)
+
+    def step(self, first, count, dR, dt, exTlb, thres_dist, gn_iters, x):
+        x = _f64(x).reshape(count, 6).copy()
+        self._ck(lib().mml_step(self._h, C.c_int(first), C.c_int(count), _p(_f64(dR).reshape(count, 9)),
+                                _p(_f64(dt).reshape(count, 3)), _p(_f64(exTlb).reshape(16)), C.c_double(thres_dist),
+                                C.c_int(gn_iters), _p(x)))
+        return x
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        self._ck(lib().mml_profile_enable(self._h, C.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        self._ck(lib().mml_profile_reset(self._h))
+
+    def profile_get(self):
+        pr = Profile()
+        self._ck(lib().mml_profile_get(self._h, C.byref(pr)))
+        return {pr.name[i].decode(): (pr.total_ms[i], pr.launches[i]) for i in range(pr.n_stages)}
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int(0)
+        mem = C.c_size_t(0)
+        self._ck(lib().mml_device_info(self._h, name, C.c_int(256), C.byref(cus), C.byref(mem)))
+        return name.value.decode(), cus.value, mem.value
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        g = C.c_double(0)
+        self._ck(lib().mml_copy_bandwidth(self._h, C.c_size_t(nbytes), C.c_int(reps), C.byref(g)))
+        return g.value
+
+
+class WindowSolver:
+    """Host-side joint dogleg over W all-gathered 32-double records; needs no device."""
+
+    def __init__(self, W, max_iters=10, fixed=False, huber=0.0, w_tan=3e-4):
+        self.W = W
+        self._opts = SolveOpts(max_iters, 1 if fixed else 0, huber, w_tan)
+        self._h = lib().mml_window_solver_create(C.c_int(W), C.byref(self._opts))
+        if not self._h:
+            raise MmlError(MML_ERR_INVALID, "mml_window_solver_create failed")
+
+    def step(self, records, x_eval):
+        """records: (W,32) at x_eval (W,6).  Returns (done, next x_eval)."""
+        rec = _f64(records).reshape(self.W, NEQ_RECORD_DOUBLES)
+        x = _f64(x_eval).reshape(self.W, 6).copy()
+        rc = lib().mml_window_solver_step(self._h, _p(rec), _p(x))
+        if rc < 0:
+            raise MmlError(rc, "mml_window_solver_step")
+        return rc == 1, x
+
+    def summary(self):
+        s = SolveSummary()
+        lib().mml_window_solver_summary(self._h, C.byref(s))
+        return s
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mml_window_solver_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def pack_record(H, g, cost, n_line_used=0, n_plane_used=0):
+    """(6x6 H, g, cost) -> the 32-double all-gather record of include/mmloam_hip.h."""
+    rec = np.zeros(NEQ_RECORD_DOUBLES)
+    k = 0
+    for a in range(6):
+        for b in range(a, 6):
+            rec[k] = H[a, b]
+            k += 1
+    rec[21:27] = g
+    rec[27] = cost
+    rec[28] = n_line_used
+    rec[29] = n_plane_used
+    return rec

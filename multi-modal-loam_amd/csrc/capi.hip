@@ -1,0 +1,873 @@
+// capi.hip -- the C-ABI of libmmloam_hip.so (include/mmloam_hip.h): context, buffers, call sequencing.
+// No compute lives here; every entry point validates, stages small parameter blocks through a pinned ring and
+// enqueues the kernels of feature.hip / undistort_voxel.hip / map_assoc.hip / solve.hip on the ctx stream.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "mml_internal.h"
+
+int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);
+
+namespace {
+
+template <typename T>
+hipError_t dalloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1));
+}
+
+// pinned staging ring for small host<->device parameter blocks
+constexpr size_t kStageDoubles = 1u << 19;  // 4 MiB
+
+double* stage_alloc(mml_ctx* ctx, size_t doubles) {
+    if (ctx->stage_cursor + doubles > ctx->h_stage_doubles) {
+        hipStreamSynchronize(ctx->stream);
+        ctx->stage_cursor = 0;
+    }
+    double* p = ctx->h_stage + ctx->stage_cursor;
+    ctx->stage_cursor += (doubles + 7) & ~size_t(7);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+void mml_config_default(mml_config* cfg, int max_scans) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->max_scans = max_scans;
+    cfg->max_velo_points = 16 * 1800;
+    cfg->max_livox_points = 24000;
+    cfg->n_rings = 16;
+    cfg->pitch0_deg = -15.0f;
+    cfg->pitch_step_deg = 2.0f;
+    cfg->n_livox_lines = 6;
+    cfg->near_th = 2.0f;
+    cfg->far_th = 50.0f;
+    cfg->leaf_corner = 0.4f;
+    cfg->leaf_surf = 0.2f;
+    cfg->cell_corner = 0.f;
+    cfg->cell_surf = 0.f;
+    cfg->max_features = 0;
+    cfg->max_map_points = 0;
+}
+
+int mml_abi_version(void) { return MML_ABI_VERSION; }
+
+const char* mml_last_error(const mml_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+void mml_destroy(mml_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    void* ptrs[] = {ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
+                    ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
+                    ctx->ln_ord_c, ctx->ln_ord_r, ctx->ln_flag,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
+                    ctx->cb_label, ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
+                    ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
+                    ctx->pf,       ctx->assoc_stats, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
+                    ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
+                    ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_summ, ctx->d_trace, ctx->d_rec,
+                    ctx->d_extr,   ctx->d_misc};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    for (auto& pe : ctx->pending) {
+        hipEventDestroy(pe.a);
+        hipEventDestroy(pe.b);
+    }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
+    if (!cfg || !out) return MML_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MML_ERR_NO_DEVICE;  // no CPU fallback
+    if (device < 0 || device >= ndev) return MML_ERR_NO_DEVICE;
+    if (cfg->max_scans <= 0 || cfg->max_velo_points < 0 || cfg->max_livox_points < 0 || cfg->n_rings <= 0 ||
+        cfg->n_rings > 128 || cfg->n_livox_lines <= 0 || cfg->n_livox_lines > 32)
+        return MML_ERR_INVALID;
+    mml_ctx* ctx = new mml_ctx();
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    if (ctx->cfg.cell_corner <= 0) ctx->cfg.cell_corner = 2.5f * ctx->cfg.leaf_corner;
+    if (ctx->cfg.cell_surf <= 0) ctx->cfg.cell_surf = 2.5f * ctx->cfg.leaf_surf;
+    if (ctx->cfg.max_features <= 0) ctx->cfg.max_features = 8192;
+    if (ctx->cfg.max_map_points <= 0) ctx->cfg.max_map_points = 1 << 21;
+    ctx->B = cfg->max_scans;
+    ctx->NV = (cfg->max_velo_points + 63) & ~63;
+    ctx->NL = (cfg->max_livox_points + 63) & ~63;
+    ctx->NT = ctx->NV + ctx->NL;
+    ctx->L = cfg->n_rings + cfg->n_livox_lines;
+    ctx->MF = ctx->cfg.max_features;
+    ctx->MM = ctx->cfg.max_map_points;
+    ctx->VX_CAP = 8192;
+    ctx->h_n_in.assign((size_t)ctx->B * 2, 0);
+    auto fail = [&](hipError_t e, const char* what) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        // keep ctx alive so the caller can read the message? No: report through the return code only.
+        mml_destroy(ctx);
+        return MML_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail(e, "hipStreamCreate");
+    const size_t B = ctx->B, NV = ctx->NV, NL = ctx->NL, NT = ctx->NT, L = ctx->L, MF = ctx->MF, MM = ctx->MM;
+#define ALLOC(ptr, n)                                                  \
+    if ((e = dalloc(&(ptr), (n))) != hipSuccess) return fail(e, #ptr); \
+    if ((e = hipMemsetAsync((ptr), 0, sizeof(*(ptr)) * ((n) ? (n) : 1), ctx->stream)) != hipSuccess) return fail(e, #ptr)
+    ALLOC(ctx->velo_in, B * NV);
+    ALLOC(ctx->livox_in, B * NL);
+    ALLOC(ctx->d_n_in, B * 2);
+    ALLOC(ctx->raw_line, B * NT);
+    ALLOC(ctx->raw_ori, B * NV);
+    ALLOC(ctx->ln_pts, B * NT);
+    ALLOC(ctx->ln_gidx, B * NT);
+    ALLOC(ctx->line_start, B * L);
+    ALLOC(ctx->line_len, B * L);
+    ALLOC(ctx->ln_curv, B * NT);
+    ALLOC(ctx->ln_refl, B * NT);
+    ALLOC(ctx->ln_attr, B * NT);
+    ALLOC(ctx->ln_ord_c, B * NT);
+    ALLOC(ctx->ln_ord_r, B * NT);
+    ALLOC(ctx->ln_flag, B * NT);
+    ALLOC(ctx->cb_xyzi, B * NT);
+    ALLOC(ctx->cb_rel, B * NT);
+    ALLOC(ctx->cb_line, B * NT);
+    ALLOC(ctx->cb_label, B * NT);
+    ALLOC(ctx->cb_n, B * 2);
+    ALLOC(ctx->fu_xyzi, B * NT);
+    ALLOC(ctx->fu_rel, B * NT);
+    ALLOC(ctx->fu_line, B * NT);
+    ALLOC(ctx->fu_label, B * NT);
+    ALLOC(ctx->fu_info, B * 8);
+    ALLOC(ctx->ft_xyz[0], B * MF);
+    ALLOC(ctx->ft_xyz[1], B * MF);
+    ALLOC(ctx->ft_n, B * 2);
+    ALLOC(ctx->vx_keys, B * (size_t)ctx->VX_CAP);  // B*2*VX_CAP unsigned
+    ALLOC(ctx->lf, B * MF);
+    ALLOC(ctx->pf, B * MF);
+    ALLOC(ctx->assoc_stats, B * 16);
+    for (int k = 0; k < 2; ++k) {
+        ALLOC(ctx->grid[k].pts, MM);
+        ALLOC(ctx->grid[k].cell_start, 4 * MM + 4096 + 2);
+        ctx->grid[k].m = 0;
+    }
+    ALLOC(ctx->map_tmp, 2 * MM);
+    ALLOC(ctx->map_keys, MM);
+    ALLOC(ctx->map_keys2, MM);
+    ALLOC(ctx->map_vals, MM);
+    ALLOC(ctx->map_vals2, MM);
+    ALLOC(ctx->d_x, B * 6);
+    ALLOC(ctx->d_pose_in, B * 64);
+    ALLOC(ctx->d_summ, B * 8);
+    ALLOC(ctx->d_trace, B * 6 * 64);
+    ALLOC(ctx->d_rec, B * 32);
+    ALLOC(ctx->d_extr, 16);
+    ALLOC(ctx->d_misc, 64);
+#undef ALLOC
+    ctx->h_stage_doubles = kStageDoubles;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), sizeof(double) * (ctx->h_stage_doubles + 8),
+                           hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc");
+    ctx->stage_cursor = 0;
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    *out = ctx;
+    return MML_OK;
+}
+
+int mml_synchronize(mml_ctx* ctx) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    return MML_OK;
+}
+
+static int check_slots(mml_ctx* ctx, int first, int count) {
+    MML_REQUIRE(ctx != nullptr, MML_ERR_INVALID, "null ctx");
+    MML_REQUIRE(first >= 0 && count > 0 && first + count <= ctx->B, MML_ERR_INVALID, "slot range out of bounds");
+    return MML_OK;
+}
+#define CHECK_SLOTS(first, count)                        \
+    do {                                                 \
+        if (!ctx) return MML_ERR_INVALID;                \
+        int rc_ = check_slots(ctx, (first), (count));    \
+        if (rc_ != MML_OK) return rc_;                   \
+        if (hipSetDevice(ctx->device) != hipSuccess) {   \
+            ctx->err = "hipSetDevice failed";            \
+            return MML_ERR_HIP;                          \
+        }                                                \
+    } while (0)
+
+// copy a block of doubles to the device through the pinned ring (asynchronous, safe against reuse)
+static int upload_doubles(mml_ctx* ctx, double* d_dst, const double* h_src, size_t n) {
+    double* st = stage_alloc(ctx, n);
+    memcpy(st, h_src, sizeof(double) * n);
+    MML_HIP(hipMemcpyAsync(d_dst, st, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    return MML_OK;
+}
+
+int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo, const mml_livox_point* livox,
+                    int n_livox) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(n_velo >= 0 && n_livox >= 0, MML_ERR_INVALID, "negative point count");
+    MML_REQUIRE(n_velo <= ctx->cfg.max_velo_points && n_livox <= ctx->cfg.max_livox_points, MML_ERR_CAPACITY,
+                "scan exceeds max_velo_points / max_livox_points");
+    MML_REQUIRE((n_velo == 0 || velo_xyzi) && (n_livox == 0 || livox), MML_ERR_INVALID, "null point buffer");
+    if (n_velo)
+        MML_HIP(hipMemcpyAsync(ctx->velo_in + (size_t)slot * ctx->NV, velo_xyzi, sizeof(float) * 4 * (size_t)n_velo,
+                               hipMemcpyHostToDevice, ctx->stream));
+    if (n_livox)
+        MML_HIP(hipMemcpyAsync(ctx->livox_in + (size_t)slot * ctx->NL, livox, sizeof(mml_livox_point) * (size_t)n_livox,
+                               hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_n_in[2 * slot] = n_velo;
+    ctx->h_n_in[2 * slot + 1] = n_livox;
+    // counts travel through the pinned ring as raw bytes
+    double* st = stage_alloc(ctx, 1);
+    int* sti = reinterpret_cast<int*>(st);
+    sti[0] = n_velo;
+    sti[1] = n_livox;
+    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * slot, sti, sizeof(int) * 2, hipMemcpyHostToDevice, ctx->stream));
+    return MML_OK;
+}
+
+int mml_extract(mml_ctx* ctx, int first_slot, int count, const float* livox_extrinsic) {
+    CHECK_SLOTS(first_slot, count);
+    bool have = false;
+    if (livox_extrinsic) {
+        static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        have = memcmp(I, livox_extrinsic, sizeof(I)) != 0;
+        if (have) {
+            double* st = stage_alloc(ctx, 8);
+            memcpy(st, livox_extrinsic, sizeof(float) * 16);
+            MML_HIP(hipMemcpyAsync(ctx->d_extr, st, sizeof(float) * 16, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    return mml_launch_extract(ctx, first_slot, count, have);
+}
+
+int mml_scan_info_get(mml_ctx* ctx, int slot, mml_scan_info* info) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(info != nullptr, MML_ERR_INVALID, "null info");
+    int h[8];
+    MML_HIP(hipMemcpyAsync(h, ctx->fu_info + 8 * slot, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    info->n_points = h[0];
+    info->n_velo = h[1];
+    info->velo_corner_num = h[2];
+    info->velo_surf_num = h[3];
+    info->livox_corner_num = h[4];
+    info->livox_surf_num = h[5];
+    return MML_OK;
+}
+
+int mml_scan_download(mml_ctx* ctx, int slot, float* xyzi, float* reltime, uint8_t* line, uint8_t* label,
+                      int capacity) {
+    CHECK_SLOTS(slot, 1);
+    mml_scan_info info;
+    int rc = mml_scan_info_get(ctx, slot, &info);
+    if (rc != MML_OK) return rc;
+    MML_REQUIRE(capacity >= info.n_points, MML_ERR_CAPACITY, "download capacity too small");
+    const size_t n = info.n_points, off = (size_t)slot * ctx->NT;
+    if (n == 0) return MML_OK;
+    if (xyzi) MML_HIP(hipMemcpyAsync(xyzi, ctx->fu_xyzi + off, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (reltime) MML_HIP(hipMemcpyAsync(reltime, ctx->fu_rel + off, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (line) MML_HIP(hipMemcpyAsync(line, ctx->fu_line + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (label) MML_HIP(hipMemcpyAsync(label, ctx->fu_label + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    return MML_OK;
+}
+
+int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sharp, int* flat, int* n_flat,
+                    int* flags) {
+    CHECK_SLOTS(0, 1);
+    MML_REQUIRE(n >= 0 && n_sharp && n_flat && (n == 0 || (pts && sharp && flat)), MML_ERR_INVALID, "bad arguments");
+    MML_REQUIRE(n <= ctx->NV, MML_ERR_CAPACITY, "line longer than max_velo_points");
+    *n_sharp = 0;
+    *n_flat = 0;
+    if (n == 0) return MML_OK;
+    for (int i = 0; i < n; ++i)
+        MML_REQUIRE(std::isfinite(pts[4 * i]) && std::isfinite(pts[4 * i + 1]) && std::isfinite(pts[4 * i + 2]),
+                    MML_ERR_INVALID, "detectFeaturePoints: non-finite input (reference indexes pre-compaction)");
+    MML_HIP(hipMemcpyAsync(ctx->ln_pts, pts, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    // ln_final scratch: reuse ln_ord_c of slot 0's livox region?  Use a dedicated view of raw_ori (NV floats >= n*2 bytes).
+    uint16_t* d_final = reinterpret_cast<uint16_t*>(ctx->raw_ori);
+    int rc = mml_launch_detect_line(ctx, n, d_final);
+    if (rc != MML_OK) return rc;
+    std::vector<uint8_t> lab(n);
+    std::vector<uint16_t> fin(n);
+    MML_HIP(hipMemcpyAsync(lab.data(), ctx->cb_label, n, hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipMemcpyAsync(fin.data(), d_final, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    int ns = 0, nf = 0;
+    for (int i = 0; i < n; ++i) {  // ascending i, as the emit loop at unionFeatureExtract.cpp:818-842
+        if (lab[i] == 2) flat[nf++] = i;
+        if (lab[i] == 1) sharp[ns++] = i;
+        if (flags) flags[i] = fin[i];
+    }
+    *n_sharp = ns;
+    *n_flat = nf;
+    return MML_OK;
+}
+
+int mml_undistort(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(dR && dt, MML_ERR_INVALID, "null dR/dt");
+    double* st = stage_alloc(ctx, 12 * (size_t)count);
+    for (int i = 0; i < count; ++i) {
+        memcpy(st + 12 * i, dR + 9 * i, sizeof(double) * 9);
+        memcpy(st + 12 * i + 9, dt + 3 * i, sizeof(double) * 3);
+    }
+    double* d_par = ctx->d_pose_in;  // B*64 doubles: [0, 12*count)
+    MML_HIP(hipMemcpyAsync(d_par, st, sizeof(double) * 12 * count, hipMemcpyHostToDevice, ctx->stream));
+    return mml_launch_undistort(ctx, first_slot, count, d_par);
+}
+
+int mml_downsample(mml_ctx* ctx, int first_slot, int count) {
+    CHECK_SLOTS(first_slot, count);
+    return mml_launch_downsample(ctx, first_slot, count);
+}
+
+int mml_features_download(mml_ctx* ctx, int slot, int kind, float* xyz, int capacity, int* n) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad kind");
+    int h = 0;
+    MML_HIP(hipMemcpyAsync(&h, ctx->ft_n + kind * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_REQUIRE(h >= 0, MML_ERR_CAPACITY, "down-sample overflowed max_features / voxel capacity");
+    *n = h;
+    if (!xyz || h == 0) return MML_OK;
+    MML_REQUIRE(capacity >= h, MML_ERR_CAPACITY, "download capacity too small");
+    std::vector<float4> tmp(h);
+    MML_HIP(hipMemcpyAsync(tmp.data(), ctx->ft_xyz[kind] + (size_t)slot * ctx->MF, sizeof(float4) * h,
+                           hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < h; ++i) {
+        xyz[3 * i] = tmp[i].x;
+        xyz[3 * i + 1] = tmp[i].y;
+        xyz[3 * i + 2] = tmp[i].z;
+    }
+    return MML_OK;
+}
+
+int mml_features_upload(mml_ctx* ctx, int slot, int kind, const float* xyz, int n) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE((kind == 0 || kind == 1) && n >= 0 && (n == 0 || xyz), MML_ERR_INVALID, "bad arguments");
+    MML_REQUIRE(n <= ctx->MF, MML_ERR_CAPACITY, "more features than max_features");
+    std::vector<float4> tmp(n ? n : 1);
+    for (int i = 0; i < n; ++i) tmp[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+    if (n)
+        MML_HIP(hipMemcpyAsync(ctx->ft_xyz[kind] + (size_t)slot * ctx->MF, tmp.data(), sizeof(float4) * n,
+                               hipMemcpyHostToDevice, ctx->stream));
+    MML_HIP(hipMemcpyAsync(ctx->ft_n + kind * ctx->B + slot, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    return MML_OK;
+}
+
+int mml_map_set_local(mml_ctx* ctx, int kind, const float* xyz, int m) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(m >= 0 && (m == 0 || xyz), MML_ERR_INVALID, "bad map arguments");
+    MML_HIP(hipSetDevice(ctx->device));
+    return mml_build_grid(ctx, kind, xyz, m);
+}
+
+int mml_knn5(mml_ctx* ctx, int kind, const float* q, int nq, float max_d2, int* idx, float* d2) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE((kind == 0 || kind == 1) && nq >= 0 && (nq == 0 || (q && idx && d2)), MML_ERR_INVALID, "bad arguments");
+    MML_REQUIRE(ctx->have_map[kind], MML_ERR_STATE, "mml_knn5 before mml_map_set_local");
+    if (nq == 0) return MML_OK;
+    MML_HIP(hipSetDevice(ctx->device));
+    float* d_q = nullptr;
+    int* d_idx = nullptr;
+    float* d_d2 = nullptr;
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(float) * 3 * nq));
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), sizeof(int) * 5 * nq));
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&d_d2), sizeof(float) * 5 * nq));
+    MML_HIP(hipMemcpyAsync(d_q, q, sizeof(float) * 3 * nq, hipMemcpyHostToDevice, ctx->stream));
+    int rc = mml_launch_knn5(ctx, kind, d_q, nq, max_d2, d_idx, d_d2);
+    if (rc == MML_OK) {
+        hipMemcpyAsync(idx, d_idx, sizeof(int) * 5 * nq, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(d2, d_d2, sizeof(float) * 5 * nq, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_q);
+    hipFree(d_idx);
+    hipFree(d_d2);
+    if (e != hipSuccess) {
+        ctx->err = std::string("mml_knn5: ") + hipGetErrorString(e);
+        return MML_ERR_HIP;
+    }
+    return rc;
+}
+
+static void finish_stats(const double* s, mml_assoc_stats* o) {
+    o->n_line = (int)s[0];
+    o->n_plane = (int)s[1];
+    o->n_line_used = (int)s[2];
+    o->n_plane_used = (int)s[3];
+    for (int k = 0; k < 9; ++k) o->normal_gram[k] = s[4 + k];
+    // checkLocalizability (Estimator.cpp:536-565): smallest singular value of the M x 3 normal matrix =
+    // sqrt(lambda_min(gram)); 3x3 symmetric eigenvalues by the trigonometric closed form (host, once per call)
+    if (!(o->n_plane > 10)) {
+        o->min_singular = -1;
+    } else {
+        const double* A = o->normal_gram;
+        double p1 = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        double lam_min;
+        double q = (A[0] + A[4] + A[8]) / 3.0;
+        double p2 = (A[0] - q) * (A[0] - q) + (A[4] - q) * (A[4] - q) + (A[8] - q) * (A[8] - q) + 2 * p1;
+        double p = sqrt(p2 / 6.0);
+        if (p < 1e-300) {
+            lam_min = q;
+        } else {
+            double Bm[9];
+            for (int k = 0; k < 9; ++k) Bm[k] = (A[k] - ((k % 4 == 0) ? q : 0.0)) / p;
+            double detB = Bm[0] * (Bm[4] * Bm[8] - Bm[5] * Bm[7]) - Bm[1] * (Bm[3] * Bm[8] - Bm[5] * Bm[6]) +
+                          Bm[2] * (Bm[3] * Bm[7] - Bm[4] * Bm[6]);
+            double r = detB / 2.0;
+            r = r < -1 ? -1 : (r > 1 ? 1 : r);
+            double phi = acos(r) / 3.0;
+            lam_min = q + 2 * p * cos(phi + 2.0 * M_PI / 3.0);
+        }
+        o->min_singular = sqrt(lam_min > 0 ? lam_min : 0.0);
+    }
+    o->is_degenerate = o->min_singular < 3.0 ? 1 : 0;  // Estimator.cpp:772-775
+}
+
+int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, double thres_dist,
+                  mml_assoc_stats* stats) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(T_wl != nullptr, MML_ERR_INVALID, "null T_wl");
+    MML_REQUIRE(ctx->have_map[0] && ctx->have_map[1], MML_ERR_STATE, "mml_associate before both maps were set");
+    double* d_T = ctx->d_pose_in;
+    int rc = upload_doubles(ctx, d_T, T_wl, 16 * (size_t)count);
+    if (rc != MML_OK) return rc;
+    rc = mml_launch_associate(ctx, first_slot, count, d_T, thres_dist);
+    if (rc != MML_OK) return rc;
+    if (stats) {
+        std::vector<double> h(16 * (size_t)count);
+        MML_HIP(hipMemcpyAsync(h.data(), ctx->assoc_stats + 16 * (size_t)first_slot, sizeof(double) * h.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+        MML_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < count; ++i) finish_stats(h.data() + 16 * i, &stats[i]);
+    }
+    return MML_OK;
+}
+
+int mml_factors_download(mml_ctx* ctx, int slot, int kind, double* out, int* src, int capacity, int* n) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad arguments");
+    int nf = 0;
+    MML_HIP(hipMemcpyAsync(&nf, ctx->ft_n + kind * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_REQUIRE(nf >= 0, MML_ERR_CAPACITY, "feature stack overflowed");
+    int cnt = 0;
+    if (kind == 0) {
+        std::vector<MmlLineFactor> h(nf ? nf : 1);
+        if (nf) MML_HIP(hipMemcpy(h.data(), ctx->lf + (size_t)slot * ctx->MF, sizeof(MmlLineFactor) * nf, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nf; ++i) {
+            if (h[i].src < 0) continue;
+            if (cnt < capacity && out) {
+                double* o = out + 10 * cnt;
+                for (int c = 0; c < 3; ++c) {
+                    o[c] = h[i].ori[c];
+                    o[3 + c] = h[i].p1[c];
+                    o[6 + c] = h[i].p2[c];
+                }
+                o[9] = h[i].error;
+                if (src) src[cnt] = h[i].src;
+            }
+            ++cnt;
+        }
+    } else {
+        std::vector<MmlPlaneFactor> h(nf ? nf : 1);
+        if (nf) MML_HIP(hipMemcpy(h.data(), ctx->pf + (size_t)slot * ctx->MF, sizeof(MmlPlaneFactor) * nf, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nf; ++i) {
+            if (h[i].src < 0) continue;
+            if (cnt < capacity && out) {
+                double* o = out + 10 * cnt;
+                for (int c = 0; c < 3; ++c) {
+                    o[c] = h[i].ori[c];
+                    o[3 + c] = h[i].proj[c];
+                    o[6 + c] = h[i].omega[c];
+                }
+                o[9] = h[i].error;
+                if (src) src[cnt] = h[i].src;
+            }
+            ++cnt;
+        }
+    }
+    *n = cnt;
+    MML_REQUIRE(!out || cnt <= capacity, MML_ERR_CAPACITY, "factor download capacity too small");
+    return MML_OK;
+}
+
+int mml_linearize_record(mml_ctx* ctx, int slot, const double* x, const double* T_bl, double plan_weight_tan,
+                         double huber_delta, double* d_record) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(x && T_bl && d_record, MML_ERR_INVALID, "null argument");
+    double h[22];
+    memcpy(h, x, sizeof(double) * 6);
+    memcpy(h + 6, T_bl, sizeof(double) * 16);
+    double* d_par = ctx->d_pose_in + 64 * (size_t)slot;
+    int rc = upload_doubles(ctx, d_par, h, 22);
+    if (rc != MML_OK) return rc;
+    return mml_launch_linearize(ctx, slot, d_par, d_par + 6, plan_weight_tan, huber_delta, d_record);
+}
+
+int mml_linearize(mml_ctx* ctx, int slot, const double* x, const double* T_bl, double plan_weight_tan,
+                  double huber_delta, double* H, double* g, double* cost) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(H && g && cost, MML_ERR_INVALID, "null output");
+    double* d_rec = ctx->d_rec + 32 * (size_t)slot;
+    int rc = mml_linearize_record(ctx, slot, x, T_bl, plan_weight_tan, huber_delta, d_rec);
+    if (rc != MML_OK) return rc;
+    double rec[32];
+    MML_HIP(hipMemcpyAsync(rec, d_rec, sizeof(rec), hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            H[6 * a + b] = rec[k];
+            H[6 * b + a] = rec[k];
+            ++k;
+        }
+    for (int a = 0; a < 6; ++a) g[a] = rec[21 + a];
+    *cost = rec[27];
+    return MML_OK;
+}
+
+int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double* T_bl, const mml_solve_opts* opts,
+              double* x, mml_solve_summary* summaries, double* trace) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(T_bl && opts && x, MML_ERR_INVALID, "null argument");
+    MML_REQUIRE(opts->max_num_iterations >= 0 && opts->max_num_iterations <= 64, MML_ERR_INVALID,
+                "max_num_iterations must be in [0, 64]");
+    int rc = upload_doubles(ctx, ctx->d_x + 6 * (size_t)first_slot, x, 6 * (size_t)count);
+    if (rc != MML_OK) return rc;
+    double* d_Tbl = ctx->d_pose_in + 64 * (size_t)ctx->B - 16;
+    rc = upload_doubles(ctx, d_Tbl, T_bl, 16);
+    if (rc != MML_OK) return rc;
+    rc = mml_launch_solve(ctx, first_slot, count, window, d_Tbl, *opts, trace != nullptr);
+    if (rc != MML_OK) return rc;
+    const int nprob = count / window;
+    std::vector<double> hs(8 * (size_t)nprob);
+    MML_HIP(hipMemcpyAsync(x, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    MML_HIP(hipMemcpyAsync(hs.data(), ctx->d_summ, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (trace)
+        MML_HIP(hipMemcpyAsync(trace, ctx->d_trace, sizeof(double) * (size_t)nprob * opts->max_num_iterations * 6 * window,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    if (summaries)
+        for (int p = 0; p < nprob; ++p) {
+            summaries[p].iterations = (int)hs[8 * p];
+            summaries[p].successful = (int)hs[8 * p + 1];
+            summaries[p].initial_cost = hs[8 * p + 2];
+            summaries[p].final_cost = hs[8 * p + 3];
+            summaries[p].termination = (int)hs[8 * p + 4];
+        }
+    return MML_OK;
+}
+
+// ---- small host-side SO(3) helpers for the orchestration entry points (outside the kernels) ----------------
+static void so3_exp_h(const double* phi, double* q) {  // sophus/so3.hpp:585-622
+    double th2 = (phi[0] * phi[0] + phi[1] * phi[1]) + phi[2] * phi[2];
+    double imag, real;
+    if (th2 < 1e-20) {
+        double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+    } else {
+        double th = sqrt(th2), half = 0.5 * th;
+        imag = sin(half) / th;
+        real = cos(half);
+    }
+    q[0] = imag * phi[0];
+    q[1] = imag * phi[1];
+    q[2] = imag * phi[2];
+    q[3] = real;
+}
+static void so3_log_h(const double* qin, double* phi) {  // sophus/so3.hpp:247-287
+    double nq = sqrt((qin[0] * qin[0] + qin[2] * qin[2]) + (qin[1] * qin[1] + qin[3] * qin[3]));
+    double q[4] = {qin[0] / nq, qin[1] / nq, qin[2] / nq, qin[3] / nq};
+    double sn = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    double w = q[3], f;
+    if (sn < 1e-20) {
+        f = 2.0 / w - (2.0 / 3.0) * sn / (w * w * w);
+    } else {
+        double n = sqrt(sn);
+        if (fabs(w) < 1e-10)
+            f = (w > 0 ? M_PI : -M_PI) / n;
+        else
+            f = 2.0 * atan(n / w) / n;
+    }
+    phi[0] = f * q[0];
+    phi[1] = f * q[1];
+    phi[2] = f * q[2];
+}
+static void quat_to_R_h(const double* q, double* R) {
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+// T_bl = inverse(exTlb) (Estimator.cpp:157-159 / :1155-1156)
+static void invert_extrinsic(const double* exTlb, double* T_bl) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T_bl[4 * r + c] = exTlb[4 * c + r];
+    for (int r = 0; r < 3; ++r)
+        T_bl[4 * r + 3] = -1.0 * ((T_bl[4 * r] * exTlb[3] + T_bl[4 * r + 1] * exTlb[7]) + T_bl[4 * r + 2] * exTlb[11]);
+    T_bl[12] = T_bl[13] = T_bl[14] = 0;
+    T_bl[15] = 1;
+}
+// transformTobeMapped = [Q * exRbl, Q * exPbl + P] (Estimator.cpp:1268-1270) from x = [t, phi]
+static void pose_to_Twl(const double* q, const double* P, const double* T_bl, double* T) {
+    double R[9];
+    quat_to_R_h(q, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            T[4 * r + c] = (R[3 * r] * T_bl[c] + R[3 * r + 1] * T_bl[4 + c]) + R[3 * r + 2] * T_bl[8 + c];
+        T[4 * r + 3] = ((R[3 * r] * T_bl[3] + R[3 * r + 1] * T_bl[7]) + R[3 * r + 2] * T_bl[11]) + P[r];
+    }
+    T[12] = T[13] = T[14] = 0;
+    T[15] = 1;
+}
+
+int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, double* P, double* Q, int max_outer,
+                 int inner_iters, mml_estimate_info* info) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(exTlb && P && Q && max_outer >= 1 && inner_iters >= 0, MML_ERR_INVALID, "bad arguments");
+    MML_REQUIRE(ctx->have_map[0] && ctx->have_map[1], MML_ERR_STATE, "mml_estimate before both maps were set");
+    double T_bl[16];
+    invert_extrinsic(exTlb, T_bl);
+    std::vector<int> done(count, 0), outer(count, 0), degen(count, 0);
+    std::vector<double> x(6 * (size_t)count), Twl(16 * (size_t)count);
+    std::vector<mml_assoc_stats> st(count);
+    double thres = 25.0;  // Estimator.cpp:1207
+    mml_solve_opts so;
+    so.max_num_iterations = inner_iters;
+    so.fixed_iterations = 0;
+    so.huber_delta = 0.1 / 1.5e-3;  // :1221
+    so.plan_weight_tan = 0.0;       // :1206
+    for (int it = 0; it < max_outer; ++it) {
+        bool any = false;
+        for (int i = 0; i < count; ++i)
+            if (!done[i]) any = true;
+        if (!any) break;
+        for (int i = 0; i < count; ++i) {
+            so3_log_h(Q + 4 * i, &x[6 * i + 3]);  // vector2double :937-950
+            x[6 * i] = P[3 * i];
+            x[6 * i + 1] = P[3 * i + 1];
+            x[6 * i + 2] = P[3 * i + 2];
+            pose_to_Twl(Q + 4 * i, P + 3 * i, T_bl, &Twl[16 * i]);
+        }
+        int rc = mml_associate(ctx, first_slot, count, Twl.data(), thres, st.data());
+        if (rc != MML_OK) return rc;
+        thres = (it == 0) ? 10.0 : 1.0;  // :1377-1381
+        std::vector<double> xs = x;
+        rc = mml_solve(ctx, first_slot, count, 1, T_bl, &so, xs.data(), nullptr, nullptr);
+        if (rc != MML_OK) return rc;
+        for (int i = 0; i < count; ++i) {
+            if (done[i]) continue;
+            if (st[i].is_degenerate) degen[i] = 1;
+            double qa[4];
+            so3_exp_h(&xs[6 * i + 3], qa);  // double2vector :952-964
+            const double* qb = Q + 4 * i;
+            // angularDistance (:1444): d = qb * conj(qa); 2 atan2(|d.vec|, |d.w|)
+            double cx = -qa[0], cy = -qa[1], cz = -qa[2], cw = qa[3];
+            double dx = qb[3] * cx + qb[0] * cw + qb[1] * cz - qb[2] * cy;
+            double dy = qb[3] * cy + qb[1] * cw + qb[2] * cx - qb[0] * cz;
+            double dz = qb[3] * cz + qb[2] * cw + qb[0] * cy - qb[1] * cx;
+            double dw = qb[3] * cw - qb[0] * cx - qb[1] * cy - qb[2] * cz;
+            double deltaR = (2.0 * atan2(sqrt((dx * dx + dy * dy) + dz * dz), fabs(dw))) * 180.0 / M_PI;
+            double ex = P[3 * i] - xs[6 * i], ey = P[3 * i + 1] - xs[6 * i + 1], ez = P[3 * i + 2] - xs[6 * i + 2];
+            double deltaT = sqrt((ex * ex + ey * ey) + ez * ez);
+            for (int c = 0; c < 3; ++c) P[3 * i + c] = xs[6 * i + c];
+            for (int c = 0; c < 4; ++c) Q[4 * i + c] = qa[c];
+            outer[i] = it + 1;
+            if ((deltaR < 0.05 && deltaT < 0.05) || (it + 1) == max_outer) done[i] = 1;  // :1448
+        }
+    }
+    if (info) {
+        std::vector<int> fn(2 * (size_t)ctx->B);
+        MML_HIP(hipMemcpy(fn.data(), ctx->ft_n, sizeof(int) * fn.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; ++i) {
+            info[i].outer_iterations = outer[i];
+            info[i].is_degenerate = degen[i];
+            info[i].n_corner_feat = fn[first_slot + i];
+            info[i].n_surf_feat = fn[ctx->B + first_slot + i];
+        }
+    }
+    return MML_OK;
+}
+
+int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt, const double* exTlb,
+             double thres_dist, int gn_iters, double* x_inout) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(dR && dt && exTlb && x_inout, MML_ERR_INVALID, "null argument");
+    MML_REQUIRE(gn_iters >= 0 && gn_iters <= 64, MML_ERR_INVALID, "gn_iters must be in [0, 64]");
+    MML_REQUIRE(ctx->have_map[0] && ctx->have_map[1], MML_ERR_STATE, "mml_step before both maps were set");
+    int rc = mml_launch_extract(ctx, first_slot, count, false);
+    if (rc != MML_OK) return rc;
+    rc = mml_undistort(ctx, first_slot, count, dR, dt);
+    if (rc != MML_OK) return rc;
+    rc = mml_launch_downsample(ctx, first_slot, count);
+    if (rc != MML_OK) return rc;
+    double T_bl[16];
+    invert_extrinsic(exTlb, T_bl);
+    std::vector<double> Twl(16 * (size_t)count);
+    for (int i = 0; i < count; ++i) {
+        double q[4];
+        so3_exp_h(x_inout + 6 * i + 3, q);
+        pose_to_Twl(q, x_inout + 6 * i, T_bl, &Twl[16 * i]);
+    }
+    rc = mml_associate(ctx, first_slot, count, Twl.data(), thres_dist, nullptr);
+    if (rc != MML_OK) return rc;
+    mml_solve_opts so;
+    so.max_num_iterations = gn_iters;
+    so.fixed_iterations = 1;
+    so.huber_delta = 0.1 / 1.5e-3;
+    so.plan_weight_tan = 0.0;
+    return mml_solve(ctx, first_slot, count, 1, T_bl, &so, x_inout, nullptr, nullptr);
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------------
+int mml_profile_enable(mml_ctx* ctx, int on) {
+    if (!ctx) return MML_ERR_INVALID;
+    ctx->profiling = on != 0;
+    return MML_OK;
+}
+
+static int drain_pending(mml_ctx* ctx) {
+    MML_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& pe : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            ctx->stages[pe.stage].total_ms += ms;
+            ctx->stages[pe.stage].launches += 1;
+        }
+        ctx->event_pool.push_back(pe.a);
+        ctx->event_pool.push_back(pe.b);
+    }
+    ctx->pending.clear();
+    return MML_OK;
+}
+
+int mml_profile_reset(mml_ctx* ctx) {
+    if (!ctx) return MML_ERR_INVALID;
+    int rc = drain_pending(ctx);
+    for (auto& s : ctx->stages) {
+        s.total_ms = 0;
+        s.launches = 0;
+    }
+    return rc;
+}
+
+int mml_profile_get(mml_ctx* ctx, mml_profile* out) {
+    if (!ctx || !out) return MML_ERR_INVALID;
+    int rc = drain_pending(ctx);
+    if (rc != MML_OK) return rc;
+    out->n_stages = (int)std::min<size_t>(ctx->stages.size(), MML_MAX_STAGES);
+    for (int i = 0; i < out->n_stages; ++i) {
+        out->name[i] = ctx->stages[i].name.c_str();
+        out->total_ms[i] = ctx->stages[i].total_ms;
+        out->launches[i] = ctx->stages[i].launches;
+    }
+    return MML_OK;
+}
+
+int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes) {
+    if (!ctx) return MML_ERR_INVALID;
+    hipDeviceProp_t prop;
+    MML_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap > 0) {
+        strncpy(name, prop.name, name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return MML_OK;
+}
+
+}  // extern "C"
+
+namespace {
+__global__ void k_copy16(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) b[i] = a[i];
+}
+}  // namespace
+
+extern "C" int mml_copy_bandwidth(mml_ctx* ctx, size_t bytes, int reps, double* gbps) {
+    if (!ctx || !gbps || reps <= 0) return MML_ERR_INVALID;
+    MML_HIP(hipSetDevice(ctx->device));
+    size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&a), n * 16));
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&b), n * 16));
+    MML_HIP(hipMemsetAsync(a, 1, n * 16, ctx->stream));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
+    hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
+    hipEventRecord(e1, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(a);
+    hipFree(b);
+    if (e != hipSuccess) {
+        ctx->err = hipGetErrorString(e);
+        return MML_ERR_HIP;
+    }
+    *gbps = (2.0 * n * 16 * reps) / (ms * 1e-3) / 1e9;
+    return MML_OK;
+}
+
+int mml_stage_begin(mml_ctx* ctx, const char* name) {
+    if (!ctx->profiling) return -1;
+    int idx = -1;
+    for (size_t i = 0; i < ctx->stages.size(); ++i)
+        if (ctx->stages[i].name == name) idx = (int)i;
+    if (idx < 0) {
+        MmlStageTimer t;
+        t.name = name;
+        ctx->stages.push_back(t);
+        idx = (int)ctx->stages.size() - 1;
+    }
+    mml_ctx::Pending pe;
+    pe.stage = idx;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!ctx->event_pool.empty()) {
+            e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            hipEventCreate(&e);
+        }
+        return e;
+    };
+    pe.a = get();
+    pe.b = get();
+    hipEventRecord(pe.a, ctx->stream);
+    ctx->pending.push_back(pe);
+    return (int)ctx->pending.size() - 1;
+}
+
+void mml_stage_end(mml_ctx* ctx, int token) {
+    if (token < 0) return;
+    hipEventRecord(ctx->pending[token].b, ctx->stream);
+}

@@ -1,0 +1,968 @@
+// feature.hip -- rows a1..a8 of SURVEY.md section 8: per-scan edge / planar feature extraction on gfx950.
+//
+// Reference: mm-loam/src/unionFeatureExtract.cpp (getVeloFeature :1113-1317, getHoriFeatureExtract :952-1035,
+// detectFeaturePoints :341-844) and include/lidars_extrinsic_cali.h:424-477 (crop filters).
+//
+// Kernel chain for a batch of scan slots (one launch each, all slots at once):
+//   k_assign_velo / k_assign_livox : ring / line id, in-scan time, order-preserving bucketing by line
+//   k_stencil                      : one point per lane: curvature / depth / reflect stencil + every
+//                                    per-point predicate of the flag state machine packed in 16 bits
+//   k_partition_sort               : stable rank sort of each of the 50 partitions per line
+//   k_select                       : one wavefront per scan line: the order-dependent part of the state
+//                                    machine (flags 3/1/2/300, stride walk for 150) + label scatter
+//   k_crop_compact                 : near/far crop, order-preserving compaction into the fused cloud
+// Everything that is order-independent was hoisted out of the serial walk; what remains per line is a chain
+// of LDS byte reads/writes executed by one wave with wave-uniform control flow.
+//
+// Floating point: compiled with -ffp-contract=off; float expressions are written exactly as in the reference
+// (left-to-right, float), double expressions follow Eigen's (x0+x1)+x2 reduction order.  libm calls on
+// float arguments follow the "double libm, round on assignment" convention documented in DESIGN.md.
+#include <math.h>
+
+#include "mml_internal.h"
+
+namespace {
+
+// ---- attr bits written by k_stencil ---------------------------------------------------------------------
+enum : unsigned {
+    A_W2 = 1u << 0,        // thNumCurvSize == 2 at this point (:424-428)
+    A_ANGLE = 1u << 1,     // cloudAngle[i] = 1 (:430-432)
+    A_CAND3 = 1u << 2,     // curvature < flat threshold (:488)
+    A_FAR = 1u << 3,       // depth > thDistanceFaraway (:499,512,524)
+    A_REFL = 1u << 4,      // reflect corner candidate (:534-535)
+    A_A3_SHIFT = 5,        // 2 bits: neighbours markable to the right with window 3 (:492-504)
+    A_B3_SHIFT = 7,        // 2 bits: neighbours markable to the left (:505-517)
+    A_LFLAT = 1u << 9,     // left half-window flat (:565)
+    A_RFLAT = 1u << 10,    // right half-window flat (:597) -> stride 4
+    A_C150 = 1u << 11,     // included-angle test passes (:644)
+    A_F5_SHIFT = 12,       // 2 bits: 0 none, 1 -> flag 100, 2 -> flag 101 (:677-802)
+    A_NEAR = 1u << 14      // r^2 < thLidarNearestDis^2 (:824)
+};
+
+struct FeatParams {
+    int first, NV, NL, NT, L, n_rings, n_lines;
+    float pitch0, pitch_step, near_th, far_th;
+    const float4* velo_in;
+    const mml_livox_point* livox_in;
+    const int* n_in;
+    uint8_t* raw_line;
+    float* raw_ori;
+    float4* ln_pts;
+    int* ln_gidx;
+    int* line_start;
+    int* line_len;
+    float* ln_curv;
+    float* ln_refl;
+    uint16_t* ln_attr;
+    int* ln_ord_c;
+    int* ln_ord_r;
+    uint8_t* ln_flag;
+    uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
+    float4* cb_xyzi;
+    float* cb_rel;
+    uint8_t* cb_line;
+    uint8_t* cb_label;
+    int* cb_n;
+    float4* fu_xyzi;
+    float* fu_rel;
+    uint8_t* fu_line;
+    uint8_t* fu_label;
+    int* fu_info;
+    const float* extr;  // 16 floats or nullptr
+};
+
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ double ddot(const D3& a, const D3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ double dnorm(const D3& a) { return sqrt(ddot(a, a)); }
+__device__ __forceinline__ void dnormalize(D3& a) {
+    double z = ddot(a, a);
+    if (z > 0.0) {
+        double n = sqrt(z);
+        a.x /= n;
+        a.y /= n;
+        a.z /= n;
+    }
+}
+
+constexpr int ASSIGN_THREADS = 1024;
+constexpr int ASSIGN_WAVES = ASSIGN_THREADS / MML_WAVE;
+constexpr int MAX_LINES = 160;  // n_rings + n_livox_lines upper bound
+
+// Order-preserving multi-way scatter of one chunk of ASSIGN_THREADS items: returns the destination offset of
+// this thread's item inside its line (running over chunks), and its index among all valid items.
+// wcnt: [ASSIGN_WAVES][nkeys], base: [nkeys] running per-key counts, wtot: [ASSIGN_WAVES], *gbase running total.
+__device__ __forceinline__ void chunk_stable_scatter(bool valid, int key, int nkeys, int* wcnt, int* base, int* wtot,
+                                                    int* gbase, int& pos_in_key, int& gidx) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < ASSIGN_WAVES * nkeys; i += ASSIGN_THREADS) wcnt[i] = 0;
+    __syncthreads();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long vmask = __ballot(valid);
+    int rank = 0;
+    unsigned long long todo = vmask;
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int k = __shfl(key, leader);
+        unsigned long long m = __ballot(valid && key == k);
+        if (valid && key == k) rank = __popcll(m & lt);
+        if (lane == leader) wcnt[wave * nkeys + k] = __popcll(m);
+        todo &= ~m;
+    }
+    if (lane == 0) wtot[wave] = __popcll(vmask);
+    __syncthreads();
+    int off = 0, goff = 0;
+    if (valid) {
+        off = base[key];
+        for (int w = 0; w < wave; ++w) off += wcnt[w * nkeys + key];
+        goff = *gbase;
+        for (int w = 0; w < wave; ++w) goff += wtot[w];
+        goff += __popcll(vmask & lt);
+    }
+    pos_in_key = off + rank;
+    gidx = goff;
+    __syncthreads();
+    for (int k = tid; k < nkeys; k += ASSIGN_THREADS) {
+        int s = 0;
+        for (int w = 0; w < ASSIGN_WAVES; ++w) s += wcnt[w * nkeys + k];
+        base[k] += s;
+    }
+    if (tid == 0) {
+        int s = 0;
+        for (int w = 0; w < ASSIGN_WAVES; ++w) s += wtot[w];
+        *gbase += s;
+    }
+    __syncthreads();
+}
+
+// ---- a1: getVeloFeature ring + relTime assignment (:1129-1218) -------------------------------------------
+// One workgroup per scan slot.  The serial `halfPassed` flag (:1148,1169-1184) is a prefix-OR: the first valid
+// point whose unwrapped azimuth exceeds startOri + pi flips it, so a min-reduction finds the flip index.
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_velo(FeatParams P) {
+    __shared__ int s_cnt[MAX_LINES];
+    __shared__ int s_base[MAX_LINES];
+    __shared__ int s_wcnt[ASSIGN_WAVES * MAX_LINES];
+    __shared__ int s_wtot[ASSIGN_WAVES];
+    __shared__ int s_first, s_last, s_trig, s_gbase;
+    __shared__ float s_startOri, s_endOri;
+
+    const int b = blockIdx.x + P.first;
+    const int tid = threadIdx.x;
+    const int n = P.n_in[2 * b];
+    const float4* in = P.velo_in + (size_t)b * P.NV;
+    uint8_t* rline = P.raw_line + (size_t)b * P.NT;
+    float* rori = P.raw_ori + (size_t)b * P.NV;
+    const int R = P.n_rings;
+
+    for (int i = tid; i < R; i += ASSIGN_THREADS) {
+        s_cnt[i] = 0;
+        s_base[i] = 0;
+    }
+    if (tid == 0) {
+        s_first = 0x7fffffff;
+        s_last = -1;
+        s_trig = 0x7fffffff;
+        s_gbase = 0;
+    }
+    __syncthreads();
+
+    // pass 1: NaN filter (:1133), ring id (:1159-1166), raw azimuth (:1168), per-ring counts
+    for (int i = tid; i < n; i += ASSIGN_THREADS) {
+        float4 p = in[i];
+        bool fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+        int ring = 255;
+        float ori = 0.f;
+        if (fin) {
+            atomicMin(&s_first, i);
+            atomicMax(&s_last, i);
+            float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;
+            int scanID = int((angle - P.pitch0) / P.pitch_step + 0.5);
+            if (!(scanID > (R - 1) || scanID < 0)) {
+                ring = scanID;
+                atomicAdd(&s_cnt[ring], 1);
+            }
+            ori = -atan2((double)p.y, (double)p.x);
+        }
+        rline[i] = (uint8_t)ring;
+        rori[i] = ori;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float startOri = 0.f, endOri = 0.f;
+        if (s_last >= 0) {
+            float4 p0 = in[s_first], p1 = in[s_last];
+            startOri = -atan2((double)p0.y, (double)p0.x);
+            endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
+            if (endOri - startOri > 3 * M_PI)
+                endOri -= 2 * M_PI;
+            else if (endOri - startOri < M_PI)
+                endOri += 2 * M_PI;
+        }
+        s_startOri = startOri;
+        s_endOri = endOri;
+        int acc = 0;
+        int* ls = P.line_start + (size_t)b * P.L;
+        int* ll = P.line_len + (size_t)b * P.L;
+        for (int r = 0; r < R; ++r) {
+            ls[r] = acc;
+            ll[r] = s_cnt[r];
+            acc += s_cnt[r];
+        }
+        P.cb_n[2 * b] = acc;
+    }
+    __syncthreads();
+    const float startOri = s_startOri, endOri = s_endOri;
+
+    // pass 2: index of the point that sets halfPassed (:1169-1177)
+    for (int i = tid; i < n; i += ASSIGN_THREADS) {
+        if (rline[i] == 255) continue;
+        float ori = rori[i];
+        if (ori < startOri - M_PI / 2)
+            ori += 2 * M_PI;
+        else if (ori > startOri + M_PI * 3 / 2)
+            ori -= 2 * M_PI;
+        if (ori - startOri > M_PI) atomicMin(&s_trig, i);
+    }
+    __syncthreads();
+    const int trig = s_trig;
+
+    // pass 3: relTime (:1186) + stable bucketing (:1193-1194, :1209-1218)
+    const int* ls = P.line_start + (size_t)b * P.L;
+    float4* lp = P.ln_pts + (size_t)b * P.NT;
+    int* lg = P.ln_gidx + (size_t)b * P.NT;
+    float4* cbx = P.cb_xyzi + (size_t)b * P.NT;
+    float* cbr = P.cb_rel + (size_t)b * P.NT;
+    uint8_t* cbl = P.cb_line + (size_t)b * P.NT;
+    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
+    for (int c0 = 0; c0 < n; c0 += ASSIGN_THREADS) {
+        int i = c0 + tid;
+        bool valid = false;
+        int ring = 0;
+        float4 p = make_float4(0, 0, 0, 0);
+        float relTime = 0.f;
+        if (i < n) {
+            ring = rline[i];
+            valid = ring != 255;
+            if (valid) {
+                p = in[i];
+                float ori = rori[i];
+                if (i <= trig) {
+                    if (ori < startOri - M_PI / 2)
+                        ori += 2 * M_PI;
+                    else if (ori > startOri + M_PI * 3 / 2)
+                        ori -= 2 * M_PI;
+                } else {
+                    ori += 2 * M_PI;
+                    if (ori < endOri - M_PI * 3 / 2)
+                        ori += 2 * M_PI;
+                    else if (ori > endOri + M_PI / 2)
+                        ori -= 2 * M_PI;
+                }
+                relTime = (ori - startOri) / (endOri - startOri);
+            } else {
+                ring = 0;
+            }
+        }
+        int pos, gidx;
+        chunk_stable_scatter(valid, ring, R, s_wcnt, s_base, s_wtot, &s_gbase, pos, gidx);
+        if (valid) {
+            int dst = ls[ring] + pos;
+            lp[dst] = p;
+            lg[dst] = gidx;
+            cbx[gidx] = make_float4(p.x, p.y, p.z, 0.f);  // intensity zeroed, :1254-1256
+            cbr[gidx] = relTime;
+            cbl[gidx] = (uint8_t)ring;
+            cblab[gidx] = 0;
+        }
+    }
+}
+
+// ---- a2: getHoriFeatureExtract line split (:985-1006) -----------------------------------------------------
+__device__ __forceinline__ double livox_to_sec(uint32_t t) {  // ros::Time().fromNSec(t).toSec()
+    uint32_t sec = (uint32_t)(t / 1000000000ull);
+    uint32_t nsec = (uint32_t)(t % 1000000000ull);
+    return (double)sec + 1e-9 * (double)nsec;
+}
+
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_livox(FeatParams P) {
+    __shared__ int s_cnt[MAX_LINES];
+    __shared__ int s_base[MAX_LINES];
+    __shared__ int s_wcnt[ASSIGN_WAVES * MAX_LINES];
+    __shared__ int s_wtot[ASSIGN_WAVES];
+    __shared__ int s_gbase;
+
+    const int b = blockIdx.x + P.first;
+    const int tid = threadIdx.x;
+    const int n = P.n_in[2 * b + 1];
+    const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
+    const int NLN = P.n_lines;
+    for (int i = tid; i < NLN; i += ASSIGN_THREADS) {
+        s_cnt[i] = 0;
+        s_base[i] = 0;
+    }
+    if (tid == 0) s_gbase = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += ASSIGN_THREADS) {
+        mml_livox_point p = in[i];
+        int line_num = (int)p.line;
+        bool valid = !(line_num > NLN - 1) && !(p.x < 0.01);
+        if (valid) atomicAdd(&s_cnt[line_num], 1);
+    }
+    __syncthreads();
+    int* ls = P.line_start + (size_t)b * P.L + P.n_rings;
+    int* ll = P.line_len + (size_t)b * P.L + P.n_rings;
+    if (tid == 0) {
+        int acc = P.NV;  // livox lines live behind the velodyne region
+        for (int r = 0; r < NLN; ++r) {
+            ls[r] = acc;
+            ll[r] = s_cnt[r];
+            acc += s_cnt[r];
+        }
+        P.cb_n[2 * b + 1] = acc - P.NV;
+    }
+    __syncthreads();
+    const double timeSpan = n > 0 ? livox_to_sec(in[n - 1].offset_time) : 1.0;
+    float4* lp = P.ln_pts + (size_t)b * P.NT;
+    int* lg = P.ln_gidx + (size_t)b * P.NT;
+    float4* cbx = P.cb_xyzi + (size_t)b * P.NT;
+    float* cbr = P.cb_rel + (size_t)b * P.NT;
+    uint8_t* cbl = P.cb_line + (size_t)b * P.NT;
+    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
+    for (int c0 = 0; c0 < n; c0 += ASSIGN_THREADS) {
+        int i = c0 + tid;
+        bool valid = false;
+        int line_num = 0;
+        mml_livox_point p;
+        p.x = p.y = p.z = 0.f;
+        p.offset_time = 0;
+        p.reflectivity = 0;
+        if (i < n) {
+            p = in[i];
+            line_num = (int)p.line;
+            valid = !(line_num > NLN - 1) && !(p.x < 0.01);
+            if (!valid) line_num = 0;
+        }
+        int pos, gidx;
+        chunk_stable_scatter(valid, line_num, NLN, s_wcnt, s_base, s_wtot, &s_gbase, pos, gidx);
+        if (valid) {
+            float inten = p.reflectivity;
+            float rel = livox_to_sec(p.offset_time) / timeSpan;
+            int dst = ls[line_num] + pos;
+            lp[dst] = make_float4(p.x, p.y, p.z, inten);
+            lg[dst] = P.NV + gidx;
+            cbx[P.NV + gidx] = make_float4(p.x, p.y, p.z, inten);
+            cbr[P.NV + gidx] = rel;
+            cbl[P.NV + gidx] = (uint8_t)line_num;
+            cblab[P.NV + gidx] = 0;
+        }
+    }
+}
+
+// locate the scan line that owns bucketed position p of slot b
+__device__ __forceinline__ bool find_line(const FeatParams& P, int b, int p, int& line, int& i, int& n, int& start) {
+    const int* ls = P.line_start + (size_t)b * P.L;
+    const int* ll = P.line_len + (size_t)b * P.L;
+    int lo, hi;
+    if (p < P.NV) {
+        lo = 0;
+        hi = P.n_rings;
+    } else {
+        lo = P.n_rings;
+        hi = P.L;
+    }
+    // line_start is non-decreasing inside each region: last line with start <= p
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ls[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    // skip back over empty lines that share the same start
+    line = lo;
+    start = ls[line];
+    n = ll[line];
+    i = p - start;
+    return i >= 0 && i < n;
+}
+
+// ---- a3 + every order-independent predicate of a5..a7: one point per lane -----------------------------------
+__global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
+    const int b = blockIdx.y + P.first;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P.NT) return;
+    int line, i, n, start;
+    if (!find_line(P, b, p, line, i, n, start)) return;
+    const size_t base = (size_t)b * P.NT + start;
+    const float4* pt = P.ln_pts + base;
+    unsigned attr = 0;
+    float curv = 0.f, refl = 0.f;
+    if (i >= 5 && i < n - 5) {
+        const float thDistanceFaraway = 50.0;
+        const float thFlatThreshold = 0.02;
+        const float thLidarNearestDis = 1.0;
+        const float thBreakCornerDis = 1;
+        float4 q[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) q[k] = pt[i - 5 + k];
+#define PT(o) q[5 + (o)]
+        // ---- :407-451 ----
+        float diffX = 0, diffY = 0, diffZ = 0;
+        float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
+        float dis = sqrt((double)dis2);
+        D3 pt_last = d3(PT(-1).x, PT(-1).y, PT(-1).z);
+        D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
+        D3 pt_next = d3(PT(1).x, PT(1).y, PT(1).z);
+        D3 dl = d3(pt_last.x - pt_cur.x, pt_last.y - pt_cur.y, pt_last.z - pt_cur.z);
+        D3 dn = d3(pt_next.x - pt_cur.x, pt_next.y - pt_cur.y, pt_next.z - pt_cur.z);
+        double ncur = dnorm(pt_cur);
+        double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
+        double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
+        bool grazing = fabs(angle_last) > 0.966 && fabs(angle_next) > 0.966;
+        int thNumCurvSize;
+        if (dis > thDistanceFaraway || grazing) {
+            thNumCurvSize = 2;
+            attr |= A_W2;
+        } else {
+            thNumCurvSize = 3;
+        }
+        if (grazing) attr |= A_ANGLE;
+        float diffR = -2 * thNumCurvSize * PT(0).w;
+        // the loop at :435-440, unrolled (j = 1, 2 always; j = 3 when the window is 3)
+        diffX += PT(-1).x + PT(1).x;
+        diffY += PT(-1).y + PT(1).y;
+        diffZ += PT(-1).z + PT(1).z;
+        diffR += PT(-1).w + PT(1).w;
+        diffX += PT(-2).x + PT(2).x;
+        diffY += PT(-2).y + PT(2).y;
+        diffZ += PT(-2).z + PT(2).z;
+        diffR += PT(-2).w + PT(2).w;
+        if (thNumCurvSize == 3) {
+            diffX += PT(-3).x + PT(3).x;
+            diffY += PT(-3).y + PT(3).y;
+            diffZ += PT(-3).z + PT(3).z;
+            diffR += PT(-3).w + PT(3).w;
+        }
+        diffX -= 2 * thNumCurvSize * PT(0).x;
+        diffY -= 2 * thNumCurvSize * PT(0).y;
+        diffZ -= 2 * thNumCurvSize * PT(0).z;
+        curv = diffX * diffX + diffY * diffY + diffZ * diffZ;
+        refl = diffR;
+        // ---- predicates of :488, :499/:512, :524, :534-535 ----
+        if (curv < thFlatThreshold * dis * thFlatThreshold * dis) attr |= A_CAND3;
+        bool far = dis > thDistanceFaraway;
+        if (far) attr |= A_FAR;
+        if (curv < 0.7 * thFlatThreshold * dis * thFlatThreshold * dis && refl > 20.0) attr |= A_REFL;
+        {
+            int a3 = 0;
+#pragma unroll
+            for (int l = 1; l <= 3; l++) {
+                float dX = PT(l).x - PT(l - 1).x;
+                float dY = PT(l).y - PT(l - 1).y;
+                float dZ = PT(l).z - PT(l - 1).z;
+                if (dX * dX + dY * dY + dZ * dZ > 0.02 || far) break;
+                a3 = l;
+            }
+            int b3 = 0;
+#pragma unroll
+            for (int l = -1; l >= -3; l--) {
+                float dX = PT(l).x - PT(l + 1).x;
+                float dY = PT(l).y - PT(l + 1).y;
+                float dZ = PT(l).z - PT(l + 1).z;
+                if (dX * dX + dY * dY + dZ * dZ > 0.02 || far) break;
+                b3 = -l;
+            }
+            attr |= (unsigned)a3 << A_A3_SHIFT;
+            attr |= (unsigned)b3 << A_B3_SHIFT;
+        }
+        // ---- :543-650 (per visited point; which points are visited is decided in k_select) ----
+        {
+            float depth = dis;
+            float ldiffX = PT(-4).x + PT(-3).x - 4 * PT(-2).x + PT(-1).x + PT(0).x;
+            float ldiffY = PT(-4).y + PT(-3).y - 4 * PT(-2).y + PT(-1).y + PT(0).y;
+            float ldiffZ = PT(-4).z + PT(-3).z - 4 * PT(-2).z + PT(-1).z + PT(0).z;
+            float left_curvature = ldiffX * ldiffX + ldiffY * ldiffY + ldiffZ * ldiffZ;
+            bool lflat = left_curvature < thFlatThreshold * depth;
+            float rdiffX = PT(4).x + PT(3).x - 4 * PT(2).x + PT(1).x + PT(0).x;
+            float rdiffY = PT(4).y + PT(3).y - 4 * PT(2).y + PT(1).y + PT(0).y;
+            float rdiffZ = PT(4).z + PT(3).z - 4 * PT(2).z + PT(1).z + PT(0).z;
+            float right_curvature = rdiffX * rdiffX + rdiffY * rdiffY + rdiffZ * rdiffZ;
+            bool rflat = right_curvature < thFlatThreshold * depth;
+            if (lflat) attr |= A_LFLAT;
+            if (rflat) attr |= A_RFLAT;
+            if (lflat && rflat) {
+                D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
+#pragma unroll
+                for (int k = 1; k < 5; k++) {
+                    D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+                    dnormalize(tmp);
+                    norm_left.x += (k / 10.0) * tmp.x;
+                    norm_left.y += (k / 10.0) * tmp.y;
+                    norm_left.z += (k / 10.0) * tmp.z;
+                }
+#pragma unroll
+                for (int k = 1; k < 5; k++) {
+                    D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+                    dnormalize(tmp);
+                    norm_right.x += (k / 10.0) * tmp.x;
+                    norm_right.y += (k / 10.0) * tmp.y;
+                    norm_right.z += (k / 10.0) * tmp.z;
+                }
+                double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
+                D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
+                D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
+                double last_dis = dnorm(last_tmp);
+                double current_dis = dnorm(current_tmp);
+                if (cc < 0.5 && last_dis > 0.05 && current_dis > 0.05) attr |= A_C150;
+            }
+        }
+        // ---- :651-806 break points ----
+        {
+            float dX1 = PT(1).x - PT(0).x, dY1 = PT(1).y - PT(0).y, dZ1 = PT(1).z - PT(0).z;
+            float diff_right0 = sqrt((double)(dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1));
+            float dX2 = PT(-1).x - PT(0).x, dY2 = PT(-1).y - PT(0).y, dZ2 = PT(-1).z - PT(0).z;
+            float diff_left0 = sqrt((double)(dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2));
+            float depth_right = sqrt((double)(PT(1).x * PT(1).x + PT(1).y * PT(1).y + PT(1).z * PT(1).z));
+            float depth_left = sqrt((double)(PT(-1).x * PT(-1).x + PT(-1).y * PT(-1).y + PT(-1).z * PT(-1).z));
+            bool f100 = false;
+            if (fabs((double)(diff_right0 - diff_left0)) > thBreakCornerDis) {
+                if (diff_right0 > diff_left0) {
+                    D3 surf_vector = d3(PT(-1).x - PT(0).x, PT(-1).y - PT(0).y, PT(-1).z - PT(0).z);
+                    D3 lidar_vector = d3(PT(0).x, PT(0).y, PT(0).z);
+                    double cc = fabs(ddot(surf_vector, lidar_vector) / (dnorm(surf_vector) * dnorm(lidar_vector)));
+                    if (cc < 0.95) {
+                        if (depth_right > depth_left)
+                            f100 = true;
+                        else if (depth_right == 0)
+                            f100 = true;
+                    }
+                } else {
+                    D3 surf_vector = d3(PT(1).x - PT(0).x, PT(1).y - PT(0).y, PT(1).z - PT(0).z);
+                    D3 lidar_vector = d3(PT(0).x, PT(0).y, PT(0).z);
+                    double cc = fabs(ddot(surf_vector, lidar_vector) / (dnorm(surf_vector) * dnorm(lidar_vector)));
+                    if (cc < 0.95) {
+                        if (depth_right < depth_left)
+                            f100 = true;
+                        else if (depth_left == 0)
+                            f100 = true;
+                    }
+                }
+            }
+            if (f100) {
+                D3 norm_front = d3(0, 0, 0), norm_back = d3(0, 0, 0);
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    float temp_depth = sqrt((double)(PT(-k).x * PT(-k).x + PT(-k).y * PT(-k).y + PT(-k).z * PT(-k).z));
+                    if (temp_depth < 1) continue;
+                    D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+                    dnormalize(tmp);
+                    norm_front.x += (k / 6.0) * tmp.x;
+                    norm_front.y += (k / 6.0) * tmp.y;
+                    norm_front.z += (k / 6.0) * tmp.z;
+                }
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    // the reference tests the depth of i-k here as well (:782-784)
+                    float temp_depth = sqrt((double)(PT(-k).x * PT(-k).x + PT(-k).y * PT(-k).y + PT(-k).z * PT(-k).z));
+                    if (temp_depth < 1) continue;
+                    D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+                    dnormalize(tmp);
+                    norm_back.x += (k / 6.0) * tmp.x;
+                    norm_back.y += (k / 6.0) * tmp.y;
+                    norm_back.z += (k / 6.0) * tmp.z;
+                }
+                double cc = fabs(ddot(norm_front, norm_back) / (dnorm(norm_front) * dnorm(norm_back)));
+                attr |= (cc < 0.95 ? 1u : 2u) << A_F5_SHIFT;
+            }
+        }
+        if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
+#undef PT
+    }
+    P.ln_curv[base + i] = curv;
+    P.ln_refl[base + i] = refl;
+    P.ln_attr[base + i] = (uint16_t)attr;
+}
+
+// ---- a4: the two stable insertion sorts of every partition (:453-479) as a rank sort ------------------------
+// rank(i) = #{j in partition : key[j] < key[i] or (key[j] == key[i] and j < i)}; strict `<` in the reference
+// keeps ties in index order, which is exactly this total order.
+__device__ __forceinline__ void partition_bounds(int n, int j, int& sp, int& ep) {
+    const int scanStartInd = 5, scanEndInd = n - 6;
+    sp = scanStartInd + (scanEndInd - scanStartInd) * j / 50;
+    ep = scanStartInd + (scanEndInd - scanStartInd) * (j + 1) / 50 - 1;
+}
+
+__global__ __launch_bounds__(256) void k_partition_sort(FeatParams P) {
+    const int b = blockIdx.y + P.first;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P.NT) return;
+    int line, i, n, start;
+    if (!find_line(P, b, p, line, i, n, start)) return;
+    if (n < 12 || i < 5 || i > n - 7) return;
+    const size_t base = (size_t)b * P.NT + start;
+    // partition of i: sp_j <= i <= ep_j
+    const int range = n - 11;
+    int j = (int)(((long long)(i - 5) * 50) / range);
+    if (j > 49) j = 49;
+    int sp, ep;
+    partition_bounds(n, j, sp, ep);
+    while (i > ep) {
+        ++j;
+        partition_bounds(n, j, sp, ep);
+    }
+    while (i < sp) {
+        --j;
+        partition_bounds(n, j, sp, ep);
+    }
+    const float* curv = P.ln_curv + base;
+    const float* refl = P.ln_refl + base;
+    const float kc = curv[i], kr = refl[i];
+    int rc = 0, rr = 0;
+    for (int q = sp; q <= ep; ++q) {
+        float c = curv[q], r = refl[q];
+        rc += (c < kc) || (c == kc && q < i);
+        rr += (r < kr) || (r == kr && q < i);
+    }
+    P.ln_ord_c[base + sp + rc] = i;
+    P.ln_ord_r[base + sp + rr] = i;
+}
+
+// ---- a5 + a6 walk + a8 emit: one wavefront per scan line -------------------------------------------------------
+constexpr int SELECT_LDS_FLAGS = 16384;
+
+__global__ __launch_bounds__(64) void k_select(FeatParams P) {
+    __shared__ unsigned char s_flags[SELECT_LDS_FLAGS];
+    const int b = blockIdx.y + P.first;
+    const int line = blockIdx.x;
+    const int n = P.line_len[(size_t)b * P.L + line];
+    if (n <= 0) return;
+    const int start = P.line_start[(size_t)b * P.L + line];
+    const size_t base = (size_t)b * P.NT + start;
+    const int lane = threadIdx.x;
+    const uint16_t* attr = P.ln_attr + base;
+    const int* ord_c = P.ln_ord_c + base;
+    const int* ord_r = P.ln_ord_r + base;
+    // flags live in LDS when the line fits, else in the global scratch (flat pointer, same code path)
+    unsigned char* flags = (n <= SELECT_LDS_FLAGS) ? s_flags : (P.ln_flag + base);
+    for (int i = lane; i < n; i += 64) flags[i] = 0;  // CloudFeatureFlag zero-initialised (convention)
+    __syncthreads();
+
+    // thNumCurvSize as the last stencil iteration (i = n-6) left it (:492,505 read it after loop :407)
+    int T = 2;
+    if (n >= 11) T = (attr[n - 6] & A_W2) ? 2 : 3;
+
+    for (int j = 0; j < 50; ++j) {
+        int sp, ep;
+        partition_bounds(n, j, sp, ep);
+        const int m = ep - sp + 1;
+        if (m <= 0) continue;
+        // ---- :483-519: ascending curvature, flag 3 + neighbour suppression ----
+        for (int c0 = 0; c0 < m; c0 += 64) {
+            const int k = c0 + lane;
+            int ind = 0;
+            unsigned att = 0;
+            if (k < m) {
+                ind = ord_c[sp + k];
+                att = attr[ind];
+            }
+            const int cnt = min(64, m - c0);
+            for (int kk = 0; kk < cnt; ++kk) {
+                const int indu = __builtin_amdgcn_readlane(ind, kk);
+                const unsigned au = __builtin_amdgcn_readlane(att, kk);
+                if (!(au & A_CAND3)) continue;
+                if (flags[indu] != 0) continue;
+                const int a = min((int)((au >> A_A3_SHIFT) & 3u), T);
+                const int bb = min((int)((au >> A_B3_SHIFT) & 3u), T);
+                const int off = lane - 3;
+                if (lane < 7) {
+                    if (off == 0)
+                        flags[indu] = 3;
+                    else if (off > 0 && off <= a)
+                        flags[indu + off] = 1;
+                    else if (off < 0 && -off <= bb)
+                        flags[indu + off] = 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+        // ---- :521-539: promote to flag 2 / reflect corners to flag 300 (encoded 4) ----
+        int smallestPickedNum = 1, sharpestPickedNum = 1;
+        for (int c0 = 0; c0 < m; c0 += 64) {
+            const int k = c0 + lane;
+            int ind = 0, idx = 0;
+            unsigned att = 0, atr = 0;
+            if (k < m) {
+                ind = ord_c[sp + k];
+                att = attr[ind];
+                idx = ord_r[sp + k];
+                atr = attr[idx];
+            }
+            const int cnt = min(64, m - c0);
+            for (int kk = 0; kk < cnt; ++kk) {
+                const int indu = __builtin_amdgcn_readlane(ind, kk);
+                const unsigned au = __builtin_amdgcn_readlane(att, kk);
+                const int idxu = __builtin_amdgcn_readlane(idx, kk);
+                const unsigned aru = __builtin_amdgcn_readlane(atr, kk);
+                const unsigned char f = flags[indu];
+                if (((f == 3) && (smallestPickedNum <= 1)) || ((f == 3) && (au & A_FAR)) || (au & A_ANGLE)) {
+                    smallestPickedNum++;
+                    if (lane == 0) flags[indu] = 2;
+                }
+                if ((aru & A_REFL) && sharpestPickedNum <= 3) {
+                    sharpestPickedNum++;
+                    if (lane == 0) flags[idxu] = 4;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- :543-650 stride walk (stride 4 after a flat right half-window) + :651-806 + :818-842 + label scatter ----
+    const int* gidx = P.ln_gidx + base;
+    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
+    int pos = 5;
+    for (int w0 = 0; w0 < n; w0 += 64) {
+        const int i = w0 + lane;
+        const unsigned at = (i < n) ? attr[i] : 0u;
+        const unsigned long long rmask = __ballot((at & A_RFLAT) != 0);
+        unsigned long long vis = 0ull;
+        while (pos < w0 + 64 && pos < n - 5) {
+            const int o = pos - w0;
+            vis |= 1ull << o;
+            pos += ((rmask >> o) & 1ull) ? 4 : 1;
+        }
+        if (i < n) {
+            int f = flags[i];
+            if (f == 4) f = 300;
+            const bool inner = i >= 5 && i < n - 5;
+            if (inner) {
+                if (((vis >> lane) & 1ull) && (at & A_LFLAT) && (at & A_RFLAT) && (at & A_C150)) f = 150;
+                const unsigned f5 = (at >> A_F5_SHIFT) & 3u;
+                if (f5 == 1) f = 100;
+                if (f5 == 2) f = 101;
+            }
+            if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
+            if (inner && !(at & A_NEAR)) {
+                if (f == 2)
+                    cblab[gidx[i]] = 2;
+                else if (f == 100 || f == 150)
+                    cblab[gidx[i]] = 1;
+            }
+        }
+    }
+}
+
+// ---- a8: removeNearFarPoints / removeNearPointCloud + compaction into the fused cloud ---------------------------
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_crop_compact(FeatParams P) {
+    __shared__ int s_cnt[4];
+    __shared__ int s_wtot[ASSIGN_WAVES];
+    __shared__ int s_base;
+    const int b = blockIdx.x + P.first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = P.cb_n[2 * b], nl = P.cb_n[2 * b + 1];
+    const float4* cbx = P.cb_xyzi + (size_t)b * P.NT;
+    const float* cbr = P.cb_rel + (size_t)b * P.NT;
+    const uint8_t* cbl = P.cb_line + (size_t)b * P.NT;
+    const uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
+    float4* fx = P.fu_xyzi + (size_t)b * P.NT;
+    float* fr = P.fu_rel + (size_t)b * P.NT;
+    uint8_t* fl = P.fu_line + (size_t)b * P.NT;
+    uint8_t* flab = P.fu_label + (size_t)b * P.NT;
+    const float near2 = P.near_th * P.near_th, far2 = P.far_th * P.far_th;
+    if (tid < 4) s_cnt[tid] = 0;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    // counts: velo corner/surf after near+far crop (:1287-1300), livox corner/surf after near crop only (:925-940)
+    int c[4] = {0, 0, 0, 0};
+    for (int i = tid; i < nv; i += ASSIGN_THREADS) {
+        int lab = cblab[i];
+        if (lab) {
+            float4 p = cbx[i];
+            float dis = p.x * p.x + p.y * p.y + p.z * p.z;
+            if (!(dis < near2 || dis > far2)) c[lab - 1]++;
+        }
+    }
+    for (int i = tid; i < nl; i += ASSIGN_THREADS) {
+        int lab = cblab[P.NV + i];
+        if (lab) {
+            float4 p = cbx[P.NV + i];
+            if (!(p.x * p.x + p.y * p.y + p.z * p.z < near2)) c[2 + lab - 1]++;
+        }
+    }
+    for (int k = 0; k < 4; ++k)
+        if (c[k]) atomicAdd(&s_cnt[k], c[k]);
+    __syncthreads();
+    const bool do_extr = P.extr != nullptr && s_cnt[2] > 100;  // :302-318
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int n_velo_out = 0;
+    for (int part = 0; part < 2; ++part) {
+        const int np = part == 0 ? nv : nl;
+        const int off = part == 0 ? 0 : P.NV;
+        for (int c0 = 0; c0 < np; c0 += ASSIGN_THREADS) {
+            const int i = c0 + tid;
+            bool keep = false;
+            float4 p = make_float4(0, 0, 0, 0);
+            if (i < np) {
+                p = cbx[off + i];
+                float dis = p.x * p.x + p.y * p.y + p.z * p.z;
+                keep = !(dis < near2 || dis > far2);
+            }
+            unsigned long long m = __ballot(keep);
+            if (lane == 0) s_wtot[wave] = __popcll(m);
+            __syncthreads();
+            int dst = s_base;
+            for (int w = 0; w < wave; ++w) dst += s_wtot[w];
+            dst += __popcll(m & lt);
+            if (keep) {
+                if (part == 1 && do_extr) {
+                    // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float
+                    const float* e = P.extr;
+                    float x = e[0] * p.x + e[1] * p.y + e[2] * p.z + e[3];
+                    float y = e[4] * p.x + e[5] * p.y + e[6] * p.z + e[7];
+                    float z = e[8] * p.x + e[9] * p.y + e[10] * p.z + e[11];
+                    p.x = x;
+                    p.y = y;
+                    p.z = z;
+                }
+                fx[dst] = p;
+                fr[dst] = cbr[off + i];
+                fl[dst] = cbl[off + i];
+                flab[dst] = cblab[off + i];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int s = 0;
+                for (int w = 0; w < ASSIGN_WAVES; ++w) s += s_wtot[w];
+                s_base += s;
+            }
+            __syncthreads();
+        }
+        if (part == 0) n_velo_out = s_base;
+    }
+    if (tid == 0) {
+        int* info = P.fu_info + 8 * b;
+        info[0] = s_base;
+        info[1] = n_velo_out;
+        info[2] = s_cnt[0];
+        info[3] = s_cnt[1];
+        info[4] = s_cnt[2];
+        info[5] = s_cnt[3];
+        info[6] = 0;
+        info[7] = 0;
+    }
+}
+
+// single-line setup for mml_detect_line: slot 0 holds one line (ring 0) of n points already in ln_pts
+__global__ void k_setup_single_line(FeatParams P, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.L) {
+        P.line_start[t] = (t < P.n_rings) ? (t == 0 ? 0 : n) : P.NV;
+        P.line_len[t] = (t == 0) ? n : 0;
+    }
+    if (t < n) {
+        P.ln_gidx[t] = t;
+        P.cb_label[t] = 0;
+    }
+    if (t == 0) {
+        P.cb_n[0] = n;
+        P.cb_n[1] = 0;
+    }
+}
+
+FeatParams make_params(mml_ctx* ctx, int first) {
+    FeatParams P;
+    P.first = first;
+    P.NV = ctx->NV;
+    P.NL = ctx->NL;
+    P.NT = ctx->NT;
+    P.L = ctx->L;
+    P.n_rings = ctx->cfg.n_rings;
+    P.n_lines = ctx->cfg.n_livox_lines;
+    P.pitch0 = ctx->cfg.pitch0_deg;
+    P.pitch_step = ctx->cfg.pitch_step_deg;
+    P.near_th = ctx->cfg.near_th;
+    P.far_th = ctx->cfg.far_th;
+    P.velo_in = ctx->velo_in;
+    P.livox_in = ctx->livox_in;
+    P.n_in = ctx->d_n_in;
+    P.raw_line = ctx->raw_line;
+    P.raw_ori = ctx->raw_ori;
+    P.ln_pts = ctx->ln_pts;
+    P.ln_gidx = ctx->ln_gidx;
+    P.line_start = ctx->line_start;
+    P.line_len = ctx->line_len;
+    P.ln_curv = ctx->ln_curv;
+    P.ln_refl = ctx->ln_refl;
+    P.ln_attr = ctx->ln_attr;
+    P.ln_ord_c = ctx->ln_ord_c;
+    P.ln_ord_r = ctx->ln_ord_r;
+    P.ln_flag = ctx->ln_flag;
+    P.ln_final = nullptr;
+    P.cb_xyzi = ctx->cb_xyzi;
+    P.cb_rel = ctx->cb_rel;
+    P.cb_line = ctx->cb_line;
+    P.cb_label = ctx->cb_label;
+    P.cb_n = ctx->cb_n;
+    P.fu_xyzi = ctx->fu_xyzi;
+    P.fu_rel = ctx->fu_rel;
+    P.fu_line = ctx->fu_line;
+    P.fu_label = ctx->fu_label;
+    P.fu_info = ctx->fu_info;
+    P.extr = nullptr;
+    return P;
+}
+
+}  // namespace
+
+int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) {
+    FeatParams P = make_params(ctx, first);
+    P.extr = have_extrinsic ? ctx->d_extr : nullptr;
+    hipStream_t s = ctx->stream;
+    const int pblocks = (ctx->NT + 255) / 256;
+    {
+        MmlStageScope t(ctx, "assign_velo");
+        hipLaunchKernelGGL(k_assign_velo, dim3(count), dim3(ASSIGN_THREADS), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "assign_livox");
+        hipLaunchKernelGGL(k_assign_livox, dim3(count), dim3(ASSIGN_THREADS), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "stencil");
+        hipLaunchKernelGGL(k_stencil, dim3(pblocks, count), dim3(256), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "partition_sort");
+        hipLaunchKernelGGL(k_partition_sort, dim3(pblocks, count), dim3(256), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "select");
+        hipLaunchKernelGGL(k_select, dim3(ctx->L, count), dim3(64), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "crop_compact");
+        hipLaunchKernelGGL(k_crop_compact, dim3(count), dim3(ASSIGN_THREADS), 0, s, P);
+    }
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+// mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in cb_label[0..n) and ln_final.
+int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
+    FeatParams P = make_params(ctx, 0);
+    P.ln_final = d_final;
+    hipStream_t s = ctx->stream;
+    const int t = (n > ctx->L ? n : ctx->L);
+    hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
+    const int pblocks = (n + 255) / 256;
+    if (pblocks > 0) {
+        hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_partition_sort, dim3(pblocks, 1), dim3(256), 0, s, P);
+    }
+    hipLaunchKernelGGL(k_select, dim3(1, 1), dim3(64), 0, s, P);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}

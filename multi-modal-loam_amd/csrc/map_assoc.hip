@@ -1,0 +1,803 @@
+// map_assoc.hip -- rows a11..a16 of SURVEY.md section 8.
+//   map side  : radix-sorted uniform grid over laserCloud{Corner,Surf}FromLocal -- replaces the
+//               pcl::KdTreeFLANN::setInputCloud rebuild at mm-loam/src/lio/Estimator.cpp:1159-1167.
+//   a13       : exact 5-NN (FLANN L2_Simple<float> semantics: d2 = ((dx*dx + dy*dy) + dz*dz) in float,
+//               ascending, ties by lower index), one query per lane, ring-expanding cell search with an
+//               exactness bound (all points within r*cell + margin are visited before stopping).
+//   a11/a14/a15/a16 : pointAssociateToMap (Map_Manager.cpp:75-89), line fit (Estimator.cpp:283-361),
+//               plane fit (:702-767), FeatureLine / FeaturePlanVec::ComputeError (Estimator.h:71-83,118-121),
+//               fused behind the kNN in the same lane so the 5 neighbours never leave registers.
+// Compiled with -ffp-contract=off.
+#include <math.h>
+
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+#include "mml_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// grid build
+__global__ void k_bbox(const float4* pts, int m, float* out /*6: min xyz, max xyz*/) {
+    __shared__ float s[6][4];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        float4 p = pts[i];
+        mn[0] = fminf(mn[0], p.x);
+        mn[1] = fminf(mn[1], p.y);
+        mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x);
+        mx[1] = fmaxf(mx[1], p.y);
+        mx[2] = fmaxf(mx[2], p.z);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+        if (lane == 0) {
+            s[c][wave] = mn[c];
+            s[3 + c][wave] = mx[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float v = s[c][0];
+        for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, s[c][w]) : fmaxf(v, s[c][w]);
+        // float atomics via int reinterpretation (monotone for the sign handled below)
+        if (c < 3) {
+            // atomic min on float
+            int* a = reinterpret_cast<int*>(out + c);
+            int old = *a;
+            while (v < __int_as_float(old)) {
+                int assumed = old;
+                old = atomicCAS(a, assumed, __float_as_int(v));
+                if (old == assumed) break;
+            }
+        } else {
+            int* a = reinterpret_cast<int*>(out + c);
+            int old = *a;
+            while (v > __int_as_float(old)) {
+                int assumed = old;
+                old = atomicCAS(a, assumed, __float_as_int(v));
+                if (old == assumed) break;
+            }
+        }
+    }
+}
+
+struct GridDev {
+    float ox, oy, oz, inv_cell, cell;
+    int dx, dy, dz, ncell;
+};
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv, int dim) {
+    int c = (int)floorf((v - o) * inv);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+__global__ void k_cell_keys(const float4* pts, int m, GridDev g, unsigned* keys, unsigned* vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float4 p = pts[i];
+    int cx = cell_coord(p.x, g.ox, g.inv_cell, g.dx);
+    int cy = cell_coord(p.y, g.oy, g.inv_cell, g.dy);
+    int cz = cell_coord(p.z, g.oz, g.inv_cell, g.dz);
+    keys[i] = (unsigned)(cx + g.dx * (cy + g.dy * cz));
+    vals[i] = (unsigned)i;
+}
+
+__global__ void k_gather_sorted(const float4* pts, const unsigned* vals, int m, float4* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    unsigned src = vals[i];
+    float4 p = pts[src];
+    p.w = __uint_as_float(src);
+    out[i] = p;
+}
+
+// cell_start[c] = first sorted position whose key >= c (lower bound); cell_start[ncell] = m
+__global__ void k_cell_start(const unsigned* keys, int m, int ncell, int* cell_start) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncell) return;
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (keys[mid] < (unsigned)c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    cell_start[c] = lo;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// exact 5-NN
+struct Knn5 {
+    float d[5];
+    int id[5];
+};
+__device__ __forceinline__ void knn_init(Knn5& k) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        k.d[i] = INFINITY;
+        k.id[i] = 0x7fffffff;
+    }
+}
+// sorted insert, order (d, id) ascending
+__device__ __forceinline__ void knn_insert(Knn5& k, float dd, int ii) {
+    if (!(dd < k.d[4] || (dd == k.d[4] && ii < k.id[4]))) return;
+    k.d[4] = dd;
+    k.id[4] = ii;
+#pragma unroll
+    for (int s = 4; s > 0; --s) {
+        bool sw = (k.d[s] < k.d[s - 1]) || (k.d[s] == k.d[s - 1] && k.id[s] < k.id[s - 1]);
+        if (sw) {
+            float td = k.d[s];
+            k.d[s] = k.d[s - 1];
+            k.d[s - 1] = td;
+            int ti = k.id[s];
+            k.id[s] = k.id[s - 1];
+            k.id[s - 1] = ti;
+        }
+    }
+}
+
+__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int s, int e, float qx, float qy, float qz,
+                                           Knn5& k) {
+    for (int i = s; i < e; ++i) {
+        float4 p = pts[i];
+        float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        float r = 0;
+        r += dx * dx;
+        r += dy * dy;
+        r += dz * dz;
+        knn_insert(k, r, (int)__float_as_uint(p.w));
+    }
+}
+
+// Ring-expanding search.  After ring r every map point with Chebyshev cell distance <= r from the query's
+// (clamped) home cell has been visited, which includes every point within Euclidean distance
+// rho_r = r * cell + (distance from the query to the nearest face of its home cell, 0 when outside the grid).
+// Stop when the 5th best distance is safely below rho_r^2 or when rho_r^2 >= max_d2 (the caller rejects
+// anything with d5 >= max_d2, Estimator.cpp:285,705).
+__device__ void knn5_search(const MmlGrid& g, float qx, float qy, float qz, float max_d2, Knn5& k) {
+    knn_init(k);
+    const float fx = (qx - g.origin[0]) * g.inv_cell, fy = (qy - g.origin[1]) * g.inv_cell,
+                fz = (qz - g.origin[2]) * g.inv_cell;
+    int hx = (int)floorf(fx), hy = (int)floorf(fy), hz = (int)floorf(fz);
+    // distance (in cells) from the query to the nearest face of its home cell; queries outside the grid get 0
+    float inset = fminf(fminf(fminf(fx - hx, hx + 1 - fx), fminf(fy - hy, hy + 1 - fy)), fminf(fz - hz, hz + 1 - fz));
+    if (!(inset > 0.f)) inset = 0.f;
+    const int rmax = (int)ceilf(sqrtf(max_d2) * g.inv_cell) + 1;
+    const int DX = g.dim[0], DY = g.dim[1], DZ = g.dim[2];
+    for (int r = 0; r <= rmax; ++r) {
+        const int z0 = hz - r, z1 = hz + r, y0 = hy - r, y1 = hy + r, x0 = hx - r, x1 = hx + r;
+        for (int z = max(z0, 0); z <= min(z1, DZ - 1); ++z) {
+            const bool zface = (z == z0 || z == z1);
+            for (int y = max(y0, 0); y <= min(y1, DY - 1); ++y) {
+                const bool face = zface || y == y0 || y == y1;
+                const int rowbase = DX * (y + DY * z);
+                if (face) {
+                    int xa = max(x0, 0), xb = min(x1, DX - 1);
+                    if (xa <= xb) scan_range(g.pts, g.cell_start[rowbase + xa], g.cell_start[rowbase + xb + 1], qx, qy, qz, k);
+                } else {
+                    if (x0 >= 0 && x0 < DX) scan_range(g.pts, g.cell_start[rowbase + x0], g.cell_start[rowbase + x0 + 1], qx, qy, qz, k);
+                    if (x1 >= 0 && x1 < DX && x1 != x0)
+                        scan_range(g.pts, g.cell_start[rowbase + x1], g.cell_start[rowbase + x1 + 1], qx, qy, qz, k);
+                }
+            }
+        }
+        // exactness bound, with a relative margin that dominates float rounding of d2 and of the cell mapping
+        float rho = ((float)r + inset) * g.cell;
+        rho = rho - 1e-3f * g.cell;
+        if (rho > 0.f) {
+            float rho2 = rho * rho;
+            if (k.d[4] < rho2) break;
+            if (rho2 >= max_d2) break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn5(MmlGrid g, const float* q, int nq, float max_d2, int* idx, float* d2) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    Knn5 k;
+    knn5_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, k);
+    for (int j = 0; j < 5; ++j) {
+        bool ok = k.d[j] < max_d2 && k.d[4] < max_d2;
+        idx[5 * i + j] = ok ? k.id[j] : -1;
+        d2[5 * i + j] = ok ? k.d[j] : INFINITY;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Eigen 3.3.4 SelfAdjointEigenSolver<Matrix3d>::compute restated for one lane (see oracle/linalg.h for the
+// line-by-line citation of the algorithm: scaling, 3x3 tridiagonalisation, implicit QR with Wilkinson shift).
+__device__ __forceinline__ void make_givens(double p, double q, double& c, double& s) {
+    if (q == 0.0) {
+        c = p < 0.0 ? -1.0 : 1.0;
+        s = 0.0;
+    } else if (p == 0.0) {
+        c = 0.0;
+        s = q < 0.0 ? 1.0 : -1.0;
+    } else if (fabs(p) > fabs(q)) {
+        double t = q / p;
+        double u = sqrt(1.0 + t * t);
+        if (p < 0.0) u = -u;
+        c = 1.0 / u;
+        s = -t * c;
+    } else {
+        double t = p / q;
+        double u = sqrt(1.0 + t * t);
+        if (q < 0.0) u = -u;
+        s = -1.0 / u;
+        c = -t * s;
+    }
+}
+__device__ __forceinline__ double eig_hypot(double x, double y) {
+    double ax = fabs(x), ay = fabs(y), p, qp;
+    if (ax > ay) {
+        p = ax;
+        qp = ay / p;
+    } else {
+        p = ay;
+        qp = ax / p;
+    }
+    if (p == 0.0) return 0.0;
+    return p * sqrt(1.0 + qp * qp);
+}
+// A: lower triangle m00,m10,m11,m20,m21,m22.  Returns eigenvalues ascending in ev[], eigenvector of ev[2] in v2[].
+__device__ void eig3_sym(double m00, double m10, double m11, double m20, double m21, double m22, double* ev,
+                         double* v2) {
+    double scale = fabs(m00);
+    scale = fmax(scale, fabs(m10));
+    scale = fmax(scale, fabs(m11));
+    scale = fmax(scale, fabs(m20));
+    scale = fmax(scale, fabs(m21));
+    scale = fmax(scale, fabs(m22));
+    if (scale == 0.0) scale = 1.0;
+    m00 /= scale;
+    m10 /= scale;
+    m11 /= scale;
+    m20 /= scale;
+    m21 /= scale;
+    m22 /= scale;
+    double diag[3], sub[2], Q[9];
+    const double tol = 2.2250738585072014e-308;
+    diag[0] = m00;
+    double v1norm2 = m20 * m20;
+    if (v1norm2 <= tol) {
+        diag[1] = m11;
+        diag[2] = m22;
+        sub[0] = m10;
+        sub[1] = m21;
+        Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = 1; Q[5] = 0; Q[6] = 0; Q[7] = 0; Q[8] = 1;
+    } else {
+        double beta = sqrt(m10 * m10 + v1norm2);
+        double invBeta = 1.0 / beta;
+        double m01 = m10 * invBeta;
+        double m02 = m20 * invBeta;
+        double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+        diag[1] = m11 + m02 * q;
+        diag[2] = m22 - m02 * q;
+        sub[0] = beta;
+        sub[1] = m21 - m01 * q;
+        Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = m01; Q[5] = m02; Q[6] = 0; Q[7] = m02; Q[8] = -m01;
+    }
+    int end = 2, start = 0, iter = 0;
+    const double precision = 2.0 * 2.220446049250313e-16;
+    while (end > 0) {
+        for (int i = start; i < end; ++i)
+            if (fabs(sub[i]) <= (fabs(diag[i]) + fabs(diag[i + 1])) * precision || fabs(sub[i]) <= tol) sub[i] = 0;
+        while (end > 0 && sub[end - 1] == 0.0) end--;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 90) break;
+        start = end - 1;
+        while (start > 0 && sub[start - 1] != 0.0) start--;
+        double td = (diag[end - 1] - diag[end]) * 0.5;
+        double e = sub[end - 1];
+        double mu = diag[end];
+        if (td == 0.0) {
+            mu -= fabs(e);
+        } else {
+            double e2 = e * e;
+            double h = eig_hypot(td, e);
+            if (e2 == 0.0)
+                mu -= (e / (td + (td > 0.0 ? 1.0 : -1.0))) * (e / h);
+            else
+                mu -= e2 / (td + (td > 0.0 ? h : -h));
+        }
+        double x = diag[start] - mu;
+        double z = sub[start];
+        for (int k = start; k < end; ++k) {
+            double c, s;
+            make_givens(x, z, c, s);
+            double sdk = s * diag[k] + c * sub[k];
+            double dkp1 = s * sub[k] + c * diag[k + 1];
+            diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+            diag[k + 1] = s * sdk + c * dkp1;
+            sub[k] = c * sdk - s * dkp1;
+            if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+            x = sub[k];
+            if (k < end - 1) {
+                z = -s * sub[k + 1];
+                sub[k + 1] = c * sub[k + 1];
+            }
+            for (int r = 0; r < 3; ++r) {
+                double xi = Q[3 * r + k], yi = Q[3 * r + k + 1];
+                Q[3 * r + k] = c * xi - s * yi;
+                Q[3 * r + k + 1] = s * xi + c * yi;
+            }
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        int k = 0;
+        double mn = diag[i];
+        for (int j = 1; j < 3 - i; ++j)
+            if (diag[i + j] < mn) {
+                mn = diag[i + j];
+                k = j;
+            }
+        if (k > 0) {
+            double t = diag[i];
+            diag[i] = diag[k + i];
+            diag[k + i] = t;
+            for (int r = 0; r < 3; ++r) {
+                double u = Q[3 * r + i];
+                Q[3 * r + i] = Q[3 * r + k + i];
+                Q[3 * r + k + i] = u;
+            }
+        }
+    }
+    ev[0] = diag[0] * scale;
+    ev[1] = diag[1] * scale;
+    ev[2] = diag[2] * scale;
+    v2[0] = Q[2];
+    v2[1] = Q[5];
+    v2[2] = Q[8];
+}
+
+// Eigen 3.3.4 ColPivHouseholderQR<Matrix<double,5,3>>::compute + solve(-1): see oracle/linalg.h.
+__device__ void plane_fit5(const double (*Ain)[3], double* xout) {
+    const int rows = 5, cols = 3, size = 3;
+    double qr[5][3];
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) qr[r][c] = Ain[r][c];
+    double hCoeffs[3];
+    int transp[3];
+    double normsUpdated[3], normsDirect[3];
+    for (int k = 0; k < cols; ++k) {
+        double s = 0;
+        for (int r = 0; r < rows; ++r) s += qr[r][k] * qr[r][k];
+        normsDirect[k] = sqrt(s);
+        normsUpdated[k] = normsDirect[k];
+    }
+    const double eps = 2.220446049250313e-16;
+    double maxn = normsUpdated[0];
+    for (int k = 1; k < cols; ++k)
+        if (normsUpdated[k] > maxn) maxn = normsUpdated[k];
+    double threshold_helper = (maxn * eps) * (maxn * eps) / double(rows);
+    double norm_downdate_threshold = sqrt(eps);
+    int nonzero_pivots = size;
+    for (int k = 0; k < size; ++k) {
+        int big = k;
+        double bigv = normsUpdated[k];
+        for (int j = k + 1; j < cols; ++j)
+            if (normsUpdated[j] > bigv) {
+                bigv = normsUpdated[j];
+                big = j;
+            }
+        double biggest_col_sq_norm = bigv * bigv;
+        if (nonzero_pivots == size && biggest_col_sq_norm < threshold_helper * double(rows - k)) nonzero_pivots = k;
+        transp[k] = big;
+        if (k != big) {
+            for (int r = 0; r < rows; ++r) {
+                double t = qr[r][k];
+                qr[r][k] = qr[r][big];
+                qr[r][big] = t;
+            }
+            double t = normsUpdated[k];
+            normsUpdated[k] = normsUpdated[big];
+            normsUpdated[big] = t;
+            t = normsDirect[k];
+            normsDirect[k] = normsDirect[big];
+            normsDirect[big] = t;
+        }
+        double tailSqNorm = 0;
+        for (int r = k + 1; r < rows; ++r) tailSqNorm += qr[r][k] * qr[r][k];
+        double c0 = qr[k][k];
+        double tau, beta;
+        const double tol = 2.2250738585072014e-308;
+        if (tailSqNorm <= tol) {
+            tau = 0;
+            beta = c0;
+            for (int r = k + 1; r < rows; ++r) qr[r][k] = 0;
+        } else {
+            beta = sqrt(c0 * c0 + tailSqNorm);
+            if (c0 >= 0.0) beta = -beta;
+            for (int r = k + 1; r < rows; ++r) qr[r][k] = qr[r][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        hCoeffs[k] = tau;
+        qr[k][k] = beta;
+        if (tau != 0.0) {
+            for (int j = k + 1; j < cols; ++j) {
+                double tmp = 0;
+                for (int r = k + 1; r < rows; ++r) tmp += qr[r][k] * qr[r][j];
+                tmp += qr[k][j];
+                qr[k][j] -= tau * tmp;
+                for (int r = k + 1; r < rows; ++r) qr[r][j] -= tau * qr[r][k] * tmp;
+            }
+        }
+        for (int j = k + 1; j < cols; ++j) {
+            if (normsUpdated[j] != 0.0) {
+                double temp = fabs(qr[k][j]) / normsUpdated[j];
+                temp = (1.0 + temp) * (1.0 - temp);
+                temp = temp < 0.0 ? 0.0 : temp;
+                double ratio = normsUpdated[j] / normsDirect[j];
+                double temp2 = temp * (ratio * ratio);
+                if (temp2 <= norm_downdate_threshold) {
+                    double s = 0;
+                    for (int r = k + 1; r < rows; ++r) s += qr[r][j] * qr[r][j];
+                    normsDirect[j] = sqrt(s);
+                    normsUpdated[j] = normsDirect[j];
+                } else {
+                    normsUpdated[j] *= sqrt(temp);
+                }
+            }
+        }
+    }
+    int perm[3] = {0, 1, 2};
+    for (int k = 0; k < size; ++k) {
+        int t = perm[k];
+        perm[k] = perm[transp[k]];
+        perm[transp[k]] = t;
+    }
+    xout[0] = xout[1] = xout[2] = 0;
+    if (nonzero_pivots == 0) return;
+    double c[5] = {-1, -1, -1, -1, -1};
+    for (int k = 0; k < nonzero_pivots; ++k) {
+        double tau = hCoeffs[k];
+        if (tau != 0.0) {
+            double tmp = 0;
+            for (int r = k + 1; r < rows; ++r) tmp += qr[r][k] * c[r];
+            tmp += c[k];
+            c[k] -= tau * tmp;
+            for (int r = k + 1; r < rows; ++r) c[r] -= tau * qr[r][k] * tmp;
+        }
+    }
+    for (int i = nonzero_pivots - 1; i >= 0; --i) {
+        double s = c[i];
+        for (int j = i + 1; j < nonzero_pivots; ++j) s -= qr[i][j] * c[j];
+        c[i] = s / qr[i][i];
+    }
+    for (int i = 0; i < nonzero_pivots; ++i) xout[perm[i]] = c[i];
+}
+
+// original (unsorted) coordinates of a neighbour are needed in index order: the sorted grid carries xyz next
+// to the original index, so the search returns positions; keep a second lookup by original index.
+struct AssocParams {
+    int first, B, MF;
+    MmlGrid g[2];
+    const float4* map_orig[2];  // unsorted map clouds (index = original index)
+    const float4* ft[2];
+    const int* ft_n;
+    MmlLineFactor* lf;
+    MmlPlaneFactor* pf;
+    const double* Twl;  // count x 16
+    float thres;     // search bound (float)
+    double thres_d;  // gate, compared as in the reference: (double)d2[4] < thres_dist
+    int map_m[2];
+};
+
+__device__ __forceinline__ void tf_point(const double* T, double x, double y, double z, double& ox, double& oy,
+                                         double& oz) {
+    ox = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+    oy = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+    oz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+}
+
+// one lane per feature: grid.x covers MF features, grid.y = slot, grid.z = kind
+__global__ __launch_bounds__(128) void k_associate(AssocParams P) {
+    const int slot = blockIdx.y;
+    const int b = slot + P.first;
+    const int kind = blockIdx.z;
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const int nf = P.ft_n[kind * P.B + b];
+    if (i >= nf) return;
+    const double* T = P.Twl + 16 * slot;
+    const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+    // Map_Manager.cpp:75-89 pointAssociateToMap: double transform stored to float
+    double wx, wy, wz;
+    tf_point(T, f.x, f.y, f.z, wx, wy, wz);
+    const float sx = wx, sy = wy, sz = wz;
+    bool ok = !(isnan(sx) || isnan(sy) || isnan(sz)) && P.map_m[kind] > 20;  // :196, :283 / :702
+    Knn5 k;
+    if (ok) {
+        knn5_search(P.g[kind], sx, sy, sz, P.thres, k);
+        ok = (double)k.d[4] < P.thres_d;  // :285 / :705
+    }
+    const float4* mp = P.map_orig[kind];
+    if (kind == 0) {
+        MmlLineFactor out;
+        out.src = -1;
+        out.error = 0;
+        if (ok) {
+            float nx[5], ny[5], nz[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                float4 q = mp[k.id[j]];
+                nx[j] = q.x;
+                ny[j] = q.y;
+                nz[j] = q.z;
+            }
+            float cx = 0, cy = 0, cz = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                cx += nx[j];
+                cy += ny[j];
+                cz += nz[j];
+            }
+            cx /= 5;
+            cy /= 5;
+            cz /= 5;
+            float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                float ax = nx[j] - cx, ay = ny[j] - cy, az = nz[j] - cz;
+                a11 += ax * ax;
+                a12 += ax * ay;
+                a13 += ax * az;
+                a22 += ay * ay;
+                a23 += ay * az;
+                a33 += az * az;
+            }
+            a11 /= 5;
+            a12 /= 5;
+            a13 /= 5;
+            a22 /= 5;
+            a23 /= 5;
+            a33 /= 5;
+            double ev[3], ud[3];
+            eig3_sym(a11, a12, a22, a13, a23, a33, ev, ud);
+            if (ev[2] > 3 * ev[1]) {
+                float x1 = cx + 0.1 * ud[0];
+                float y1 = cy + 0.1 * ud[1];
+                float z1 = cz + 0.1 * ud[2];
+                float x2 = cx - 0.1 * ud[0];
+                float y2 = cy - 0.1 * ud[1];
+                float z2 = cz - 0.1 * ud[2];
+                out.ori[0] = f.x;
+                out.ori[1] = f.y;
+                out.ori[2] = f.z;
+                out.p1[0] = x1;
+                out.p1[1] = y1;
+                out.p1[2] = z1;
+                out.p2[0] = x2;
+                out.p2[1] = y2;
+                out.p2[2] = z2;
+                out.src = i;
+                // FeatureLine::ComputeError (Estimator.h:71-83)
+                double Px, Py, Pz;
+                tf_point(T, f.x, f.y, f.z, Px, Py, Pz);
+                double ax = x1, ay = y1, az = z1, bx = x2, by = y2, bz = z2;
+                double l12 = sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz));
+                double c0 = (Px - ax) * (Py - by) - (Px - bx) * (Py - ay);
+                double c1 = (Px - ax) * (Pz - bz) - (Px - bx) * (Pz - az);
+                double c2 = (Py - ay) * (Pz - bz) - (Py - by) * (Pz - az);
+                double a012 = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+                out.error = a012 / l12;
+            }
+        }
+        P.lf[(size_t)b * P.MF + i] = out;
+    } else {
+        MmlPlaneFactor out;
+        out.src = -1;
+        out.error = 0;
+        out._pad = 0;
+        if (ok) {
+            double A[5][3];
+            float nx[5], ny[5], nz[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                float4 q = mp[k.id[j]];
+                nx[j] = q.x;
+                ny[j] = q.y;
+                nz[j] = q.z;
+                A[j][0] = q.x;
+                A[j][1] = q.y;
+                A[j][2] = q.z;
+            }
+            double X[3];
+            plane_fit5(A, X);
+            float pa = X[0], pb = X[1], pc = X[2], pd = 1;
+            float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+            pa /= ps;
+            pb /= ps;
+            pc /= ps;
+            pd /= ps;
+            bool planeValid = true;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                if (fabs((double)(pa * nx[j] + pb * ny[j] + pc * nz[j] + pd)) > 0.2) {
+                    planeValid = false;
+                    break;
+                }
+            }
+            if (planeValid) {
+                double dist = pa * sx + pb * sy + pc * sz + pd;  // float expression, :740-742
+                out.ori[0] = f.x;
+                out.ori[1] = f.y;
+                out.ori[2] = f.z;
+                out.omega[0] = pa;
+                out.omega[1] = pb;
+                out.omega[2] = pc;
+                out.proj[0] = (double)sx - dist * (double)pa;
+                out.proj[1] = (double)sy - dist * (double)pb;
+                out.proj[2] = (double)sz - dist * (double)pc;
+                double Px, Py, Pz;
+                tf_point(T, f.x, f.y, f.z, Px, Py, Pz);
+                double ex = Px - out.proj[0], ey = Py - out.proj[1], ez = Pz - out.proj[2];
+                out.error = sqrt((ex * ex + ey * ey) + ez * ez);  // Estimator.h:118-121
+                out.src = i;
+            }
+        }
+        P.pf[(size_t)b * P.MF + i] = out;
+    }
+}
+
+// per-slot statistics: counts, used counts, normal Gram matrix (checkLocalizability input)
+__global__ __launch_bounds__(256) void k_assoc_stats(int first, int B, int MF, const int* ft_n, const MmlLineFactor* lf,
+                                                    const MmlPlaneFactor* pf, double* stats) {
+    __shared__ double s_red[4][13];
+    const int b = blockIdx.x + first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[13];
+    for (int k = 0; k < 13; ++k) acc[k] = 0;
+    const int nl = ft_n[b], np = ft_n[B + b];
+    for (int i = tid; i < nl; i += 256) {
+        const MmlLineFactor& f = lf[(size_t)b * MF + i];
+        if (f.src >= 0) {
+            acc[0] += 1;
+            if (fabs(f.error) > 1e-5) acc[2] += 1;
+        }
+    }
+    for (int i = tid; i < np; i += 256) {
+        const MmlPlaneFactor& f = pf[(size_t)b * MF + i];
+        if (f.src >= 0) {
+            acc[1] += 1;
+            if (fabs(f.error) > 1e-5) acc[3] += 1;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) acc[4 + 3 * r + c] += (double)f.omega[r] * (double)f.omega[c];
+        }
+    }
+    for (int k = 0; k < 13; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < 13) stats[16 * b + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+}
+
+}  // namespace
+
+int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
+    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
+    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "map larger than max_map_points");
+    MmlGrid& g = ctx->grid[kind];
+    hipStream_t s = ctx->stream;
+    ctx->have_map[kind] = false;
+    g.m = m;
+    if (m == 0) {
+        g.dim[0] = g.dim[1] = g.dim[2] = 1;
+        g.ncell = 1;
+        g.cell = 1.f;
+        g.inv_cell = 1.f;
+        g.origin[0] = g.origin[1] = g.origin[2] = 0.f;
+        MML_HIP(hipMemsetAsync(g.cell_start, 0, 2 * sizeof(int), s));
+        ctx->have_map[kind] = true;
+        return MML_OK;
+    }
+    // host xyz (3 floats) -> device float4 (original order, w unused)
+    std::vector<float4> tmp((size_t)m);
+    for (int i = 0; i < m; ++i) tmp[i] = make_float4(h_xyz[3 * i], h_xyz[3 * i + 1], h_xyz[3 * i + 2], 0.f);
+    float4* orig = ctx->map_tmp + (size_t)kind * ctx->MM;
+    MML_HIP(hipMemcpyAsync(orig, tmp.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, s));
+    MML_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
+    MmlStageScope t(ctx, "map_build");
+    float init[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float* d_bbox = reinterpret_cast<float*>(ctx->d_misc);
+    MML_HIP(hipMemcpyAsync(d_bbox, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bbox, dim3(256), dim3(256), 0, s, orig, m, d_bbox);
+    float bbox[6];
+    MML_HIP(hipMemcpyAsync(bbox, d_bbox, sizeof(bbox), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipStreamSynchronize(s));
+    float cell = kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf;
+    // cap the cell count: enlarge the cell until the grid fits
+    const long long max_cells = (long long)4 * ctx->MM + 4096;
+    int dim[3];
+    for (;;) {
+        long long total = 1;
+        for (int c = 0; c < 3; ++c) {
+            dim[c] = (int)floorf((bbox[3 + c] - bbox[c]) / cell) + 1;
+            if (dim[c] < 1) dim[c] = 1;
+            total *= dim[c];
+        }
+        if (total <= max_cells) break;
+        cell *= 1.26f;
+    }
+    g.cell = cell;
+    g.inv_cell = 1.0f / cell;
+    for (int c = 0; c < 3; ++c) {
+        g.origin[c] = bbox[c];
+        g.dim[c] = dim[c];
+    }
+    g.ncell = dim[0] * dim[1] * dim[2];
+    GridDev gd{g.origin[0], g.origin[1], g.origin[2], g.inv_cell, g.cell, dim[0], dim[1], dim[2], g.ncell};
+    const int blocks = (m + 255) / 256;
+    hipLaunchKernelGGL(k_cell_keys, dim3(blocks), dim3(256), 0, s, orig, m, gd, ctx->map_keys, ctx->map_vals);
+    int bits = 1;
+    while ((1ll << bits) < g.ncell) ++bits;
+    size_t need = 0;
+    MML_HIP(rocprim::radix_sort_pairs(nullptr, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals, ctx->map_vals2,
+                                      (size_t)m, 0, bits, s));
+    if (need > ctx->sort_tmp_bytes) {
+        if (ctx->sort_tmp) MML_HIP(hipFree(ctx->sort_tmp));
+        MML_HIP(hipMalloc(&ctx->sort_tmp, need));
+        ctx->sort_tmp_bytes = need;
+    }
+    MML_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
+                                      ctx->map_vals2, (size_t)m, 0, bits, s));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(blocks), dim3(256), 0, s, orig, ctx->map_vals2, m, g.pts);
+    hipLaunchKernelGGL(k_cell_start, dim3((g.ncell + 1 + 255) / 256), dim3(256), 0, s, ctx->map_keys2, m, g.ncell,
+                       g.cell_start);
+    MML_HIP(hipGetLastError());
+    ctx->have_map[kind] = true;
+    return MML_OK;
+}
+
+int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2) {
+    MmlStageScope t(ctx, "knn5");
+    hipLaunchKernelGGL(k_knn5, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, ctx->grid[kind], d_q, nq, max_d2,
+                       d_idx, d_d2);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist) {
+    AssocParams P;
+    P.first = first;
+    P.B = ctx->B;
+    P.MF = ctx->MF;
+    for (int k = 0; k < 2; ++k) {
+        P.g[k] = ctx->grid[k];
+        P.map_orig[k] = ctx->map_tmp + (size_t)k * ctx->MM;
+        P.ft[k] = ctx->ft_xyz[k];
+        P.map_m[k] = ctx->grid[k].m;
+    }
+    P.ft_n = ctx->ft_n;
+    P.lf = ctx->lf;
+    P.pf = ctx->pf;
+    P.Twl = d_Twl;
+    P.thres = (float)thres_dist;
+    if ((double)P.thres < thres_dist) P.thres = nextafterf(P.thres, INFINITY);
+    P.thres_d = thres_dist;
+    {
+        MmlStageScope t(ctx, "associate");
+        hipLaunchKernelGGL(k_associate, dim3((ctx->MF + 127) / 128, count, 2), dim3(128), 0, ctx->stream, P);
+    }
+    {
+        MmlStageScope t(ctx, "assoc_stats");
+        hipLaunchKernelGGL(k_assoc_stats, dim3(count), dim3(256), 0, ctx->stream, first, ctx->B, ctx->MF, ctx->ft_n,
+                           ctx->lf, ctx->pf, ctx->assoc_stats);
+    }
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}

@@ -1,0 +1,183 @@
+// mml_internal.h -- private definitions shared by the HIP translation units of libmmloam_hip.so.
+// gfx950 (MI355X) only.  All device code is compiled with -ffp-contract=off: the reference arithmetic
+// is x86-64 SSE2 without FMA and the parity tests are bit-exact on float paths.
+#ifndef MML_INTERNAL_H
+#define MML_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "mmloam_hip.h"
+
+#define MML_WAVE 64
+
+// ---- factor records kept on the device (SoA would save little: every field is read once per GN pass) ----
+struct MmlLineFactor {   // Estimator.h:59-84 FeatureLine (values are floats in the reference, :256-271)
+    float ori[3];
+    float p1[3];
+    float p2[3];
+    int src;             // feature index, -1 = no factor for this feature
+    double error;        // FeatureLine::ComputeError
+};
+struct MmlPlaneFactor {  // Estimator.h:105-122 FeaturePlanVec with sqrt_info replaced by omega
+    float ori[3];
+    float omega[3];
+    double proj[3];
+    double error;
+    int src;
+    int _pad;
+};
+
+struct MmlGrid {         // radix-sorted uniform grid over one map cloud (replaces pcl::KdTreeFLANN)
+    float4* pts;         // sorted by cell key: x, y, z, original index (bit pattern)
+    int* cell_start;     // ncell + 1
+    int m;
+    float origin[3];
+    float cell;
+    float inv_cell;
+    int dim[3];
+    int ncell;
+};
+
+struct MmlStageTimer {
+    std::string name;
+    double total_ms = 0;
+    long launches = 0;
+};
+
+struct mml_ctx {
+    mml_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int B = 0, NV = 0, NL = 0, NT = 0, L = 0, MF = 0;
+
+    // inputs
+    float4* velo_in = nullptr;            // B * NV
+    mml_livox_point* livox_in = nullptr;  // B * NL
+    int* d_n_in = nullptr;                // B * 2 (velo, livox)
+    std::vector<int> h_n_in;
+
+    // per raw point scratch
+    uint8_t* raw_line = nullptr;  // B * NT   line id or 255
+    float* raw_ori = nullptr;     // B * NV   -atan2(y,x) as float
+
+    // line-bucketed points
+    float4* ln_pts = nullptr;   // B * NT
+    int* ln_gidx = nullptr;     // B * NT
+    int* line_start = nullptr;  // B * L
+    int* line_len = nullptr;    // B * L
+    float* ln_curv = nullptr;
+    float* ln_refl = nullptr;
+    uint16_t* ln_attr = nullptr;
+    int* ln_ord_c = nullptr;
+    int* ln_ord_r = nullptr;
+    uint8_t* ln_flag = nullptr;
+
+    // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
+    float4* cb_xyzi = nullptr;
+    float* cb_rel = nullptr;
+    uint8_t* cb_line = nullptr;
+    uint8_t* cb_label = nullptr;
+    int* cb_n = nullptr;  // B * 2
+
+    // fused cropped cloud
+    float4* fu_xyzi = nullptr;
+    float* fu_rel = nullptr;
+    uint8_t* fu_line = nullptr;
+    uint8_t* fu_label = nullptr;
+    int* fu_info = nullptr;  // B * 8: n_points, n_velo, vc, vs, lc, ls, -, -
+
+    // down-sampled feature stacks: kind 0 corner, 1 surf
+    float4* ft_xyz[2] = {nullptr, nullptr};  // B * MF
+    int* ft_n = nullptr;                     // 2 * B
+    unsigned long long* vx_keys = nullptr;   // voxel sort scratch: B * 2 * VX_CAP
+    int VX_CAP = 0;
+
+    // factors
+    MmlLineFactor* lf = nullptr;   // B * MF
+    MmlPlaneFactor* pf = nullptr;  // B * MF
+    double* assoc_stats = nullptr; // B * 16: n_line, n_plane, n_line_used, n_plane_used, gram[9], ...
+
+    // maps
+    MmlGrid grid[2];
+    bool have_map[2] = {false, false};
+    float4* map_tmp = nullptr;
+    unsigned* map_keys = nullptr;
+    unsigned* map_keys2 = nullptr;
+    unsigned* map_vals = nullptr;
+    unsigned* map_vals2 = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int MM = 0;
+
+    // solver state
+    double* d_x = nullptr;        // B * 6
+    double* d_pose_in = nullptr;  // B * 32 generic double params (T_wl, dR/dt ...)
+    double* d_summ = nullptr;     // B * 8
+    double* d_trace = nullptr;    // B * 6 * MAX_ITERS
+    double* d_rec = nullptr;      // B * 32
+    float* d_extr = nullptr;      // 16 floats
+    int* d_misc = nullptr;        // misc ints
+
+    // pinned host staging
+    double* h_stage = nullptr;
+    size_t h_stage_doubles = 0;
+    size_t stage_cursor = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<MmlStageTimer> stages;
+    struct Pending {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+#define MML_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return MML_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define MML_REQUIRE(cond, code, msg) \
+    do {                             \
+        if (!(cond)) {               \
+            ctx->err = (msg);        \
+            return (code);           \
+        }                            \
+    } while (0)
+
+// profiling bracket (no-op unless enabled)
+int mml_stage_begin(mml_ctx* ctx, const char* name);
+void mml_stage_end(mml_ctx* ctx, int token);
+struct MmlStageScope {
+    mml_ctx* c;
+    int t;
+    MmlStageScope(mml_ctx* ctx, const char* name) : c(ctx), t(mml_stage_begin(ctx, name)) {}
+    ~MmlStageScope() { mml_stage_end(c, t); }
+};
+
+// launchers implemented in the .hip files (all asynchronous on ctx->stream)
+int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic);
+int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params);
+int mml_launch_downsample(mml_ctx* ctx, int first, int count);
+int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
+int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2);
+int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);
+int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
+                     bool want_trace);
+int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);
+int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan,
+                         double huber, double* d_record);
+
+#endif

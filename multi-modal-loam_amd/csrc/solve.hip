@@ -1,0 +1,702 @@
+// solve.hip -- rows a17..a21 of SURVEY.md section 8.
+//   a17/a18 Cost_NavState_IMU_Line / Cost_NavState_IMU_Plan_Vec (mm-loam/include/utils/ceresfunc.h:397-458, 517-570)
+//   a19     analytic Jacobians replacing ceres::AutoDiffCostFunction<...,6> through Sophus::SO3<Jet>::exp
+//           (include/sophus/so3.hpp:585-622): dP/dt = I, dP/dphi = -[R p_b]x J_l(phi)
+//   a20     J^T J / J^T r with Ceres' Huber correction (corrector.cc: rho'' <= 0 => scale by sqrt(rho')),
+//           wavefront shuffle reduction of the 28 unique doubles (21 upper H + 6 g + cost)
+//   a20/a21 ceres::Solve replacement (mm-loam/src/lio/Estimator.cpp:1425-1432): Ceres 2.1.0 trust-region loop with
+//           TRADITIONAL_DOGLEG and Jacobi scaling, one workgroup per window problem, no host round trip between
+//           the iterations.  The 6x6 per-frame Cholesky and the dogleg bookkeeping run on lane 0.
+// Each iteration makes ONE fused pass over the factors at the candidate point (cost + H + g), instead of Ceres'
+// cost-only pass followed by a Jacobian pass after acceptance.
+#include <math.h>
+
+#include "mml_internal.h"
+
+namespace {
+
+constexpr int SOLVE_THREADS = 256;
+constexpr int SOLVE_WAVES = SOLVE_THREADS / 64;
+constexpr int MAXW = 8;  // frames per window problem
+constexpr double kLidarM = 1.5e-3;  // IMUIntegrator.h:83
+
+struct Pose {
+    double R[9];   // R_wl
+    double t[3];   // t_wl
+    double tb[3];  // t_wb (= x[0:3])
+    double Jl[9];  // left Jacobian of SO(3) at phi
+};
+
+__device__ void quat_to_R(double qx, double qy, double qz, double qw, double* R) {
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz);
+    R[1] = txy - twz;
+    R[2] = txz + twy;
+    R[3] = txy + twz;
+    R[4] = 1 - (txx + tzz);
+    R[5] = tyz - twx;
+    R[6] = txz - twy;
+    R[7] = tyz + twx;
+    R[8] = 1 - (txx + tyy);
+}
+
+// x = [t, phi]; T_bl row-major 4x4.  sophus/so3.hpp:585-622 exp with the theta^2 < 1e-20 Taylor branch.
+__device__ void make_pose(const double* x, const double* T_bl, Pose& P) {
+    const double px = x[3], py = x[4], pz = x[5];
+    const double th2 = (px * px + py * py) + pz * pz;
+    double imag, real, a, b;
+    if (th2 < 1e-10 * 1e-10) {
+        double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+        a = 0.5;
+        b = 1.0 / 6.0;
+    } else {
+        double th = sqrt(th2);
+        double half = 0.5 * th;
+        imag = sin(half) / th;
+        real = cos(half);
+        a = (1.0 - cos(th)) / th2;
+        b = (th - sin(th)) / (th2 * th);
+    }
+    double Rwb[9];
+    quat_to_R(imag * px, imag * py, imag * pz, real, Rwb);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            P.R[3 * r + c] = (Rwb[3 * r] * T_bl[c] + Rwb[3 * r + 1] * T_bl[4 + c]) + Rwb[3 * r + 2] * T_bl[8 + c];
+        P.t[r] = ((Rwb[3 * r] * T_bl[3] + Rwb[3 * r + 1] * T_bl[7]) + Rwb[3 * r + 2] * T_bl[11]) + x[r];
+        P.tb[r] = x[r];
+    }
+    const double K[9] = {0, -pz, py, pz, 0, -px, -py, px, 0};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double k2 = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+            P.Jl[3 * r + c] = a * K[3 * r + c] + b * k2 + (r == c ? 1.0 : 0.0);
+        }
+}
+
+// ceres/loss_function.cc HuberLoss::Evaluate
+__device__ __forceinline__ void huber(double s, double a, double& rho0, double& rho1) {
+    rho0 = s;
+    rho1 = 1.0;
+    if (a > 0) {
+        double bb = a * a;
+        if (s > bb) {
+            double r = sqrt(s);
+            rho0 = 2.0 * a * r - bb;
+            rho1 = fmax(2.2250738585072014e-308, a / r);
+        }
+    }
+}
+
+// accumulate rho1 * J J^T (upper triangle, 21) and rho1 * J r (6) for one scalar residual row with dr/dP = gr
+__device__ __forceinline__ void row_jacobian(const Pose& P, const double* Pw, const double* gr, double* J) {
+    // dP/dx = [I, -[Rpb]x Jl],  Rpb = P - t_wb
+    const double rx = Pw[0] - P.tb[0], ry = Pw[1] - P.tb[1], rz = Pw[2] - P.tb[2];
+    // gr^T * (-[Rpb]x) = (Rpb x gr)^T ... (-[a]x)^T g = a x g  => row = (gr x Rpb)?  use explicit form:
+    // (-[r]x) = [[0, rz, -ry], [-rz, 0, rx], [ry, -rx, 0]] ; v^T = gr^T (-[r]x)
+    const double v0 = -gr[1] * rz + gr[2] * ry;
+    const double v1 = gr[0] * rz - gr[2] * rx;
+    const double v2 = -gr[0] * ry + gr[1] * rx;
+    J[0] = gr[0];
+    J[1] = gr[1];
+    J[2] = gr[2];
+    J[3] = (v0 * P.Jl[0] + v1 * P.Jl[3]) + v2 * P.Jl[6];
+    J[4] = (v0 * P.Jl[1] + v1 * P.Jl[4]) + v2 * P.Jl[7];
+    J[5] = (v0 * P.Jl[2] + v1 * P.Jl[5]) + v2 * P.Jl[8];
+}
+
+__device__ __forceinline__ void accum(double* acc, const double* J, double r, double w) {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += w * J[a] * J[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += w * J[a] * r;
+}
+
+// Evaluate one frame at pose P: thread-strided over the factors; acc[28] per thread.
+__device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
+                           double w_tan, double huber_delta, double* acc) {
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    const double ka = 1.0 / kLidarM;
+    for (int i = threadIdx.x; i < nlf; i += SOLVE_THREADS) {
+        const MmlLineFactor f = lf[i];
+        if (f.src < 0 || !(fabs(f.error) > 1e-5)) continue;  // Estimator.cpp:1385
+        const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
+        const double ax = f.p1[0], ay = f.p1[1], az = f.p1[2], bx = f.p2[0], by = f.p2[1], bz = f.p2[2];
+        double Pw[3];
+        Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
+        Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
+        Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
+        const double l12 = sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz));
+        const double c0 = (Pw[0] - ax) * (Pw[1] - by) - (Pw[0] - bx) * (Pw[1] - ay);
+        const double c1 = (Pw[0] - ax) * (Pw[2] - bz) - (Pw[0] - bx) * (Pw[2] - az);
+        const double c2 = (Pw[1] - ay) * (Pw[2] - bz) - (Pw[1] - by) * (Pw[2] - az);
+        const double a012 = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+        const double ld2 = a012 / l12;
+        const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+        const double rs = sqrt(sqrt(s));
+        const double weight = 1.0 - 0.9 * fabs(ld2) / rs;
+        const double r = ka * weight * ld2;
+        // gradient of ld wrt P: ((a-b) x u_hat) / l12, u = (c2, -c1, c0)
+        const double ux = c2 / a012, uy = -c1 / a012, uz = c0 / a012;
+        const double dx = ax - bx, dy = ay - by, dz = az - bz;
+        double gl[3] = {(dy * uz - dz * uy) / l12, (dz * ux - dx * uz) / l12, (dx * uy - dy * ux) / l12};
+        const double sm14 = 1.0 / rs, sm54 = sm14 / s;
+        double gr[3];
+        for (int c = 0; c < 3; ++c) {
+            double gw = (-0.9) * (sm14 * gl[c] + (fabs(ld2) * (-0.5) * sm54) * Pw[c]);
+            gr[c] = ka * (weight * gl[c] + ld2 * gw);
+        }
+        double J[6];
+        row_jacobian(P, Pw, gr, J);
+        double rho0, rho1;
+        huber(r * r, huber_delta, rho0, rho1);
+        acc[27] += 0.5 * rho0;
+        accum(acc, J, r, rho1);
+    }
+    const double kb = w_tan / kLidarM;
+    for (int i = threadIdx.x; i < npf; i += SOLVE_THREADS) {
+        const MmlPlaneFactor f = pf[i];
+        if (f.src < 0 || !(fabs(f.error) > 1e-5)) continue;  // Estimator.cpp:1396
+        const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
+        double Pw[3];
+        Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
+        Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
+        Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
+        const double d[3] = {Pw[0] - f.proj[0], Pw[1] - f.proj[1], Pw[2] - f.proj[2]};
+        const double nd = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+        const double rs = sqrt(sqrt(s));
+        const double weight = 1.0 - 0.9 * nd / rs;
+        const double sm14 = 1.0 / rs, sm54 = sm14 / s;
+        double gw[3];
+        for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * ((sm14 / nd) * d[c] + (nd * (-0.5) * sm54) * Pw[c]);
+        // e = weight * d ;  de/dP = weight I + d gw^T ;  row^T de/dP = weight row + (row . d) gw
+        const double w[3] = {f.omega[0], f.omega[1], f.omega[2]};
+        double rows[3][3];
+        int nrows = 1;
+        rows[0][0] = ka * w[0];
+        rows[0][1] = ka * w[1];
+        rows[0][2] = ka * w[2];
+        if (kb != 0.0) {
+            // deterministic tangent basis (any orthonormal completion gives the same H, g, cost)
+            double h[3] = {0, 0, 0};
+            if (fabs(w[0]) <= fabs(w[1]) && fabs(w[0]) <= fabs(w[2]))
+                h[0] = 1;
+            else if (fabs(w[1]) <= fabs(w[2]))
+                h[1] = 1;
+            else
+                h[2] = 1;
+            double t0 = w[1] * h[2] - w[2] * h[1], t1 = w[2] * h[0] - w[0] * h[2], t2 = w[0] * h[1] - w[1] * h[0];
+            double n = sqrt((t0 * t0 + t1 * t1) + t2 * t2);
+            t0 /= n;
+            t1 /= n;
+            t2 /= n;
+            rows[1][0] = kb * t0;
+            rows[1][1] = kb * t1;
+            rows[1][2] = kb * t2;
+            rows[2][0] = kb * (w[1] * t2 - w[2] * t1);
+            rows[2][1] = kb * (w[2] * t0 - w[0] * t2);
+            rows[2][2] = kb * (w[0] * t1 - w[1] * t0);
+            nrows = 3;
+        }
+        double rr[3], sq = 0;
+        for (int q = 0; q < nrows; ++q) {
+            rr[q] = weight * ((rows[q][0] * d[0] + rows[q][1] * d[1]) + rows[q][2] * d[2]);
+            sq += rr[q] * rr[q];
+        }
+        double rho0, rho1;
+        huber(sq, huber_delta, rho0, rho1);
+        acc[27] += 0.5 * rho0;
+        for (int q = 0; q < nrows; ++q) {
+            const double rd = (rows[q][0] * d[0] + rows[q][1] * d[1]) + rows[q][2] * d[2];
+            double gr[3] = {weight * rows[q][0] + rd * gw[0], weight * rows[q][1] + rd * gw[1],
+                            weight * rows[q][2] + rd * gw[2]};
+            double J[6];
+            row_jacobian(P, Pw, gr, J);
+            accum(acc, J, rr[q], rho1);
+        }
+    }
+}
+
+// block reduction of acc[28] into out[28] (LDS or global); result valid for thread 0 after the trailing barrier
+__device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, double* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_part[wave * 28 + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double v = s_part[threadIdx.x];
+        for (int w = 1; w < SOLVE_WAVES; ++w) v += s_part[w * 28 + threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+__host__ __device__ __forceinline__ int tri(int a, int b) {  // index into 21-entry upper triangle, a <= b
+    return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
+__host__ __device__ __forceinline__ double Hget(const double* rec, int a, int b) { return a <= b ? rec[tri(a, b)] : rec[tri(b, a)]; }
+
+// 6x6 Cholesky solve on one lane.  A (36, row-major) is destroyed; b -> x.  false if not positive definite.
+__host__ __device__ bool chol6(double* A, double* b) {
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s / d;
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * b[k];
+        b[i] = s / A[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * b[k];
+        b[i] = s / A[i * 6 + i];
+    }
+    return true;
+}
+
+struct SolveParams {
+    int first, B, MF, window, max_iters, fixed;
+    double huber, w_tan;
+    const int* ft_n;
+    const MmlLineFactor* lf;
+    const MmlPlaneFactor* pf;
+    const double* Tbl;  // 16
+    double* x;          // B * 6
+    double* summ;       // per problem 8 doubles
+    double* trace;      // per problem max_iters * 6 * window, or nullptr
+};
+
+// Trust-region state kept in LDS, manipulated by lane 0 (restates ceres 2.1.0 trust_region_minimizer.cc +
+// dogleg_strategy.cc; constants are Ceres defaults, see oracle/estimate.cpp for the line-by-line commentary).
+struct TRState {
+    double x[6 * MAXW], xc[6 * MAXW];
+    double rec[28 * MAXW], recc[28 * MAXW];  // per frame: H upper (21), g (6), cost
+    double scale[6 * MAXW], diag[6 * MAXW], grad[6 * MAXW], gn[6 * MAXW], step[6 * MAXW];
+    double cost, radius, mu, alpha, dogleg_norm, x_norm, model_change, step_norm;
+    int reuse, num_invalid, iter, successful, termination, go, evaluate;
+};
+
+__host__ __device__ double quad_form(const TRState& S, int W, const double* v) {  // v^T (S H S) v
+    double q = 0;
+    for (int f = 0; f < W; ++f)
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b)
+                q += v[6 * f + a] * (Hget(S.rec + 28 * f, a, b) * S.scale[6 * f + a] * S.scale[6 * f + b]) * v[6 * f + b];
+    return q;
+}
+
+__host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
+    const int n = 6 * W;
+    S.evaluate = 0;
+    if (S.iter >= max_iters || S.radius < 1e-32 || S.num_invalid > 5) {
+        S.go = 0;
+        return;
+    }
+    S.iter++;
+    bool solve_ok = true;
+    if (!S.reuse) {
+        S.reuse = 1;
+        for (int f = 0; f < W; ++f)
+            for (int i = 0; i < 6; ++i) {
+                double d = Hget(S.rec + 28 * f, i, i) * S.scale[6 * f + i] * S.scale[6 * f + i];
+                d = fmin(fmax(d, 1e-6), 1e32);
+                S.diag[6 * f + i] = sqrt(d);
+            }
+        double gg = 0;
+        double sg[6 * MAXW];
+        for (int f = 0; f < W; ++f)
+            for (int i = 0; i < 6; ++i) {
+                int k = 6 * f + i;
+                S.grad[k] = S.rec[28 * f + 21 + i] * S.scale[k] / S.diag[k];
+                sg[k] = S.grad[k] / S.diag[k];
+                gg += S.grad[k] * S.grad[k];
+            }
+        S.alpha = gg / quad_form(S, W, sg);
+        solve_ok = false;
+        while (S.mu < 1.0) {
+            bool ok = true;
+            for (int f = 0; f < W && ok; ++f) {
+                double A[36], bvec[6];
+                for (int a = 0; a < 6; ++a) {
+                    for (int b = 0; b < 6; ++b)
+                        A[6 * a + b] = Hget(S.rec + 28 * f, a, b) * S.scale[6 * f + a] * S.scale[6 * f + b];
+                    A[7 * a] += S.mu * S.diag[6 * f + a] * S.diag[6 * f + a];
+                    bvec[a] = S.rec[28 * f + 21 + a] * S.scale[6 * f + a];
+                }
+                ok = chol6(A, bvec);
+                for (int a = 0; a < 6 && ok; ++a) {
+                    if (!isfinite(bvec[a])) ok = false;
+                    S.gn[6 * f + a] = bvec[a];
+                }
+            }
+            if (!ok) {
+                S.mu *= 10.0;
+                continue;
+            }
+            solve_ok = true;
+            break;
+        }
+        if (solve_ok)
+            for (int i = 0; i < n; ++i) S.gn[i] *= -S.diag[i];
+    }
+    bool step_valid = solve_ok;
+    if (solve_ok) {
+        double gradient_norm = 0, gn_norm = 0;
+        for (int i = 0; i < n; ++i) {
+            gradient_norm += S.grad[i] * S.grad[i];
+            gn_norm += S.gn[i] * S.gn[i];
+        }
+        gradient_norm = sqrt(gradient_norm);
+        gn_norm = sqrt(gn_norm);
+        if (gn_norm <= S.radius) {
+            for (int i = 0; i < n; ++i) S.step[i] = S.gn[i];
+            S.dogleg_norm = gn_norm;
+        } else if (gradient_norm * S.alpha >= S.radius) {
+            for (int i = 0; i < n; ++i) S.step[i] = -(S.radius / gradient_norm) * S.grad[i];
+            S.dogleg_norm = S.radius;
+        } else {
+            double gdot = 0;
+            for (int i = 0; i < n; ++i) gdot += S.grad[i] * S.gn[i];
+            double b_dot_a = -S.alpha * gdot;
+            double a_sq = (S.alpha * gradient_norm) * (S.alpha * gradient_norm);
+            double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+            double c = b_dot_a - a_sq;
+            double d = sqrt(c * c + bma_sq * (S.radius * S.radius - a_sq));
+            double beta = (c <= 0) ? (d - c) / bma_sq : (S.radius * S.radius - a_sq) / (d + c);
+            double sn = 0;
+            for (int i = 0; i < n; ++i) {
+                S.step[i] = (-S.alpha * (1.0 - beta)) * S.grad[i] + beta * S.gn[i];
+                sn += S.step[i] * S.step[i];
+            }
+            S.dogleg_norm = sqrt(sn);
+        }
+        for (int i = 0; i < n; ++i) S.step[i] /= S.diag[i];
+        double sgd = 0;
+        for (int f = 0; f < W; ++f)
+            for (int i = 0; i < 6; ++i) sgd += S.step[6 * f + i] * S.rec[28 * f + 21 + i] * S.scale[6 * f + i];
+        S.model_change = -(sgd + 0.5 * quad_form(S, W, S.step));
+        if (!(S.model_change > 0.0)) step_valid = false;
+    }
+    if (!step_valid) {
+        S.num_invalid++;
+        S.mu *= 10.0;
+        S.reuse = 0;
+        return;  // go stays 1, evaluate 0: next round proposes again
+    }
+    S.num_invalid = 0;
+    double sn = 0;
+    for (int i = 0; i < n; ++i) {
+        double delta = S.step[i] * S.scale[i];
+        S.xc[i] = S.x[i] + delta;
+        sn += delta * delta;
+    }
+    S.step_norm = sqrt(sn);
+    S.evaluate = 1;
+}
+
+__host__ __device__ void tr_decide(TRState& S, int W, int fixed) {
+    const int n = 6 * W;
+    double cand = 0;
+    for (int f = 0; f < W; ++f) cand += S.recc[28 * f + 27];
+    if (!fixed) {
+        if (S.step_norm <= 1e-8 * (S.x_norm + 1e-8)) {
+            S.termination = 2;
+            S.go = 0;
+            return;
+        }
+        if (fabs(S.cost - cand) <= 1e-6 * S.cost) {
+            S.termination = 3;
+            S.go = 0;
+            return;
+        }
+    }
+    double rel = (S.cost - cand) / S.model_change;
+    if (rel > 1e-3) {
+        double xn = 0;
+        for (int i = 0; i < n; ++i) {
+            S.x[i] = S.xc[i];
+            xn += S.x[i] * S.x[i];
+        }
+        S.x_norm = sqrt(xn);
+        for (int i = 0; i < 28 * W; ++i) S.rec[i] = S.recc[i];
+        S.cost = cand;
+        S.successful++;
+        if (!fixed) {
+            double gm = 0;
+            for (int f = 0; f < W; ++f)
+                for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(S.rec[28 * f + 21 + i]));
+            if (gm <= 1e-10) {
+                S.termination = 1;
+                S.go = 0;
+                return;
+            }
+        }
+        if (rel < 0.25) S.radius *= 0.5;
+        if (rel > 0.75) S.radius = fmax(S.radius, 3.0 * S.dogleg_norm);
+        S.mu = fmax(1e-8, 2.0 * S.mu / 10.0);
+        S.reuse = 0;
+    } else {
+        S.radius *= 0.5;
+        S.reuse = 1;
+    }
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
+    __shared__ TRState S;
+    __shared__ double s_part[SOLVE_WAVES * 28];
+    const int prob = blockIdx.x;
+    const int W = P.window;
+    const int b0 = P.first + prob * W;
+    const int tid = threadIdx.x;
+    if (tid < 6 * W) S.x[tid] = P.x[(size_t)b0 * 6 + tid];
+    __syncthreads();
+
+    double acc[28];
+    // initial evaluation
+    for (int f = 0; f < W; ++f) {
+        Pose pose;
+        make_pose(S.x + 6 * f, P.Tbl, pose);
+        const int b = b0 + f;
+        eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan,
+                   P.huber, acc);
+        block_reduce28(acc, s_part, S.rec + 28 * f);
+    }
+    if (tid == 0) {
+        S.cost = 0;
+        double xn = 0;
+        for (int f = 0; f < W; ++f) {
+            S.cost += S.rec[28 * f + 27];
+            for (int i = 0; i < 6; ++i) {
+                S.scale[6 * f + i] = 1.0 / (1.0 + sqrt(Hget(S.rec + 28 * f, i, i)));
+                xn += S.x[6 * f + i] * S.x[6 * f + i];
+            }
+        }
+        S.x_norm = sqrt(xn);
+        S.radius = 1e4;
+        S.mu = 1e-8;
+        S.reuse = 0;
+        S.num_invalid = 0;
+        S.iter = 0;
+        S.successful = 0;
+        S.termination = 0;
+        S.go = 1;
+        S.alpha = 0;
+        S.dogleg_norm = 0;
+        P.summ[8 * prob + 2] = S.cost;  // initial cost
+        if (!P.fixed) {
+            double gm = 0;
+            for (int f = 0; f < W; ++f)
+                for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(S.rec[28 * f + 21 + i]));
+            if (gm <= 1e-10) {
+                S.termination = 1;
+                S.go = 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    int go = S.go;
+    __syncthreads();
+    while (go) {
+        // lane 0 owns the trust-region state between the barriers; every other lane only reads it after one
+        if (tid == 0) tr_propose(S, W, P.max_iters);
+        __syncthreads();
+        go = S.go;
+        const int ev = S.evaluate;
+        if (!go) break;
+        if (ev) {
+            for (int f = 0; f < W; ++f) {
+                Pose pose;
+                make_pose(S.xc + 6 * f, P.Tbl, pose);
+                const int b = b0 + f;
+                eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose,
+                           P.w_tan, P.huber, acc);
+                block_reduce28(acc, s_part, S.recc + 28 * f);
+            }
+            if (tid == 0) tr_decide(S, W, P.fixed);
+        }
+        __syncthreads();
+        go = S.go;
+        if (P.trace && tid < 6 * W) P.trace[((size_t)prob * P.max_iters + (S.iter - 1)) * 6 * W + tid] = S.x[tid];
+        __syncthreads();
+    }
+    if (tid < 6 * W) P.x[(size_t)b0 * 6 + tid] = S.x[tid];
+    if (tid == 0) {
+        double* o = P.summ + 8 * prob;
+        o[0] = S.iter;
+        o[1] = S.successful;
+        o[3] = S.cost;
+        o[4] = S.termination;
+    }
+}
+
+// single-frame linearisation to a 32-double record (SURVEY 8(e) all-gather payload)
+__global__ __launch_bounds__(SOLVE_THREADS) void k_linearize(int b, int B, int MF, const int* ft_n,
+                                                            const MmlLineFactor* lf, const MmlPlaneFactor* pf,
+                                                            const double* x, const double* Tbl, double w_tan,
+                                                            double huber_delta, const double* stats, double* record) {
+    __shared__ double s_part[SOLVE_WAVES * 28];
+    __shared__ double s_out[28];
+    Pose pose;
+    make_pose(x, Tbl, pose);
+    double acc[28];
+    eval_frame(lf + (size_t)b * MF, ft_n[b], pf + (size_t)b * MF, ft_n[B + b], pose, w_tan, huber_delta, acc);
+    block_reduce28(acc, s_part, s_out);
+    if (threadIdx.x < 28) record[threadIdx.x] = s_out[threadIdx.x];
+    if (threadIdx.x == 0) {
+        record[28] = stats[16 * b + 2];
+        record[29] = stats[16 * b + 3];
+        record[30] = 0;
+        record[31] = 0;
+    }
+}
+
+}  // namespace
+
+int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
+                     bool want_trace) {
+    MML_REQUIRE(window >= 1 && window <= MAXW && count % window == 0, MML_ERR_INVALID,
+                "window must be in [1,8] and divide count");
+    SolveParams P;
+    P.first = first;
+    P.B = ctx->B;
+    P.MF = ctx->MF;
+    P.window = window;
+    P.max_iters = opts.max_num_iterations;
+    P.fixed = opts.fixed_iterations;
+    P.huber = opts.huber_delta;
+    P.w_tan = opts.plan_weight_tan;
+    P.ft_n = ctx->ft_n;
+    P.lf = ctx->lf;
+    P.pf = ctx->pf;
+    P.Tbl = d_Tbl;
+    P.x = ctx->d_x;
+    P.summ = ctx->d_summ;
+    P.trace = want_trace ? ctx->d_trace : nullptr;
+    MmlStageScope t(ctx, "solve");
+    hipLaunchKernelGGL(k_solve, dim3(count / window), dim3(SOLVE_THREADS), 0, ctx->stream, P);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan, double huber,
+                         double* d_record) {
+    MmlStageScope t(ctx, "linearize");
+    hipLaunchKernelGGL(k_linearize, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, slot, ctx->B, ctx->MF, ctx->ft_n,
+                       ctx->lf, ctx->pf, d_x, d_Tbl, w_tan, huber, ctx->assoc_stats, d_record);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+// ---- host-side joint window solver: the same trust-region code, fed by all-gathered records ----
+struct mml_window_solver {
+    TRState S;
+    int W;
+    mml_solve_opts opts;
+    int phase;  // 0: waiting for the records at x0, 1: waiting for the records at xc, 2: finished
+    double initial_cost;
+};
+
+extern "C" mml_window_solver* mml_window_solver_create(int W, const mml_solve_opts* opts) {
+    if (W < 1 || W > MAXW || !opts) return nullptr;
+    mml_window_solver* s = new mml_window_solver();
+    s->W = W;
+    s->opts = *opts;
+    s->phase = 0;
+    s->initial_cost = 0;
+    return s;
+}
+extern "C" void mml_window_solver_destroy(mml_window_solver* s) { delete s; }
+
+extern "C" int mml_window_solver_step(mml_window_solver* s, const double* records, double* x_eval) {
+    if (!s || !records || !x_eval) return MML_ERR_INVALID;
+    TRState& S = s->S;
+    const int W = s->W, n = 6 * W;
+    if (s->phase == 2) {
+        for (int i = 0; i < n; ++i) x_eval[i] = S.x[i];
+        return 1;
+    }
+    if (s->phase == 0) {
+        double xn = 0;
+        S.cost = 0;
+        for (int f = 0; f < W; ++f) {
+            for (int k = 0; k < 28; ++k) S.rec[28 * f + k] = records[MML_NEQ_RECORD_DOUBLES * f + k];
+            S.cost += S.rec[28 * f + 27];
+            for (int i = 0; i < 6; ++i) {
+                S.x[6 * f + i] = x_eval[6 * f + i];
+                S.scale[6 * f + i] = 1.0 / (1.0 + sqrt(Hget(S.rec + 28 * f, i, i)));
+                xn += S.x[6 * f + i] * S.x[6 * f + i];
+            }
+        }
+        S.x_norm = sqrt(xn);
+        S.radius = 1e4;
+        S.mu = 1e-8;
+        S.reuse = 0;
+        S.num_invalid = 0;
+        S.iter = 0;
+        S.successful = 0;
+        S.termination = 0;
+        S.go = 1;
+        S.alpha = 0;
+        S.dogleg_norm = 0;
+        s->initial_cost = S.cost;
+        if (!s->opts.fixed_iterations) {
+            double gm = 0;
+            for (int f = 0; f < W; ++f)
+                for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(S.rec[28 * f + 21 + i]));
+            if (gm <= 1e-10) {
+                S.termination = 1;
+                S.go = 0;
+            }
+        }
+        s->phase = 1;
+    } else {
+        for (int f = 0; f < W; ++f)
+            for (int k = 0; k < 28; ++k) S.recc[28 * f + k] = records[MML_NEQ_RECORD_DOUBLES * f + k];
+        tr_decide(S, W, s->opts.fixed_iterations);
+    }
+    while (S.go) {
+        tr_propose(S, W, s->opts.max_num_iterations);
+        if (!S.go) break;
+        if (S.evaluate) {
+            for (int i = 0; i < n; ++i) x_eval[i] = S.xc[i];
+            return 0;
+        }
+    }
+    s->phase = 2;
+    for (int i = 0; i < n; ++i) x_eval[i] = S.x[i];
+    return 1;
+}
+
+extern "C" int mml_window_solver_summary(const mml_window_solver* s, mml_solve_summary* out) {
+    if (!s || !out) return MML_ERR_INVALID;
+    out->iterations = s->S.iter;
+    out->successful = s->S.successful;
+    out->initial_cost = s->initial_cost;
+    out->final_cost = s->S.cost;
+    out->termination = s->S.termination;
+    return MML_OK;
+}

@@ -1,0 +1,313 @@
+// undistort_voxel.hip -- rows a9 and a10 of SURVEY.md section 8.
+//   a9  RemoveLidarDistortion (mm-loam/src/unionPoseEstimation.cpp:402-421): one point per lane, the
+//       per-scan quaternion normalisation / angle is hoisted to one lane-uniform prologue.
+//   a10 label split + pcl::VoxelGrid centroid down-sample (mm-loam/src/lio/Estimator.cpp:992-1026,
+//       leaf sizes :78-80): one workgroup per (slot, kind): order-preserving compaction of the labelled
+//       points, float min/max, voxel key, in-LDS bitonic sort of (key, sequence) pairs, one lane per voxel
+//       sums its points in input order.
+#include <math.h>
+
+#include "mml_internal.h"
+
+namespace {
+
+struct Q4 {
+    double x, y, z, w;
+};
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 vcross(const V3& a, const V3& b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// Eigen Vector4d reduction with 2-wide packets: (c0 + c2) + (c1 + c3), coefficients stored x,y,z,w
+__device__ __forceinline__ double qdot(const Q4& a, const Q4& b) {
+    return (a.x * b.x + a.z * b.z) + (a.y * b.y + a.w * b.w);
+}
+__device__ __forceinline__ Q4 qnormalized(const Q4& q) {
+    double n = sqrt(qdot(q, q));
+    return Q4{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+// Eigen quaternionbase_assign_impl<Matrix3d>: rotation matrix (row-major) -> quaternion
+__device__ Q4 quat_from_matrix(const double* m) {
+    Q4 q;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m[7] - m[5]) * t;
+        q.y = (m[2] - m[6]) * t;
+        q.z = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        int j = (i + 1) % 3;
+        int k = (j + 1) % 3;
+        double qv[3];
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        qv[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (m[3 * k + j] - m[3 * j + k]) * t;
+        qv[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        qv[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+        q.x = qv[0];
+        q.y = qv[1];
+        q.z = qv[2];
+    }
+    return q;
+}
+
+// params: per slot 12 doubles (dR row-major 9, dt 3)
+__global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int* fu_info, float4* fu_xyzi,
+                                                  float* fu_rel, const double* params) {
+    const int b = blockIdx.y + first;
+    const int n = fu_info[8 * b];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* dR = params + 12 * blockIdx.y;
+    const double* dt = dR + 9;
+    // Eigen::Quaterniond(dRlc).normalized()  (:410) -- identical for every point of the scan
+    const Q4 qlc = qnormalized(quat_from_matrix(dR));
+    const double d = qlc.w;  // Identity().dot(qlc) = (0*x + 0*z) + (0*y + 1*w)
+    const double dd = (0.0 * qlc.x + 0.0 * qlc.z) + (0.0 * qlc.y + 1.0 * qlc.w);
+    (void)d;
+    const double absD = fabs(dd);
+    const double one = 1.0 - 2.220446049250313e-16;
+    float4 p = fu_xyzi[(size_t)b * NT + i];
+    const float s = fu_rel[(size_t)b * NT + i];
+    // Quaternion::slerp (Eigen 3.3.4)
+    double scale0, scale1;
+    const double t = s;
+    if (absD >= one) {
+        scale0 = 1.0 - t;
+        scale1 = t;
+    } else {
+        double theta = acos(absD);
+        double sinTheta = sin(theta);
+        scale0 = sin((1.0 - t) * theta) / sinTheta;
+        scale1 = sin((t * theta)) / sinTheta;
+    }
+    if (dd < 0.0) scale1 = -scale1;
+    Q4 q{scale0 * 0.0 + scale1 * qlc.x, scale0 * 0.0 + scale1 * qlc.y, scale0 * 0.0 + scale1 * qlc.z,
+         scale0 * 1.0 + scale1 * qlc.w};
+    const Q4 dq = qnormalized(q);
+    // delta_qlc * p + s * dtlc   (QuaternionBase::_transformVector)
+    V3 qv = v3(dq.x, dq.y, dq.z);
+    V3 v = v3(p.x, p.y, p.z);
+    V3 uv = vcross(qv, v);
+    uv = v3(uv.x + uv.x, uv.y + uv.y, uv.z + uv.z);
+    V3 c2 = vcross(qv, uv);
+    V3 startP = v3((v.x + dq.w * uv.x) + c2.x, (v.y + dq.w * uv.y) + c2.y, (v.z + dq.w * uv.z) + c2.z);
+    startP = v3(startP.x + s * dt[0], startP.y + s * dt[1], startP.z + s * dt[2]);
+    V3 w = v3(startP.x - dt[0], startP.y - dt[1], startP.z - dt[2]);
+    // dRlc.transpose() * w
+    p.x = (dR[0] * w.x + dR[3] * w.y) + dR[6] * w.z;
+    p.y = (dR[1] * w.x + dR[4] * w.y) + dR[7] * w.z;
+    p.z = (dR[2] * w.x + dR[5] * w.y) + dR[8] * w.z;
+    fu_xyzi[(size_t)b * NT + i] = p;
+    fu_rel[(size_t)b * NT + i] = 1.0f;  // :419
+}
+
+// ------------------------------------------------------------------------------------------------------------
+constexpr int VX_THREADS = 1024;
+constexpr int VX_WAVES = VX_THREADS / 64;
+
+__device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float* s_red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        float other = __shfl_xor(v, o);
+        v = is_min ? fminf(v, other) : fmaxf(v, other);
+    }
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    float r = s_red[0];
+    for (int w = 1; w < VX_WAVES; ++w) r = is_min ? fminf(r, s_red[w]) : fmaxf(r, s_red[w]);
+    __syncthreads();
+    return r;
+}
+
+// One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
+__global__ __launch_bounds__(VX_THREADS) void k_voxel(int first, int NT, int MF, int B, int cap, const int* fu_info,
+                                                     const float4* fu_xyzi, const uint8_t* fu_label,
+                                                     float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
+                                                     int* ft_n, unsigned* seq_scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ int s_wtot[VX_WAVES];
+    __shared__ int s_base;
+    __shared__ float s_red[VX_WAVES];
+    __shared__ int s_nout;
+
+    const int b = blockIdx.x + first;
+    const int kind = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = fu_info[8 * b];
+    const float4* px = fu_xyzi + (size_t)b * NT;
+    const uint8_t* lab = fu_label + (size_t)b * NT;
+    const int want = kind + 1;  // normal_z == 1 corner (:996), == 2 surf (:1003)
+    const float leaf = kind == 0 ? leaf_corner : leaf_surf;
+    float4* out = (kind == 0 ? ft0 : ft1) + (size_t)b * MF;
+    // sequence -> fused index map lives in global scratch (cap entries per (slot, kind))
+    unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * cap;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    // 1. order-preserving selection of the labelled points + min / max of their coordinates (getMinMax3D)
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c0 = 0; c0 < n; c0 += VX_THREADS) {
+        const int i = c0 + tid;
+        bool sel = (i < n) && lab[i] == want;
+        unsigned long long m = __ballot(sel);
+        if (lane == 0) s_wtot[wave] = __popcll(m);
+        __syncthreads();
+        int dst = s_base;
+        for (int w = 0; w < wave; ++w) dst += s_wtot[w];
+        dst += __popcll(m & lt);
+        if (sel && dst < cap) {
+            seq2idx[dst] = (unsigned)i;
+            float4 p = px[i];
+            mn[0] = fminf(mn[0], p.x);
+            mn[1] = fminf(mn[1], p.y);
+            mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x);
+            mx[1] = fmaxf(mx[1], p.y);
+            mx[2] = fmaxf(mx[2], p.z);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int s = 0;
+            for (int w = 0; w < VX_WAVES; ++w) s += s_wtot[w];
+            s_base += s;
+        }
+        __syncthreads();
+    }
+    int cnt = s_base;
+    if (cnt > cap) cnt = cap;  // capacity overflow is reported by the host wrapper through ft_n (negative)
+    const bool overflow = s_base > cap;
+    float gmn[3], gmx[3];
+    for (int c = 0; c < 3; ++c) {
+        gmn[c] = block_reduce_minmax(mn[c], true, s_red);
+        gmx[c] = block_reduce_minmax(mx[c], false, s_red);
+    }
+    if (cnt == 0) {
+        if (tid == 0) ft_n[kind * B + b] = 0;
+        return;
+    }
+    // 2. voxel index (PCL 1.8.1 voxel_grid.hpp applyFilter): inverse leaf in float, floor, int, min_b offset
+    const float inv = 1.0f / leaf;
+    int min_b[3], div_b[3];
+    for (int c = 0; c < 3; ++c) {
+        min_b[c] = static_cast<int>(floor(gmn[c] * inv));
+        int max_b = static_cast<int>(floor(gmx[c] * inv));
+        div_b[c] = max_b - min_b[c] + 1;
+    }
+    const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+    // pad to a power of two for the bitonic network
+    int npad = 1;
+    while (npad < cnt) npad <<= 1;
+    for (int s = tid; s < npad; s += VX_THREADS) {
+        unsigned long long key = ~0ull;
+        if (s < cnt) {
+            float4 p = px[seq2idx[s]];
+            int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
+            int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
+            int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
+            int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
+            key = ((unsigned long long)(unsigned)idx << 32) | (unsigned)s;
+        }
+        keys[s] = key;
+    }
+    __syncthreads();
+    // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < npad; t += VX_THREADS) {
+                int ixj = t ^ j;
+                if (ixj > t) {
+                    unsigned long long a = keys[t], c = keys[ixj];
+                    bool up = (t & k) == 0;
+                    if ((a > c) == up) {
+                        keys[t] = c;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 4. one lane per voxel head: centroid in input order (AccumulatorXYZ: float sum, then / n)
+    if (tid == 0) {
+        s_base = 0;
+        s_nout = 0;
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < cnt; c0 += VX_THREADS) {
+        const int s = c0 + tid;
+        bool head = false;
+        unsigned vox = 0;
+        if (s < cnt) {
+            vox = (unsigned)(keys[s] >> 32);
+            head = (s == 0) || ((unsigned)(keys[s - 1] >> 32) != vox);
+        }
+        unsigned long long m = __ballot(head);
+        if (lane == 0) s_wtot[wave] = __popcll(m);
+        __syncthreads();
+        int dst = s_base;
+        for (int w = 0; w < wave; ++w) dst += s_wtot[w];
+        dst += __popcll(m & lt);
+        if (head && dst < MF) {
+            float sx = 0, sy = 0, sz = 0;
+            int e = s;
+            while (e < cnt && (unsigned)(keys[e] >> 32) == vox) {
+                float4 p = px[seq2idx[(unsigned)(keys[e] & 0xffffffffu)]];
+                sx += p.x;
+                sy += p.y;
+                sz += p.z;
+                ++e;
+            }
+            float c = static_cast<float>(e - s);
+            out[dst] = make_float4(sx / c, sy / c, sz / c, 0.f);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < VX_WAVES; ++w) t += s_wtot[w];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int nout = s_base;
+        if (overflow || nout > MF) nout = -1;  // MML_ERR_CAPACITY at the host
+        ft_n[kind * B + b] = nout;
+    }
+}
+
+}  // namespace
+
+int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params) {
+    MmlStageScope t(ctx, "undistort");
+    dim3 grid((ctx->NT + 255) / 256, count);
+    hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, ctx->stream, first, ctx->NT, ctx->fu_info, ctx->fu_xyzi,
+                       ctx->fu_rel, d_params);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
+    MmlStageScope t(ctx, "voxel_downsample");
+    const int cap = ctx->VX_CAP;
+    int npad = 1;
+    while (npad < cap) npad <<= 1;
+    size_t lds = (size_t)npad * sizeof(unsigned long long);
+    hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, ctx->stream, first, ctx->NT, ctx->MF, ctx->B,
+                       cap, ctx->fu_info, ctx->fu_xyzi, ctx->fu_label, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
+                       ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}

@@ -1,0 +1,121 @@
+"""Synthetic LiDAR scans for parity tests and bench.py.
+
+Scene: axis-aligned box room 20 x 15 x 3 m with box pillars, sensor 1 m above the floor, constant-twist
+motion (0.5 m/s, 0.2 rad/s yaw, 0.1 s per scan), range noise N(0, 0.01 m), numpy default_rng(1234 + scan).
+VLP-16: n_rings x n_az points, azimuth-major (ring inner), pitch -15..+15 deg; Livox Horizon: 24 000 points on
+6 lines, Lissajous sweep inside 81.7 x 25.1 deg, offset_time linear over 0.1 s.
+
+Pure numpy, no reference code, no oracle: this only produces *inputs*.
+"""
+import numpy as np
+
+ROOM_MIN = np.array([-10.0, -7.5, 0.0])
+ROOM_MAX = np.array([10.0, 7.5, 3.0])
+# (cx, cy, half_x, half_y) pillars, full height
+PILLARS = [
+    (4.0, 3.0, 0.2, 0.2), (-5.0, 4.5, 0.25, 0.25), (6.5, -4.0, 0.3, 0.2), (-3.0, -5.0, 0.2, 0.3),
+    (8.0, 1.0, 0.15, 0.4), (2.0, -2.5, 0.2, 0.2), (-7.5, -1.0, 0.3, 0.3), (5.0, 6.0, 0.5, 0.15),
+    (7.0, 0.0, 0.2, 0.2), (6.0, 2.0, 0.15, 0.15), (9.0, -2.0, 0.25, 0.25),
+]
+
+LIVOX_DTYPE = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+                        ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1"), ("_pad", "u1")])
+assert LIVOX_DTYPE.itemsize == 20
+
+
+def pose_at(k, dt=0.1, v=0.5, w=0.2):
+    """Sensor pose (R, t) of scan k under a constant twist (forward v, yaw rate w), start (0,0,1)."""
+    th = w * dt * k
+    if abs(w) < 1e-12:
+        x, y = v * dt * k, 0.0
+    else:
+        x = v / w * np.sin(th)
+        y = v / w * (1.0 - np.cos(th))
+    c, s = np.cos(th), np.sin(th)
+    R = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    return R, np.array([x, y, 1.0])
+
+
+def _raycast(origin, dirs):
+    """Nearest hit range for unit directions `dirs` (n,3) from `origin` inside the room."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / dirs
+        # room: we are inside, so the exit distance is the min over axes of the positive slab distance
+        t1 = (ROOM_MIN - origin) * inv
+        t2 = (ROOM_MAX - origin) * inv
+        tfar = np.maximum(t1, t2)
+        rng = np.min(tfar, axis=1)
+        for (cx, cy, hx, hy) in PILLARS:
+            bmin = np.array([cx - hx, cy - hy, 0.0])
+            bmax = np.array([cx + hx, cy + hy, 3.0])
+            a = (bmin - origin) * inv
+            b = (bmax - origin) * inv
+            tn = np.max(np.minimum(a, b), axis=1)
+            tf = np.min(np.maximum(a, b), axis=1)
+            hit = (tn <= tf) & (tn > 0.0)
+            rng = np.where(hit & (tn < rng), tn, rng)
+    return rng
+
+
+def velo_scan(k, n_rings=16, n_az=1800, pitch0=-15.0, pitch_step=2.0, noise=0.01):
+    """VLP-16 style scan k in the sensor frame: float32 (n_rings*n_az, 4) = x,y,z,intensity."""
+    rng = np.random.default_rng(1234 + k)
+    R, t = pose_at(k)
+    az = -np.linspace(0.0, 2.0 * np.pi, n_az, endpoint=False) - 0.01  # clockwise like a Velodyne
+    pitch = np.deg2rad(pitch0 + pitch_step * np.arange(n_rings))
+    azg, pg = np.meshgrid(az, pitch, indexing="ij")  # azimuth-major
+    d = np.stack([np.cos(pg) * np.cos(azg), np.cos(pg) * np.sin(azg), np.sin(pg)], axis=-1).reshape(-1, 3)
+    r = _raycast(t, d @ R.T)
+    r = r + rng.normal(0.0, noise, size=r.shape)
+    pts = d * r[:, None]
+    inten = rng.uniform(0.0, 100.0, size=r.shape)
+    return np.concatenate([pts, inten[:, None]], axis=1).astype(np.float32)
+
+
+def livox_scan(k, n=24000, n_lines=6, noise=0.01):
+    """Livox Horizon style scan k (structured array LIVOX_DTYPE, 20 B records) in the sensor frame."""
+    rng = np.random.default_rng(91234 + k)
+    R, t = pose_at(k)
+    j = np.arange(n)
+    line = (j % n_lines).astype(np.uint8)
+    tt = j / float(n)
+    half_h = np.deg2rad(81.7 / 2.0) * 0.98
+    half_v = np.deg2rad(25.1 / 2.0) * 0.80
+    az = half_h * np.sin(2.0 * np.pi * 5.0 * tt + 0.3)
+    el = half_v * np.sin(2.0 * np.pi * 3.7 * tt + 1.1) + np.deg2rad(0.28) * (line.astype(np.float64) - 2.5)
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=-1)
+    r = _raycast(t, d @ R.T)
+    r = r + rng.normal(0.0, noise, size=r.shape)
+    pts = d * r[:, None]
+    out = np.zeros(n, dtype=LIVOX_DTYPE)
+    out["offset_time"] = np.round(np.linspace(0.0, 0.1, n) * 1e9).astype(np.uint32)
+    out["x"], out["y"], out["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    out["reflectivity"] = rng.integers(0, 256, size=n).astype(np.uint8)
+    out["line"] = line
+    return out
+
+
+def transform(T, xyz):
+    """Apply a 4x4 to (n,3) float64."""
+    return xyz @ T[:3, :3].T + T[:3, 3]
+
+
+def pose_matrix(k):
+    R, t = pose_at(k)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def grow_map(xyz, target, seed=7, jitter=0.05):
+    """Replicate / jitter a (m,3) float32 feature cloud up to `target` points."""
+    xyz = np.asarray(xyz, dtype=np.float32)
+    if len(xyz) >= target:
+        return xyz[:target].copy()
+    rng = np.random.default_rng(seed)
+    reps = int(np.ceil(target / len(xyz)))
+    out = [xyz]
+    for _ in range(reps - 1):
+        out.append(xyz + rng.normal(0.0, jitter, size=xyz.shape).astype(np.float32))
+    return np.concatenate(out, axis=0)[:target].astype(np.float32)

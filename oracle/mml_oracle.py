@@ -1,0 +1,264 @@
+"""ctypes binding of the CPU oracle (oracle/build/libmml_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (multi-modal-loam_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "libmml_oracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("feature.cpp", "estimate.cpp", "linalg.h", "mml_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class LineFactor(C.Structure):
+    _fields_ = [("point_ori", C.c_double * 3), ("p1", C.c_double * 3), ("p2", C.c_double * 3), ("error", C.c_double)]
+
+
+class PlaneFactor(C.Structure):
+    _fields_ = [("point_ori", C.c_double * 3), ("point_proj", C.c_double * 3), ("omega", C.c_double * 3),
+                ("error", C.c_double)]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("fixed_iterations", C.c_int), ("huber_delta", C.c_double),
+                ("plan_weight_tan", C.c_double)]
+
+
+class SolveSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("successful", C.c_int), ("initial_cost", C.c_double),
+                ("final_cost", C.c_double), ("termination", C.c_int)]
+
+
+LINE_DT = np.dtype([("point_ori", "<f8", 3), ("p1", "<f8", 3), ("p2", "<f8", 3), ("error", "<f8")])
+PLANE_DT = np.dtype([("point_ori", "<f8", 3), ("point_proj", "<f8", 3), ("omega", "<f8", 3), ("error", "<f8")])
+assert LINE_DT.itemsize == C.sizeof(LineFactor) and PLANE_DT.itemsize == C.sizeof(PlaneFactor)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.mmlo_kdtree_build.restype = C.c_void_p
+        _lib.mmlo_check_localizability.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def detect_feature_points(pts):
+    """pts (n,4) float32 -> (sharp idx, flat idx, flags)."""
+    pts = _f32(pts).reshape(-1, 4)
+    n = len(pts)
+    sharp = np.zeros(max(n, 1), np.int32)
+    flat = np.zeros(max(n, 1), np.int32)
+    flags = np.zeros(max(n, 1), np.int32)
+    ns, nf = C.c_int(0), C.c_int(0)
+    lib().mmlo_detect_feature_points(_p(pts), C.c_int(n), _p(sharp), C.byref(ns), _p(flat), C.byref(nf), _p(flags))
+    return sharp[:ns.value].copy(), flat[:nf.value].copy(), flags[:n].copy()
+
+
+def extract_velo(xyzi, n_rings=16, pitch0=-15.0, pitch_step=2.0, near=2.0, far=50.0):
+    xyzi = _f32(xyzi).reshape(-1, 4)
+    n = len(xyzi)
+    out = np.zeros((max(n, 1), 4), np.float32)
+    rel = np.zeros(max(n, 1), np.float32)
+    ring = np.zeros(max(n, 1), np.int32)
+    label = np.zeros(max(n, 1), np.int32)
+    nc, nsf = C.c_int(0), C.c_int(0)
+    m = lib().mmlo_extract_velo(_p(xyzi), C.c_int(n), C.c_int(n_rings), C.c_float(pitch0), C.c_float(pitch_step),
+                                C.c_float(near), C.c_float(far), _p(out), _p(rel), _p(ring), _p(label),
+                                C.byref(nc), C.byref(nsf))
+    return dict(xyzi=out[:m].copy(), reltime=rel[:m].copy(), ring=ring[:m].copy(), label=label[:m].copy(),
+                n_corner=nc.value, n_surf=nsf.value)
+
+
+def extract_livox(rec, n_lines=6, near=2.0, far=50.0):
+    rec = np.ascontiguousarray(rec)
+    assert rec.dtype.itemsize == 20
+    n = len(rec)
+    out = np.zeros((max(n, 1), 4), np.float32)
+    rel = np.zeros(max(n, 1), np.float32)
+    line = np.zeros(max(n, 1), np.int32)
+    label = np.zeros(max(n, 1), np.int32)
+    nc, nsf = C.c_int(0), C.c_int(0)
+    m = lib().mmlo_extract_livox(_p(rec), C.c_int(n), C.c_int(n_lines), C.c_float(near), C.c_float(far), _p(out),
+                                 _p(rel), _p(line), _p(label), C.byref(nc), C.byref(nsf))
+    return dict(xyzi=out[:m].copy(), reltime=rel[:m].copy(), ring=line[:m].copy(), label=label[:m].copy(),
+                n_corner=nc.value, n_surf=nsf.value)
+
+
+def undistort(xyz, s, dR, dt):
+    xyz = _f32(xyz).reshape(-1, 3).copy()
+    s = _f32(s)
+    lib().mmlo_undistort(_p(xyz), _p(s), C.c_int(len(xyz)), _p(_f64(dR).reshape(9)), _p(_f64(dt)))
+    return xyz
+
+
+def voxel_downsample(xyz, leaf):
+    xyz = _f32(xyz).reshape(-1, 3)
+    out = np.zeros((max(len(xyz), 1), 3), np.float32)
+    m = lib().mmlo_voxel_downsample(_p(xyz), C.c_int(len(xyz)), C.c_float(leaf), _p(out))
+    return out[:m].copy()
+
+
+class KdTree:
+    def __init__(self, xyz):
+        self.xyz = _f32(xyz).reshape(-1, 3)
+        self.h = C.c_void_p(lib().mmlo_kdtree_build(_p(self.xyz), C.c_int(len(self.xyz))))
+
+    def __del__(self):
+        try:
+            lib().mmlo_kdtree_free(self.h)
+        except Exception:
+            pass
+
+    def knn5(self, q):
+        q = _f32(q).reshape(-1, 3)
+        idx = np.zeros((len(q), 5), np.int32)
+        d2 = np.zeros((len(q), 5), np.float32)
+        for i in range(len(q)):
+            lib().mmlo_kdtree_knn5(self.h, _p(q[i]), _p(idx[i]), _p(d2[i]))
+        return idx, d2
+
+
+def bruteforce_knn5(xyz, q):
+    xyz = _f32(xyz).reshape(-1, 3)
+    q = _f32(q).reshape(-1, 3)
+    idx = np.zeros((len(q), 5), np.int32)
+    d2 = np.zeros((len(q), 5), np.float32)
+    for i in range(len(q)):
+        lib().mmlo_bruteforce_knn5(_p(xyz), C.c_int(len(xyz)), _p(q[i]), _p(idx[i]), _p(d2[i]))
+    return idx, d2
+
+
+def associate_lines(feat, tree, T_wl, thres):
+    feat = _f32(feat).reshape(-1, 3)
+    out = np.zeros(max(len(feat), 1), LINE_DT)
+    src = np.zeros(max(len(feat), 1), np.int32)
+    m = lib().mmlo_associate_lines(_p(feat), C.c_int(len(feat)), _p(tree.xyz), C.c_int(len(tree.xyz)), tree.h,
+                                   _p(_f64(T_wl).reshape(16)), C.c_double(thres), _p(out), _p(src))
+    return out[:m].copy(), src[:m].copy()
+
+
+def associate_planes(feat, tree, T_wl, thres):
+    feat = _f32(feat).reshape(-1, 3)
+    out = np.zeros(max(len(feat), 1), PLANE_DT)
+    src = np.zeros(max(len(feat), 1), np.int32)
+    m = lib().mmlo_associate_planes(_p(feat), C.c_int(len(feat)), _p(tree.xyz), C.c_int(len(tree.xyz)), tree.h,
+                                    _p(_f64(T_wl).reshape(16)), C.c_double(thres), _p(out), _p(src))
+    return out[:m].copy(), src[:m].copy()
+
+
+def check_localizability(pf):
+    pf = np.ascontiguousarray(pf, dtype=PLANE_DT)
+    return lib().mmlo_check_localizability(_p(pf), C.c_int(len(pf)))
+
+
+def line_residual(f, x, T_bl, jac=True):
+    f = np.ascontiguousarray(f, dtype=LINE_DT).reshape(1)
+    r = np.zeros(1)
+    J = np.zeros(6)
+    lib().mmlo_line_residual(_p(f), _p(_f64(x)), _p(_f64(T_bl).reshape(16)), _p(r), _p(J) if jac else None)
+    return r[0], J
+
+
+def plane_residual(f, x, T_bl, w_tan, jac=True):
+    f = np.ascontiguousarray(f, dtype=PLANE_DT).reshape(1)
+    r = np.zeros(3)
+    J = np.zeros((3, 6))
+    lib().mmlo_plane_residual(_p(f), _p(_f64(x)), _p(_f64(T_bl).reshape(16)), C.c_double(w_tan), _p(r),
+                              _p(J) if jac else None)
+    return r, J
+
+
+def linearize(lf, pf, x, T_bl, w_tan, huber):
+    lf = np.ascontiguousarray(lf, dtype=LINE_DT)
+    pf = np.ascontiguousarray(pf, dtype=PLANE_DT)
+    H = np.zeros((6, 6))
+    g = np.zeros(6)
+    c = C.c_double(0)
+    lib().mmlo_linearize(_p(lf), C.c_int(len(lf)), _p(pf), C.c_int(len(pf)), _p(_f64(x)),
+                         _p(_f64(T_bl).reshape(16)), C.c_double(w_tan), C.c_double(huber), _p(H), _p(g), C.byref(c))
+    return H, g, c.value
+
+
+def solve_window(lfs, pfs, x0, T_bl, max_iters=10, fixed=False, huber=0.1 / 1.5e-3, w_tan=0.0):
+    """lfs / pfs: lists (one per frame) of factor arrays. x0: (W,6). Returns x, summary dict, trace (iters,W,6)."""
+    W = len(lfs)
+    lf = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=LINE_DT) for a in lfs]) if W else np.zeros(0, LINE_DT))
+    pf = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=PLANE_DT) for a in pfs]) if W else np.zeros(0, PLANE_DT))
+    nl = np.array([len(a) for a in lfs], np.int32)
+    npl = np.array([len(a) for a in pfs], np.int32)
+    x = _f64(x0).reshape(W * 6).copy()
+    opts = SolveOpts(max_iters, 1 if fixed else 0, huber, w_tan)
+    summ = SolveSummary()
+    trace = np.zeros((max_iters, W, 6))
+    lib().mmlo_solve_window(_p(lf), _p(nl), _p(pf), _p(npl), C.c_int(W), _p(_f64(T_bl).reshape(16)), C.byref(opts),
+                            _p(x), C.byref(summ), _p(trace))
+    s = dict(iterations=summ.iterations, successful=summ.successful, initial_cost=summ.initial_cost,
+             final_cost=summ.final_cost, termination=summ.termination)
+    return x.reshape(W, 6), s, trace[:summ.iterations]
+
+
+def estimate_single(corner_feat, surf_feat, corner_map, surf_map, exTlb, P, Q, max_outer=5, inner_iters=10):
+    cf, sf = _f32(corner_feat).reshape(-1, 3), _f32(surf_feat).reshape(-1, 3)
+    cm, sm = _f32(corner_map).reshape(-1, 3), _f32(surf_map).reshape(-1, 3)
+    P = _f64(P).copy()
+    Q = _f64(Q).copy()
+    deg = C.c_int(0)
+    trace = np.zeros((max(max_outer, 1), 7))
+    it = lib().mmlo_estimate_single(_p(cf), C.c_int(len(cf)), _p(sf), C.c_int(len(sf)), _p(cm), C.c_int(len(cm)),
+                                    _p(sm), C.c_int(len(sm)), _p(_f64(exTlb).reshape(16)), _p(P), _p(Q),
+                                    C.c_int(max_outer), C.c_int(inner_iters), C.byref(deg), _p(trace))
+    return P, Q, it, bool(deg.value), trace[:it]
+
+
+def so3_exp(phi):
+    q = np.zeros(4)
+    lib().mmlo_so3_exp(_p(_f64(phi)), _p(q))
+    return q
+
+
+def so3_log(q):
+    phi = np.zeros(3)
+    lib().mmlo_so3_log(_p(_f64(q)), _p(phi))
+    return phi
+
+
+def eig3_sym(A):
+    ev = np.zeros(3)
+    V = np.zeros((3, 3))
+    lib().mmlo_eig3_sym(_p(_f64(A).reshape(9)), _p(ev), _p(V))
+    return ev, V
+
+
+def plane_fit5(A):
+    x = np.zeros(3)
+    lib().mmlo_plane_fit5(_p(_f64(A).reshape(15)), _p(x))
+    return x
