@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/s of the mm-loam scan-registration hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): fused VLP-16 (16 x 1800) + Livox Horizon (24 000) scans = 52 800 points,
+local map of 200 000 points, one step = feature extraction + undistortion + down-sampling + one 5-NN association
+pass + 10 trust-region (GN/dogleg) iterations for a batch of B scans whose raw points are already resident in
+HBM.  value = whole-job scans/s.  One process per GPU (torch.distributed / RCCL only for the barrier and the
+max-over-ranks clock; the path shards by scan, no data-path collective: "scaling": "weak").
+
+Adds to the JSON line:
+  roofline     -- dominant kernel, algorithmic bytes per launch / its mean launch time (HIP events on the library's
+                  own stream, recorded around every launch inside the timed region) against 8 TB/s HBM
+  cpu_baseline -- the CPU oracle (oracle/, a line-by-line port of the reference arithmetic; the reference binary
+                  cannot be built here) timed on this box's host cores over a bounded sample of the same scans
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+# Algorithmic bytes per unit for every stage (DESIGN.md section "Kernels"): N fused points, F features per scan.
+# The SURVEY 8(d) figures: extraction 20 B/pt in total, undistort 28 B/pt, association 112 B/feature,
+# linearisation 72 B/factor/iteration.  The extraction chain is split over its kernels by what each must move.
+STAGE_BYTES = {
+    "assign_velo":      lambda n_v, n_l, nf, it: 16 * n_v,            # read xyzi once
+    "assign_livox":     lambda n_v, n_l, nf, it: 20 * n_l,            # read the 20-byte records once
+    "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),    # read xyzi of every bucketed point
+    "partition_sort":   lambda n_v, n_l, nf, it: 8 * (n_v + n_l),     # read 2 keys per point
+    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),    # attr 2 B + 2 order idx 8 B + label 1 B
+    "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),     # write the 4 B label/line/time record
+    "undistort":        lambda n_v, n_l, nf, it: 28 * (n_v + n_l),
+    "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),    # label scan + xyz of labelled points
+    "associate":        lambda n_v, n_l, nf, it: 112 * nf,
+    "assoc_stats":      lambda n_v, n_l, nf, it: 0,
+    "solve":            lambda n_v, n_l, nf, it: 72 * nf * (it + 1),  # it iterations + the initial linearisation
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="scans per step per GPU")
+    ap.add_argument("--map-points", type=int, default=200000)
+    ap.add_argument("--gn-iters", type=int, default=10)
+    ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans cycled through the batch")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    M = importlib.import_module("multi-modal-loam_amd")
+    synth = importlib.import_module("multi-modal-loam_amd.synth")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    B = args.batch
+    ctx = M.Context(max_scans=B, device=local_rank, max_map_points=max(args.map_points, 1 << 16))
+    dev_name, cus, hbm = ctx.device_info()
+
+    # ---- synthetic inputs (same on every rank except the seed offset) ---------------------------------------
+    base = 100 + 1000 * rank
+    nd = max(1, min(args.distinct, B))
+    scans = [(synth.velo_scan(base + k, motion=True), synth.livox_scan(base + k, motion=True)) for k in range(nd)]
+    # map: features of 8 earlier scans of the same scene (extracted with the product path itself), moved to the
+    # world frame with the generating poses, replicated / jittered to --map-points
+    cm, sm = [], []
+    for k in range(8):
+        ctx.scan_upload(0, synth.velo_scan(k), synth.livox_scan(k))
+        ctx.extract(0, 1)
+        ctx.undistort(0, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+        ctx.downsample(0, 1)
+        T = synth.pose_matrix(k)
+        cm.append(synth.transform(T, ctx.features_download(0, 0).astype(np.float64)).astype(np.float32))
+        sm.append(synth.transform(T, ctx.features_download(0, 1).astype(np.float64)).astype(np.float32))
+    cm, sm = np.concatenate(cm), np.concatenate(sm)
+    n_corner_map = max(64, args.map_points // 10)
+    corner_map = synth.grow_map(cm, n_corner_map, seed=7)
+    surf_map = synth.grow_map(sm, args.map_points - n_corner_map, seed=8)
+    ctx.map_set_local(0, corner_map)
+    ctx.map_set_local(1, surf_map)
+
+    from scipy.spatial.transform import Rotation as Rsc
+    dR = np.zeros((B, 9))
+    dt = np.zeros((B, 3))
+    x0 = np.zeros((B, 6))
+    for s in range(B):
+        k = s % nd
+        ctx.scan_upload(s, scans[k][0], scans[k][1])
+        # true motion over the sweep (the scans are simulated with it) and a perturbed initial pose
+        mR, mt = synth.sweep_motion(base + k)
+        dR[s], dt[s] = mR.reshape(9), mt
+        Tp = synth.pose_matrix(base + k).copy()
+        Tp[:3, 3] += [0.03, -0.02, 0.01]
+        Tp[:3, :3] = Tp[:3, :3] @ Rsc.from_rotvec([0.002, -0.001, 0.004]).as_matrix()
+        x0[s] = np.concatenate([Tp[:3, 3], Rsc.from_matrix(Tp[:3, :3]).as_rotvec()])
+    ctx.synchronize()
+    exTlb = np.eye(4)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # pose sanity: the step must actually have registered the scans
+    gt_err = max(np.abs(x[s][:3] - synth.pose_matrix(base + (s % nd))[:3, 3]).max() for s in range(B))
+
+    # ---- roofline for the dominant kernel ---------------------------------------------------------------------
+    info = [ctx.scan_info(s) for s in range(min(B, nd))]
+    n_v = float(np.mean([i.n_velo for i in info])) * B
+    n_l = float(np.mean([i.n_points - i.n_velo for i in info])) * B
+    nf = float(np.mean([len(ctx.features_download(s, 0)) + len(ctx.features_download(s, 1)) for s in range(min(B, nd))])) * B
+    stage_ms = {k: v[0] / max(v[1], 1) for k, v in prof.items() if v[1] > 0}
+    dom = max(stage_ms, key=stage_ms.get)
+    alg_bytes = STAGE_BYTES.get(dom, lambda *a: 0)(n_v, n_l, nf, args.gn_iters)
+    achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    traffic = None
+    tr_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tr_file):
+        try:
+            traffic = json.load(open(tr_file)).get(dom)
+        except Exception:
+            traffic = None
+    bytes_per_scan = 48 * (n_v + n_l) / B + 112 * nf / B + 72 * nf / B * args.gn_iters
+    total_scans = world * B * args.steps
+    value = total_scans / elapsed
+
+    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) ----------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_scans != 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mml_oracle as O
+        O.build()
+        tc, ts = O.KdTree(corner_map), O.KdTree(surf_map)  # map build excluded on both sides
+        T_bl = np.eye(4)
+
+        def cpu_scan(k):
+            v, l = scans[k % nd]
+            ev, el = O.extract_velo(v), O.extract_livox(l)
+            xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+            rel = np.concatenate([ev["reltime"], el["reltime"]])
+            lab = np.concatenate([ev["label"], el["label"]])
+            und = O.undistort(xyz, rel, dR[k % B].reshape(3, 3), dt[k % B])
+            cf = O.voxel_downsample(und[lab == 1], 0.4)
+            sf = O.voxel_downsample(und[lab == 2], 0.2)
+            xx = x0[k % B]
+            Tw = np.eye(4)
+            Tw[:3, :3] = Rsc.from_rotvec(xx[3:]).as_matrix()
+            Tw[:3, 3] = xx[:3]
+            lf, _ = O.associate_lines(cf, tc, Tw, 25.0)
+            pf, _ = O.associate_planes(sf, ts, Tw, 25.0)
+            xs, _, _ = O.solve_window([lf], [pf], xx[None], T_bl, args.gn_iters, fixed=True)
+            return xs
+
+        t1 = time.perf_counter()
+        xs = cpu_scan(0)
+        one = time.perf_counter() - t1
+        n_cpu = args.cpu_scans if args.cpu_scans > 0 else int(max(8, min(512, 12.0 / max(one, 1e-3))))
+        t1 = time.perf_counter()
+        for k in range(n_cpu):
+            xs = cpu_scan(k)
+        cpu_t = time.perf_counter() - t1
+        cpu = {"value": n_cpu / cpu_t, "unit": "scans/s", "cores": 1, "kind": "port",
+               "sample": "%d fused 52.8k-pt scans (cycled over %d distinct), same map / poses / 10 fixed iterations, "
+                         "single thread of %d host cores, kd-tree build excluded" % (n_cpu, nd, os.cpu_count()),
+               "pose_diff_vs_gpu": float(np.abs(xs[0] - x[(n_cpu - 1) % B]).max())}
+
+    if rank == 0:
+        out = {
+            "metric": "scans/s (feature-extract+kNN+10 GN iters) on 16-ring x1800 + Livox 24k fused cloud",
+            "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: fused VLP-16 16x1800 + Livox Horizon 24000 scan (52800 pts), "
+                                   "local map %d pts, 1 association pass (thres_dist 25), %d GN iterations, W=1"
+                                   % (args.map_points, args.gn_iters),
+                       "scans_per_step_per_gpu": B, "distinct_scans": nd, "parallelism": "scan-sharded x%d" % world,
+                       "device": dev_name, "cus": cus, "features_per_scan": nf / B,
+                       "algorithmic_bytes_per_scan": bytes_per_scan, "max_pose_err_vs_gt_m": float(gt_err)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "avg_launch_ms": stage_ms[dom], "algorithmic_bytes_per_launch": alg_bytes,
+                         "whole_path_frac": bytes_per_scan * value / world / 1e9 / HBM_PEAK_GBPS,
+                         "stage_ms_per_launch": stage_ms},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,7 @@ def pose_at(k, dt=0.1, v=0.5, w=0.2):
 
 
 def _raycast(origin, dirs):
-    """Nearest hit range for unit directions `dirs` (n,3) from `origin` inside the room."""
+    """Nearest hit range for unit directions `dirs` (n,3) from `origin` ((3,) or (n,3)) inside the room."""
     with np.errstate(divide="ignore", invalid="ignore"):
         inv = 1.0 / dirs
         # room: we are inside, so the exit distance is the min over axes of the positive slab distance
@@ -57,25 +57,47 @@ def _raycast(origin, dirs):
     return rng
 
 
-def velo_scan(k, n_rings=16, n_az=1800, pitch0=-15.0, pitch_step=2.0, noise=0.01):
-    """VLP-16 style scan k in the sensor frame: float32 (n_rings*n_az, 4) = x,y,z,intensity."""
+def sweep_motion(k):
+    """(dR, dt): sensor motion over sweep k, start frame -> end frame (the arguments of RemoveLidarDistortion)."""
+    rel = np.linalg.inv(pose_matrix(k - 1)) @ pose_matrix(k)
+    return rel[:3, :3].copy(), rel[:3, 3].copy()
+
+
+def _sweep_rays(k, s, d, motion):
+    """World-frame origins and directions for sensor-frame unit rays d fired at in-sweep time s in [0,1]."""
+    if not motion:
+        R, t = pose_at(k)
+        return np.broadcast_to(t, d.shape), d @ R.T
+    from scipy.spatial.transform import Rotation as Rsc
+    T0 = pose_matrix(k - 1)
+    dR, dt = sweep_motion(k)
+    rv = Rsc.from_matrix(dR).as_rotvec()
+    Rs = Rsc.from_rotvec(s[:, None] * rv[None, :]).as_matrix()          # slerp(identity, dR, s)
+    Rw = np.einsum("ij,njk->nik", T0[:3, :3], Rs)
+    org = (s[:, None] * dt[None, :]) @ T0[:3, :3].T + T0[:3, 3]
+    return org, np.einsum("nij,nj->ni", Rw, d)
+
+
+def velo_scan(k, n_rings=16, n_az=1800, pitch0=-15.0, pitch_step=2.0, noise=0.01, motion=False):
+    """VLP-16 style scan k in the sensor frame: float32 (n_rings*n_az, 4) = x,y,z,intensity.
+    motion=True: every azimuth column is fired from the pose interpolated over the sweep (pose k-1 -> k)."""
     rng = np.random.default_rng(1234 + k)
-    R, t = pose_at(k)
     az = -np.linspace(0.0, 2.0 * np.pi, n_az, endpoint=False) - 0.01  # clockwise like a Velodyne
     pitch = np.deg2rad(pitch0 + pitch_step * np.arange(n_rings))
     azg, pg = np.meshgrid(az, pitch, indexing="ij")  # azimuth-major
     d = np.stack([np.cos(pg) * np.cos(azg), np.cos(pg) * np.sin(azg), np.sin(pg)], axis=-1).reshape(-1, 3)
-    r = _raycast(t, d @ R.T)
+    s = np.repeat(np.arange(n_az) / float(n_az), n_rings)
+    org, dw = _sweep_rays(k, s, d, motion)
+    r = _raycast(org, dw)
     r = r + rng.normal(0.0, noise, size=r.shape)
     pts = d * r[:, None]
     inten = rng.uniform(0.0, 100.0, size=r.shape)
     return np.concatenate([pts, inten[:, None]], axis=1).astype(np.float32)
 
 
-def livox_scan(k, n=24000, n_lines=6, noise=0.01):
+def livox_scan(k, n=24000, n_lines=6, noise=0.01, motion=False):
     """Livox Horizon style scan k (structured array LIVOX_DTYPE, 20 B records) in the sensor frame."""
     rng = np.random.default_rng(91234 + k)
-    R, t = pose_at(k)
     j = np.arange(n)
     line = (j % n_lines).astype(np.uint8)
     tt = j / float(n)
@@ -84,7 +106,8 @@ def livox_scan(k, n=24000, n_lines=6, noise=0.01):
     az = half_h * np.sin(2.0 * np.pi * 5.0 * tt + 0.3)
     el = half_v * np.sin(2.0 * np.pi * 3.7 * tt + 1.1) + np.deg2rad(0.28) * (line.astype(np.float64) - 2.5)
     d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=-1)
-    r = _raycast(t, d @ R.T)
+    org, dw = _sweep_rays(k, np.linspace(0.0, 1.0, n), d, motion)
+    r = _raycast(org, dw)
     r = r + rng.normal(0.0, noise, size=r.shape)
     pts = d * r[:, None]
     out = np.zeros(n, dtype=LIVOX_DTYPE)

@@ -1,0 +1,85 @@
+"""Shared fixtures.  `-m "not gpu"`: oracle vs golden vectors / independent numpy checks, host logic, C-ABI symbol
+export.  `-m gpu`: parity of the HIP path (through the C-ABI) against the oracle."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    import mml_oracle
+    mml_oracle.build()
+    mml_oracle.lib()
+    return mml_oracle
+
+
+@pytest.fixture(scope="session")
+def M():
+    return importlib.import_module("multi-modal-loam_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("multi-modal-loam_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def scene(O, synth):
+    """Maps built from scans 0..7 of the synthetic room + down-sampled feature stacks of scans 10..13."""
+    cm, sm = [], []
+    for k in range(8):
+        ev = O.extract_velo(synth.velo_scan(k))
+        el = O.extract_livox(synth.livox_scan(k))
+        xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+        lab = np.concatenate([ev["label"], el["label"]])
+        T = synth.pose_matrix(k)
+        cm.append(synth.transform(T, O.voxel_downsample(xyz[lab == 1], 0.4).astype(np.float64)).astype(np.float32))
+        sm.append(synth.transform(T, O.voxel_downsample(xyz[lab == 2], 0.2).astype(np.float64)).astype(np.float32))
+    cm = O.voxel_downsample(np.concatenate(cm), 0.4)
+    sm = O.voxel_downsample(np.concatenate(sm), 0.2)
+    frames = []
+    for k in range(10, 14):
+        v, l = synth.velo_scan(k), synth.livox_scan(k)
+        ev, el = O.extract_velo(v), O.extract_livox(l)
+        xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+        lab = np.concatenate([ev["label"], el["label"]])
+        T = synth.pose_matrix(k).copy()
+        frames.append(dict(k=k, velo=v, livox=l, xyz=xyz, label=lab, rel=np.concatenate([ev["reltime"], el["reltime"]]),
+                           ring=np.concatenate([ev["ring"], el["ring"]]), ev=ev, el=el,
+                           corner=O.voxel_downsample(xyz[lab == 1], 0.4), surf=O.voxel_downsample(xyz[lab == 2], 0.2),
+                           T_gt=T))
+    return dict(corner_map=cm, surf_map=sm, frames=frames)
+
+
+def perturbed(T, dt=(0.03, -0.02, 0.01), rotvec=(0.002, -0.001, 0.004)):
+    from scipy.spatial.transform import Rotation as Rsc
+    T2 = T.copy()
+    T2[:3, :3] = T[:3, :3] @ Rsc.from_rotvec(rotvec).as_matrix()
+    T2[:3, 3] = T[:3, 3] + np.asarray(dt)
+    return T2
+
+
+def pose_to_x(T):
+    from scipy.spatial.transform import Rotation as Rsc
+    return np.concatenate([T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_rotvec()])

