@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="scans per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU")
     ap.add_argument("--map-points", type=int, default=200000)
     ap.add_argument("--gn-iters", type=int, default=10)
     ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
@@ -83,10 +83,11 @@ def main():
     base = 100 + 1000 * rank
     nd = max(1, min(args.distinct, B))
     scans = [(synth.velo_scan(base + k, motion=True), synth.livox_scan(base + k, motion=True)) for k in range(nd)]
-    # map: features of 8 earlier scans of the same scene (extracted with the product path itself), moved to the
-    # world frame with the generating poses, replicated / jittered to --map-points
+    # map: features of the 8 scans preceding the batch (the role of the 50-keyframe local map, Estimator.cpp:1585-1643),
+    # extracted with the product path itself, moved to the world frame with the generating poses, then grown to
+    # --map-points by tiled replication (synth.grow_map)
     cm, sm = [], []
-    for k in range(8):
+    for k in range(base - 8, base):
         ctx.scan_upload(0, synth.velo_scan(k), synth.livox_scan(k))
         ctx.extract(0, 1)
         ctx.undistort(0, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))

