@@ -1,0 +1,215 @@
+// mmloam_adapter.hpp -- host-side mirror of the reference's C++ surface on top of the C-ABI (include/mmloam_hip.h).
+//
+// The reference exposes the hot path through two classes (there is no plugin / FFI layer):
+//   feature_extraction          mm-loam/src/unionFeatureExtract.cpp:143     detectFeaturePoints :341, getVeloFeature :1113,
+//                                                                            getHoriFeatureExtract :952
+//   Estimator                   mm-loam/include/Estimator/Estimator.h:25     EstimateLidarPose :211, Estimate :216,
+//                                                                            failureDetected :278
+//   RemoveLidarDistortion       mm-loam/src/unionPoseEstimation.cpp:402
+// This header re-creates those names, argument meanings and error behaviour (no exceptions on the data path, status
+// through flags; out-of-grid / NaN points are skipped silently exactly like the reference) over plain buffers.
+// PCL / Eigen / ROS are not available in the build image, so clouds are passed as mml::PointXYZINormal arrays with
+// pcl::PointXYZINormal's 48-byte layout and field reuse (normal_x = in-scan time, normal_y = ring / line,
+// normal_z = label, Estimator.cpp:992-1011); inside a catkin workspace the same struct aliases the PCL type, so the
+// adapter works on `cloud->points.data()` without copies of the caller's cloud.
+//
+// Header-only; link with -lmmloam_hip.  One adapter object per caller thread (the reference's Estimator is not
+// re-entrant either, Estimator.h:284-318).
+#ifndef MMLOAM_ADAPTER_HPP
+#define MMLOAM_ADAPTER_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <list>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mmloam_hip.h"
+
+namespace mml {
+
+// pcl::PointXYZINormal memory layout (48 bytes, 16-byte aligned): x,y,z,pad | normal_x,normal_y,normal_z,pad |
+// intensity, curvature, pad, pad
+struct alignas(16) PointXYZINormal {
+    float x, y, z, data_pad;
+    float normal_x, normal_y, normal_z, normal_pad;
+    float intensity, curvature, pad0, pad1;
+};
+static_assert(sizeof(PointXYZINormal) == 48, "must match pcl::PointXYZINormal");
+using PointCloud = std::vector<PointXYZINormal>;
+
+struct Matrix3d {  // row-major
+    double m[9];
+};
+struct Vector3d {
+    double v[3];
+};
+struct Matrix4d {  // row-major
+    double m[16];
+};
+struct Quaterniond {  // x, y, z, w
+    double x = 0, y = 0, z = 0, w = 1;
+};
+
+inline void check(mml_ctx* ctx, int rc, const char* what) {
+    if (rc != MML_OK) throw std::runtime_error(std::string(what) + ": " + (ctx ? mml_last_error(ctx) : "no context"));
+}
+
+// RAII owner of one mml_ctx, shared by the two adapter classes of a node pair living in one process
+class Context {
+   public:
+    explicit Context(int max_scans = 1, int device = 0, const mml_config* cfg = nullptr) {
+        mml_config c;
+        if (cfg)
+            c = *cfg;
+        else
+            mml_config_default(&c, max_scans);
+        int rc = mml_create(&c, device, &ctx_);
+        if (rc != MML_OK) throw std::runtime_error("mml_create failed (no HIP device? there is no CPU fallback)");
+    }
+    ~Context() { mml_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    mml_ctx* get() const { return ctx_; }
+
+   private:
+    mml_ctx* ctx_ = nullptr;
+};
+
+// ---- feature_extraction (unionFeatureExtract.cpp:143-1320), hot-path members only -----------------------------------
+class feature_extraction {
+   public:
+    explicit feature_extraction(Context& ctx) : ctx_(ctx) {}
+
+    // unionFeatureExtract.cpp:341-343.  `cloud` is one scan line; indices refer to it.
+    void detectFeaturePoints(const PointCloud& cloud, std::vector<int>& pointsLessSharp, std::vector<int>& pointsLessFlat) {
+        const int n = (int)cloud.size();
+        std::vector<float> pts(4 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            pts[4 * i] = cloud[i].x;
+            pts[4 * i + 1] = cloud[i].y;
+            pts[4 * i + 2] = cloud[i].z;
+            pts[4 * i + 3] = cloud[i].intensity;
+        }
+        std::vector<int> sharp(n ? n : 1), flat(n ? n : 1);
+        int ns = 0, nf = 0;
+        check(ctx_.get(), mml_detect_line(ctx_.get(), pts.data(), n, sharp.data(), &ns, flat.data(), &nf, nullptr),
+              "detectFeaturePoints");
+        pointsLessSharp.insert(pointsLessSharp.end(), sharp.begin(), sharp.begin() + ns);
+        pointsLessFlat.insert(pointsLessFlat.end(), flat.begin(), flat.begin() + nf);
+    }
+
+    // unionCloudHandler (:266-321) minus ROS (de)serialisation and the PCL GICP refresh: one union_cloud message in,
+    // the labelled fused cloud [velo_combine ; livox_combine] out, plus the four counters of union_cloud.msg:16-19.
+    // velo_xyzi: n_velo x (x,y,z,intensity); livox: msg->livox_time_aligned.points.data().
+    void unionCloud(const float* velo_xyzi, int n_velo, const mml_livox_point* livox, int n_livox,
+                    const float* livox_extrinsic /*row-major 4x4 or nullptr*/, PointCloud& fused, mml_scan_info& info,
+                    int slot = 0) {
+        mml_ctx* c = ctx_.get();
+        check(c, mml_scan_upload(c, slot, velo_xyzi, n_velo, livox, n_livox), "scan_upload");
+        check(c, mml_extract(c, slot, 1, livox_extrinsic), "extract");
+        check(c, mml_scan_info_get(c, slot, &info), "scan_info");
+        download(slot, info.n_points, fused);
+    }
+
+    // getVeloFeature (:1113-1117) and getHoriFeatureExtract (:952-956) on their own
+    void getVeloFeature(const float* velo_xyzi, int n, PointCloud& points_normal, mml_scan_info& info, int slot = 0) {
+        unionCloud(velo_xyzi, n, nullptr, 0, nullptr, points_normal, info, slot);
+    }
+    void getHoriFeatureExtract(const mml_livox_point* pts, int n, PointCloud& laserCloud, mml_scan_info& info, int slot = 0) {
+        unionCloud(nullptr, 0, pts, n, nullptr, laserCloud, info, slot);
+    }
+
+    void download(int slot, int n, PointCloud& out) {
+        std::vector<float> xyzi(4 * (size_t)(n ? n : 1)), rel(n ? n : 1);
+        std::vector<uint8_t> line(n ? n : 1), label(n ? n : 1);
+        check(ctx_.get(), mml_scan_download(ctx_.get(), slot, xyzi.data(), rel.data(), line.data(), label.data(), n ? n : 1),
+              "scan_download");
+        out.assign(n, PointXYZINormal{});
+        for (int i = 0; i < n; ++i) {
+            out[i].x = xyzi[4 * i];
+            out[i].y = xyzi[4 * i + 1];
+            out[i].z = xyzi[4 * i + 2];
+            out[i].data_pad = 1.f;
+            out[i].intensity = xyzi[4 * i + 3];
+            out[i].normal_x = rel[i];
+            out[i].normal_y = (float)line[i];
+            out[i].normal_z = (float)label[i];
+        }
+    }
+
+   private:
+    Context& ctx_;
+};
+
+// ---- RemoveLidarDistortion (unionPoseEstimation.cpp:402-403): in place on the slot's device-resident fused cloud ----
+inline void RemoveLidarDistortion(Context& ctx, int slot, const Matrix3d& dRlc, const Vector3d& dtlc) {
+    check(ctx.get(), mml_undistort(ctx.get(), slot, 1, dRlc.m, dtlc.v), "RemoveLidarDistortion");
+}
+
+// ---- Estimator (Estimator.h:25-343), hot-path members only ------------------------------------------------------------
+class Estimator {
+   public:
+    static const int SLIDEWINDOWSIZE = 5;  // Estimator.h:30
+
+    struct LidarFrame {  // Estimator.h:33-56; the cloud lives in scan slot `slot` of the context
+        int slot = 0;
+        Vector3d P{{0, 0, 0}};
+        Vector3d V{{0, 0, 0}};
+        Quaterniond Q;
+        Vector3d bg{{0, 0, 0}};
+        Vector3d ba{{0, 0, 0}};
+        double timeStamp = 0;
+        int lidarType = 0;
+    };
+
+    // Estimator(const float& filter_corner, const float& filter_surf) (Estimator.h:147): the leaf sizes are part of
+    // mml_config (leaf_corner / leaf_surf) and must match the context's.
+    Estimator(Context& ctx, float filter_corner, float filter_surf) : ctx_(ctx) {
+        (void)filter_corner;
+        (void)filter_surf;
+    }
+
+    // laserCloud{Corner,Surf}FromLocal (Estimator.cpp:1159-1167): replaces kdtree->setInputCloud
+    void setLocalMap(const float* corner_xyz, int n_corner, const float* surf_xyz, int n_surf) {
+        check(ctx_.get(), mml_map_set_local(ctx_.get(), 0, corner_xyz, n_corner), "map corner");
+        check(ctx_.get(), mml_map_set_local(ctx_.get(), 1, surf_xyz, n_surf), "map surf");
+        n_corner_map_ = n_corner;
+        n_surf_map_ = n_surf;
+    }
+
+    // EstimateLidarPose(std::list<LidarFrame>&, exTlb, gravity, lidarMode) (Estimator.h:211-214, Estimator.cpp:967-1140).
+    // Live 1-frame mode: every frame of the list is registered independently against the local map.
+    // Poses are updated in place; failureDetected() reports the degeneracy flag (:1139).
+    void EstimateLidarPose(std::list<LidarFrame>& lidarFrameList, const Matrix4d& exTlb, const Vector3d& gravity,
+                           int lidarMode) {
+        (void)gravity;
+        (void)lidarMode;
+        _fail_detected = false;
+        // gate of Estimator.cpp:1032-1035
+        if (!((n_corner_map_ > 0 && n_surf_map_ > 100))) return;
+        for (auto& f : lidarFrameList) {
+            check(ctx_.get(), mml_downsample(ctx_.get(), f.slot, 1), "downsample");
+            double Q[4] = {f.Q.x, f.Q.y, f.Q.z, f.Q.w};
+            mml_estimate_info info;
+            check(ctx_.get(), mml_estimate(ctx_.get(), f.slot, 1, exTlb.m, f.P.v, Q, 5, 10, &info), "Estimate");
+            f.Q.x = Q[0];
+            f.Q.y = Q[1];
+            f.Q.z = Q[2];
+            f.Q.w = Q[3];
+            if (info.is_degenerate) _fail_detected = true;
+        }
+    }
+
+    bool failureDetected() const { return _fail_detected; }  // Estimator.h:278
+
+   private:
+    Context& ctx_;
+    int n_corner_map_ = 0, n_surf_map_ = 0;
+    bool _fail_detected = false;
+};
+
+}  // namespace mml
+#endif
