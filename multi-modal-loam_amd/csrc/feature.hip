@@ -56,6 +56,8 @@ struct FeatParams {
     uint16_t* ln_attr;
     int* ln_ord_c;
     int* ln_ord_r;
+    unsigned* ln_rank;   // per point: rank by curvature | rank by reflect << 16, within its partition
+    int sel_cap;         // points per line the parallel select kernel keeps in LDS
     uint8_t* ln_flag;
     uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
     float4* cb_xyzi;
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(256) void k_partition_sort(FeatParams P) {
     }
     P.ln_ord_c[base + sp + rc] = i;
     P.ln_ord_r[base + sp + rr] = i;
+    P.ln_rank[base + i] = (unsigned)rc | ((unsigned)rr << 16);
 }
 
 // ---- a5 + a6 walk + a8 emit: one wavefront per scan line -------------------------------------------------------
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(64) void k_select(FeatParams P) {
     const int b = blockIdx.y + P.first;
     const int line = blockIdx.x;
     const int n = P.line_len[(size_t)b * P.L + line];
-    if (n <= 0) return;
+    if (n <= P.sel_cap) return;  // short lines are handled by k_select_par
     const int start = P.line_start[(size_t)b * P.L + line];
     const size_t base = (size_t)b * P.NT + start;
     const int lane = threadIdx.x;
@@ -753,6 +756,277 @@ __global__ __launch_bounds__(64) void k_select(FeatParams P) {
             }
         }
     }
+}
+
+
+// ---- a5 + a6 walk + a8 emit, parallel form: one 256-thread workgroup per scan line -----------------------------
+// The reference visits the points of a line in the order (partition, curvature rank) and greedily flags 3 / marks
+// neighbours 1 (:483-519); then per partition promotes to 2 / 300 (:521-539).  Written as data flow:
+//   * whether a candidate is picked depends only on the picked status of candidates with a LOWER visiting rank whose
+//     mark range covers it (|distance| <= 3): a DAG.  Rounds of "decide everything whose predecessors are decided"
+//     resolve it; flags written by :521-539 never feed back (they only touch the partition's own, already visited
+//     points).
+//   * the value a point holds when :521-539 reads it, the promotion itself (first flag-3 in curvature order unless a
+//     grazing/far pick came earlier, all far flag-3 and all grazing points; the first three reflect candidates in
+//     reflect order -> 300) and later overwrites by the next partition's marks are closed-form given the ranks.
+//   * the stride-1-or-4 walk of :543-650 is resolved per 64-point window for each of the 4 possible entry offsets,
+//     then chained across windows.
+// Results are bit-identical to the serial form (k_select, kept for lines longer than the LDS capacity).
+constexpr int SELP_THREADS = 256;
+enum : unsigned { I_RC_MASK = 0xffffu, I_PART_SHIFT = 16, I_GRANK_MASK = 0x3fffffu, I_A_SHIFT = 22, I_B_SHIFT = 24,
+                  I_CAND = 1u << 26, I_INPART = 1u << 27 };
+enum : unsigned char { ST_N = 0, ST_U = 1, ST_S = 2 };
+
+__device__ __forceinline__ bool covers(unsigned info_j, int d /* i - j */) {
+    const int a = (info_j >> I_A_SHIFT) & 3, bb = (info_j >> I_B_SHIFT) & 3;
+    return d > 0 ? d <= a : -d <= bb;
+}
+
+__global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.y + P.first;
+    const int line = blockIdx.x;
+    const int n = P.line_len[(size_t)b * P.L + line];
+    if (n <= 0 || n > P.sel_cap) return;
+    const int start = P.line_start[(size_t)b * P.L + line];
+    const size_t base = (size_t)b * P.NT + start;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint16_t* attr = P.ln_attr + base;
+    const unsigned* rank = P.ln_rank + base;
+
+    const int cap = P.sel_cap;
+    const int nwin = (cap + 63) / 64;
+    unsigned* info = reinterpret_cast<unsigned*>(smem);                                  // cap
+    unsigned long long* wmask = reinterpret_cast<unsigned long long*>(info + cap);       // nwin
+    unsigned long long* wvis = wmask + nwin;                                             // nwin * 4
+    unsigned char* st = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);               // cap
+    unsigned char* flg = st + cap;                                                       // cap
+    unsigned char* aux = flg + cap;                                                      // cap
+    unsigned char* wexit = aux + cap;                                                    // nwin * 4
+    unsigned char* wsel = wexit + 4 * nwin;                                              // nwin
+    __shared__ unsigned s_pm[50][3];   // three smallest reflect ranks among the reflect candidates of a partition
+    __shared__ unsigned s_minE[50], s_minG[50];
+
+    int T = 2;
+    if (n >= 11) T = (attr[n - 6] & A_W2) ? 2 : 3;
+    const int range = n - 11;
+
+    // ---- phase 0: per-point record --------------------------------------------------------------------------
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        unsigned inf = 0;
+        unsigned char s0 = ST_N;
+        if (range >= 1 && i >= 5 && i <= n - 7) {
+            const unsigned at = attr[i];
+            int j = (int)(((long long)(i - 5) * 50) / range);
+            if (j > 49) j = 49;
+            int sp, ep;
+            partition_bounds(n, j, sp, ep);
+            while (i > ep) {
+                ++j;
+                partition_bounds(n, j, sp, ep);
+            }
+            while (i < sp) {
+                --j;
+                partition_bounds(n, j, sp, ep);
+            }
+            const unsigned rk = rank[i];
+            const unsigned a = min((int)((at >> A_A3_SHIFT) & 3u), T), bb = min((int)((at >> A_B3_SHIFT) & 3u), T);
+            inf = (rk & I_RC_MASK) | ((unsigned)j << I_PART_SHIFT) | (a << I_A_SHIFT) | (bb << I_B_SHIFT) | I_INPART;
+            if (at & A_CAND3) {
+                inf |= I_CAND;
+                s0 = ST_U;
+            }
+        }
+        info[i] = inf;
+        st[i] = s0;
+    }
+    for (int t = tid; t < 50 * 3; t += SELP_THREADS) (&s_pm[0][0])[t] = 0xffffffffu;
+    for (int t = tid; t < 50; t += SELP_THREADS) {
+        s_minE[t] = 0xffffffffu;
+        s_minG[t] = 0xffffffffu;
+    }
+    __syncthreads();
+
+    // ---- phase 1: which neighbours can suppress me (static), then dependency rounds ----------------------------
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        unsigned m = 0;
+        const unsigned me = info[i];
+        if (me & I_CAND) {
+            const unsigned gr = me & I_GRANK_MASK;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
+                const int j = i + d;
+                if (j < 0 || j >= n) continue;
+                const unsigned o = info[j];
+                if ((o & I_CAND) && (o & I_GRANK_MASK) < gr && covers(o, -d)) m |= 1u << q;
+            }
+        }
+        aux[i] = (unsigned char)m;
+    }
+    __syncthreads();
+    for (;;) {
+        int undecided = 0;
+        for (int i = tid; i < n; i += SELP_THREADS) {
+            if (st[i] != ST_U) continue;
+            const unsigned m = aux[i];
+            bool anyS = false, anyU = false;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (!(m & (1u << q))) continue;
+                const int d = q < 3 ? q - 3 : q - 2;
+                const unsigned char s = st[i + d];
+                anyS |= (s == ST_S);
+                anyU |= (s == ST_U);
+            }
+            if (anyS)
+                st[i] = ST_N;
+            else if (!anyU)
+                st[i] = ST_S;
+            else
+                undecided = 1;
+        }
+        if (!__syncthreads_or(undecided)) break;
+    }
+
+    // ---- phase 2: value held when :521-539 runs (f3a) + "a later partition marks me" ------------------------------
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        const unsigned me = info[i];
+        const bool sel = st[i] == ST_S;
+        const int mypart = (me & I_INPART) ? (int)((me >> I_PART_SHIFT) & 63u) : (i < 5 ? -1 : 64);
+        const unsigned gr = me & I_GRANK_MASK;
+        bool covL = false, covLater = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int d = q < 3 ? q - 3 : q - 2;
+            const int j = i + d;
+            if (j < 0 || j >= n) continue;
+            if (st[j] != ST_S) continue;
+            const unsigned o = info[j];
+            if (!covers(o, -d)) continue;
+            const int pj = (int)((o >> I_PART_SHIFT) & 63u);
+            if (pj > mypart)
+                covLater = true;
+            else if (!sel || (o & I_GRANK_MASK) > gr)
+                covL = true;
+        }
+        const unsigned f3a = covL ? 1u : (sel ? 3u : 0u);
+        flg[i] = (unsigned char)(f3a | (covLater ? 4u : 0u));
+    }
+    __syncthreads();
+
+    // ---- phase 3: :521-539 in closed form ---------------------------------------------------------------------------
+    // (a) the three smallest reflect ranks among reflect candidates, per partition
+    for (int round = 0; round < 3; ++round) {
+        for (int i = tid; i < n; i += SELP_THREADS) {
+            const unsigned me = info[i];
+            if (!(me & I_INPART) || !(attr[i] & A_REFL)) continue;
+            const int j = (me >> I_PART_SHIFT) & 63u;
+            const unsigned rr = rank[i] >> 16;
+            if (round > 0 && rr <= s_pm[j][round - 1]) continue;
+            atomicMin(&s_pm[j][round], rr);
+        }
+        __syncthreads();
+    }
+    // (b) eff3 / G bits, min curvature rank of each class per partition
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        const unsigned me = info[i];
+        unsigned char bits = 0;
+        if (me & I_INPART) {
+            const unsigned at = attr[i];
+            const int j = (me >> I_PART_SHIFT) & 63u;
+            const unsigned rc = me & I_RC_MASK, rr = rank[i] >> 16;
+            const bool inB = (at & A_REFL) && rr <= s_pm[j][2];
+            const bool eff3 = ((flg[i] & 3u) == 3u) && !(inB && rr < rc);
+            const bool G = (at & A_ANGLE) || (eff3 && (at & A_FAR));
+            bits = (inB ? 1 : 0) | (eff3 ? 2 : 0) | (G ? 4 : 0);
+            if (eff3) atomicMin(&s_minE[j], rc);
+            if (G) atomicMin(&s_minG[j], rc);
+        }
+        aux[i] = bits;
+    }
+    __syncthreads();
+    // (c) final value of the serial part
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        const unsigned me = info[i];
+        unsigned f = flg[i] & 3u;
+        if (me & I_INPART) {
+            const unsigned at = attr[i];
+            const int j = (me >> I_PART_SHIFT) & 63u;
+            const unsigned rc = me & I_RC_MASK, rr = rank[i] >> 16;
+            const unsigned char bits = aux[i];
+            const bool inB = bits & 1, eff3 = bits & 2, G = bits & 4;
+            const bool first = eff3 && rc == s_minE[j] && !(s_minG[j] < s_minE[j]);
+            const bool picked = G || first;
+            if (inB)
+                f = (picked && (at & A_ANGLE) && rr < rc) ? 2u : 4u;
+            else if (picked)
+                f = 2u;
+        }
+        if (flg[i] & 4u) f = 1u;  // marked by a point of a later partition (:503,516 of the next partitions)
+        st[i] = (unsigned char)f;  // st[] now holds the serial-part flag (4 encodes 300)
+    }
+    __syncthreads();
+
+    // ---- phase 4: stride walk of :543-650, window transfer functions ------------------------------------------------
+    const int nw = (n + 63) / 64;
+    for (int w0 = (tid >> 6) * 64; w0 < n; w0 += SELP_THREADS) {
+        const int i = w0 + lane;
+        const unsigned long long m = __ballot(i < n && (attr[i] & A_RFLAT));
+        if (lane == 0) wmask[w0 >> 6] = m;
+    }
+    __syncthreads();
+    for (int t = tid; t < nw * 4; t += SELP_THREADS) {
+        const int w = t >> 2, e = t & 3;
+        const unsigned long long m = wmask[w];
+        unsigned long long vis = 0;
+        int pos = (w == 0) ? 5 : e;  // the walk starts at index 5
+        while (pos < 64) {
+            vis |= 1ull << pos;
+            pos += ((m >> pos) & 1ull) ? 4 : 1;
+        }
+        wvis[t] = vis;
+        wexit[t] = (unsigned char)(pos - 64);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int e = 0;
+        for (int w = 0; w < nw; ++w) {
+            wsel[w] = (unsigned char)e;
+            e = wexit[w * 4 + e];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 5: overrides (150, 100/101), emit, label scatter -------------------------------------------------------
+    const int* gidx = P.ln_gidx + base;
+    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        const unsigned at = attr[i];
+        int f = st[i];
+        if (f == 4) f = 300;
+        const bool inner = i >= 5 && i < n - 5;
+        if (inner) {
+            const int w = i >> 6;
+            const bool visited = (wvis[w * 4 + wsel[w]] >> (i & 63)) & 1ull;
+            if (visited && (at & A_LFLAT) && (at & A_RFLAT) && (at & A_C150)) f = 150;
+            const unsigned f5 = (at >> A_F5_SHIFT) & 3u;
+            if (f5 == 1) f = 100;
+            if (f5 == 2) f = 101;
+        }
+        if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
+        if (inner && !(at & A_NEAR)) {
+            if (f == 2)
+                cblab[gidx[i]] = 2;
+            else if (f == 100 || f == 150)
+                cblab[gidx[i]] = 1;
+        }
+    }
+}
+
+static size_t select_par_lds(int cap) {
+    const size_t nwin = (cap + 63) / 64;
+    return (size_t)cap * 4 + nwin * 8 + nwin * 4 * 8 + (size_t)cap * 3 + nwin * 4 + nwin + 64;
 }
 
 // ---- a8: removeNearFarPoints / removeNearPointCloud + compaction into the fused cloud ---------------------------
@@ -899,6 +1173,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.ln_attr = ctx->ln_attr;
     P.ln_ord_c = ctx->ln_ord_c;
     P.ln_ord_r = ctx->ln_ord_r;
+    P.ln_rank = ctx->ln_rank;
+    P.sel_cap = ctx->sel_cap;
     P.ln_flag = ctx->ln_flag;
     P.ln_final = nullptr;
     P.cb_xyzi = ctx->cb_xyzi;
@@ -940,6 +1216,10 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "select");
+        hipLaunchKernelGGL(k_select_par, dim3(ctx->L, count), dim3(SELP_THREADS), select_par_lds(ctx->sel_cap), s, P);
+    }
+    if (ctx->max_line_may_exceed_cap) {  // serial wavefront-per-line form for lines that do not fit the LDS budget
+        MmlStageScope t(ctx, "select_long");
         hipLaunchKernelGGL(k_select, dim3(ctx->L, count), dim3(64), 0, s, P);
     }
     {
@@ -962,7 +1242,23 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_partition_sort, dim3(pblocks, 1), dim3(256), 0, s, P);
     }
+    hipLaunchKernelGGL(k_select_par, dim3(1, 1), dim3(SELP_THREADS), select_par_lds(ctx->sel_cap), s, P);
     hipLaunchKernelGGL(k_select, dim3(1, 1), dim3(64), 0, s, P);
     MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+int mml_feature_init(mml_ctx* ctx) {
+    // LDS budget of k_select_par: twice the nominal ring length / 1.5x the nominal Livox line length, <= 12288 points
+    int cap = 2 * (ctx->NV / (ctx->cfg.n_rings > 0 ? ctx->cfg.n_rings : 1));
+    int capl = (5 * (ctx->NL / (ctx->cfg.n_livox_lines > 0 ? ctx->cfg.n_livox_lines : 1))) / 4;
+    if (capl > cap) cap = capl;
+    if (cap < 1024) cap = 1024;
+    if (cap > 12288) cap = 12288;
+    cap = (cap + 63) & ~63;
+    ctx->sel_cap = cap;
+    ctx->max_line_may_exceed_cap = (ctx->NV > cap) || (ctx->NL > cap);
+    MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_par), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)select_par_lds(cap)));
     return MML_OK;
 }

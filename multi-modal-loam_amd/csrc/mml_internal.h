@@ -76,6 +76,9 @@ struct mml_ctx {
     uint16_t* ln_attr = nullptr;
     int* ln_ord_c = nullptr;
     int* ln_ord_r = nullptr;
+    unsigned* ln_rank = nullptr;
+    int sel_cap = 0;
+    bool max_line_may_exceed_cap = true;
     uint8_t* ln_flag = nullptr;
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
@@ -176,6 +179,7 @@ int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_
 int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
                      bool want_trace);
+int mml_feature_init(mml_ctx* ctx);
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan,
                          double huber, double* d_record);
