@@ -34,8 +34,7 @@ STAGE_BYTES = {
     "assign_velo":      lambda n_v, n_l, nf, it: 16 * n_v,            # read xyzi once
     "assign_livox":     lambda n_v, n_l, nf, it: 20 * n_l,            # read the 20-byte records once
     "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),    # read xyzi of every bucketed point
-    "partition_sort":   lambda n_v, n_l, nf, it: 8 * (n_v + n_l),     # read 2 keys per point
-    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),    # attr 2 B + 2 order idx 8 B + label 1 B
+    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),    # attr 2 B + 2 order keys 8 B + label 1 B
     "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),     # write the 4 B label/line/time record
     "undistort":        lambda n_v, n_l, nf, it: 28 * (n_v + n_l),
     "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),    # label scan + xyz of labelled points
@@ -95,7 +94,9 @@ def main():
         T = synth.pose_matrix(k)
         cm.append(synth.transform(T, ctx.features_download(0, 0).astype(np.float64)).astype(np.float32))
         sm.append(synth.transform(T, ctx.features_download(0, 1).astype(np.float64)).astype(np.float32))
-    cm, sm = np.concatenate(cm), np.concatenate(sm)
+    # the reference voxel-filters the merged local map on every update (Estimator.cpp:1630-1637)
+    cm = synth.voxel_filter(np.concatenate(cm), ctx.cfg.leaf_corner)
+    sm = synth.voxel_filter(np.concatenate(sm), ctx.cfg.leaf_surf)
     n_corner_map = max(64, args.map_points // 10)
     corner_map = synth.grow_map(cm, n_corner_map, seed=7)
     surf_map = synth.grow_map(sm, args.map_points - n_corner_map, seed=8)

@@ -7,12 +7,11 @@
 //   k_assign_velo / k_assign_livox : ring / line id, in-scan time, order-preserving bucketing by line
 //   k_stencil                      : one point per lane: curvature / depth / reflect stencil + every
 //                                    per-point predicate of the flag state machine packed in 16 bits
-//   k_partition_sort               : stable rank sort of each of the 50 partitions per line
-//   k_select                       : one wavefront per scan line: the order-dependent part of the state
-//                                    machine (flags 3/1/2/300, stride walk for 150) + label scatter
+//   k_select                       : one workgroup per scan line: the order-dependent part of the state machine
+//                                    (flags 3/1/2/300 by dependency rounds on order keys -- the partition sorts
+//                                    are never materialised -- stride walk for 150) + label scatter
 //   k_crop_compact                 : near/far crop, order-preserving compaction into the fused cloud
-// Everything that is order-independent was hoisted out of the serial walk; what remains per line is a chain
-// of LDS byte reads/writes executed by one wave with wave-uniform control flow.
+// Everything that is order-independent was hoisted into per-point predicates (k_stencil).
 //
 // Floating point: compiled with -ffp-contract=off; float expressions are written exactly as in the reference
 // (left-to-right, float), double expressions follow Eigen's (x0+x1)+x2 reduction order.  libm calls on
@@ -54,11 +53,9 @@ struct FeatParams {
     float* ln_curv;
     float* ln_refl;
     uint16_t* ln_attr;
-    int* ln_ord_c;
-    int* ln_ord_r;
-    unsigned* ln_rank;   // per point: rank by curvature | rank by reflect << 16, within its partition
-    int sel_cap;         // points per line the parallel select kernel keeps in LDS
-    uint8_t* ln_flag;
+    unsigned* sel_scratch;  // global-memory scratch for lines longer than sel_cap: 4 x B*NT unsigned
+    int sel_cap;            // points per line k_select keeps in LDS
+    int B;
     uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
     float4* cb_xyzi;
     float* cb_rel;
@@ -587,233 +584,71 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     P.ln_attr[base + i] = (uint16_t)attr;
 }
 
-// ---- a4: the two stable insertion sorts of every partition (:453-479) as a rank sort ------------------------
-// rank(i) = #{j in partition : key[j] < key[i] or (key[j] == key[i] and j < i)}; strict `<` in the reference
-// keeps ties in index order, which is exactly this total order.
+// ---- a4 + a5 + a6 walk + a8 emit: one 256-thread workgroup per scan line ---------------------------------------
+// Partition bounds of :454-455.
 __device__ __forceinline__ void partition_bounds(int n, int j, int& sp, int& ep) {
     const int scanStartInd = 5, scanEndInd = n - 6;
     sp = scanStartInd + (scanEndInd - scanStartInd) * j / 50;
     ep = scanStartInd + (scanEndInd - scanStartInd) * (j + 1) / 50 - 1;
 }
 
-__global__ __launch_bounds__(256) void k_partition_sort(FeatParams P) {
-    const int b = blockIdx.y + P.first;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P.NT) return;
-    int line, i, n, start;
-    if (!find_line(P, b, p, line, i, n, start)) return;
-    if (n < 12 || i < 5 || i > n - 7) return;
-    const size_t base = (size_t)b * P.NT + start;
-    // partition of i: sp_j <= i <= ep_j
-    const int range = n - 11;
-    int j = (int)(((long long)(i - 5) * 50) / range);
-    if (j > 49) j = 49;
-    int sp, ep;
-    partition_bounds(n, j, sp, ep);
-    while (i > ep) {
-        ++j;
-        partition_bounds(n, j, sp, ep);
-    }
-    while (i < sp) {
-        --j;
-        partition_bounds(n, j, sp, ep);
-    }
-    const float* curv = P.ln_curv + base;
-    const float* refl = P.ln_refl + base;
-    const float kc = curv[i], kr = refl[i];
-    int rc = 0, rr = 0;
-    for (int q = sp; q <= ep; ++q) {
-        float c = curv[q], r = refl[q];
-        rc += (c < kc) || (c == kc && q < i);
-        rr += (r < kr) || (r == kr && q < i);
-    }
-    P.ln_ord_c[base + sp + rc] = i;
-    P.ln_ord_r[base + sp + rr] = i;
-    P.ln_rank[base + i] = (unsigned)rc | ((unsigned)rr << 16);
-}
-
-// ---- a5 + a6 walk + a8 emit: one wavefront per scan line -------------------------------------------------------
-constexpr int SELECT_LDS_FLAGS = 16384;
-
-__global__ __launch_bounds__(64) void k_select(FeatParams P) {
-    __shared__ unsigned char s_flags[SELECT_LDS_FLAGS];
-    const int b = blockIdx.y + P.first;
-    const int line = blockIdx.x;
-    const int n = P.line_len[(size_t)b * P.L + line];
-    if (n <= P.sel_cap) return;  // short lines are handled by k_select_par
-    const int start = P.line_start[(size_t)b * P.L + line];
-    const size_t base = (size_t)b * P.NT + start;
-    const int lane = threadIdx.x;
-    const uint16_t* attr = P.ln_attr + base;
-    const int* ord_c = P.ln_ord_c + base;
-    const int* ord_r = P.ln_ord_r + base;
-    // flags live in LDS when the line fits, else in the global scratch (flat pointer, same code path)
-    unsigned char* flags = (n <= SELECT_LDS_FLAGS) ? s_flags : (P.ln_flag + base);
-    for (int i = lane; i < n; i += 64) flags[i] = 0;  // CloudFeatureFlag zero-initialised (convention)
-    __syncthreads();
-
-    // thNumCurvSize as the last stencil iteration (i = n-6) left it (:492,505 read it after loop :407)
-    int T = 2;
-    if (n >= 11) T = (attr[n - 6] & A_W2) ? 2 : 3;
-
-    for (int j = 0; j < 50; ++j) {
-        int sp, ep;
-        partition_bounds(n, j, sp, ep);
-        const int m = ep - sp + 1;
-        if (m <= 0) continue;
-        // ---- :483-519: ascending curvature, flag 3 + neighbour suppression ----
-        for (int c0 = 0; c0 < m; c0 += 64) {
-            const int k = c0 + lane;
-            int ind = 0;
-            unsigned att = 0;
-            if (k < m) {
-                ind = ord_c[sp + k];
-                att = attr[ind];
-            }
-            const int cnt = min(64, m - c0);
-            for (int kk = 0; kk < cnt; ++kk) {
-                const int indu = __builtin_amdgcn_readlane(ind, kk);
-                const unsigned au = __builtin_amdgcn_readlane(att, kk);
-                if (!(au & A_CAND3)) continue;
-                if (flags[indu] != 0) continue;
-                const int a = min((int)((au >> A_A3_SHIFT) & 3u), T);
-                const int bb = min((int)((au >> A_B3_SHIFT) & 3u), T);
-                const int off = lane - 3;
-                if (lane < 7) {
-                    if (off == 0)
-                        flags[indu] = 3;
-                    else if (off > 0 && off <= a)
-                        flags[indu + off] = 1;
-                    else if (off < 0 && -off <= bb)
-                        flags[indu + off] = 1;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            }
-        }
-        // ---- :521-539: promote to flag 2 / reflect corners to flag 300 (encoded 4) ----
-        int smallestPickedNum = 1, sharpestPickedNum = 1;
-        for (int c0 = 0; c0 < m; c0 += 64) {
-            const int k = c0 + lane;
-            int ind = 0, idx = 0;
-            unsigned att = 0, atr = 0;
-            if (k < m) {
-                ind = ord_c[sp + k];
-                att = attr[ind];
-                idx = ord_r[sp + k];
-                atr = attr[idx];
-            }
-            const int cnt = min(64, m - c0);
-            for (int kk = 0; kk < cnt; ++kk) {
-                const int indu = __builtin_amdgcn_readlane(ind, kk);
-                const unsigned au = __builtin_amdgcn_readlane(att, kk);
-                const int idxu = __builtin_amdgcn_readlane(idx, kk);
-                const unsigned aru = __builtin_amdgcn_readlane(atr, kk);
-                const unsigned char f = flags[indu];
-                if (((f == 3) && (smallestPickedNum <= 1)) || ((f == 3) && (au & A_FAR)) || (au & A_ANGLE)) {
-                    smallestPickedNum++;
-                    if (lane == 0) flags[indu] = 2;
-                }
-                if ((aru & A_REFL) && sharpestPickedNum <= 3) {
-                    sharpestPickedNum++;
-                    if (lane == 0) flags[idxu] = 4;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- :543-650 stride walk (stride 4 after a flat right half-window) + :651-806 + :818-842 + label scatter ----
-    const int* gidx = P.ln_gidx + base;
-    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
-    int pos = 5;
-    for (int w0 = 0; w0 < n; w0 += 64) {
-        const int i = w0 + lane;
-        const unsigned at = (i < n) ? attr[i] : 0u;
-        const unsigned long long rmask = __ballot((at & A_RFLAT) != 0);
-        unsigned long long vis = 0ull;
-        while (pos < w0 + 64 && pos < n - 5) {
-            const int o = pos - w0;
-            vis |= 1ull << o;
-            pos += ((rmask >> o) & 1ull) ? 4 : 1;
-        }
-        if (i < n) {
-            int f = flags[i];
-            if (f == 4) f = 300;
-            const bool inner = i >= 5 && i < n - 5;
-            if (inner) {
-                if (((vis >> lane) & 1ull) && (at & A_LFLAT) && (at & A_RFLAT) && (at & A_C150)) f = 150;
-                const unsigned f5 = (at >> A_F5_SHIFT) & 3u;
-                if (f5 == 1) f = 100;
-                if (f5 == 2) f = 101;
-            }
-            if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
-            if (inner && !(at & A_NEAR)) {
-                if (f == 2)
-                    cblab[gidx[i]] = 2;
-                else if (f == 100 || f == 150)
-                    cblab[gidx[i]] = 1;
-            }
-        }
-    }
-}
-
-
-// ---- a5 + a6 walk + a8 emit, parallel form: one 256-thread workgroup per scan line -----------------------------
-// The reference visits the points of a line in the order (partition, curvature rank) and greedily flags 3 / marks
-// neighbours 1 (:483-519); then per partition promotes to 2 / 300 (:521-539).  Written as data flow:
-//   * whether a candidate is picked depends only on the picked status of candidates with a LOWER visiting rank whose
-//     mark range covers it (|distance| <= 3): a DAG.  Rounds of "decide everything whose predecessors are decided"
-//     resolve it; flags written by :521-539 never feed back (they only touch the partition's own, already visited
-//     points).
-//   * the value a point holds when :521-539 reads it, the promotion itself (first flag-3 in curvature order unless a
-//     grazing/far pick came earlier, all far flag-3 and all grazing points; the first three reflect candidates in
-//     reflect order -> 300) and later overwrites by the next partition's marks are closed-form given the ranks.
+// The reference sorts every partition twice with a stable insertion sort (strict `<`, :453-479) and then visits the
+// points of a line in the order (partition, curvature rank): flag 3 + neighbour marks (:483-519), then per partition
+// the promotion to 2 / 300 (:521-539).  Nothing downstream needs the sorted arrays themselves, only ORDER
+// COMPARISONS, so the sort is never materialised: the visiting order of point i is the key
+// (partition(i), bits(curvature[i]), i) -- curvature is a non-negative float, so its bit pattern orders like the
+// value and the index breaks ties exactly as the stable sort does; the reflect order uses the usual sign-flipped
+// bit pattern of diffR.  Written as data flow:
+//   * whether a candidate is picked depends only on the picked status of candidates with a LOWER visiting key whose
+//     mark range covers it (|distance| <= 3): a DAG, resolved by rounds of "decide everything whose predecessors
+//     are decided".  Flags written by :521-539 never feed back (they only touch already visited points).
+//   * the value a point holds when :521-539 reads it, the promotion (first flag-3 in curvature order unless a grazing
+//     / far pick came earlier, all far flag-3 and all grazing points; the first three reflect candidates in reflect
+//     order -> 300) and later overwrites by the next partition's marks are closed-form given the keys; the only
+//     place two different orders are compared (`300` written before or after the point's own visit) is resolved by
+//     counting ranks on demand for the <= 3 reflect picks of a partition.
 //   * the stride-1-or-4 walk of :543-650 is resolved per 64-point window for each of the 4 possible entry offsets,
 //     then chained across windows.
-// Results are bit-identical to the serial form (k_select, kept for lines longer than the LDS capacity).
+// Bit-identical to the serial form (checked against the oracle on every test line).  Lines that do not fit the LDS
+// budget run the same code on a global-memory scratch.
 constexpr int SELP_THREADS = 256;
-enum : unsigned { I_RC_MASK = 0xffffu, I_PART_SHIFT = 16, I_GRANK_MASK = 0x3fffffu, I_A_SHIFT = 22, I_B_SHIFT = 24,
-                  I_CAND = 1u << 26, I_INPART = 1u << 27 };
+enum : unsigned { I_PART_MASK = 63u, I_A_SHIFT = 6, I_B_SHIFT = 8, I_CAND = 1u << 10, I_INPART = 1u << 11 };
 enum : unsigned char { ST_N = 0, ST_U = 1, ST_S = 2 };
 
 __device__ __forceinline__ bool covers(unsigned info_j, int d /* i - j */) {
     const int a = (info_j >> I_A_SHIFT) & 3, bb = (info_j >> I_B_SHIFT) & 3;
     return d > 0 ? d <= a : -d <= bb;
 }
+__device__ __forceinline__ unsigned refl_key(float r) {
+    r = r + 0.0f;  // -0 -> +0 (they compare equal in the reference's `<`)
+    const unsigned u = __float_as_uint(r);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// visiting order: (partition, curvature bits, index)
+__device__ __forceinline__ bool visits_before(unsigned info_j, unsigned key_j, int j, unsigned info_i, unsigned key_i, int i) {
+    const unsigned pj = info_j & I_PART_MASK, pi = info_i & I_PART_MASK;
+    if (pj != pi) return pj < pi;
+    if (key_j != key_i) return key_j < key_i;
+    return j < i;
+}
 
-__global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.y + P.first;
-    const int line = blockIdx.x;
-    const int n = P.line_len[(size_t)b * P.L + line];
-    if (n <= 0 || n > P.sel_cap) return;
-    const int start = P.line_start[(size_t)b * P.L + line];
-    const size_t base = (size_t)b * P.NT + start;
+template <typename KeyP, typename InfoP, typename ByteP, typename U64P>
+__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, KeyP key, InfoP info, ByteP st,
+                                            ByteP flg, ByteP aux, U64P wmask, U64P wvis, ByteP wexit, ByteP wsel,
+                                            unsigned long long (*s_pm)[3], unsigned long long* s_minE,
+                                            unsigned long long* s_minG, unsigned char* s_bfirst) {
     const int tid = threadIdx.x, lane = tid & 63;
     const uint16_t* attr = P.ln_attr + base;
-    const unsigned* rank = P.ln_rank + base;
+    const float* curv = P.ln_curv + base;
+    const float* refl = P.ln_refl + base;
 
-    const int cap = P.sel_cap;
-    const int nwin = (cap + 63) / 64;
-    unsigned* info = reinterpret_cast<unsigned*>(smem);                                  // cap
-    unsigned long long* wmask = reinterpret_cast<unsigned long long*>(info + cap);       // nwin
-    unsigned long long* wvis = wmask + nwin;                                             // nwin * 4
-    unsigned char* st = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);               // cap
-    unsigned char* flg = st + cap;                                                       // cap
-    unsigned char* aux = flg + cap;                                                      // cap
-    unsigned char* wexit = aux + cap;                                                    // nwin * 4
-    unsigned char* wsel = wexit + 4 * nwin;                                              // nwin
-    __shared__ unsigned s_pm[50][3];   // three smallest reflect ranks among the reflect candidates of a partition
-    __shared__ unsigned s_minE[50], s_minG[50];
-
-    int T = 2;
+    int T = 2;  // thNumCurvSize as the last stencil iteration (i = n-6) left it (:492,505)
     if (n >= 11) T = (attr[n - 6] & A_W2) ? 2 : 3;
     const int range = n - 11;
 
     // ---- phase 0: per-point record --------------------------------------------------------------------------
     for (int i = tid; i < n; i += SELP_THREADS) {
-        unsigned inf = 0;
+        unsigned inf = 0, k = 0;
         unsigned char s0 = ST_N;
         if (range >= 1 && i >= 5 && i <= n - 7) {
             const unsigned at = attr[i];
@@ -829,21 +664,22 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
                 --j;
                 partition_bounds(n, j, sp, ep);
             }
-            const unsigned rk = rank[i];
             const unsigned a = min((int)((at >> A_A3_SHIFT) & 3u), T), bb = min((int)((at >> A_B3_SHIFT) & 3u), T);
-            inf = (rk & I_RC_MASK) | ((unsigned)j << I_PART_SHIFT) | (a << I_A_SHIFT) | (bb << I_B_SHIFT) | I_INPART;
+            inf = (unsigned)j | (a << I_A_SHIFT) | (bb << I_B_SHIFT) | I_INPART;
+            k = __float_as_uint(curv[i]);
             if (at & A_CAND3) {
                 inf |= I_CAND;
                 s0 = ST_U;
             }
         }
-        info[i] = inf;
+        key[i] = k;
+        info[i] = (unsigned short)inf;
         st[i] = s0;
     }
-    for (int t = tid; t < 50 * 3; t += SELP_THREADS) (&s_pm[0][0])[t] = 0xffffffffu;
+    for (int t = tid; t < 50 * 3; t += SELP_THREADS) (&s_pm[0][0])[t] = ~0ull;
     for (int t = tid; t < 50; t += SELP_THREADS) {
-        s_minE[t] = 0xffffffffu;
-        s_minG[t] = 0xffffffffu;
+        s_minE[t] = ~0ull;
+        s_minG[t] = ~0ull;
     }
     __syncthreads();
 
@@ -852,14 +688,14 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
         unsigned m = 0;
         const unsigned me = info[i];
         if (me & I_CAND) {
-            const unsigned gr = me & I_GRANK_MASK;
+            const unsigned mk = key[i];
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
                 const int j = i + d;
                 if (j < 0 || j >= n) continue;
                 const unsigned o = info[j];
-                if ((o & I_CAND) && (o & I_GRANK_MASK) < gr && covers(o, -d)) m |= 1u << q;
+                if ((o & I_CAND) && covers(o, -d) && visits_before(o, key[j], j, me, mk, i)) m |= 1u << q;
             }
         }
         aux[i] = (unsigned char)m;
@@ -892,9 +728,9 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
     // ---- phase 2: value held when :521-539 runs (f3a) + "a later partition marks me" ------------------------------
     for (int i = tid; i < n; i += SELP_THREADS) {
         const unsigned me = info[i];
+        const unsigned mk = key[i];
         const bool sel = st[i] == ST_S;
-        const int mypart = (me & I_INPART) ? (int)((me >> I_PART_SHIFT) & 63u) : (i < 5 ? -1 : 64);
-        const unsigned gr = me & I_GRANK_MASK;
+        const int mypart = (me & I_INPART) ? (int)(me & I_PART_MASK) : (i < 5 ? -1 : 64);
         bool covL = false, covLater = false;
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -904,10 +740,10 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
             if (st[j] != ST_S) continue;
             const unsigned o = info[j];
             if (!covers(o, -d)) continue;
-            const int pj = (int)((o >> I_PART_SHIFT) & 63u);
+            const int pj = (int)(o & I_PART_MASK);
             if (pj > mypart)
                 covLater = true;
-            else if (!sel || (o & I_GRANK_MASK) > gr)
+            else if (!sel || visits_before(me, mk, i, o, key[j], j))
                 covL = true;
         }
         const unsigned f3a = covL ? 1u : (sel ? 3u : 0u);
@@ -916,32 +752,66 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
     __syncthreads();
 
     // ---- phase 3: :521-539 in closed form ---------------------------------------------------------------------------
-    // (a) the three smallest reflect ranks among reflect candidates, per partition
+    // (a) the three first reflect candidates in reflect order, per partition
     for (int round = 0; round < 3; ++round) {
         for (int i = tid; i < n; i += SELP_THREADS) {
             const unsigned me = info[i];
             if (!(me & I_INPART) || !(attr[i] & A_REFL)) continue;
-            const int j = (me >> I_PART_SHIFT) & 63u;
-            const unsigned rr = rank[i] >> 16;
-            if (round > 0 && rr <= s_pm[j][round - 1]) continue;
-            atomicMin(&s_pm[j][round], rr);
+            const int j = me & I_PART_MASK;
+            const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
+            if (round > 0 && rk <= s_pm[j][round - 1]) continue;
+            atomicMin(&s_pm[j][round], rk);
         }
         __syncthreads();
     }
-    // (b) eff3 / G bits, min curvature rank of each class per partition
+    // (a2) for each of the <= 3 reflect picks of a partition: does its reflect visit (B_k, k = reflect rank) come
+    //      before its own curvature visit (A_k)?  One wavefront per pick counts both ranks over the partition.
+    for (int t = (tid >> 6); t < 150; t += SELP_THREADS / 64) {
+        const int j = t / 3, r = t % 3;
+        const unsigned long long e = s_pm[j][r];
+        if (e == ~0ull) continue;  // wave-uniform
+        const int i = (int)(unsigned)e;
+        int sp, ep;
+        partition_bounds(n, j, sp, ep);
+        const unsigned mk = key[i];
+        const unsigned mr = (unsigned)(e >> 32);
+        int rc = 0, rr = 0;
+        for (int q = sp + lane; q <= ep; q += 64) {
+            const unsigned kq = key[q], rq = refl_key(refl[q]);
+            rc += (kq < mk) || (kq == mk && q < i);
+            rr += (rq < mr) || (rq == mr && q < i);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            rc += __shfl_xor(rc, o);
+            rr += __shfl_xor(rr, o);
+        }
+        if (lane == 0) s_bfirst[t] = (unsigned char)(rr < rc);
+    }
+    __syncthreads();
+    // (b) eff3 / G bits, first point of each class in curvature order per partition
     for (int i = tid; i < n; i += SELP_THREADS) {
         const unsigned me = info[i];
         unsigned char bits = 0;
         if (me & I_INPART) {
             const unsigned at = attr[i];
-            const int j = (me >> I_PART_SHIFT) & 63u;
-            const unsigned rc = me & I_RC_MASK, rr = rank[i] >> 16;
-            const bool inB = (at & A_REFL) && rr <= s_pm[j][2];
-            const bool eff3 = ((flg[i] & 3u) == 3u) && !(inB && rr < rc);
+            const int j = me & I_PART_MASK;
+            bool inB = false, b_first = false;
+            if (at & A_REFL) {
+                const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (rk == s_pm[j][r]) {
+                        inB = true;
+                        b_first = s_bfirst[j * 3 + r];
+                    }
+            }
+            const bool eff3 = ((flg[i] & 3u) == 3u) && !(inB && b_first);
             const bool G = (at & A_ANGLE) || (eff3 && (at & A_FAR));
-            bits = (inB ? 1 : 0) | (eff3 ? 2 : 0) | (G ? 4 : 0);
-            if (eff3) atomicMin(&s_minE[j], rc);
-            if (G) atomicMin(&s_minG[j], rc);
+            bits = (inB ? 1 : 0) | (eff3 ? 2 : 0) | (G ? 4 : 0) | (b_first ? 8 : 0);
+            const unsigned long long ck = ((unsigned long long)key[i] << 32) | (unsigned)i;
+            if (eff3) atomicMin(&s_minE[j], ck);
+            if (G) atomicMin(&s_minG[j], ck);
         }
         aux[i] = bits;
     }
@@ -952,18 +822,18 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
         unsigned f = flg[i] & 3u;
         if (me & I_INPART) {
             const unsigned at = attr[i];
-            const int j = (me >> I_PART_SHIFT) & 63u;
-            const unsigned rc = me & I_RC_MASK, rr = rank[i] >> 16;
+            const int j = me & I_PART_MASK;
             const unsigned char bits = aux[i];
-            const bool inB = bits & 1, eff3 = bits & 2, G = bits & 4;
-            const bool first = eff3 && rc == s_minE[j] && !(s_minG[j] < s_minE[j]);
+            const bool inB = bits & 1, eff3 = bits & 2, G = bits & 4, b_first = bits & 8;
+            const unsigned long long ck = ((unsigned long long)key[i] << 32) | (unsigned)i;
+            const bool first = eff3 && ck == s_minE[j] && !(s_minG[j] < s_minE[j]);
             const bool picked = G || first;
             if (inB)
-                f = (picked && (at & A_ANGLE) && rr < rc) ? 2u : 4u;
+                f = (picked && (at & A_ANGLE) && b_first) ? 2u : 4u;
             else if (picked)
                 f = 2u;
         }
-        if (flg[i] & 4u) f = 1u;  // marked by a point of a later partition (:503,516 of the next partitions)
+        if (flg[i] & 4u) f = 1u;   // marked by a point of a later partition (:503,516 of the next partitions)
         st[i] = (unsigned char)f;  // st[] now holds the serial-part flag (4 encodes 300)
     }
     __syncthreads();
@@ -1024,9 +894,54 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select_par(FeatParams P) {
     }
 }
 
-static size_t select_par_lds(int cap) {
+__host__ __device__ inline size_t select_lds_bytes(int cap) {
     const size_t nwin = (cap + 63) / 64;
-    return (size_t)cap * 4 + nwin * 8 + nwin * 4 * 8 + (size_t)cap * 3 + nwin * 4 + nwin + 64;
+    // key u32 | wmask u64 | wvis 4 x u64 | info u16 | st, flg, aux u8 | wexit 4 x u8 | wsel u8
+    return (size_t)cap * 4 + nwin * 8 + nwin * 32 + (size_t)cap * 2 + (size_t)cap * 3 + nwin * 4 + nwin + 64;
+}
+
+__global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_pm[50][3];
+    __shared__ unsigned long long s_minE[50], s_minG[50];
+    __shared__ unsigned char s_bfirst[152];
+    const int b = blockIdx.y + P.first;
+    const int line = blockIdx.x;
+    const int n = P.line_len[(size_t)b * P.L + line];
+    if (n <= 0) return;
+    const int start = P.line_start[(size_t)b * P.L + line];
+    const size_t base = (size_t)b * P.NT + start;
+    if (n <= P.sel_cap) {
+        const int cap = P.sel_cap;
+        const int nwin = (cap + 63) / 64;
+        unsigned* key = reinterpret_cast<unsigned*>(smem);
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(key + cap);
+        unsigned long long* wvis = wmask + nwin;
+        unsigned short* info = reinterpret_cast<unsigned short*>(wvis + 4 * nwin);
+        unsigned char* st = reinterpret_cast<unsigned char*>(info + cap);
+        unsigned char* flg = st + cap;
+        unsigned char* aux = flg + cap;
+        unsigned char* wexit = aux + cap;
+        unsigned char* wsel = wexit + 4 * nwin;
+        select_body(P, b, n, base, key, info, st, flg, aux, wmask, wvis, wexit, wsel, s_pm, s_minE, s_minG, s_bfirst);
+    } else {
+        // global scratch: four 4-byte slots per bucketed point (key | info | st,flg,aux | window tables)
+        const size_t BNT = (size_t)P.B * P.NT;
+        unsigned* key = P.sel_scratch + base;
+        unsigned short* info = reinterpret_cast<unsigned short*>(P.sel_scratch + BNT + base);
+        unsigned char* bytes = reinterpret_cast<unsigned char*>(P.sel_scratch + 2 * BNT + base);
+        unsigned char* st = bytes;
+        unsigned char* flg = bytes + n;
+        unsigned char* aux = bytes + 2 * (size_t)n;
+        const int nwin = (n + 63) / 64;
+        uintptr_t wp = reinterpret_cast<uintptr_t>(P.sel_scratch + 3 * BNT + base);
+        wp = (wp + 7) & ~uintptr_t(7);
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wp);
+        unsigned long long* wvis = wmask + nwin;
+        unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * (size_t)nwin);
+        unsigned char* wsel = wexit + 4 * (size_t)nwin;
+        select_body(P, b, n, base, key, info, st, flg, aux, wmask, wvis, wexit, wsel, s_pm, s_minE, s_minG, s_bfirst);
+    }
 }
 
 // ---- a8: removeNearFarPoints / removeNearPointCloud + compaction into the fused cloud ---------------------------
@@ -1171,11 +1086,9 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.ln_curv = ctx->ln_curv;
     P.ln_refl = ctx->ln_refl;
     P.ln_attr = ctx->ln_attr;
-    P.ln_ord_c = ctx->ln_ord_c;
-    P.ln_ord_r = ctx->ln_ord_r;
-    P.ln_rank = ctx->ln_rank;
+    P.sel_scratch = ctx->sel_scratch;
     P.sel_cap = ctx->sel_cap;
-    P.ln_flag = ctx->ln_flag;
+    P.B = ctx->B;
     P.ln_final = nullptr;
     P.cb_xyzi = ctx->cb_xyzi;
     P.cb_rel = ctx->cb_rel;
@@ -1211,16 +1124,8 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, count), dim3(256), 0, s, P);
     }
     {
-        MmlStageScope t(ctx, "partition_sort");
-        hipLaunchKernelGGL(k_partition_sort, dim3(pblocks, count), dim3(256), 0, s, P);
-    }
-    {
         MmlStageScope t(ctx, "select");
-        hipLaunchKernelGGL(k_select_par, dim3(ctx->L, count), dim3(SELP_THREADS), select_par_lds(ctx->sel_cap), s, P);
-    }
-    if (ctx->max_line_may_exceed_cap) {  // serial wavefront-per-line form for lines that do not fit the LDS budget
-        MmlStageScope t(ctx, "select_long");
-        hipLaunchKernelGGL(k_select, dim3(ctx->L, count), dim3(64), 0, s, P);
+        hipLaunchKernelGGL(k_select, dim3(ctx->L, count), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     }
     {
         MmlStageScope t(ctx, "crop_compact");
@@ -1238,18 +1143,14 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     const int t = (n > ctx->L ? n : ctx->L);
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
     const int pblocks = (n + 255) / 256;
-    if (pblocks > 0) {
-        hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(k_partition_sort, dim3(pblocks, 1), dim3(256), 0, s, P);
-    }
-    hipLaunchKernelGGL(k_select_par, dim3(1, 1), dim3(SELP_THREADS), select_par_lds(ctx->sel_cap), s, P);
-    hipLaunchKernelGGL(k_select, dim3(1, 1), dim3(64), 0, s, P);
+    if (pblocks > 0) hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_select, dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
 
 int mml_feature_init(mml_ctx* ctx) {
-    // LDS budget of k_select_par: twice the nominal ring length / 1.5x the nominal Livox line length, <= 12288 points
+    // LDS budget of k_select: twice the nominal ring length / 1.25x the nominal Livox line length, <= 12288 points
     int cap = 2 * (ctx->NV / (ctx->cfg.n_rings > 0 ? ctx->cfg.n_rings : 1));
     int capl = (5 * (ctx->NL / (ctx->cfg.n_livox_lines > 0 ? ctx->cfg.n_livox_lines : 1))) / 4;
     if (capl > cap) cap = capl;
@@ -1257,8 +1158,7 @@ int mml_feature_init(mml_ctx* ctx) {
     if (cap > 12288) cap = 12288;
     cap = (cap + 63) & ~63;
     ctx->sel_cap = cap;
-    ctx->max_line_may_exceed_cap = (ctx->NV > cap) || (ctx->NL > cap);
-    MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_par), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)select_par_lds(cap)));
+    MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)select_lds_bytes(cap)));
     return MML_OK;
 }

@@ -168,54 +168,152 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int s
     }
 }
 
-// Ring-expanding search.  After ring r every map point with Chebyshev cell distance <= r from the query's
-// (clamped) home cell has been visited, which includes every point within Euclidean distance
-// rho_r = r * cell + (distance from the query to the nearest face of its home cell, 0 when outside the grid).
-// Stop when the 5th best distance is safely below rho_r^2 or when rho_r^2 >= max_d2 (the caller rejects
-// anything with d5 >= max_d2, Estimator.cpp:285,705).
-__device__ void knn5_search(const MmlGrid& g, float qx, float qy, float qz, float max_d2, Knn5& k) {
-    knn_init(k);
+// Ring-expanding search.  After ring r every map point with Chebyshev cell distance <= r from the query's home
+// cell has been visited, which includes every point within Euclidean distance
+// rho_r = (r + inset) * cell - margin  (inset = distance from the query to the nearest face of its home cell).
+// A query is finished when its 5th best squared distance is below rho_r^2 (exact 5-NN), or when rho_r^2 >= max_d2
+// (the caller rejects anything with d5 >= max_d2, Estimator.cpp:285,705).
+//
+// Two-level schedule: every lane walks rings 0 and 1 of its own query (27 cells, the common case for a
+// voxel-filtered map); queries that are still open are then finished one at a time by the WHOLE wavefront, the 64
+// lanes splitting the rows of each further shell and merging their private top-5 lists with shuffles.  That bounds
+// the cost of the rare far query (hundreds of mostly empty cells) by ~1/64 of a private walk.
+struct KnnQuery {
+    float qx, qy, qz, inset;
+    int hx, hy, hz;
+};
+
+__device__ __forceinline__ KnnQuery knn_query(const MmlGrid& g, float qx, float qy, float qz) {
+    KnnQuery q;
+    q.qx = qx;
+    q.qy = qy;
+    q.qz = qz;
     const float fx = (qx - g.origin[0]) * g.inv_cell, fy = (qy - g.origin[1]) * g.inv_cell,
                 fz = (qz - g.origin[2]) * g.inv_cell;
-    int hx = (int)floorf(fx), hy = (int)floorf(fy), hz = (int)floorf(fz);
-    // distance (in cells) from the query to the nearest face of its home cell; queries outside the grid get 0
-    float inset = fminf(fminf(fminf(fx - hx, hx + 1 - fx), fminf(fy - hy, hy + 1 - fy)), fminf(fz - hz, hz + 1 - fz));
-    if (!(inset > 0.f)) inset = 0.f;
-    const int rmax = (int)ceilf(sqrtf(max_d2) * g.inv_cell) + 1;
+    q.hx = (int)floorf(fx);
+    q.hy = (int)floorf(fy);
+    q.hz = (int)floorf(fz);
+    float inset = fminf(fminf(fminf(fx - q.hx, q.hx + 1 - fx), fminf(fy - q.hy, q.hy + 1 - fy)),
+                        fminf(fz - q.hz, q.hz + 1 - fz));
+    q.inset = (inset > 0.f) ? inset : 0.f;
+    return q;
+}
+
+// true when the search may stop after shell r
+__device__ __forceinline__ bool knn_done(const MmlGrid& g, float inset, int r, float d5, float max_d2) {
+    float rho = ((float)r + inset) * g.cell;
+    rho = rho - 1e-3f * g.cell;  // margin dominating the float rounding of d2 and of the cell mapping
+    if (!(rho > 0.f)) return false;
+    const float rho2 = rho * rho;
+    return d5 < rho2 || rho2 >= max_d2;
+}
+
+// one row (fixed y,z) of shell r: the whole x-span on a face, the two end cells otherwise
+__device__ __forceinline__ void scan_shell_row(const MmlGrid& g, const KnnQuery& q, int r, int y, int z, Knn5& k) {
     const int DX = g.dim[0], DY = g.dim[1], DZ = g.dim[2];
-    for (int r = 0; r <= rmax; ++r) {
-        const int z0 = hz - r, z1 = hz + r, y0 = hy - r, y1 = hy + r, x0 = hx - r, x1 = hx + r;
-        for (int z = max(z0, 0); z <= min(z1, DZ - 1); ++z) {
-            const bool zface = (z == z0 || z == z1);
-            for (int y = max(y0, 0); y <= min(y1, DY - 1); ++y) {
-                const bool face = zface || y == y0 || y == y1;
-                const int rowbase = DX * (y + DY * z);
-                if (face) {
-                    int xa = max(x0, 0), xb = min(x1, DX - 1);
-                    if (xa <= xb) scan_range(g.pts, g.cell_start[rowbase + xa], g.cell_start[rowbase + xb + 1], qx, qy, qz, k);
-                } else {
-                    if (x0 >= 0 && x0 < DX) scan_range(g.pts, g.cell_start[rowbase + x0], g.cell_start[rowbase + x0 + 1], qx, qy, qz, k);
-                    if (x1 >= 0 && x1 < DX && x1 != x0)
-                        scan_range(g.pts, g.cell_start[rowbase + x1], g.cell_start[rowbase + x1 + 1], qx, qy, qz, k);
-                }
+    if (y < 0 || y >= DY || z < 0 || z >= DZ) return;
+    const int x0 = q.hx - r, x1 = q.hx + r;
+    const bool face = (z == q.hz - r || z == q.hz + r || y == q.hy - r || y == q.hy + r);
+    const int rowbase = DX * (y + DY * z);
+    if (face) {
+        const int xa = max(x0, 0), xb = min(x1, DX - 1);
+        if (xa <= xb) scan_range(g.pts, g.cell_start[rowbase + xa], g.cell_start[rowbase + xb + 1], q.qx, q.qy, q.qz, k);
+    } else {
+        if (x0 >= 0 && x0 < DX) scan_range(g.pts, g.cell_start[rowbase + x0], g.cell_start[rowbase + x0 + 1], q.qx, q.qy, q.qz, k);
+        if (x1 >= 0 && x1 < DX && x1 != x0)
+            scan_range(g.pts, g.cell_start[rowbase + x1], g.cell_start[rowbase + x1 + 1], q.qx, q.qy, q.qz, k);
+    }
+}
+
+__device__ __forceinline__ void knn_head(const Knn5& k, int head, float& d, int& id) {
+    d = INFINITY;
+    id = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+        if (head == s) {
+            d = k.d[s];
+            id = k.id[s];
+        }
+}
+
+// wave-wide merge of the lanes' private sorted lists (disjoint point sets) into the global top-5, same in all lanes
+__device__ __forceinline__ void wave_merge5(const Knn5& local, Knn5& out) {
+    int head = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        float d;
+        int id;
+        knn_head(local, head, d, id);
+        float md = d;
+        int mid = id;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(md, o);
+            const int oid = __shfl_xor(mid, o);
+            const bool take = (od < md) || (od == md && oid < mid);
+            md = take ? od : md;
+            mid = take ? oid : mid;
+        }
+        out.d[r] = md;
+        out.id[r] = mid;
+        if (d == md && id == mid && md < INFINITY) head++;
+    }
+}
+
+// Must be called by ALL 64 lanes of the wavefront (inactive queries pass valid = false and only help).
+__device__ void knn5_search(const MmlGrid& g, bool valid, float qx, float qy, float qz, float max_d2, Knn5& k) {
+    knn_init(k);
+    const KnnQuery q = knn_query(g, qx, qy, qz);
+    const int rmax = (int)ceilf(sqrtf(max_d2) * g.inv_cell) + 1;
+    bool pending = false;
+    if (valid) {
+        pending = true;
+        for (int r = 0; r <= 1 && r <= rmax; ++r) {
+            for (int z = q.hz - r; z <= q.hz + r; ++z)
+                for (int y = q.hy - r; y <= q.hy + r; ++y) scan_shell_row(g, q, r, y, z, k);
+            if (knn_done(g, q.inset, r, k.d[4], max_d2)) {
+                pending = false;
+                break;
             }
         }
-        // exactness bound, with a relative margin that dominates float rounding of d2 and of the cell mapping
-        float rho = ((float)r + inset) * g.cell;
-        rho = rho - 1e-3f * g.cell;
-        if (rho > 0.f) {
-            float rho2 = rho * rho;
-            if (k.d[4] < rho2) break;
-            if (rho2 >= max_d2) break;
+        if (rmax < 2) pending = false;
+    }
+    unsigned long long todo = __ballot(pending);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        KnnQuery s;
+        s.qx = __shfl(q.qx, src);
+        s.qy = __shfl(q.qy, src);
+        s.qz = __shfl(q.qz, src);
+        s.inset = __shfl(q.inset, src);
+        s.hx = __shfl(q.hx, src);
+        s.hy = __shfl(q.hy, src);
+        s.hz = __shfl(q.hz, src);
+        Knn5 loc;
+        if (lane == src)
+            loc = k;
+        else
+            knn_init(loc);
+        Knn5 best;
+        knn_init(best);
+        for (int r = 2; r <= rmax; ++r) {
+            const int w = 2 * r + 1;
+            for (int t = lane; t < w * w; t += 64) scan_shell_row(g, s, r, s.hy - r + (t % w), s.hz - r + (t / w), loc);
+            wave_merge5(loc, best);
+            if (knn_done(g, s.inset, r, best.d[4], max_d2)) break;
         }
+        if (lane == src) k = best;
     }
 }
 
 __global__ __launch_bounds__(256) void k_knn5(MmlGrid g, const float* q, int nq, float max_d2, int* idx, float* d2) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nq) return;
+    const bool valid = i < nq;
     Knn5 k;
-    knn5_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, k);
+    knn5_search(g, valid, valid ? q[3 * i] : 0.f, valid ? q[3 * i + 1] : 0.f, valid ? q[3 * i + 2] : 0.f, max_d2, k);
+    if (!valid) return;
     for (int j = 0; j < 5; ++j) {
         bool ok = k.d[j] < max_d2 && k.d[4] < max_d2;
         idx[5 * i + j] = ok ? k.id[j] : -1;
@@ -518,19 +616,19 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
     const int kind = blockIdx.z;
     const int i = blockIdx.x * 128 + threadIdx.x;
     const int nf = P.ft_n[kind * P.B + b];
-    if (i >= nf) return;
+    if ((int)(blockIdx.x * 128) >= nf) return;  // whole workgroup beyond the stack: uniform exit
+    const bool live = i < nf;
     const double* T = P.Twl + 16 * slot;
-    const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+    const float4 f = live ? P.ft[kind][(size_t)b * P.MF + i] : make_float4(0, 0, 0, 0);
     // Map_Manager.cpp:75-89 pointAssociateToMap: double transform stored to float
     double wx, wy, wz;
     tf_point(T, f.x, f.y, f.z, wx, wy, wz);
     const float sx = wx, sy = wy, sz = wz;
-    bool ok = !(isnan(sx) || isnan(sy) || isnan(sz)) && P.map_m[kind] > 20;  // :196, :283 / :702
+    bool ok = live && !(isnan(sx) || isnan(sy) || isnan(sz)) && P.map_m[kind] > 20;  // :196, :283 / :702
     Knn5 k;
-    if (ok) {
-        knn5_search(P.g[kind], sx, sy, sz, P.thres, k);
-        ok = (double)k.d[4] < P.thres_d;  // :285 / :705
-    }
+    knn5_search(P.g[kind], ok, sx, sy, sz, P.thres, k);  // wave-cooperative: every lane takes part
+    if (!live) return;
+    ok = ok && (double)k.d[4] < P.thres_d;  // :285 / :705
     const float4* mp = P.map_orig[kind];
     if (kind == 0) {
         MmlLineFactor out;

@@ -74,12 +74,8 @@ struct mml_ctx {
     float* ln_curv = nullptr;
     float* ln_refl = nullptr;
     uint16_t* ln_attr = nullptr;
-    int* ln_ord_c = nullptr;
-    int* ln_ord_r = nullptr;
-    unsigned* ln_rank = nullptr;
+    unsigned* sel_scratch = nullptr;  // 4 x B*NT unsigned: k_select scratch for lines beyond the LDS budget
     int sel_cap = 0;
-    bool max_line_may_exceed_cap = true;
-    uint8_t* ln_flag = nullptr;
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
     float4* cb_xyzi = nullptr;

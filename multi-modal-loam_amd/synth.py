@@ -131,6 +131,24 @@ def pose_matrix(k):
     return T
 
 
+def voxel_filter(xyz, leaf):
+    """Centroid per occupied voxel (numpy): the role of downSizeFilter on the local map (Estimator.cpp:1630-1637).
+    Only used to prepare INPUT maps for bench / tests; the product's own voxel kernel is k_voxel."""
+    xyz = np.asarray(xyz, dtype=np.float32)
+    if len(xyz) == 0:
+        return xyz
+    ijk = np.floor(xyz / np.float32(leaf)).astype(np.int64)
+    ijk -= ijk.min(0)
+    dims = ijk.max(0) + 1
+    key = ijk[:, 0] + dims[0] * (ijk[:, 1] + dims[1] * ijk[:, 2])
+    order = np.argsort(key, kind="stable")
+    key = key[order]
+    starts = np.concatenate([[0], np.nonzero(np.diff(key))[0] + 1])
+    sums = np.add.reduceat(xyz[order].astype(np.float64), starts, axis=0)
+    cnt = np.diff(np.concatenate([starts, [len(key)]]))
+    return (sums / cnt[:, None]).astype(np.float32)
+
+
 def grow_map(xyz, target, seed=7, jitter=0.02, tile=(40.0, 30.0)):
     """Grow a (m,3) float32 feature cloud to `target` points ("replicated / jittered").
 
