@@ -39,6 +39,7 @@ STAGE_BYTES = {
     "undistort":        lambda n_v, n_l, nf, it: 28 * (n_v + n_l),
     "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),    # label scan + xyz of labelled points
     "associate":        lambda n_v, n_l, nf, it: 112 * nf,
+    "associate_far":    lambda n_v, n_l, nf, it: 0,                   # queue of the few far queries (bytes counted in associate)
     "assoc_stats":      lambda n_v, n_l, nf, it: 0,
     "solve":            lambda n_v, n_l, nf, it: 72 * nf * (it + 1),  # it iterations + the initial linearisation
 }
@@ -54,6 +55,8 @@ def parse():
     ap.add_argument("--gn-iters", type=int, default=10)
     ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans cycled through the batch")
+    ap.add_argument("--cell-corner", type=float, default=0.0, help="kNN grid cell edge for the corner map (0: library default)")
+    ap.add_argument("--cell-surf", type=float, default=0.0, help="kNN grid cell edge for the surf map (0: library default)")
     return ap.parse_args()
 
 
@@ -75,7 +78,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     B = args.batch
-    ctx = M.Context(max_scans=B, device=local_rank, max_map_points=max(args.map_points, 1 << 16))
+    ctx = M.Context(max_scans=B, device=local_rank, max_map_points=max(args.map_points, 1 << 16),
+                    cell_corner=args.cell_corner, cell_surf=args.cell_surf)
     dev_name, cus, hbm = ctx.device_info()
 
     # ---- synthetic inputs (same on every rank except the seed offset) ---------------------------------------

@@ -66,7 +66,7 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->sel_scratch,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
                     ctx->cb_label, ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
-                    ctx->pf,       ctx->assoc_stats, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
+                    ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
                     ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_summ, ctx->d_trace, ctx->d_rec,
                     ctx->d_extr,   ctx->d_misc};
@@ -151,6 +151,8 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->lf, B * MF);
     ALLOC(ctx->pf, B * MF);
     ALLOC(ctx->assoc_stats, B * 16);
+    ALLOC(ctx->hard_list, B * MF * 2);
+    ALLOC(ctx->work_off, 2 * B + 2);
     for (int k = 0; k < 2; ++k) {
         ALLOC(ctx->grid[k].pts, MM);
         ALLOC(ctx->grid[k].cell_start, 4 * MM + 4096 + 2);

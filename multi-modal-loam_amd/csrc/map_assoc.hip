@@ -358,6 +358,24 @@ __device__ __forceinline__ double eig_hypot(double x, double y) {
     return p * sqrt(1.0 + qp * qp);
 }
 // A: lower triangle m00,m10,m11,m20,m21,m22.  Returns eigenvalues ascending in ev[], eigenvector of ev[2] in v2[].
+// Register-only formulation: every array index is a compile-time constant after unrolling (dynamic positions are
+// resolved with selects), so nothing spills to scratch memory -- the per-lane scratch traffic of an indexed
+// implementation dominated the association kernel.
+struct Tri3 {
+    double d0, d1, d2, e0, e1;
+};
+__device__ __forceinline__ double tri_d(const Tri3& t, int i) { return i == 0 ? t.d0 : (i == 1 ? t.d1 : t.d2); }
+__device__ __forceinline__ double tri_e(const Tri3& t, int i) { return i == 0 ? t.e0 : t.e1; }
+__device__ __forceinline__ void tri_set_d(Tri3& t, int i, double v) {
+    t.d0 = i == 0 ? v : t.d0;
+    t.d1 = i == 1 ? v : t.d1;
+    t.d2 = i == 2 ? v : t.d2;
+}
+__device__ __forceinline__ void tri_set_e(Tri3& t, int i, double v) {
+    t.e0 = i == 0 ? v : t.e0;
+    t.e1 = i == 1 ? v : t.e1;
+}
+
 __device__ void eig3_sym(double m00, double m10, double m11, double m20, double m21, double m22, double* ev,
                          double* v2) {
     double scale = fabs(m00);
@@ -373,217 +391,332 @@ __device__ void eig3_sym(double m00, double m10, double m11, double m20, double 
     m20 /= scale;
     m21 /= scale;
     m22 /= scale;
-    double diag[3], sub[2], Q[9];
+    Tri3 t;
+    // Q as three columns q0,q1,q2 (each 3 rows)
+    double q00, q10, q20, q01, q11, q21, q02, q12, q22;
     const double tol = 2.2250738585072014e-308;
-    diag[0] = m00;
-    double v1norm2 = m20 * m20;
+    t.d0 = m00;
+    const double v1norm2 = m20 * m20;
     if (v1norm2 <= tol) {
-        diag[1] = m11;
-        diag[2] = m22;
-        sub[0] = m10;
-        sub[1] = m21;
-        Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = 1; Q[5] = 0; Q[6] = 0; Q[7] = 0; Q[8] = 1;
+        t.d1 = m11;
+        t.d2 = m22;
+        t.e0 = m10;
+        t.e1 = m21;
+        q00 = 1; q10 = 0; q20 = 0;
+        q01 = 0; q11 = 1; q21 = 0;
+        q02 = 0; q12 = 0; q22 = 1;
     } else {
-        double beta = sqrt(m10 * m10 + v1norm2);
-        double invBeta = 1.0 / beta;
-        double m01 = m10 * invBeta;
-        double m02 = m20 * invBeta;
-        double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
-        diag[1] = m11 + m02 * q;
-        diag[2] = m22 - m02 * q;
-        sub[0] = beta;
-        sub[1] = m21 - m01 * q;
-        Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = m01; Q[5] = m02; Q[6] = 0; Q[7] = m02; Q[8] = -m01;
+        const double beta = sqrt(m10 * m10 + v1norm2);
+        const double invBeta = 1.0 / beta;
+        const double m01 = m10 * invBeta;
+        const double m02 = m20 * invBeta;
+        const double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+        t.d1 = m11 + m02 * q;
+        t.d2 = m22 - m02 * q;
+        t.e0 = beta;
+        t.e1 = m21 - m01 * q;
+        q00 = 1; q10 = 0; q20 = 0;
+        q01 = 0; q11 = m01; q21 = m02;
+        q02 = 0; q12 = m02; q22 = -m01;
     }
     int end = 2, start = 0, iter = 0;
     const double precision = 2.0 * 2.220446049250313e-16;
     while (end > 0) {
-        for (int i = start; i < end; ++i)
-            if (fabs(sub[i]) <= (fabs(diag[i]) + fabs(diag[i + 1])) * precision || fabs(sub[i]) <= tol) sub[i] = 0;
-        while (end > 0 && sub[end - 1] == 0.0) end--;
+        for (int i = start; i < end; ++i) {
+            const double si = tri_e(t, i);
+            if (fabs(si) <= (fabs(tri_d(t, i)) + fabs(tri_d(t, i + 1))) * precision || fabs(si) <= tol) tri_set_e(t, i, 0.0);
+        }
+        while (end > 0 && tri_e(t, end - 1) == 0.0) end--;
         if (end <= 0) break;
         iter++;
         if (iter > 90) break;
         start = end - 1;
-        while (start > 0 && sub[start - 1] != 0.0) start--;
-        double td = (diag[end - 1] - diag[end]) * 0.5;
-        double e = sub[end - 1];
-        double mu = diag[end];
+        while (start > 0 && tri_e(t, start - 1) != 0.0) start--;
+        const double td = (tri_d(t, end - 1) - tri_d(t, end)) * 0.5;
+        const double e = tri_e(t, end - 1);
+        double mu = tri_d(t, end);
         if (td == 0.0) {
             mu -= fabs(e);
         } else {
-            double e2 = e * e;
-            double h = eig_hypot(td, e);
+            const double e2 = e * e;
+            const double h = eig_hypot(td, e);
             if (e2 == 0.0)
                 mu -= (e / (td + (td > 0.0 ? 1.0 : -1.0))) * (e / h);
             else
                 mu -= e2 / (td + (td > 0.0 ? h : -h));
         }
-        double x = diag[start] - mu;
-        double z = sub[start];
+        double x = tri_d(t, start) - mu;
+        double z = tri_e(t, start);
         for (int k = start; k < end; ++k) {
             double c, s;
             make_givens(x, z, c, s);
-            double sdk = s * diag[k] + c * sub[k];
-            double dkp1 = s * sub[k] + c * diag[k + 1];
-            diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
-            diag[k + 1] = s * sdk + c * dkp1;
-            sub[k] = c * sdk - s * dkp1;
-            if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
-            x = sub[k];
+            const double dk = tri_d(t, k), dk1 = tri_d(t, k + 1), sk = tri_e(t, k);
+            const double sdk = s * dk + c * sk;
+            const double dkp1 = s * sk + c * dk1;
+            tri_set_d(t, k, c * (c * dk - s * sk) - s * (c * sk - s * dk1));
+            tri_set_d(t, k + 1, s * sdk + c * dkp1);
+            tri_set_e(t, k, c * sdk - s * dkp1);
+            if (k > start) tri_set_e(t, k - 1, c * tri_e(t, k - 1) - s * z);
+            x = tri_e(t, k);
             if (k < end - 1) {
-                z = -s * sub[k + 1];
-                sub[k + 1] = c * sub[k + 1];
+                const double sk1 = tri_e(t, k + 1);
+                z = -s * sk1;
+                tri_set_e(t, k + 1, c * sk1);
             }
-            for (int r = 0; r < 3; ++r) {
-                double xi = Q[3 * r + k], yi = Q[3 * r + k + 1];
-                Q[3 * r + k] = c * xi - s * yi;
-                Q[3 * r + k + 1] = s * xi + c * yi;
+            // Q = Q * G on columns (k, k+1)
+            if (k == 0) {
+                double a, b;
+                a = q00; b = q01; q00 = c * a - s * b; q01 = s * a + c * b;
+                a = q10; b = q11; q10 = c * a - s * b; q11 = s * a + c * b;
+                a = q20; b = q21; q20 = c * a - s * b; q21 = s * a + c * b;
+            } else {
+                double a, b;
+                a = q01; b = q02; q01 = c * a - s * b; q02 = s * a + c * b;
+                a = q11; b = q12; q11 = c * a - s * b; q12 = s * a + c * b;
+                a = q21; b = q22; q21 = c * a - s * b; q22 = s * a + c * b;
             }
         }
     }
-    for (int i = 0; i < 2; ++i) {
+    // ascending selection sort (two passes), columns follow
+    double d0 = t.d0, d1 = t.d1, d2 = t.d2;
+    {
+        // i = 0: k = argmin(d0,d1,d2) (first minimum)
         int k = 0;
-        double mn = diag[i];
-        for (int j = 1; j < 3 - i; ++j)
-            if (diag[i + j] < mn) {
-                mn = diag[i + j];
-                k = j;
-            }
-        if (k > 0) {
-            double t = diag[i];
-            diag[i] = diag[k + i];
-            diag[k + i] = t;
-            for (int r = 0; r < 3; ++r) {
-                double u = Q[3 * r + i];
-                Q[3 * r + i] = Q[3 * r + k + i];
-                Q[3 * r + k + i] = u;
-            }
+        double mn = d0;
+        if (d1 < mn) { mn = d1; k = 1; }
+        if (d2 < mn) { mn = d2; k = 2; }
+        if (k == 1) {
+            double u;
+            u = d0; d0 = d1; d1 = u;
+            u = q00; q00 = q01; q01 = u;
+            u = q10; q10 = q11; q11 = u;
+            u = q20; q20 = q21; q21 = u;
+        } else if (k == 2) {
+            double u;
+            u = d0; d0 = d2; d2 = u;
+            u = q00; q00 = q02; q02 = u;
+            u = q10; q10 = q12; q12 = u;
+            u = q20; q20 = q22; q22 = u;
+        }
+        // i = 1
+        if (d2 < d1) {
+            double u;
+            u = d1; d1 = d2; d2 = u;
+            u = q01; q01 = q02; q02 = u;
+            u = q11; q11 = q12; q12 = u;
+            u = q21; q21 = q22; q22 = u;
         }
     }
-    ev[0] = diag[0] * scale;
-    ev[1] = diag[1] * scale;
-    ev[2] = diag[2] * scale;
-    v2[0] = Q[2];
-    v2[1] = Q[5];
-    v2[2] = Q[8];
+    ev[0] = d0 * scale;
+    ev[1] = d1 * scale;
+    ev[2] = d2 * scale;
+    v2[0] = q02;
+    v2[1] = q12;
+    v2[2] = q22;
 }
 
-// Eigen 3.3.4 ColPivHouseholderQR<Matrix<double,5,3>>::compute + solve(-1): see oracle/linalg.h.
+// Eigen 3.3.4 ColPivHouseholderQR<Matrix<double,5,3>>::compute + solve(-1): see oracle/linalg.h.  Register-only:
+// the three columns are separate 5-vectors and the column pivoting is done with conditional swaps.
+struct Col5 {
+    double v[5];
+};
+__device__ __forceinline__ void col_swap(Col5& a, Col5& b, bool doit) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const double x = a.v[r], y = b.v[r];
+        a.v[r] = doit ? y : x;
+        b.v[r] = doit ? x : y;
+    }
+}
+__device__ __forceinline__ void dswap(double& a, double& b, bool doit) {
+    const double x = a, y = b;
+    a = doit ? y : x;
+    b = doit ? x : y;
+}
+__device__ __forceinline__ void iswap(int& a, int& b, bool doit) {
+    const int x = a, y = b;
+    a = doit ? y : x;
+    b = doit ? x : y;
+}
+// Householder step K on column `ck` (rows K..4), applied to the `NO` remaining columns; norm downdate for them.
+template <int K>
+__device__ __forceinline__ void qr_step(Col5& ck, Col5& o1, Col5& o2, double& nu1, double& nd1, double& nu2, double& nd2,
+                                        double& tau_out, bool has1, bool has2) {
+    const double tol = 2.2250738585072014e-308;
+    const double norm_downdate_threshold = 1.4901161193847656e-08;  // sqrt(eps)
+    double tailSqNorm = 0;
+#pragma unroll
+    for (int r = K + 1; r < 5; ++r) tailSqNorm += ck.v[r] * ck.v[r];
+    const double c0 = ck.v[K];
+    double tau, beta;
+    if (tailSqNorm <= tol) {
+        tau = 0;
+        beta = c0;
+#pragma unroll
+        for (int r = K + 1; r < 5; ++r) ck.v[r] = 0;
+    } else {
+        beta = sqrt(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0) beta = -beta;
+#pragma unroll
+        for (int r = K + 1; r < 5; ++r) ck.v[r] = ck.v[r] / (c0 - beta);
+        tau = (beta - c0) / beta;
+    }
+    tau_out = tau;
+    ck.v[K] = beta;
+    if (tau != 0.0) {
+        if (has1) {
+            double tmp = 0;
+#pragma unroll
+            for (int r = K + 1; r < 5; ++r) tmp += ck.v[r] * o1.v[r];
+            tmp += o1.v[K];
+            o1.v[K] -= tau * tmp;
+#pragma unroll
+            for (int r = K + 1; r < 5; ++r) o1.v[r] -= tau * ck.v[r] * tmp;
+        }
+        if (has2) {
+            double tmp = 0;
+#pragma unroll
+            for (int r = K + 1; r < 5; ++r) tmp += ck.v[r] * o2.v[r];
+            tmp += o2.v[K];
+            o2.v[K] -= tau * tmp;
+#pragma unroll
+            for (int r = K + 1; r < 5; ++r) o2.v[r] -= tau * ck.v[r] * tmp;
+        }
+    }
+    auto downdate = [&](Col5& o, double& nu, double& nd) {
+        if (nu != 0.0) {
+            double temp = fabs(o.v[K]) / nu;
+            temp = (1.0 + temp) * (1.0 - temp);
+            temp = temp < 0.0 ? 0.0 : temp;
+            const double ratio = nu / nd;
+            const double temp2 = temp * (ratio * ratio);
+            if (temp2 <= norm_downdate_threshold) {
+                double s = 0;
+#pragma unroll
+                for (int r = K + 1; r < 5; ++r) s += o.v[r] * o.v[r];
+                nd = sqrt(s);
+                nu = nd;
+            } else {
+                nu *= sqrt(temp);
+            }
+        }
+    };
+    if (has1) downdate(o1, nu1, nd1);
+    if (has2) downdate(o2, nu2, nd2);
+}
+
 __device__ void plane_fit5(const double (*Ain)[3], double* xout) {
-    const int rows = 5, cols = 3, size = 3;
-    double qr[5][3];
-    for (int r = 0; r < rows; ++r)
-        for (int c = 0; c < cols; ++c) qr[r][c] = Ain[r][c];
-    double hCoeffs[3];
-    int transp[3];
-    double normsUpdated[3], normsDirect[3];
-    for (int k = 0; k < cols; ++k) {
+    Col5 c0, c1, c2;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        c0.v[r] = Ain[r][0];
+        c1.v[r] = Ain[r][1];
+        c2.v[r] = Ain[r][2];
+    }
+    auto colnorm = [](const Col5& c) {
         double s = 0;
-        for (int r = 0; r < rows; ++r) s += qr[r][k] * qr[r][k];
-        normsDirect[k] = sqrt(s);
-        normsUpdated[k] = normsDirect[k];
-    }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) s += c.v[r] * c.v[r];
+        return sqrt(s);
+    };
+    double nd0 = colnorm(c0), nd1 = colnorm(c1), nd2 = colnorm(c2);
+    double nu0 = nd0, nu1 = nd1, nu2 = nd2;
     const double eps = 2.220446049250313e-16;
-    double maxn = normsUpdated[0];
-    for (int k = 1; k < cols; ++k)
-        if (normsUpdated[k] > maxn) maxn = normsUpdated[k];
-    double threshold_helper = (maxn * eps) * (maxn * eps) / double(rows);
-    double norm_downdate_threshold = sqrt(eps);
-    int nonzero_pivots = size;
-    for (int k = 0; k < size; ++k) {
-        int big = k;
-        double bigv = normsUpdated[k];
-        for (int j = k + 1; j < cols; ++j)
-            if (normsUpdated[j] > bigv) {
-                bigv = normsUpdated[j];
-                big = j;
-            }
-        double biggest_col_sq_norm = bigv * bigv;
-        if (nonzero_pivots == size && biggest_col_sq_norm < threshold_helper * double(rows - k)) nonzero_pivots = k;
-        transp[k] = big;
-        if (k != big) {
-            for (int r = 0; r < rows; ++r) {
-                double t = qr[r][k];
-                qr[r][k] = qr[r][big];
-                qr[r][big] = t;
-            }
-            double t = normsUpdated[k];
-            normsUpdated[k] = normsUpdated[big];
-            normsUpdated[big] = t;
-            t = normsDirect[k];
-            normsDirect[k] = normsDirect[big];
-            normsDirect[big] = t;
-        }
-        double tailSqNorm = 0;
-        for (int r = k + 1; r < rows; ++r) tailSqNorm += qr[r][k] * qr[r][k];
-        double c0 = qr[k][k];
-        double tau, beta;
-        const double tol = 2.2250738585072014e-308;
-        if (tailSqNorm <= tol) {
-            tau = 0;
-            beta = c0;
-            for (int r = k + 1; r < rows; ++r) qr[r][k] = 0;
-        } else {
-            beta = sqrt(c0 * c0 + tailSqNorm);
-            if (c0 >= 0.0) beta = -beta;
-            for (int r = k + 1; r < rows; ++r) qr[r][k] = qr[r][k] / (c0 - beta);
-            tau = (beta - c0) / beta;
-        }
-        hCoeffs[k] = tau;
-        qr[k][k] = beta;
-        if (tau != 0.0) {
-            for (int j = k + 1; j < cols; ++j) {
-                double tmp = 0;
-                for (int r = k + 1; r < rows; ++r) tmp += qr[r][k] * qr[r][j];
-                tmp += qr[k][j];
-                qr[k][j] -= tau * tmp;
-                for (int r = k + 1; r < rows; ++r) qr[r][j] -= tau * qr[r][k] * tmp;
-            }
-        }
-        for (int j = k + 1; j < cols; ++j) {
-            if (normsUpdated[j] != 0.0) {
-                double temp = fabs(qr[k][j]) / normsUpdated[j];
-                temp = (1.0 + temp) * (1.0 - temp);
-                temp = temp < 0.0 ? 0.0 : temp;
-                double ratio = normsUpdated[j] / normsDirect[j];
-                double temp2 = temp * (ratio * ratio);
-                if (temp2 <= norm_downdate_threshold) {
-                    double s = 0;
-                    for (int r = k + 1; r < rows; ++r) s += qr[r][j] * qr[r][j];
-                    normsDirect[j] = sqrt(s);
-                    normsUpdated[j] = normsDirect[j];
-                } else {
-                    normsUpdated[j] *= sqrt(temp);
-                }
-            }
-        }
+    double maxn = nu0;
+    if (nu1 > maxn) maxn = nu1;
+    if (nu2 > maxn) maxn = nu2;
+    const double threshold_helper = (maxn * eps) * (maxn * eps) / 5.0;
+    int nonzero_pivots = 3;
+    int p0 = 0, p1 = 1, p2 = 2;  // perm: position -> original column
+    double tau0, tau1, tau2;
+    // ---- k = 0: pivot among columns 0,1,2 (first maximum) ----
+    {
+        int big = 0;
+        double bigv = nu0;
+        if (nu1 > bigv) { bigv = nu1; big = 1; }
+        if (nu2 > bigv) { bigv = nu2; big = 2; }
+        if (nonzero_pivots == 3 && bigv * bigv < threshold_helper * 5.0) nonzero_pivots = 0;
+        col_swap(c0, c1, big == 1);
+        dswap(nu0, nu1, big == 1);
+        dswap(nd0, nd1, big == 1);
+        iswap(p0, p1, big == 1);
+        col_swap(c0, c2, big == 2);
+        dswap(nu0, nu2, big == 2);
+        dswap(nd0, nd2, big == 2);
+        iswap(p0, p2, big == 2);
+        qr_step<0>(c0, c1, c2, nu1, nd1, nu2, nd2, tau0, true, true);
     }
-    int perm[3] = {0, 1, 2};
-    for (int k = 0; k < size; ++k) {
-        int t = perm[k];
-        perm[k] = perm[transp[k]];
-        perm[transp[k]] = t;
+    // ---- k = 1: pivot among columns 1,2 ----
+    {
+        const bool sw = nu2 > nu1;
+        const double bigv = sw ? nu2 : nu1;
+        if (nonzero_pivots == 3 && bigv * bigv < threshold_helper * 4.0) nonzero_pivots = 1;
+        col_swap(c1, c2, sw);
+        dswap(nu1, nu2, sw);
+        dswap(nd1, nd2, sw);
+        iswap(p1, p2, sw);
+        double dum_u = 0, dum_d = 1;
+        Col5 dummy = c2;
+        qr_step<1>(c1, c2, dummy, nu2, nd2, dum_u, dum_d, tau1, true, false);
+    }
+    // ---- k = 2 ----
+    {
+        if (nonzero_pivots == 3 && nu2 * nu2 < threshold_helper * 3.0) nonzero_pivots = 2;
+        double du1 = 0, dd1 = 1, du2 = 0, dd2 = 1;
+        Col5 dmy1 = c2, dmy2 = c2;
+        qr_step<2>(c2, dmy1, dmy2, du1, dd1, du2, dd2, tau2, false, false);
     }
     xout[0] = xout[1] = xout[2] = 0;
     if (nonzero_pivots == 0) return;
     double c[5] = {-1, -1, -1, -1, -1};
-    for (int k = 0; k < nonzero_pivots; ++k) {
-        double tau = hCoeffs[k];
+    // c = Q^T b : apply H_0, H_1, H_2 (only the first nonzero_pivots reflectors)
+    auto apply = [&](const Col5& h, double tau, int K) {
         if (tau != 0.0) {
             double tmp = 0;
-            for (int r = k + 1; r < rows; ++r) tmp += qr[r][k] * c[r];
-            tmp += c[k];
-            c[k] -= tau * tmp;
-            for (int r = k + 1; r < rows; ++r) c[r] -= tau * qr[r][k] * tmp;
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                if (r > K) tmp += h.v[r] * c[r];
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                if (r == K) tmp += c[r];
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                if (r == K) c[r] -= tau * tmp;
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                if (r > K) c[r] -= tau * h.v[r] * tmp;
         }
+    };
+    if (nonzero_pivots > 0) apply(c0, tau0, 0);
+    if (nonzero_pivots > 1) apply(c1, tau1, 1);
+    if (nonzero_pivots > 2) apply(c2, tau2, 2);
+    // back substitution on the leading nonzero_pivots block of R (R(i,j) = column j, row i)
+    double y0 = 0, y1 = 0, y2 = 0;
+    if (nonzero_pivots > 2) y2 = c[2] / c2.v[2];
+    if (nonzero_pivots > 1) {
+        double sacc = c[1];
+        if (nonzero_pivots > 2) sacc -= c2.v[1] * y2;
+        y1 = sacc / c1.v[1];
     }
-    for (int i = nonzero_pivots - 1; i >= 0; --i) {
-        double s = c[i];
-        for (int j = i + 1; j < nonzero_pivots; ++j) s -= qr[i][j] * c[j];
-        c[i] = s / qr[i][i];
+    {
+        double sacc = c[0];
+        if (nonzero_pivots > 1) sacc -= c1.v[0] * y1;
+        if (nonzero_pivots > 2) sacc -= c2.v[0] * y2;
+        y0 = sacc / c0.v[0];
     }
-    for (int i = 0; i < nonzero_pivots; ++i) xout[perm[i]] = c[i];
+    // dst.row(perm[i]) = c.row(i)
+    double x0 = 0, x1 = 0, x2 = 0;
+    auto put = [&](int dst, double v) {
+        x0 = dst == 0 ? v : x0;
+        x1 = dst == 1 ? v : x1;
+        x2 = dst == 2 ? v : x2;
+    };
+    put(p0, y0);
+    if (nonzero_pivots > 1) put(p1, y1);
+    if (nonzero_pivots > 2) put(p2, y2);
+    xout[0] = x0;
+    xout[1] = x1;
+    xout[2] = x2;
 }
 
 // original (unsorted) coordinates of a neighbour are needed in index order: the sorted grid carries xyz next
@@ -600,6 +733,10 @@ struct AssocParams {
     float thres;     // search bound (float)
     double thres_d;  // gate, compared as in the reference: (double)d2[4] < thres_dist
     int map_m[2];
+    int count;
+    const int* work_off;
+    int* hard_count;   // queue of features whose 5-NN search goes beyond ring 1
+    int4* hard_list;
 };
 
 __device__ __forceinline__ void tf_point(const double* T, double x, double y, double z, double& ox, double& oy,
@@ -610,25 +747,9 @@ __device__ __forceinline__ void tf_point(const double* T, double x, double y, do
 }
 
 // one lane per feature: grid.x covers MF features, grid.y = slot, grid.z = kind
-__global__ __launch_bounds__(128) void k_associate(AssocParams P) {
-    const int slot = blockIdx.y;
-    const int b = slot + P.first;
-    const int kind = blockIdx.z;
-    const int i = blockIdx.x * 128 + threadIdx.x;
-    const int nf = P.ft_n[kind * P.B + b];
-    if ((int)(blockIdx.x * 128) >= nf) return;  // whole workgroup beyond the stack: uniform exit
-    const bool live = i < nf;
-    const double* T = P.Twl + 16 * slot;
-    const float4 f = live ? P.ft[kind][(size_t)b * P.MF + i] : make_float4(0, 0, 0, 0);
-    // Map_Manager.cpp:75-89 pointAssociateToMap: double transform stored to float
-    double wx, wy, wz;
-    tf_point(T, f.x, f.y, f.z, wx, wy, wz);
-    const float sx = wx, sy = wy, sz = wz;
-    bool ok = live && !(isnan(sx) || isnan(sy) || isnan(sz)) && P.map_m[kind] > 20;  // :196, :283 / :702
-    Knn5 k;
-    knn5_search(P.g[kind], ok, sx, sy, sz, P.thres, k);  // wave-cooperative: every lane takes part
-    if (!live) return;
-    ok = ok && (double)k.d[4] < P.thres_d;  // :285 / :705
+// model fit + factor record for one feature (a14 / a15 / a16), given its exact 5 nearest map points
+__device__ __forceinline__ void fit_and_store(const AssocParams& P, int kind, int b, int i, const float4 f, const double* T,
+                                              float sx, float sy, float sz, bool ok, const Knn5& k) {
     const float4* mp = P.map_orig[kind];
     if (kind == 0) {
         MmlLineFactor out;
@@ -755,6 +876,127 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
             }
         }
         P.pf[(size_t)b * P.MF + i] = out;
+    }
+}
+
+// pass 1: one feature per lane, rings 0 and 1 of the grid privately.  Features whose search is still open are
+// queued for pass 2 instead of stalling their wavefront (they cluster spatially, so without the queue a few
+// wavefronts full of far queries set the kernel time).
+// work decomposition: item = (kind, slot) pair, ceil(nf / 128) workgroup-sized chunks each; work_off is the exclusive
+// prefix over the 2 * count items.  A fixed-size grid walks the chunks, so no empty workgroups are dispatched
+// (with max_features = 8192 the dense grid spent more time retiring ~30 k empty workgroups than computing).
+__global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int B, const int* ft_n, int* work_off) {
+    __shared__ int s_sum[1024];
+    const int tid = threadIdx.x;
+    const int nitems = 2 * count;
+    int acc = 0;  // running prefix over tiles of 1024 items
+    for (int t0 = 0; t0 < nitems; t0 += 1024) {
+        const int it = t0 + tid;
+        int v = 0;
+        if (it < nitems) {
+            const int kind = it / count, slot = it % count;
+            const int nf = ft_n[kind * B + first + slot];
+            v = nf > 0 ? (nf + 127) / 128 : 0;
+        }
+        s_sum[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int x = tid >= o ? s_sum[tid - o] : 0;
+            __syncthreads();
+            s_sum[tid] += x;
+            __syncthreads();
+        }
+        if (it < nitems) work_off[it] = acc + s_sum[tid] - v;
+        acc += s_sum[1023];
+        __syncthreads();
+    }
+    if (tid == 0) work_off[nitems] = acc;
+}
+
+__global__ __launch_bounds__(128) void k_associate(AssocParams P) {
+    const int nitems = 2 * P.count;
+    const int total = P.work_off[nitems];
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    // locate the item that owns chunk w: last item with work_off[item] <= w
+    int lo = 0, hi = nitems;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (P.work_off[mid] <= w)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int kind = lo / P.count, slot = lo % P.count;
+    const int b = slot + P.first;
+    const int i = (w - P.work_off[lo]) * 128 + threadIdx.x;
+    const int nf = P.ft_n[kind * P.B + b];
+    if (i >= nf) continue;
+    const double* T = P.Twl + 16 * slot;
+    const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+    // Map_Manager.cpp:75-89 pointAssociateToMap: double transform stored to float
+    double wx, wy, wz;
+    tf_point(T, f.x, f.y, f.z, wx, wy, wz);
+    const float sx = wx, sy = wy, sz = wz;
+    bool ok = !(isnan(sx) || isnan(sy) || isnan(sz)) && P.map_m[kind] > 20;  // :196, :283 / :702
+    Knn5 k;
+    knn_init(k);
+    if (ok) {
+        const MmlGrid& g = P.g[kind];
+        const KnnQuery q = knn_query(g, sx, sy, sz);
+        const int rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
+        bool done = false;
+        for (int r = 0; r <= 1 && r <= rmax; ++r) {
+            for (int z = q.hz - r; z <= q.hz + r; ++z)
+                for (int y = q.hy - r; y <= q.hy + r; ++y) scan_shell_row(g, q, r, y, z, k);
+            if (knn_done(g, q.inset, r, k.d[4], P.thres)) {
+                done = true;
+                break;
+            }
+        }
+        if (!done && rmax >= 2) {
+            const int hw = atomicAdd(P.hard_count, 1);
+            P.hard_list[hw] = make_int4(slot, kind, i, 0);
+            continue;  // finished by k_associate_hard
+        }
+    }
+    ok = ok && (double)k.d[4] < P.thres_d;  // :285 / :705
+    fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, k);
+    }
+}
+
+// pass 2: one wavefront per queued feature; the 64 lanes split the rows of every shell and merge their private
+// top-5 lists with shuffles.  Lane 0 then runs the model fit.
+__global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * 256) >> 6;
+    const int total = *P.hard_count;
+    for (int w = wave; w < total; w += nwaves) {
+        const int4 e = P.hard_list[w];
+        const int slot = e.x, kind = e.y, i = e.z;
+        const int b = slot + P.first;
+        const double* T = P.Twl + 16 * slot;
+        const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+        double wx, wy, wz;
+        tf_point(T, f.x, f.y, f.z, wx, wy, wz);
+        const float sx = wx, sy = wy, sz = wz;
+        const MmlGrid& g = P.g[kind];
+        const KnnQuery q = knn_query(g, sx, sy, sz);
+        const int rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
+        Knn5 loc, best;
+        knn_init(loc);
+        knn_init(best);
+        for (int r = 0; r <= rmax; ++r) {
+            const int ww = 2 * r + 1;
+            for (int t = lane; t < ww * ww; t += 64) scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc);
+            if (r == 0) continue;  // ring 0 alone rarely terminates; merge from ring 1 on
+            wave_merge5(loc, best);
+            if (knn_done(g, q.inset, r, best.d[4], P.thres)) break;
+        }
+        if (lane == 0) {
+            const bool ok = (double)best.d[4] < P.thres_d;
+            fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, best);
+        }
     }
 }
 
@@ -908,9 +1150,19 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     P.thres = (float)thres_dist;
     if ((double)P.thres < thres_dist) P.thres = nextafterf(P.thres, INFINITY);
     P.thres_d = thres_dist;
+    P.hard_count = ctx->d_misc + 32;
+    P.hard_list = ctx->hard_list;
+    MML_HIP(hipMemsetAsync(P.hard_count, 0, sizeof(int), ctx->stream));
+    P.count = count;
+    P.work_off = ctx->work_off;
     {
         MmlStageScope t(ctx, "associate");
-        hipLaunchKernelGGL(k_associate, dim3((ctx->MF + 127) / 128, count, 2), dim3(128), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, ctx->stream, first, count, ctx->B, ctx->ft_n, ctx->work_off);
+        hipLaunchKernelGGL(k_associate, dim3(4096), dim3(128), 0, ctx->stream, P);
+    }
+    {
+        MmlStageScope t(ctx, "associate_far");
+        hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, ctx->stream, P);
     }
     {
         MmlStageScope t(ctx, "assoc_stats");

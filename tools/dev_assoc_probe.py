@@ -9,7 +9,7 @@ from scipy.spatial.transform import Rotation as Rsc
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    ctx = M.Context(max_scans=B, max_map_points=1 << 18)
+    ctx = M.Context(max_scans=B, max_map_points=1 << 18, max_features=int(os.environ.get("MF", "8192")))
     base = 100
     cm, sm = [], []
     for k in range(base - 8, base):
