@@ -388,6 +388,26 @@ __device__ __forceinline__ bool find_line(const FeatParams& P, int b, int p, int
 }
 
 // ---- a3 + every order-independent predicate of a5..a7: one point per lane -----------------------------------
+// The reference evaluates its angle predicates as fabs(dot / (norm * norm)) > c in double, i.e. two sqrt and a
+// division per test, eight vector normalisations for the included-angle test.  Here every such predicate is first
+// evaluated in the equivalent sqrt/division-free form (dot^2 vs c^2 * n1 * n2, normalisations through v_rsq_f64 +
+// Newton) with a guard band several orders above the rounding error of either form; only when the value falls
+// inside the band (probability ~1e-10 per point) the reference expression itself is evaluated.  Decisions are
+// therefore identical to the reference arithmetic while the common path stays free of f64 sqrt / div sequences.
+__device__ __forceinline__ double rsqrt_nr(double z) {  // 1/sqrt(z), relative error ~1e-16 after two Newton steps
+    double y = __builtin_amdgcn_rsq(z);
+    y = y * (1.5 - (0.5 * z) * (y * y));
+    y = y * (1.5 - (0.5 * z) * (y * y));
+    return y;
+}
+// decides fabs(dot / (sqrt(n1) * sqrt(n2))) > c without sqrt / div; returns false through `certain` when too close
+__device__ __forceinline__ bool abs_cos_gt(double dot, double n1, double n2, double c2, bool& certain) {
+    const double lhs = dot * dot, rhs = c2 * (n1 * n2);
+    const double diff = lhs - rhs;
+    certain = fabs(diff) > 1e-10 * rhs;  // also false for degenerate (zero-length) vectors: rhs == 0
+    return diff > 0.0;
+}
+
 __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     const int b = blockIdx.y + P.first;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -409,17 +429,23 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
 #define PT(o) q[5 + (o)]
         // ---- :407-451 ----
         float diffX = 0, diffY = 0, diffZ = 0;
-        float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
-        float dis = sqrt((double)dis2);
-        D3 pt_last = d3(PT(-1).x, PT(-1).y, PT(-1).z);
-        D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
-        D3 pt_next = d3(PT(1).x, PT(1).y, PT(1).z);
-        D3 dl = d3(pt_last.x - pt_cur.x, pt_last.y - pt_cur.y, pt_last.z - pt_cur.z);
-        D3 dn = d3(pt_next.x - pt_cur.x, pt_next.y - pt_cur.y, pt_next.z - pt_cur.z);
-        double ncur = dnorm(pt_cur);
-        double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
-        double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
-        bool grazing = fabs(angle_last) > 0.966 && fabs(angle_next) > 0.966;
+        const float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
+        const float dis = sqrtf(dis2);  // == (float)sqrt((double)dis2): IEEE float sqrt
+        const D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
+        const D3 dl = d3((double)PT(-1).x - pt_cur.x, (double)PT(-1).y - pt_cur.y, (double)PT(-1).z - pt_cur.z);
+        const D3 dn = d3((double)PT(1).x - pt_cur.x, (double)PT(1).y - pt_cur.y, (double)PT(1).z - pt_cur.z);
+        const double n0 = ddot(pt_cur, pt_cur);
+        bool c1, c2;
+        bool gl = abs_cos_gt(ddot(dl, pt_cur), ddot(dl, dl), n0, 0.966 * 0.966, c1);
+        bool gn = abs_cos_gt(ddot(dn, pt_cur), ddot(dn, dn), n0, 0.966 * 0.966, c2);
+        if (!(c1 && c2)) {  // reference expression (:421-422)
+            const double ncur = dnorm(pt_cur);
+            const double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
+            const double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
+            gl = fabs(angle_last) > 0.966;
+            gn = fabs(angle_next) > 0.966;
+        }
+        const bool grazing = gl && gn;
         int thNumCurvSize;
         if (dis > thDistanceFaraway || grazing) {
             thNumCurvSize = 2;
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         refl = diffR;
         // ---- predicates of :488, :499/:512, :524, :534-535 ----
         if (curv < thFlatThreshold * dis * thFlatThreshold * dis) attr |= A_CAND3;
-        bool far = dis > thDistanceFaraway;
+        const bool far = dis > thDistanceFaraway;
         if (far) attr |= A_FAR;
         if (curv < 0.7 * thFlatThreshold * dis * thFlatThreshold * dis && refl > 20.0) attr |= A_REFL;
         {
@@ -478,55 +504,83 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         }
         // ---- :543-650 (per visited point; which points are visited is decided in k_select) ----
         {
-            float depth = dis;
+            const float depth = dis;
             float ldiffX = PT(-4).x + PT(-3).x - 4 * PT(-2).x + PT(-1).x + PT(0).x;
             float ldiffY = PT(-4).y + PT(-3).y - 4 * PT(-2).y + PT(-1).y + PT(0).y;
             float ldiffZ = PT(-4).z + PT(-3).z - 4 * PT(-2).z + PT(-1).z + PT(0).z;
             float left_curvature = ldiffX * ldiffX + ldiffY * ldiffY + ldiffZ * ldiffZ;
-            bool lflat = left_curvature < thFlatThreshold * depth;
+            const bool lflat = left_curvature < thFlatThreshold * depth;
             float rdiffX = PT(4).x + PT(3).x - 4 * PT(2).x + PT(1).x + PT(0).x;
             float rdiffY = PT(4).y + PT(3).y - 4 * PT(2).y + PT(1).y + PT(0).y;
             float rdiffZ = PT(4).z + PT(3).z - 4 * PT(2).z + PT(1).z + PT(0).z;
             float right_curvature = rdiffX * rdiffX + rdiffY * rdiffY + rdiffZ * rdiffZ;
-            bool rflat = right_curvature < thFlatThreshold * depth;
+            const bool rflat = right_curvature < thFlatThreshold * depth;
             if (lflat) attr |= A_LFLAT;
             if (rflat) attr |= A_RFLAT;
             if (lflat && rflat) {
-                D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
+                // fast form of :615-644
+                D3 nl = d3(0, 0, 0), nr = d3(0, 0, 0);
+                double last2 = 0, cur2 = 0;
 #pragma unroll
                 for (int k = 1; k < 5; k++) {
-                    D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
-                    dnormalize(tmp);
-                    norm_left.x += (k / 10.0) * tmp.x;
-                    norm_left.y += (k / 10.0) * tmp.y;
-                    norm_left.z += (k / 10.0) * tmp.z;
+                    const D3 tl = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+                    const D3 tr = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+                    const double zl = ddot(tl, tl), zr = ddot(tr, tr);
+                    const double il = zl > 0.0 ? rsqrt_nr(zl) : 1.0, ir = zr > 0.0 ? rsqrt_nr(zr) : 1.0;
+                    const double wl = (k / 10.0) * il, wr = (k / 10.0) * ir;
+                    nl.x += wl * tl.x;
+                    nl.y += wl * tl.y;
+                    nl.z += wl * tl.z;
+                    nr.x += wr * tr.x;
+                    nr.y += wr * tr.y;
+                    nr.z += wr * tr.z;
+                    if (k == 4) {
+                        last2 = zl;
+                        cur2 = zr;
+                    }
                 }
+                bool ca;
+                const bool cc_ge = abs_cos_gt(ddot(nl, nr), ddot(nl, nl), ddot(nr, nr), 0.25, ca);  // cc > 0.5
+                const bool cl = fabs(last2 - 0.0025) > 1e-12, cr = fabs(cur2 - 0.0025) > 1e-12;
+                bool c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
+                if (!(ca && cl && cr)) {  // reference expression (:615-644)
+                    D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
 #pragma unroll
-                for (int k = 1; k < 5; k++) {
-                    D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
-                    dnormalize(tmp);
-                    norm_right.x += (k / 10.0) * tmp.x;
-                    norm_right.y += (k / 10.0) * tmp.y;
-                    norm_right.z += (k / 10.0) * tmp.z;
+                    for (int k = 1; k < 5; k++) {
+                        D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+                        dnormalize(tmp);
+                        norm_left.x += (k / 10.0) * tmp.x;
+                        norm_left.y += (k / 10.0) * tmp.y;
+                        norm_left.z += (k / 10.0) * tmp.z;
+                    }
+#pragma unroll
+                    for (int k = 1; k < 5; k++) {
+                        D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+                        dnormalize(tmp);
+                        norm_right.x += (k / 10.0) * tmp.x;
+                        norm_right.y += (k / 10.0) * tmp.y;
+                        norm_right.z += (k / 10.0) * tmp.z;
+                    }
+                    double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
+                    D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
+                    D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
+                    double last_dis = dnorm(last_tmp);
+                    double current_dis = dnorm(current_tmp);
+                    c150 = cc < 0.5 && last_dis > 0.05 && current_dis > 0.05;
                 }
-                double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
-                D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
-                D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
-                double last_dis = dnorm(last_tmp);
-                double current_dis = dnorm(current_tmp);
-                if (cc < 0.5 && last_dis > 0.05 && current_dis > 0.05) attr |= A_C150;
+                if (c150) attr |= A_C150;
             }
         }
         // ---- :651-806 break points ----
         {
             float dX1 = PT(1).x - PT(0).x, dY1 = PT(1).y - PT(0).y, dZ1 = PT(1).z - PT(0).z;
-            float diff_right0 = sqrt((double)(dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1));
+            float diff_right0 = sqrtf(dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1);
             float dX2 = PT(-1).x - PT(0).x, dY2 = PT(-1).y - PT(0).y, dZ2 = PT(-1).z - PT(0).z;
-            float diff_left0 = sqrt((double)(dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2));
-            float depth_right = sqrt((double)(PT(1).x * PT(1).x + PT(1).y * PT(1).y + PT(1).z * PT(1).z));
-            float depth_left = sqrt((double)(PT(-1).x * PT(-1).x + PT(-1).y * PT(-1).y + PT(-1).z * PT(-1).z));
+            float diff_left0 = sqrtf(dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2);
             bool f100 = false;
-            if (fabs((double)(diff_right0 - diff_left0)) > thBreakCornerDis) {
+            if (fabsf(diff_right0 - diff_left0) > thBreakCornerDis) {
+                float depth_right = sqrtf(PT(1).x * PT(1).x + PT(1).y * PT(1).y + PT(1).z * PT(1).z);
+                float depth_left = sqrtf(PT(-1).x * PT(-1).x + PT(-1).y * PT(-1).y + PT(-1).z * PT(-1).z);
                 if (diff_right0 > diff_left0) {
                     D3 surf_vector = d3(PT(-1).x - PT(0).x, PT(-1).y - PT(0).y, PT(-1).z - PT(0).z);
                     D3 lidar_vector = d3(PT(0).x, PT(0).y, PT(0).z);
@@ -553,7 +607,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
                 D3 norm_front = d3(0, 0, 0), norm_back = d3(0, 0, 0);
 #pragma unroll
                 for (int k = 1; k < 4; k++) {
-                    float temp_depth = sqrt((double)(PT(-k).x * PT(-k).x + PT(-k).y * PT(-k).y + PT(-k).z * PT(-k).z));
+                    float temp_depth = sqrtf(PT(-k).x * PT(-k).x + PT(-k).y * PT(-k).y + PT(-k).z * PT(-k).z);
                     if (temp_depth < 1) continue;
                     D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
                     dnormalize(tmp);
@@ -564,7 +618,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
 #pragma unroll
                 for (int k = 1; k < 4; k++) {
                     // the reference tests the depth of i-k here as well (:782-784)
-                    float temp_depth = sqrt((double)(PT(-k).x * PT(-k).x + PT(-k).y * PT(-k).y + PT(-k).z * PT(-k).z));
+                    float temp_depth = sqrtf(PT(-k).x * PT(-k).x + PT(-k).y * PT(-k).y + PT(-k).z * PT(-k).z);
                     if (temp_depth < 1) continue;
                     D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
                     dnormalize(tmp);
@@ -611,9 +665,15 @@ __device__ __forceinline__ void partition_bounds(int n, int j, int& sp, int& ep)
 //     then chained across windows.
 // Bit-identical to the serial form (checked against the oracle on every test line).  Lines that do not fit the LDS
 // budget run the same code on a global-memory scratch.
-constexpr int SELP_THREADS = 256;
-enum : unsigned { I_PART_MASK = 63u, I_A_SHIFT = 6, I_B_SHIFT = 8, I_CAND = 1u << 10, I_INPART = 1u << 11 };
-enum : unsigned char { ST_N = 0, ST_U = 1, ST_S = 2 };
+constexpr int SELP_THREADS = 512;
+// per-point word W1 (owned and written by the point's thread only; neighbours read it):
+//   [0:5] partition  [6:7] a  [8:9] b  [10] cand  [11] inpart  [12] angle  [13] far  [14] refl candidate
+//   [15:20] static predecessor mask (which of the 6 neighbours can suppress me)  [21:22] state
+//   [23:25] f3a | covLater<<2   [26:29] inB, eff3, G, b_first
+enum : unsigned { I_PART_MASK = 63u, I_A_SHIFT = 6, I_B_SHIFT = 8, I_CAND = 1u << 10, I_INPART = 1u << 11,
+                  I_ANGLE = 1u << 12, I_FAR = 1u << 13, I_REFL = 1u << 14, I_MASK_SHIFT = 15, I_ST_SHIFT = 21,
+                  I_ST_MASK = 3u << 21, I_F_SHIFT = 23, I_X_SHIFT = 26 };
+enum : unsigned { ST_N = 0, ST_U = 1, ST_S = 2 };
 
 __device__ __forceinline__ bool covers(unsigned info_j, int d /* i - j */) {
     const int a = (info_j >> I_A_SHIFT) & 3, bb = (info_j >> I_B_SHIFT) & 3;
@@ -631,12 +691,14 @@ __device__ __forceinline__ bool visits_before(unsigned info_j, unsigned key_j, i
     if (key_j != key_i) return key_j < key_i;
     return j < i;
 }
+__device__ __forceinline__ unsigned st_of(unsigned w) { return (w >> I_ST_SHIFT) & 3u; }
 
-template <typename KeyP, typename InfoP, typename ByteP, typename U64P>
-__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, KeyP key, InfoP info, ByteP st,
-                                            ByteP flg, ByteP aux, U64P wmask, U64P wvis, ByteP wexit, ByteP wsel,
-                                            unsigned long long (*s_pm)[3], unsigned long long* s_minE,
-                                            unsigned long long* s_minG, unsigned char* s_bfirst) {
+// W: interleaved {key, W1} pairs (8 bytes per point).
+template <typename WP, typename U64P, typename ByteP>
+__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, WP W, U64P wmask, U64P wvis,
+                                            ByteP wexit, ByteP wsel, int* s_sp, unsigned long long (*s_pm)[3],
+                                            unsigned long long* s_minE, unsigned long long* s_minG,
+                                            unsigned char* s_bfirst) {
     const int tid = threadIdx.x, lane = tid & 63;
     const uint16_t* attr = P.ln_attr + base;
     const float* curv = P.ln_curv + base;
@@ -645,36 +707,10 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     int T = 2;  // thNumCurvSize as the last stencil iteration (i = n-6) left it (:492,505)
     if (n >= 11) T = (attr[n - 6] & A_W2) ? 2 : 3;
     const int range = n - 11;
-
-    // ---- phase 0: per-point record --------------------------------------------------------------------------
-    for (int i = tid; i < n; i += SELP_THREADS) {
-        unsigned inf = 0, k = 0;
-        unsigned char s0 = ST_N;
-        if (range >= 1 && i >= 5 && i <= n - 7) {
-            const unsigned at = attr[i];
-            int j = (int)(((long long)(i - 5) * 50) / range);
-            if (j > 49) j = 49;
-            int sp, ep;
-            partition_bounds(n, j, sp, ep);
-            while (i > ep) {
-                ++j;
-                partition_bounds(n, j, sp, ep);
-            }
-            while (i < sp) {
-                --j;
-                partition_bounds(n, j, sp, ep);
-            }
-            const unsigned a = min((int)((at >> A_A3_SHIFT) & 3u), T), bb = min((int)((at >> A_B3_SHIFT) & 3u), T);
-            inf = (unsigned)j | (a << I_A_SHIFT) | (bb << I_B_SHIFT) | I_INPART;
-            k = __float_as_uint(curv[i]);
-            if (at & A_CAND3) {
-                inf |= I_CAND;
-                s0 = ST_U;
-            }
-        }
-        key[i] = k;
-        info[i] = (unsigned short)inf;
-        st[i] = s0;
+    for (int j = tid; j <= 50; j += SELP_THREADS) {
+        int sp, ep;
+        partition_bounds(n, j, sp, ep);
+        s_sp[j] = sp;  // s_sp[50] = n - 6 = one past the last partition
     }
     for (int t = tid; t < 50 * 3; t += SELP_THREADS) (&s_pm[0][0])[t] = ~0ull;
     for (int t = tid; t < 50; t += SELP_THREADS) {
@@ -683,42 +719,65 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     }
     __syncthreads();
 
+    // ---- phase 0: per-point record --------------------------------------------------------------------------
+    const float inv_m = range >= 1 ? 50.0f / (float)range : 0.f;
+    for (int i = tid; i < n; i += SELP_THREADS) {
+        unsigned inf = 0, k = 0;
+        if (range >= 1 && i >= 5 && i <= n - 7) {
+            const unsigned at = attr[i];
+            int j = (int)((float)(i - 5) * inv_m);
+            j = j < 0 ? 0 : (j > 49 ? 49 : j);
+            while (i >= s_sp[j + 1]) ++j;  // partitions tile [5, n-7]; empty ones have sp[j+1] == sp[j]
+            while (i < s_sp[j]) --j;
+            const unsigned a = min((int)((at >> A_A3_SHIFT) & 3u), T), bb = min((int)((at >> A_B3_SHIFT) & 3u), T);
+            inf = (unsigned)j | (a << I_A_SHIFT) | (bb << I_B_SHIFT) | I_INPART;
+            if (at & A_ANGLE) inf |= I_ANGLE;
+            if (at & A_FAR) inf |= I_FAR;
+            if (at & A_REFL) inf |= I_REFL;
+            k = __float_as_uint(curv[i]);
+            if (at & A_CAND3) inf |= I_CAND | (ST_U << I_ST_SHIFT);
+        }
+        W[2 * i] = k;
+        W[2 * i + 1] = inf;
+    }
+    __syncthreads();
+
     // ---- phase 1: which neighbours can suppress me (static), then dependency rounds ----------------------------
     for (int i = tid; i < n; i += SELP_THREADS) {
+        const unsigned me = W[2 * i + 1];
+        if (!(me & I_CAND)) continue;
+        const unsigned mk = W[2 * i];
         unsigned m = 0;
-        const unsigned me = info[i];
-        if (me & I_CAND) {
-            const unsigned mk = key[i];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
-                const int j = i + d;
-                if (j < 0 || j >= n) continue;
-                const unsigned o = info[j];
-                if ((o & I_CAND) && covers(o, -d) && visits_before(o, key[j], j, me, mk, i)) m |= 1u << q;
-            }
+        for (int q = 0; q < 6; ++q) {
+            const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
+            const int j = i + d;
+            if (j < 0 || j >= n) continue;
+            const unsigned o = W[2 * j + 1];
+            if ((o & I_CAND) && covers(o, -d) && visits_before(o, W[2 * j], j, me, mk, i)) m |= 1u << q;
         }
-        aux[i] = (unsigned char)m;
+        W[2 * i + 1] = me | (m << I_MASK_SHIFT);
     }
     __syncthreads();
     for (;;) {
         int undecided = 0;
         for (int i = tid; i < n; i += SELP_THREADS) {
-            if (st[i] != ST_U) continue;
-            const unsigned m = aux[i];
+            const unsigned me = W[2 * i + 1];
+            if (st_of(me) != ST_U) continue;
+            const unsigned m = (me >> I_MASK_SHIFT) & 63u;
             bool anyS = false, anyU = false;
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 if (!(m & (1u << q))) continue;
                 const int d = q < 3 ? q - 3 : q - 2;
-                const unsigned char s = st[i + d];
+                const unsigned s = st_of(W[2 * (i + d) + 1]);
                 anyS |= (s == ST_S);
                 anyU |= (s == ST_U);
             }
             if (anyS)
-                st[i] = ST_N;
+                W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_N << I_ST_SHIFT);
             else if (!anyU)
-                st[i] = ST_S;
+                W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT);
             else
                 undecided = 1;
         }
@@ -727,9 +786,9 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 
     // ---- phase 2: value held when :521-539 runs (f3a) + "a later partition marks me" ------------------------------
     for (int i = tid; i < n; i += SELP_THREADS) {
-        const unsigned me = info[i];
-        const unsigned mk = key[i];
-        const bool sel = st[i] == ST_S;
+        const unsigned me = W[2 * i + 1];
+        const unsigned mk = W[2 * i];
+        const bool sel = st_of(me) == ST_S;
         const int mypart = (me & I_INPART) ? (int)(me & I_PART_MASK) : (i < 5 ? -1 : 64);
         bool covL = false, covLater = false;
 #pragma unroll
@@ -737,29 +796,33 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             const int d = q < 3 ? q - 3 : q - 2;
             const int j = i + d;
             if (j < 0 || j >= n) continue;
-            if (st[j] != ST_S) continue;
-            const unsigned o = info[j];
-            if (!covers(o, -d)) continue;
+            const unsigned o = W[2 * j + 1];
+            if (st_of(o) != ST_S || !covers(o, -d)) continue;
             const int pj = (int)(o & I_PART_MASK);
             if (pj > mypart)
                 covLater = true;
-            else if (!sel || visits_before(me, mk, i, o, key[j], j))
+            else if (!sel || visits_before(me, mk, i, o, W[2 * j], j))
                 covL = true;
         }
         const unsigned f3a = covL ? 1u : (sel ? 3u : 0u);
-        flg[i] = (unsigned char)(f3a | (covLater ? 4u : 0u));
+        const unsigned f = f3a | (covLater ? 4u : 0u);
+        // the word is only read by its owner from here on
+        W[2 * i + 1] = me | (f << I_F_SHIFT);
+        // (a) first round of the reflect-candidate minimum
+        if ((me & I_REFL) && (me & I_INPART))
+            atomicMin(&s_pm[me & I_PART_MASK][0], ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i);
     }
     __syncthreads();
 
     // ---- phase 3: :521-539 in closed form ---------------------------------------------------------------------------
-    // (a) the three first reflect candidates in reflect order, per partition
-    for (int round = 0; round < 3; ++round) {
+    // (a) the three first reflect candidates in reflect order, per partition (rounds 2 and 3)
+    for (int round = 1; round < 3; ++round) {
         for (int i = tid; i < n; i += SELP_THREADS) {
-            const unsigned me = info[i];
-            if (!(me & I_INPART) || !(attr[i] & A_REFL)) continue;
+            const unsigned me = W[2 * i + 1];
+            if (!(me & I_REFL) || !(me & I_INPART)) continue;
             const int j = me & I_PART_MASK;
             const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
-            if (round > 0 && rk <= s_pm[j][round - 1]) continue;
+            if (rk <= s_pm[j][round - 1]) continue;
             atomicMin(&s_pm[j][round], rk);
         }
         __syncthreads();
@@ -771,13 +834,12 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         const unsigned long long e = s_pm[j][r];
         if (e == ~0ull) continue;  // wave-uniform
         const int i = (int)(unsigned)e;
-        int sp, ep;
-        partition_bounds(n, j, sp, ep);
-        const unsigned mk = key[i];
+        const int sp = s_sp[j], ep = s_sp[j + 1] - 1;
+        const unsigned mk = W[2 * i];
         const unsigned mr = (unsigned)(e >> 32);
         int rc = 0, rr = 0;
         for (int q = sp + lane; q <= ep; q += 64) {
-            const unsigned kq = key[q], rq = refl_key(refl[q]);
+            const unsigned kq = W[2 * q], rq = refl_key(refl[q]);
             rc += (kq < mk) || (kq == mk && q < i);
             rr += (rq < mr) || (rq == mr && q < i);
         }
@@ -791,50 +853,28 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     __syncthreads();
     // (b) eff3 / G bits, first point of each class in curvature order per partition
     for (int i = tid; i < n; i += SELP_THREADS) {
-        const unsigned me = info[i];
-        unsigned char bits = 0;
-        if (me & I_INPART) {
-            const unsigned at = attr[i];
-            const int j = me & I_PART_MASK;
-            bool inB = false, b_first = false;
-            if (at & A_REFL) {
-                const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
+        const unsigned me = W[2 * i + 1];
+        if (!(me & I_INPART)) continue;
+        const int j = me & I_PART_MASK;
+        bool inB = false, b_first = false;
+        if (me & I_REFL) {
+            const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    if (rk == s_pm[j][r]) {
-                        inB = true;
-                        b_first = s_bfirst[j * 3 + r];
-                    }
-            }
-            const bool eff3 = ((flg[i] & 3u) == 3u) && !(inB && b_first);
-            const bool G = (at & A_ANGLE) || (eff3 && (at & A_FAR));
-            bits = (inB ? 1 : 0) | (eff3 ? 2 : 0) | (G ? 4 : 0) | (b_first ? 8 : 0);
-            const unsigned long long ck = ((unsigned long long)key[i] << 32) | (unsigned)i;
+            for (int r = 0; r < 3; ++r)
+                if (rk == s_pm[j][r]) {
+                    inB = true;
+                    b_first = s_bfirst[j * 3 + r];
+                }
+        }
+        const bool eff3 = (((me >> I_F_SHIFT) & 3u) == 3u) && !(inB && b_first);
+        const bool G = (me & I_ANGLE) || (eff3 && (me & I_FAR));
+        if (inB || eff3 || G) {
+            const unsigned bits = (inB ? 1u : 0u) | (eff3 ? 2u : 0u) | (G ? 4u : 0u) | (b_first ? 8u : 0u);
+            W[2 * i + 1] = me | (bits << I_X_SHIFT);
+            const unsigned long long ck = ((unsigned long long)W[2 * i] << 32) | (unsigned)i;
             if (eff3) atomicMin(&s_minE[j], ck);
             if (G) atomicMin(&s_minG[j], ck);
         }
-        aux[i] = bits;
-    }
-    __syncthreads();
-    // (c) final value of the serial part
-    for (int i = tid; i < n; i += SELP_THREADS) {
-        const unsigned me = info[i];
-        unsigned f = flg[i] & 3u;
-        if (me & I_INPART) {
-            const unsigned at = attr[i];
-            const int j = me & I_PART_MASK;
-            const unsigned char bits = aux[i];
-            const bool inB = bits & 1, eff3 = bits & 2, G = bits & 4, b_first = bits & 8;
-            const unsigned long long ck = ((unsigned long long)key[i] << 32) | (unsigned)i;
-            const bool first = eff3 && ck == s_minE[j] && !(s_minG[j] < s_minE[j]);
-            const bool picked = G || first;
-            if (inB)
-                f = (picked && (at & A_ANGLE) && b_first) ? 2u : 4u;
-            else if (picked)
-                f = 2u;
-        }
-        if (flg[i] & 4u) f = 1u;   // marked by a point of a later partition (:503,516 of the next partitions)
-        st[i] = (unsigned char)f;  // st[] now holds the serial-part flag (4 encodes 300)
     }
     __syncthreads();
 
@@ -868,13 +908,28 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     }
     __syncthreads();
 
-    // ---- phase 5: overrides (150, 100/101), emit, label scatter -------------------------------------------------------
+    // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
     const int* gidx = P.ln_gidx + base;
     uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
     for (int i = tid; i < n; i += SELP_THREADS) {
+        const unsigned me = W[2 * i + 1];
         const unsigned at = attr[i];
-        int f = st[i];
-        if (f == 4) f = 300;
+        int f = (me >> I_F_SHIFT) & 3u;
+        if (me & I_INPART) {
+            const int j = me & I_PART_MASK;
+            const unsigned bits = (me >> I_X_SHIFT) & 15u;
+            if (bits) {
+                const bool inB = bits & 1, eff3 = bits & 2, G = bits & 4, b_first = bits & 8;
+                const unsigned long long ck = ((unsigned long long)W[2 * i] << 32) | (unsigned)i;
+                const bool first = eff3 && ck == s_minE[j] && !(s_minG[j] < s_minE[j]);
+                const bool picked = G || first;
+                if (inB)
+                    f = (picked && (me & I_ANGLE) && b_first) ? 2 : 300;
+                else if (picked)
+                    f = 2;
+            }
+        }
+        if ((me >> I_F_SHIFT) & 4u) f = 1;  // marked by a point of a later partition (:503,516 of the next partitions)
         const bool inner = i >= 5 && i < n - 5;
         if (inner) {
             const int w = i >> 6;
@@ -896,8 +951,8 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 
 __host__ __device__ inline size_t select_lds_bytes(int cap) {
     const size_t nwin = (cap + 63) / 64;
-    // key u32 | wmask u64 | wvis 4 x u64 | info u16 | st, flg, aux u8 | wexit 4 x u8 | wsel u8
-    return (size_t)cap * 4 + nwin * 8 + nwin * 32 + (size_t)cap * 2 + (size_t)cap * 3 + nwin * 4 + nwin + 64;
+    // W: 2 x u32 per point | wmask u64 | wvis 4 x u64 | wexit 4 x u8 | wsel u8
+    return (size_t)cap * 8 + nwin * 8 + nwin * 32 + nwin * 4 + nwin + 64;
 }
 
 __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
@@ -905,6 +960,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     __shared__ unsigned long long s_pm[50][3];
     __shared__ unsigned long long s_minE[50], s_minG[50];
     __shared__ unsigned char s_bfirst[152];
+    __shared__ int s_sp[52];
     const int b = blockIdx.y + P.first;
     const int line = blockIdx.x;
     const int n = P.line_len[(size_t)b * P.L + line];
@@ -914,33 +970,24 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     if (n <= P.sel_cap) {
         const int cap = P.sel_cap;
         const int nwin = (cap + 63) / 64;
-        unsigned* key = reinterpret_cast<unsigned*>(smem);
-        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(key + cap);
+        unsigned* W = reinterpret_cast<unsigned*>(smem);
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(W + 2 * (size_t)cap);
         unsigned long long* wvis = wmask + nwin;
-        unsigned short* info = reinterpret_cast<unsigned short*>(wvis + 4 * nwin);
-        unsigned char* st = reinterpret_cast<unsigned char*>(info + cap);
-        unsigned char* flg = st + cap;
-        unsigned char* aux = flg + cap;
-        unsigned char* wexit = aux + cap;
+        unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);
         unsigned char* wsel = wexit + 4 * nwin;
-        select_body(P, b, n, base, key, info, st, flg, aux, wmask, wvis, wexit, wsel, s_pm, s_minE, s_minG, s_bfirst);
+        select_body(P, b, n, base, W, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst);
     } else {
-        // global scratch: four 4-byte slots per bucketed point (key | info | st,flg,aux | window tables)
+        // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
         const size_t BNT = (size_t)P.B * P.NT;
-        unsigned* key = P.sel_scratch + base;
-        unsigned short* info = reinterpret_cast<unsigned short*>(P.sel_scratch + BNT + base);
-        unsigned char* bytes = reinterpret_cast<unsigned char*>(P.sel_scratch + 2 * BNT + base);
-        unsigned char* st = bytes;
-        unsigned char* flg = bytes + n;
-        unsigned char* aux = bytes + 2 * (size_t)n;
+        unsigned* W = P.sel_scratch + 2 * base;
         const int nwin = (n + 63) / 64;
-        uintptr_t wp = reinterpret_cast<uintptr_t>(P.sel_scratch + 3 * BNT + base);
+        uintptr_t wp = reinterpret_cast<uintptr_t>(P.sel_scratch + 2 * BNT + 2 * base);
         wp = (wp + 7) & ~uintptr_t(7);
         unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wp);
         unsigned long long* wvis = wmask + nwin;
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * (size_t)nwin);
         unsigned char* wsel = wexit + 4 * (size_t)nwin;
-        select_body(P, b, n, base, key, info, st, flg, aux, wmask, wvis, wexit, wsel, s_pm, s_minE, s_minG, s_bfirst);
+        select_body(P, b, n, base, W, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst);
     }
 }
 
