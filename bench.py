@@ -31,8 +31,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s ach
 # The SURVEY 8(d) figures: extraction 20 B/pt in total, undistort 28 B/pt, association 112 B/feature,
 # linearisation 72 B/factor/iteration.  The extraction chain is split over its kernels by what each must move.
 STAGE_BYTES = {
-    "assign_velo":      lambda n_v, n_l, nf, it: 16 * n_v,            # read xyzi once
-    "assign_livox":     lambda n_v, n_l, nf, it: 20 * n_l,            # read the 20-byte records once
+    "assign":           lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l, # read the raw records once
     "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),    # read xyzi of every bucketed point
     "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),    # attr 2 B + 2 order keys 8 B + label 1 B
     "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),     # write the 4 B label/line/time record

@@ -63,7 +63,7 @@ void mml_destroy(mml_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
-                    ctx->sel_scratch,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
+                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
                     ctx->cb_label, ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
@@ -134,6 +134,11 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->ln_refl, B * NT);
     ALLOC(ctx->ln_attr, B * NT);
     ALLOC(ctx->sel_scratch, 4 * B * NT);
+    {
+        const size_t nblk = ((NV > NL ? NV : NL) + 255) / 256;
+        ALLOC(ctx->blk_cnt, B * 2 * nblk * 161);
+    }
+    ALLOC(ctx->assign_aux, B * 8);
     ALLOC(ctx->cb_xyzi, B * NT);
     ALLOC(ctx->cb_rel, B * NT);
     ALLOC(ctx->cb_line, B * NT);

@@ -53,6 +53,9 @@ struct FeatParams {
     float* ln_curv;
     float* ln_refl;
     uint16_t* ln_attr;
+    int* blk_cnt;        // [B][2][nblk_max][MAX_LINES + 1] per-block histograms / exclusive offsets
+    int* assign_aux;     // AssignAux per slot
+    int nblk_v, nblk_l, nblk_max, ring_bits, line_bits;
     unsigned* sel_scratch;  // global-memory scratch for lines longer than sel_cap: 4 x B*NT unsigned
     int sel_cap;            // points per line k_select keeps in LDS
     int B;
@@ -90,273 +93,288 @@ constexpr int ASSIGN_THREADS = 1024;
 constexpr int ASSIGN_WAVES = ASSIGN_THREADS / MML_WAVE;
 constexpr int MAX_LINES = 160;  // n_rings + n_livox_lines upper bound
 
-// Order-preserving multi-way scatter of one chunk of ASSIGN_THREADS items: returns the destination offset of
-// this thread's item inside its line (running over chunks), and its index among all valid items.
-// wcnt: [ASSIGN_WAVES][nkeys], base: [nkeys] running per-key counts, wtot: [ASSIGN_WAVES], *gbase running total.
-__device__ __forceinline__ void chunk_stable_scatter(bool valid, int key, int nkeys, int* wcnt, int* base, int* wtot,
-                                                    int* gbase, int& pos_in_key, int& gidx) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < ASSIGN_WAVES * nkeys; i += ASSIGN_THREADS) wcnt[i] = 0;
-    __syncthreads();
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    unsigned long long vmask = __ballot(valid);
-    int rank = 0;
-    unsigned long long todo = vmask;
-    while (todo) {
-        int leader = __ffsll((long long)todo) - 1;
-        int k = __shfl(key, leader);
-        unsigned long long m = __ballot(valid && key == k);
-        if (valid && key == k) rank = __popcll(m & lt);
-        if (lane == leader) wcnt[wave * nkeys + k] = __popcll(m);
-        todo &= ~m;
+// ---- a1 / a2: ring / line assignment + order-preserving bucketing, three fully parallel passes ------------------
+//   pass A (one point per lane) : validity, ring / line id, raw azimuth; per-256-point-block histograms
+//   pass B (one workgroup / slot / sensor): start / end azimuth, the halfPassed flip index, exclusive scans of the
+//                                  block histograms -> line offsets
+//   pass C (one point per lane) : in-scan time, destination = line start + block offset + rank inside the block
+// The rank of a point among the lanes of its wavefront that share its key comes from one ballot per key BIT
+// (lanes with equal keys = AND over bits of the matching ballot), not from a loop over distinct keys.
+constexpr int AB_THREADS = 256;
+constexpr int AB_WAVES = AB_THREADS / 64;
+
+__device__ __forceinline__ unsigned long long match_key(bool valid, int key, int nbits) {
+    unsigned long long m = __ballot(valid);
+    for (int bit = 0; bit < nbits; ++bit) {
+        const bool set = (key >> bit) & 1;
+        const unsigned long long bm = __ballot(valid && set);
+        m &= set ? bm : ~bm;
     }
-    if (lane == 0) wtot[wave] = __popcll(vmask);
-    __syncthreads();
-    int off = 0, goff = 0;
-    if (valid) {
-        off = base[key];
-        for (int w = 0; w < wave; ++w) off += wcnt[w * nkeys + key];
-        goff = *gbase;
-        for (int w = 0; w < wave; ++w) goff += wtot[w];
-        goff += __popcll(vmask & lt);
-    }
-    pos_in_key = off + rank;
-    gidx = goff;
-    __syncthreads();
-    for (int k = tid; k < nkeys; k += ASSIGN_THREADS) {
-        int s = 0;
-        for (int w = 0; w < ASSIGN_WAVES; ++w) s += wcnt[w * nkeys + k];
-        base[k] += s;
-    }
-    if (tid == 0) {
-        int s = 0;
-        for (int w = 0; w < ASSIGN_WAVES; ++w) s += wtot[w];
-        *gbase += s;
-    }
-    __syncthreads();
+    return m;
 }
 
-// ---- a1: getVeloFeature ring + relTime assignment (:1129-1218) -------------------------------------------
-// One workgroup per scan slot.  The serial `halfPassed` flag (:1148,1169-1184) is a prefix-OR: the first valid
-// point whose unwrapped azimuth exceeds startOri + pi flips it, so a min-reduction finds the flip index.
-__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_velo(FeatParams P) {
-    __shared__ int s_cnt[MAX_LINES];
-    __shared__ int s_base[MAX_LINES];
-    __shared__ int s_wcnt[ASSIGN_WAVES * MAX_LINES];
-    __shared__ int s_wtot[ASSIGN_WAVES];
-    __shared__ int s_first, s_last, s_trig, s_gbase;
-    __shared__ float s_startOri, s_endOri;
+struct AssignAux {  // per slot, written by passes A / B
+    int first_finite, last_finite, trig, pad;
+    float startOri, endOri;
+    int pad2[2];
+};
 
-    const int b = blockIdx.x + P.first;
-    const int tid = threadIdx.x;
-    const int n = P.n_in[2 * b];
-    const float4* in = P.velo_in + (size_t)b * P.NV;
-    uint8_t* rline = P.raw_line + (size_t)b * P.NT;
-    float* rori = P.raw_ori + (size_t)b * P.NV;
-    const int R = P.n_rings;
-
-    for (int i = tid; i < R; i += ASSIGN_THREADS) {
-        s_cnt[i] = 0;
-        s_base[i] = 0;
+__global__ void k_assign_init(FeatParams P, int count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) {
+        AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + (P.first + t);
+        a->first_finite = 0x7fffffff;
+        a->last_finite = -1;
+        a->trig = 0x7fffffff;
     }
+}
+
+// getVeloFeature per-point part (:1133, :1154-1168) -- ring id through a float estimate of the pitch, the reference
+// expression (double atan) only when the estimate is within 1e-3 ring widths of a rounding boundary.
+__device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pitch_step, int R) {
+    const float rxy = sqrtf(p.x * p.x + p.y * p.y);
+    const float est = atanf(p.z / rxy) * 57.29577951308232f;
+    const double t = (double)((est - pitch0) / pitch_step) + 0.5;
+    int scanID;
+    if (fabs(t - rint(t)) > 1e-3 && fabs(t) < 1e6) {
+        scanID = (int)t;
+    } else {
+        const float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;
+        scanID = int((angle - pitch0) / pitch_step + 0.5);
+    }
+    return (scanID > (R - 1) || scanID < 0) ? 255 : scanID;
+}
+
+__global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
+    __shared__ int s_bcnt[MAX_LINES];
+    __shared__ int s_valid;
+    const int b = blockIdx.y + P.first;
+    const int sensor = blockIdx.z;  // 0 velodyne, 1 livox
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = P.n_in[2 * b + sensor];
+    const int i = blockIdx.x * AB_THREADS + tid;
+    const int nblk = sensor == 0 ? P.nblk_v : P.nblk_l;
+    if ((int)blockIdx.x >= nblk) return;
+    const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
+    const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
+    for (int k = tid; k < nkeys; k += AB_THREADS) s_bcnt[k] = 0;
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    bool valid = false;
+    int key = 0;
+    if (i < n) {
+        if (sensor == 0) {
+            const float4 p = P.velo_in[(size_t)b * P.NV + i];
+            const bool fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+            int ring = 255;  // 255: non-finite (removed at :1133), 254: finite but outside the ring table (:1163-1166)
+            float ori = 0.f;
+            if (fin) {
+                ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
+                if (ring == 255) ring = 254;
+                ori = -atan2((double)p.y, (double)p.x);
+            }
+            P.raw_line[(size_t)b * P.NT + i] = (uint8_t)ring;
+            P.raw_ori[(size_t)b * P.NV + i] = ori;
+            valid = ring < 254;
+            key = valid ? ring : 0;
+        } else {
+            const mml_livox_point p = P.livox_in[(size_t)b * P.NL + i];
+            const int line_num = (int)p.line;
+            valid = !(line_num > nkeys - 1) && !(p.x < 0.01);
+            key = valid ? line_num : 0;
+            P.raw_line[(size_t)b * P.NT + P.NV + i] = (uint8_t)(valid ? line_num : 255);
+        }
+    }
+    const unsigned long long eq = match_key(valid, key, nbits);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (valid && (eq & lt) == 0) atomicAdd(&s_bcnt[key], __popcll(eq));  // first lane of each key group
+    const unsigned long long vm = __ballot(valid);
+    if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
+    __syncthreads();
+    int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * (MAX_LINES + 1);
+    for (int k = tid; k < nkeys; k += AB_THREADS) cnt[k] = s_bcnt[k];
+    if (tid == 0) cnt[MAX_LINES] = s_valid;
+}
+
+__global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
+    __shared__ int s_trig, s_first, s_last;
+    __shared__ int s_tot[MAX_LINES];
+    const int b = blockIdx.x + P.first;
+    const int sensor = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int n = P.n_in[2 * b + sensor];
+    const int nblk = (n + AB_THREADS - 1) / AB_THREADS;
+    const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
+    AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
+    int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * (MAX_LINES + 1);
     if (tid == 0) {
+        s_trig = 0x7fffffff;
         s_first = 0x7fffffff;
         s_last = -1;
-        s_trig = 0x7fffffff;
-        s_gbase = 0;
     }
     __syncthreads();
-
-    // pass 1: NaN filter (:1133), ring id (:1159-1166), raw azimuth (:1168), per-ring counts
-    for (int i = tid; i < n; i += ASSIGN_THREADS) {
-        float4 p = in[i];
-        bool fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
-        int ring = 255;
-        float ori = 0.f;
-        if (fin) {
-            atomicMin(&s_first, i);
-            atomicMax(&s_last, i);
-            float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;
-            int scanID = int((angle - P.pitch0) / P.pitch_step + 0.5);
-            if (!(scanID > (R - 1) || scanID < 0)) {
-                ring = scanID;
-                atomicAdd(&s_cnt[ring], 1);
-            }
-            ori = -atan2((double)p.y, (double)p.x);
+    // exclusive scan over blocks, one thread per key (+ one for the valid-point count)
+    if (tid <= nkeys) {
+        const int k = tid < nkeys ? tid : MAX_LINES;
+        int acc = 0;
+        for (int blk = 0; blk < nblk; ++blk) {
+            int* c = cnt0 + (size_t)blk * (MAX_LINES + 1) + k;
+            const int v = *c;
+            *c = acc;
+            acc += v;
         }
-        rline[i] = (uint8_t)ring;
-        rori[i] = ori;
+        s_tot[tid] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (sensor == 0) {
+        const uint8_t* rl = P.raw_line + (size_t)b * P.NT;
+        // first / last finite point (:1136-1139): strided search, min / max reduction
+        int ff = 0x7fffffff, lf = -1;
+        for (int i = tid; i < n; i += 1024)
+            if (rl[i] != 255) {
+                ff = i;
+                break;
+            }
+        for (int i = n - 1 - tid; i >= 0; i -= 1024)
+            if (rl[i] != 255) {
+                lf = i;
+                break;
+            }
+        for (int o = 32; o > 0; o >>= 1) {
+            ff = min(ff, __shfl_xor(ff, o));
+            lf = max(lf, __shfl_xor(lf, o));
+        }
+        if ((tid & 63) == 0) {
+            if (ff != 0x7fffffff) atomicMin(&s_first, ff);
+            if (lf >= 0) atomicMax(&s_last, lf);
+        }
+        __syncthreads();
         float startOri = 0.f, endOri = 0.f;
         if (s_last >= 0) {
-            float4 p0 = in[s_first], p1 = in[s_last];
-            startOri = -atan2((double)p0.y, (double)p0.x);
+            const float4 p0 = P.velo_in[(size_t)b * P.NV + s_first];
+            const float4 p1 = P.velo_in[(size_t)b * P.NV + s_last];
+            startOri = -atan2((double)p0.y, (double)p0.x);   // :1136
             endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
             if (endOri - startOri > 3 * M_PI)
                 endOri -= 2 * M_PI;
             else if (endOri - startOri < M_PI)
                 endOri += 2 * M_PI;
         }
-        s_startOri = startOri;
-        s_endOri = endOri;
-        int acc = 0;
-        int* ls = P.line_start + (size_t)b * P.L;
-        int* ll = P.line_len + (size_t)b * P.L;
-        for (int r = 0; r < R; ++r) {
-            ls[r] = acc;
-            ll[r] = s_cnt[r];
-            acc += s_cnt[r];
-        }
-        P.cb_n[2 * b] = acc;
-    }
-    __syncthreads();
-    const float startOri = s_startOri, endOri = s_endOri;
-
-    // pass 2: index of the point that sets halfPassed (:1169-1177)
-    for (int i = tid; i < n; i += ASSIGN_THREADS) {
-        if (rline[i] == 255) continue;
-        float ori = rori[i];
-        if (ori < startOri - M_PI / 2)
-            ori += 2 * M_PI;
-        else if (ori > startOri + M_PI * 3 / 2)
-            ori -= 2 * M_PI;
-        if (ori - startOri > M_PI) atomicMin(&s_trig, i);
-    }
-    __syncthreads();
-    const int trig = s_trig;
-
-    // pass 3: relTime (:1186) + stable bucketing (:1193-1194, :1209-1218)
-    const int* ls = P.line_start + (size_t)b * P.L;
-    float4* lp = P.ln_pts + (size_t)b * P.NT;
-    int* lg = P.ln_gidx + (size_t)b * P.NT;
-    float4* cbx = P.cb_xyzi + (size_t)b * P.NT;
-    float* cbr = P.cb_rel + (size_t)b * P.NT;
-    uint8_t* cbl = P.cb_line + (size_t)b * P.NT;
-    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
-    for (int c0 = 0; c0 < n; c0 += ASSIGN_THREADS) {
-        int i = c0 + tid;
-        bool valid = false;
-        int ring = 0;
-        float4 p = make_float4(0, 0, 0, 0);
-        float relTime = 0.f;
-        if (i < n) {
-            ring = rline[i];
-            valid = ring != 255;
-            if (valid) {
-                p = in[i];
-                float ori = rori[i];
-                if (i <= trig) {
-                    if (ori < startOri - M_PI / 2)
-                        ori += 2 * M_PI;
-                    else if (ori > startOri + M_PI * 3 / 2)
-                        ori -= 2 * M_PI;
-                } else {
-                    ori += 2 * M_PI;
-                    if (ori < endOri - M_PI * 3 / 2)
-                        ori += 2 * M_PI;
-                    else if (ori > endOri + M_PI / 2)
-                        ori -= 2 * M_PI;
-                }
-                relTime = (ori - startOri) / (endOri - startOri);
-            } else {
-                ring = 0;
+        // index of the point that sets halfPassed (:1169-1177): a prefix-OR, found with a min-reduction
+        const uint8_t* rline = P.raw_line + (size_t)b * P.NT;
+        const float* rori = P.raw_ori + (size_t)b * P.NV;
+        int best = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            if (rline[i] >= 254) continue;
+            float ori = rori[i];
+            if (ori < startOri - M_PI / 2)
+                ori += 2 * M_PI;
+            else if (ori > startOri + M_PI * 3 / 2)
+                ori -= 2 * M_PI;
+            if (ori - startOri > M_PI) {
+                best = i;
+                break;  // indices grow along this thread's stride
             }
         }
-        int pos, gidx;
-        chunk_stable_scatter(valid, ring, R, s_wcnt, s_base, s_wtot, &s_gbase, pos, gidx);
-        if (valid) {
-            int dst = ls[ring] + pos;
-            lp[dst] = p;
-            lg[dst] = gidx;
-            cbx[gidx] = make_float4(p.x, p.y, p.z, 0.f);  // intensity zeroed, :1254-1256
-            cbr[gidx] = relTime;
-            cbl[gidx] = (uint8_t)ring;
-            cblab[gidx] = 0;
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+        if ((tid & 63) == 0 && best != 0x7fffffff) atomicMin(&s_trig, best);
+        __syncthreads();
+        if (tid == 0) {
+            a->startOri = startOri;
+            a->endOri = endOri;
+            a->trig = s_trig;
         }
+    }
+    if (tid == 0) {
+        int acc = sensor == 0 ? 0 : P.NV;  // livox lines live behind the velodyne region
+        int* ls = P.line_start + (size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings);
+        int* ll = P.line_len + (size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings);
+        for (int r = 0; r < nkeys; ++r) {
+            ls[r] = acc;
+            ll[r] = s_tot[r];
+            acc += s_tot[r];
+        }
+        P.cb_n[2 * b + sensor] = s_tot[nkeys];
     }
 }
 
-// ---- a2: getHoriFeatureExtract line split (:985-1006) -----------------------------------------------------
 __device__ __forceinline__ double livox_to_sec(uint32_t t) {  // ros::Time().fromNSec(t).toSec()
     uint32_t sec = (uint32_t)(t / 1000000000ull);
     uint32_t nsec = (uint32_t)(t % 1000000000ull);
     return (double)sec + 1e-9 * (double)nsec;
 }
 
-__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign_livox(FeatParams P) {
-    __shared__ int s_cnt[MAX_LINES];
-    __shared__ int s_base[MAX_LINES];
-    __shared__ int s_wcnt[ASSIGN_WAVES * MAX_LINES];
-    __shared__ int s_wtot[ASSIGN_WAVES];
-    __shared__ int s_gbase;
-
-    const int b = blockIdx.x + P.first;
-    const int tid = threadIdx.x;
-    const int n = P.n_in[2 * b + 1];
-    const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
-    const int NLN = P.n_lines;
-    for (int i = tid; i < NLN; i += ASSIGN_THREADS) {
-        s_cnt[i] = 0;
-        s_base[i] = 0;
-    }
-    if (tid == 0) s_gbase = 0;
+__global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
+    __shared__ int s_wcnt[AB_WAVES][MAX_LINES];
+    __shared__ int s_wvalid[AB_WAVES];
+    const int b = blockIdx.y + P.first;
+    const int sensor = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n_in[2 * b + sensor];
+    const int i = blockIdx.x * AB_THREADS + tid;
+    if ((int)(blockIdx.x * AB_THREADS) >= n) return;
+    const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
+    const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
+    for (int k = tid; k < AB_WAVES * MAX_LINES; k += AB_THREADS) (&s_wcnt[0][0])[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += ASSIGN_THREADS) {
-        mml_livox_point p = in[i];
-        int line_num = (int)p.line;
-        bool valid = !(line_num > NLN - 1) && !(p.x < 0.01);
-        if (valid) atomicAdd(&s_cnt[line_num], 1);
-    }
+    const int region = sensor == 0 ? 0 : P.NV;
+    int key = 255;
+    if (i < n) key = P.raw_line[(size_t)b * P.NT + region + i];
+    const bool valid = key < 254;
+    if (!valid) key = 0;
+    const unsigned long long eq = match_key(valid, key, nbits);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long vm = __ballot(valid);
+    if (valid && (eq & lt) == 0) s_wcnt[wave][key] = __popcll(eq);
+    if (lane == 0) s_wvalid[wave] = __popcll(vm);
     __syncthreads();
-    int* ls = P.line_start + (size_t)b * P.L + P.n_rings;
-    int* ll = P.line_len + (size_t)b * P.L + P.n_rings;
-    if (tid == 0) {
-        int acc = P.NV;  // livox lines live behind the velodyne region
-        for (int r = 0; r < NLN; ++r) {
-            ls[r] = acc;
-            ll[r] = s_cnt[r];
-            acc += s_cnt[r];
-        }
-        P.cb_n[2 * b + 1] = acc - P.NV;
+    if (!valid) return;
+    const int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * (MAX_LINES + 1);
+    int pos = cnt[key] + __popcll(eq & lt);
+    int gidx = cnt[MAX_LINES] + __popcll(vm & lt);
+    for (int w = 0; w < wave; ++w) {
+        pos += s_wcnt[w][key];
+        gidx += s_wvalid[w];
     }
-    __syncthreads();
-    const double timeSpan = n > 0 ? livox_to_sec(in[n - 1].offset_time) : 1.0;
-    float4* lp = P.ln_pts + (size_t)b * P.NT;
-    int* lg = P.ln_gidx + (size_t)b * P.NT;
-    float4* cbx = P.cb_xyzi + (size_t)b * P.NT;
-    float* cbr = P.cb_rel + (size_t)b * P.NT;
-    uint8_t* cbl = P.cb_line + (size_t)b * P.NT;
-    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
-    for (int c0 = 0; c0 < n; c0 += ASSIGN_THREADS) {
-        int i = c0 + tid;
-        bool valid = false;
-        int line_num = 0;
-        mml_livox_point p;
-        p.x = p.y = p.z = 0.f;
-        p.offset_time = 0;
-        p.reflectivity = 0;
-        if (i < n) {
-            p = in[i];
-            line_num = (int)p.line;
-            valid = !(line_num > NLN - 1) && !(p.x < 0.01);
-            if (!valid) line_num = 0;
+    const int line = (sensor == 0 ? 0 : P.n_rings) + key;
+    const int dst = P.line_start[(size_t)b * P.L + line] + pos;
+    float4 out;
+    float rel;
+    if (sensor == 0) {
+        const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
+        const float startOri = a->startOri, endOri = a->endOri;
+        const float4 p = P.velo_in[(size_t)b * P.NV + i];
+        float ori = P.raw_ori[(size_t)b * P.NV + i];
+        if (i <= a->trig) {  // :1169-1177
+            if (ori < startOri - M_PI / 2)
+                ori += 2 * M_PI;
+            else if (ori > startOri + M_PI * 3 / 2)
+                ori -= 2 * M_PI;
+        } else {  // :1178-1184
+            ori += 2 * M_PI;
+            if (ori < endOri - M_PI * 3 / 2)
+                ori += 2 * M_PI;
+            else if (ori > endOri + M_PI / 2)
+                ori -= 2 * M_PI;
         }
-        int pos, gidx;
-        chunk_stable_scatter(valid, line_num, NLN, s_wcnt, s_base, s_wtot, &s_gbase, pos, gidx);
-        if (valid) {
-            float inten = p.reflectivity;
-            float rel = livox_to_sec(p.offset_time) / timeSpan;
-            int dst = ls[line_num] + pos;
-            lp[dst] = make_float4(p.x, p.y, p.z, inten);
-            lg[dst] = P.NV + gidx;
-            cbx[P.NV + gidx] = make_float4(p.x, p.y, p.z, inten);
-            cbr[P.NV + gidx] = rel;
-            cbl[P.NV + gidx] = (uint8_t)line_num;
-            cblab[P.NV + gidx] = 0;
-        }
+        rel = (ori - startOri) / (endOri - startOri);  // :1186
+        P.ln_pts[(size_t)b * P.NT + dst] = p;
+        out = make_float4(p.x, p.y, p.z, 0.f);  // intensity zeroed, :1254-1256
+    } else {
+        const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
+        const mml_livox_point p = in[i];
+        const double timeSpan = livox_to_sec(in[n - 1].offset_time);  // :985
+        const float inten = p.reflectivity;
+        rel = livox_to_sec(p.offset_time) / timeSpan;  // :995
+        out = make_float4(p.x, p.y, p.z, inten);
+        P.ln_pts[(size_t)b * P.NT + dst] = out;
     }
+    const size_t g = (size_t)b * P.NT + region + gidx;
+    P.ln_gidx[(size_t)b * P.NT + dst] = region + gidx;
+    P.cb_xyzi[g] = out;
+    P.cb_rel[g] = rel;
+    P.cb_line[g] = (uint8_t)key;
+    P.cb_label[g] = 0;
 }
 
 // locate the scan line that owns bucketed position p of slot b
@@ -1133,6 +1151,15 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.ln_curv = ctx->ln_curv;
     P.ln_refl = ctx->ln_refl;
     P.ln_attr = ctx->ln_attr;
+    P.blk_cnt = ctx->blk_cnt;
+    P.assign_aux = ctx->assign_aux;
+    P.nblk_v = (ctx->NV + 255) / 256;
+    P.nblk_l = (ctx->NL + 255) / 256;
+    P.nblk_max = P.nblk_v > P.nblk_l ? P.nblk_v : P.nblk_l;
+    P.ring_bits = 1;
+    while ((1 << P.ring_bits) < ctx->cfg.n_rings) ++P.ring_bits;
+    P.line_bits = 1;
+    while ((1 << P.line_bits) < ctx->cfg.n_livox_lines) ++P.line_bits;
     P.sel_scratch = ctx->sel_scratch;
     P.sel_cap = ctx->sel_cap;
     P.B = ctx->B;
@@ -1159,12 +1186,11 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     hipStream_t s = ctx->stream;
     const int pblocks = (ctx->NT + 255) / 256;
     {
-        MmlStageScope t(ctx, "assign_velo");
-        hipLaunchKernelGGL(k_assign_velo, dim3(count), dim3(ASSIGN_THREADS), 0, s, P);
-    }
-    {
-        MmlStageScope t(ctx, "assign_livox");
-        hipLaunchKernelGGL(k_assign_livox, dim3(count), dim3(ASSIGN_THREADS), 0, s, P);
+        MmlStageScope t(ctx, "assign");
+        hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
+        hipLaunchKernelGGL(k_assign_a, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+        hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(1024), 0, s, P);
+        hipLaunchKernelGGL(k_assign_c, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
     }
     {
         MmlStageScope t(ctx, "stencil");

@@ -74,6 +74,8 @@ struct mml_ctx {
     float* ln_curv = nullptr;
     float* ln_refl = nullptr;
     uint16_t* ln_attr = nullptr;
+    int* blk_cnt = nullptr;      // assign pass histograms
+    int* assign_aux = nullptr;   // 8 ints per slot
     unsigned* sel_scratch = nullptr;  // 4 x B*NT unsigned: k_select scratch for lines beyond the LDS budget
     int sel_cap = 0;
 
