@@ -61,7 +61,7 @@ void mml_destroy(mml_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    void* ptrs[] = {ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
+    void* ptrs[] = {ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
                     ctx->cb_label, ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
@@ -139,6 +139,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
         ALLOC(ctx->blk_cnt, B * 2 * nblk * 161);
     }
     ALLOC(ctx->assign_aux, B * 8);
+    ALLOC(ctx->crop_cnt, B * ((NT + 255) / 256) * 8);
     ALLOC(ctx->cb_xyzi, B * NT);
     ALLOC(ctx->cb_rel, B * NT);
     ALLOC(ctx->cb_line, B * NT);
@@ -173,6 +174,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->d_summ, B * 8);
     ALLOC(ctx->d_trace, B * 6 * 64);
     ALLOC(ctx->d_rec, B * 32);
+    ALLOC(ctx->d_und, B * 8);
     ALLOC(ctx->d_extr, 16);
     ALLOC(ctx->d_misc, 64);
 #undef ALLOC

@@ -38,6 +38,7 @@ enum : unsigned {
     A_NEAR = 1u << 14      // r^2 < thLidarNearestDis^2 (:824)
 };
 
+struct CropBlk;
 struct FeatParams {
     int first, NV, NL, NT, L, n_rings, n_lines;
     float pitch0, pitch_step, near_th, far_th;
@@ -56,6 +57,9 @@ struct FeatParams {
     int* blk_cnt;        // [B][2][nblk_max][MAX_LINES + 1] per-block histograms / exclusive offsets
     int* assign_aux;     // AssignAux per slot
     int nblk_v, nblk_l, nblk_max, ring_bits, line_bits;
+    CropBlk* crop_cnt;   // [B][nblk_t] per-block counts / exclusive offsets of the crop passes
+    unsigned* label_idx; // [B][2][cap] fused-cloud indices of the corner / surf labelled points
+    int nblk_t;
     unsigned* sel_scratch;  // global-memory scratch for lines longer than sel_cap: 4 x B*NT unsigned
     int sel_cap;            // points per line k_select keeps in LDS
     int B;
@@ -1010,103 +1014,153 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
 }
 
 // ---- a8: removeNearFarPoints / removeNearPointCloud + compaction into the fused cloud ---------------------------
-__global__ __launch_bounds__(ASSIGN_THREADS) void k_crop_compact(FeatParams P) {
-    __shared__ int s_cnt[4];
-    __shared__ int s_wtot[ASSIGN_WAVES];
-    __shared__ int s_base;
-    const int b = blockIdx.x + P.first;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Three parallel passes like the bucketing: per-block counts, one scan per slot, scatter.  Besides the fused cloud
+// the scatter also emits the index lists of the corner- and surf-labelled points (the label split of
+// Estimator.cpp:992-1011), so the voxel down-sampler does not have to re-scan the whole cloud.
+struct CropBlk {
+    int keep, kc, ks, lc_near, ls_near, keep_velo, pad0, pad1;
+};
+
+__device__ __forceinline__ void crop_classify(const FeatParams& P, int b, int p, bool& keep, int& lab, bool& isv,
+                                              bool& near_ok, float4& pt) {
+    keep = false;
+    lab = 0;
+    near_ok = false;
+    isv = p < P.NV;
     const int nv = P.cb_n[2 * b], nl = P.cb_n[2 * b + 1];
-    const float4* cbx = P.cb_xyzi + (size_t)b * P.NT;
-    const float* cbr = P.cb_rel + (size_t)b * P.NT;
-    const uint8_t* cbl = P.cb_line + (size_t)b * P.NT;
-    const uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
-    float4* fx = P.fu_xyzi + (size_t)b * P.NT;
-    float* fr = P.fu_rel + (size_t)b * P.NT;
-    uint8_t* fl = P.fu_line + (size_t)b * P.NT;
-    uint8_t* flab = P.fu_label + (size_t)b * P.NT;
+    const bool valid = isv ? (p < nv) : (p - P.NV < nl);
+    if (!valid) return;
+    pt = P.cb_xyzi[(size_t)b * P.NT + p];
+    lab = P.cb_label[(size_t)b * P.NT + p];
     const float near2 = P.near_th * P.near_th, far2 = P.far_th * P.far_th;
-    if (tid < 4) s_cnt[tid] = 0;
-    if (tid == 0) s_base = 0;
+    const float dis = pt.x * pt.x + pt.y * pt.y + pt.z * pt.z;
+    keep = !(dis < near2 || dis > far2);          // lidars_extrinsic_cali.h:451-477
+    near_ok = !(dis < near2);                      // lidars_extrinsic_cali.h:424-449
+}
+
+__global__ __launch_bounds__(256) void k_crop_a(FeatParams P) {
+    __shared__ int s_c[6];
+    const int b = blockIdx.y + P.first;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 6) s_c[threadIdx.x] = 0;
     __syncthreads();
-    // counts: velo corner/surf after near+far crop (:1287-1300), livox corner/surf after near crop only (:925-940)
-    int c[4] = {0, 0, 0, 0};
-    for (int i = tid; i < nv; i += ASSIGN_THREADS) {
-        int lab = cblab[i];
-        if (lab) {
-            float4 p = cbx[i];
-            float dis = p.x * p.x + p.y * p.y + p.z * p.z;
-            if (!(dis < near2 || dis > far2)) c[lab - 1]++;
-        }
+    bool keep = false, isv = true, near_ok = false;
+    int lab = 0;
+    float4 pt;
+    if (p < P.NT) crop_classify(P, b, p, keep, lab, isv, near_ok, pt);
+    const bool c[6] = {keep, keep && lab == 1, keep && lab == 2, !isv && near_ok && lab == 1, !isv && near_ok && lab == 2,
+                       keep && isv};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned long long m = __ballot(c[k]);
+        if (lane == 0 && m) atomicAdd(&s_c[k], __popcll(m));
     }
-    for (int i = tid; i < nl; i += ASSIGN_THREADS) {
-        int lab = cblab[P.NV + i];
-        if (lab) {
-            float4 p = cbx[P.NV + i];
-            if (!(p.x * p.x + p.y * p.y + p.z * p.z < near2)) c[2 + lab - 1]++;
-        }
-    }
-    for (int k = 0; k < 4; ++k)
-        if (c[k]) atomicAdd(&s_cnt[k], c[k]);
     __syncthreads();
-    const bool do_extr = P.extr != nullptr && s_cnt[2] > 100;  // :302-318
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int n_velo_out = 0;
-    for (int part = 0; part < 2; ++part) {
-        const int np = part == 0 ? nv : nl;
-        const int off = part == 0 ? 0 : P.NV;
-        for (int c0 = 0; c0 < np; c0 += ASSIGN_THREADS) {
-            const int i = c0 + tid;
-            bool keep = false;
-            float4 p = make_float4(0, 0, 0, 0);
-            if (i < np) {
-                p = cbx[off + i];
-                float dis = p.x * p.x + p.y * p.y + p.z * p.z;
-                keep = !(dis < near2 || dis > far2);
+    if (threadIdx.x < 6) reinterpret_cast<int*>(P.crop_cnt + ((size_t)b * P.nblk_t + blockIdx.x))[threadIdx.x] = s_c[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_crop_b(FeatParams P) {
+    const int b = blockIdx.x + P.first;
+    const int lane = threadIdx.x;
+    CropBlk* cb = P.crop_cnt + (size_t)b * P.nblk_t;
+    int tot[6] = {0, 0, 0, 0, 0, 0};
+    // wave-wide exclusive scan over the blocks, 64 at a time
+    for (int b0 = 0; b0 < P.nblk_t; b0 += 64) {
+        const int blk = b0 + lane;
+        int v[6];
+        const int* src = reinterpret_cast<const int*>(cb + (blk < P.nblk_t ? blk : 0));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = blk < P.nblk_t ? src[k] : 0;
+        int inc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int x = v[k];
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(x, o);
+                if (lane >= o) x += y;
             }
-            unsigned long long m = __ballot(keep);
-            if (lane == 0) s_wtot[wave] = __popcll(m);
-            __syncthreads();
-            int dst = s_base;
-            for (int w = 0; w < wave; ++w) dst += s_wtot[w];
-            dst += __popcll(m & lt);
-            if (keep) {
-                if (part == 1 && do_extr) {
-                    // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float
-                    const float* e = P.extr;
-                    float x = e[0] * p.x + e[1] * p.y + e[2] * p.z + e[3];
-                    float y = e[4] * p.x + e[5] * p.y + e[6] * p.z + e[7];
-                    float z = e[8] * p.x + e[9] * p.y + e[10] * p.z + e[11];
-                    p.x = x;
-                    p.y = y;
-                    p.z = z;
-                }
-                fx[dst] = p;
-                fr[dst] = cbr[off + i];
-                fl[dst] = cbl[off + i];
-                flab[dst] = cblab[off + i];
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int s = 0;
-                for (int w = 0; w < ASSIGN_WAVES; ++w) s += s_wtot[w];
-                s_base += s;
-            }
-            __syncthreads();
+            inc[k] = x;
         }
-        if (part == 0) n_velo_out = s_base;
+        if (blk < P.nblk_t) {
+            int* dst = reinterpret_cast<int*>(cb + blk);
+            dst[0] = tot[0] + inc[0] - v[0];
+            dst[1] = tot[1] + inc[1] - v[1];
+            dst[2] = tot[2] + inc[2] - v[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tot[k] += __shfl(inc[k], 63);
     }
-    if (tid == 0) {
+    if (lane == 0) {
         int* info = P.fu_info + 8 * b;
-        info[0] = s_base;
-        info[1] = n_velo_out;
-        info[2] = s_cnt[0];
-        info[3] = s_cnt[1];
-        info[4] = s_cnt[2];
-        info[5] = s_cnt[3];
-        info[6] = 0;
-        info[7] = 0;
+        info[0] = tot[0];  // fused points
+        info[1] = tot[5];  // ... of which velodyne
+        // velo corner / surf after near+far crop (:1287-1300) = kept labelled points of the velodyne part: accumulated
+        // by pass C; livox corner / surf after near crop only (:925-940)
+        info[2] = 0;
+        info[3] = 0;
+        info[6] = tot[1];  // all kept corner-labelled points (label split, Estimator.cpp:995-999)
+        info[7] = tot[2];
+        info[4] = tot[3];
+        info[5] = tot[4];
     }
+}
+
+// velo corner / surf counters need the velodyne-only share of kc / ks: counted in pass C of the velodyne blocks
+__global__ __launch_bounds__(256) void k_crop_c(FeatParams P, int cap) {
+    __shared__ int s_w[4][3];
+    __shared__ int s_velo[2];
+    const int b = blockIdx.y + P.first;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) s_velo[threadIdx.x] = 0;
+    bool keep = false, isv = true, near_ok = false;
+    int lab = 0;
+    float4 pt = make_float4(0, 0, 0, 0);
+    if (p < P.NT) crop_classify(P, b, p, keep, lab, isv, near_ok, pt);
+    const bool c1 = keep && lab == 1, c2 = keep && lab == 2;
+    const unsigned long long m0 = __ballot(keep), m1 = __ballot(c1), m2 = __ballot(c2);
+    if (lane == 0) {
+        s_w[wave][0] = __popcll(m0);
+        s_w[wave][1] = __popcll(m1);
+        s_w[wave][2] = __popcll(m2);
+    }
+    __syncthreads();
+    const unsigned long long mv1 = __ballot(c1 && isv), mv2 = __ballot(c2 && isv);
+    if (lane == 0) {
+        if (mv1) atomicAdd(&s_velo[0], __popcll(mv1));
+        if (mv2) atomicAdd(&s_velo[1], __popcll(mv2));
+    }
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const CropBlk* cb = P.crop_cnt + (size_t)b * P.nblk_t + blockIdx.x;
+    if (keep) {
+        int dst = cb->keep + __popcll(m0 & lt);
+        int d1 = cb->kc + __popcll(m1 & lt), d2 = cb->ks + __popcll(m2 & lt);
+        for (int w = 0; w < wave; ++w) {
+            dst += s_w[w][0];
+            d1 += s_w[w][1];
+            d2 += s_w[w][2];
+        }
+        if (!isv && P.extr != nullptr && P.fu_info[8 * b + 4] > 100) {  // :302-318
+            // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float
+            const float* e = P.extr;
+            const float x = e[0] * pt.x + e[1] * pt.y + e[2] * pt.z + e[3];
+            const float y = e[4] * pt.x + e[5] * pt.y + e[6] * pt.z + e[7];
+            const float z = e[8] * pt.x + e[9] * pt.y + e[10] * pt.z + e[11];
+            pt.x = x;
+            pt.y = y;
+            pt.z = z;
+        }
+        const size_t o = (size_t)b * P.NT;
+        P.fu_xyzi[o + dst] = pt;
+        P.fu_rel[o + dst] = P.cb_rel[o + p];
+        P.fu_line[o + dst] = P.cb_line[o + p];
+        P.fu_label[o + dst] = (uint8_t)lab;
+        if (c1 && d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)dst;
+        if (c2 && d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)dst;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_velo[threadIdx.x]) atomicAdd(&P.fu_info[8 * b + 2 + threadIdx.x], s_velo[threadIdx.x]);
 }
 
 // single-line setup for mml_detect_line: slot 0 holds one line (ring 0) of n points already in ln_pts
@@ -1160,6 +1214,9 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     while ((1 << P.ring_bits) < ctx->cfg.n_rings) ++P.ring_bits;
     P.line_bits = 1;
     while ((1 << P.line_bits) < ctx->cfg.n_livox_lines) ++P.line_bits;
+    P.crop_cnt = reinterpret_cast<CropBlk*>(ctx->crop_cnt);
+    P.label_idx = reinterpret_cast<unsigned*>(ctx->vx_keys);
+    P.nblk_t = (ctx->NT + 255) / 256;
     P.sel_scratch = ctx->sel_scratch;
     P.sel_cap = ctx->sel_cap;
     P.B = ctx->B;
@@ -1202,7 +1259,9 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "crop_compact");
-        hipLaunchKernelGGL(k_crop_compact, dim3(count), dim3(ASSIGN_THREADS), 0, s, P);
+        hipLaunchKernelGGL(k_crop_a, dim3(P.nblk_t, count), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_crop_b, dim3(count), dim3(64), 0, s, P);
+        hipLaunchKernelGGL(k_crop_c, dim3(P.nblk_t, count), dim3(256), 0, s, P, ctx->VX_CAP);
     }
     MML_HIP(hipGetLastError());
     return MML_OK;

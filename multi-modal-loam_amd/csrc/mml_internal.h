@@ -74,6 +74,7 @@ struct mml_ctx {
     float* ln_curv = nullptr;
     float* ln_refl = nullptr;
     uint16_t* ln_attr = nullptr;
+    int* crop_cnt = nullptr;     // crop pass block counts (8 ints per block)
     int* blk_cnt = nullptr;      // assign pass histograms
     int* assign_aux = nullptr;   // 8 ints per slot
     unsigned* sel_scratch = nullptr;  // 4 x B*NT unsigned: k_select scratch for lines beyond the LDS budget
@@ -123,6 +124,7 @@ struct mml_ctx {
     double* d_pose_in = nullptr;  // B * 32 generic double params (T_wl, dR/dt ...)
     double* d_summ = nullptr;     // B * 8
     double* d_trace = nullptr;    // B * 6 * MAX_ITERS
+    double* d_und = nullptr;      // B * 8 per-scan undistortion constants
     double* d_rec = nullptr;      // B * 32
     float* d_extr = nullptr;      // 16 floats
     int* d_misc = nullptr;        // misc ints

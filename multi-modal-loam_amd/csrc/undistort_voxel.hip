@@ -60,33 +60,63 @@ __device__ Q4 quat_from_matrix(const double* m) {
     return q;
 }
 
-// params: per slot 12 doubles (dR row-major 9, dt 3)
-__global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int* fu_info, float4* fu_xyzi,
-                                                  float* fu_rel, const double* params) {
-    const int b = blockIdx.y + first;
-    const int n = fu_info[8 * b];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double* dR = params + 12 * blockIdx.y;
-    const double* dt = dR + 9;
+// params: per slot 12 doubles (dR row-major 9, dt 3); derived: per slot 8 doubles written by k_undistort_prep
+// (qlc x,y,z,w | theta | sinTheta | 1/sinTheta | linear-branch flag)
+__global__ void k_undistort_prep(int count, const double* params, double* derived) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= count) return;
+    const double* dR = params + 12 * s;
     // Eigen::Quaterniond(dRlc).normalized()  (:410) -- identical for every point of the scan
     const Q4 qlc = qnormalized(quat_from_matrix(dR));
-    const double d = qlc.w;  // Identity().dot(qlc) = (0*x + 0*z) + (0*y + 1*w)
-    const double dd = (0.0 * qlc.x + 0.0 * qlc.z) + (0.0 * qlc.y + 1.0 * qlc.w);
-    (void)d;
+    const double dd = (0.0 * qlc.x + 0.0 * qlc.z) + (0.0 * qlc.y + 1.0 * qlc.w);  // Identity().dot(qlc)
     const double absD = fabs(dd);
     const double one = 1.0 - 2.220446049250313e-16;
-    float4 p = fu_xyzi[(size_t)b * NT + i];
-    const float s = fu_rel[(size_t)b * NT + i];
-    // Quaternion::slerp (Eigen 3.3.4)
+    double theta = 0, sinTheta = 1;
+    const bool linear = absD >= one;
+    if (!linear) {
+        theta = acos(absD);
+        sinTheta = sin(theta);
+    }
+    double* o = derived + 8 * s;
+    o[0] = qlc.x;
+    o[1] = qlc.y;
+    o[2] = qlc.z;
+    o[3] = qlc.w;
+    o[4] = theta;
+    o[5] = sinTheta;
+    o[6] = 1.0 / sinTheta;
+    o[7] = linear ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ double rsqrt_nr(double z) {
+    double y = __builtin_amdgcn_rsq(z);
+    y = y * (1.5 - (0.5 * z) * (y * y));
+    y = y * (1.5 - (0.5 * z) * (y * y));
+    return y;
+}
+// distance from v to the nearest float rounding boundary around (float)v; small => the float result is not safe
+__device__ __forceinline__ double round_margin(double v) {
+    const float f = (float)v;
+    const float fa = fabsf(f);
+    const int bi = __float_as_int(fa);
+    const double up = 0.5 * ((double)__int_as_float(bi + 1) - (double)fa);
+    const double dn = bi > 0 ? 0.5 * ((double)fa - (double)__int_as_float(bi - 1)) : up;
+    const double r = fabs(v) - (double)fa;
+    return r >= 0.0 ? up - r : dn + r;
+}
+
+// The per-point arithmetic of RemoveLidarDistortion in double, written exactly as the reference (slerp with two
+// divisions, normalized() with sqrt + 4 divisions).
+__device__ __forceinline__ void undistort_exact(const double* dR, const double* dt, const double* dv, float s, float4& p) {
+    const Q4 qlc{dv[0], dv[1], dv[2], dv[3]};
+    const double dd = (0.0 * qlc.x + 0.0 * qlc.z) + (0.0 * qlc.y + 1.0 * qlc.w);
     double scale0, scale1;
     const double t = s;
-    if (absD >= one) {
+    if (dv[7] != 0.0) {
         scale0 = 1.0 - t;
         scale1 = t;
     } else {
-        double theta = acos(absD);
-        double sinTheta = sin(theta);
+        const double theta = dv[4], sinTheta = dv[5];
         scale0 = sin((1.0 - t) * theta) / sinTheta;
         scale1 = sin((t * theta)) / sinTheta;
     }
@@ -94,7 +124,6 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int*
     Q4 q{scale0 * 0.0 + scale1 * qlc.x, scale0 * 0.0 + scale1 * qlc.y, scale0 * 0.0 + scale1 * qlc.z,
          scale0 * 1.0 + scale1 * qlc.w};
     const Q4 dq = qnormalized(q);
-    // delta_qlc * p + s * dtlc   (QuaternionBase::_transformVector)
     V3 qv = v3(dq.x, dq.y, dq.z);
     V3 v = v3(p.x, p.y, p.z);
     V3 uv = vcross(qv, v);
@@ -103,10 +132,64 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int*
     V3 startP = v3((v.x + dq.w * uv.x) + c2.x, (v.y + dq.w * uv.y) + c2.y, (v.z + dq.w * uv.z) + c2.z);
     startP = v3(startP.x + s * dt[0], startP.y + s * dt[1], startP.z + s * dt[2]);
     V3 w = v3(startP.x - dt[0], startP.y - dt[1], startP.z - dt[2]);
-    // dRlc.transpose() * w
     p.x = (dR[0] * w.x + dR[3] * w.y) + dR[6] * w.z;
     p.y = (dR[1] * w.x + dR[4] * w.y) + dR[7] * w.z;
     p.z = (dR[2] * w.x + dR[5] * w.y) + dR[8] * w.z;
+}
+
+// One point per lane.  Fast form: the slerp divisions become one multiplication by the per-scan 1/sin(theta), the
+// quaternion normalisation uses v_rsq_f64 + Newton; its result differs from the reference expression by ~1e-15
+// relative, so the FLOAT it rounds to is the same unless the double lies within 1e-11 of a float rounding
+// boundary -- in that case (a few points per million) the reference expression is evaluated.
+__global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int* fu_info, float4* fu_xyzi,
+                                                  float* fu_rel, const double* params, const double* derived) {
+    const int b = blockIdx.y + first;
+    const int n = fu_info[8 * b];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* dR = params + 12 * blockIdx.y;
+    const double* dt = dR + 9;
+    const double* dv = derived + 8 * blockIdx.y;
+    float4 p = fu_xyzi[(size_t)b * NT + i];
+    const float s = fu_rel[(size_t)b * NT + i];
+    const double t = s;
+    const double qx = dv[0], qy = dv[1], qz = dv[2], qw = dv[3];
+    double scale0, scale1;
+    if (dv[7] != 0.0) {
+        scale0 = 1.0 - t;
+        scale1 = t;
+    } else {
+        const double theta = dv[4], inv = dv[6];
+        scale0 = sin((1.0 - t) * theta) * inv;
+        scale1 = sin((t * theta)) * inv;
+    }
+    if (qw < 0.0) scale1 = -scale1;
+    double ax = scale1 * qx, ay = scale1 * qy, az = scale1 * qz, aw = scale0 + scale1 * qw;
+    const double inv_n = rsqrt_nr((ax * ax + az * az) + (ay * ay + aw * aw));
+    ax *= inv_n;
+    ay *= inv_n;
+    az *= inv_n;
+    aw *= inv_n;
+    const double vx = p.x, vy = p.y, vz = p.z;
+    double ux = ay * vz - az * vy, uy = az * vx - ax * vz, uz = ax * vy - ay * vx;
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    const double cx = ay * uz - az * uy, cy = az * ux - ax * uz, cz = ax * uy - ay * ux;
+    const double wx = (((vx + aw * ux) + cx) + s * dt[0]) - dt[0];
+    const double wy = (((vy + aw * uy) + cy) + s * dt[1]) - dt[1];
+    const double wz = (((vz + aw * uz) + cz) + s * dt[2]) - dt[2];
+    const double ox = (dR[0] * wx + dR[3] * wy) + dR[6] * wz;
+    const double oy = (dR[1] * wx + dR[4] * wy) + dR[7] * wz;
+    const double oz = (dR[2] * wx + dR[5] * wy) + dR[8] * wz;
+    const double tol = 1e-11 * (((fabs(vx) + fabs(vy)) + fabs(vz)) + ((fabs(dt[0]) + fabs(dt[1])) + fabs(dt[2])) + 1e-30);
+    if (round_margin(ox) > tol && round_margin(oy) > tol && round_margin(oz) > tol) {
+        p.x = ox;
+        p.y = oy;
+        p.z = oz;
+    } else {
+        undistort_exact(dR, dt, dv, s, p);
+    }
     fu_xyzi[(size_t)b * NT + i] = p;
     fu_rel[(size_t)b * NT + i] = 1.0f;  // :419
 }
@@ -155,40 +238,21 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int first, int NT, int MF,
     unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * cap;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    // 1. order-preserving selection of the labelled points + min / max of their coordinates (getMinMax3D)
+    // 1. the labelled points were listed by the crop pass (feature.hip k_crop_c) in fused-cloud order; min / max of
+    //    their coordinates (getMinMax3D)
+    const int nsel = fu_info[8 * b + 6 + kind];
+    int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
+    const bool overflow = nsel > cap;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int c0 = 0; c0 < n; c0 += VX_THREADS) {
-        const int i = c0 + tid;
-        bool sel = (i < n) && lab[i] == want;
-        unsigned long long m = __ballot(sel);
-        if (lane == 0) s_wtot[wave] = __popcll(m);
-        __syncthreads();
-        int dst = s_base;
-        for (int w = 0; w < wave; ++w) dst += s_wtot[w];
-        dst += __popcll(m & lt);
-        if (sel && dst < cap) {
-            seq2idx[dst] = (unsigned)i;
-            float4 p = px[i];
-            mn[0] = fminf(mn[0], p.x);
-            mn[1] = fminf(mn[1], p.y);
-            mn[2] = fminf(mn[2], p.z);
-            mx[0] = fmaxf(mx[0], p.x);
-            mx[1] = fmaxf(mx[1], p.y);
-            mx[2] = fmaxf(mx[2], p.z);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int s = 0;
-            for (int w = 0; w < VX_WAVES; ++w) s += s_wtot[w];
-            s_base += s;
-        }
-        __syncthreads();
+    for (int s = tid; s < cnt; s += VX_THREADS) {
+        const float4 p = px[seq2idx[s]];
+        mn[0] = fminf(mn[0], p.x);
+        mn[1] = fminf(mn[1], p.y);
+        mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x);
+        mx[1] = fmaxf(mx[1], p.y);
+        mx[2] = fmaxf(mx[2], p.z);
     }
-    int cnt = s_base;
-    if (cnt > cap) cnt = cap;  // capacity overflow is reported by the host wrapper through ft_n (negative)
-    const bool overflow = s_base > cap;
     float gmn[3], gmx[3];
     for (int c = 0; c < 3; ++c) {
         gmn[c] = block_reduce_minmax(mn[c], true, s_red);
@@ -293,8 +357,9 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int first, int NT, int MF,
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params) {
     MmlStageScope t(ctx, "undistort");
     dim3 grid((ctx->NT + 255) / 256, count);
+    hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, count, d_params, ctx->d_und);
     hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, ctx->stream, first, ctx->NT, ctx->fu_info, ctx->fu_xyzi,
-                       ctx->fu_rel, d_params);
+                       ctx->fu_rel, d_params, ctx->d_und);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
