@@ -133,7 +133,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->ln_curv, B * NT);
     ALLOC(ctx->ln_refl, B * NT);
     ALLOC(ctx->ln_attr, B * NT);
-    ALLOC(ctx->sel_scratch, 4 * B * NT);
+    ALLOC(ctx->sel_scratch, 4 * B * NT + 16 * B * (L + 2) + 64);
     {
         const size_t nblk = ((NV > NL ? NV : NL) + 255) / 256;
         ALLOC(ctx->blk_cnt, B * 2 * nblk * 161);

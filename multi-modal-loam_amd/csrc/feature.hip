@@ -762,9 +762,14 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         W[2 * i] = k;
         W[2 * i + 1] = inf;
     }
+    if (tid < 6) {  // three zero records on either side of the line: neighbour reads need no bounds checks
+        const int j = tid < 3 ? tid - 3 : n + tid - 3;
+        W[2 * j] = 0;
+        W[2 * j + 1] = 0;
+    }
     __syncthreads();
 
-    // ---- phase 1: which neighbours can suppress me (static), then dependency rounds ----------------------------
+    // ---- phase 1: which neighbours can suppress me (static); points nobody can suppress are picked at once ------
     for (int i = tid; i < n; i += SELP_THREADS) {
         const unsigned me = W[2 * i + 1];
         if (!(me & I_CAND)) continue;
@@ -774,11 +779,10 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         for (int q = 0; q < 6; ++q) {
             const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
             const int j = i + d;
-            if (j < 0 || j >= n) continue;
             const unsigned o = W[2 * j + 1];
             if ((o & I_CAND) && covers(o, -d) && visits_before(o, W[2 * j], j, me, mk, i)) m |= 1u << q;
         }
-        W[2 * i + 1] = me | (m << I_MASK_SHIFT);
+        W[2 * i + 1] = m ? (me | (m << I_MASK_SHIFT)) : ((me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT));
     }
     __syncthreads();
     for (;;) {
@@ -817,7 +821,6 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         for (int q = 0; q < 6; ++q) {
             const int d = q < 3 ? q - 3 : q - 2;
             const int j = i + d;
-            if (j < 0 || j >= n) continue;
             const unsigned o = W[2 * j + 1];
             if (st_of(o) != ST_S || !covers(o, -d)) continue;
             const int pj = (int)(o & I_PART_MASK);
@@ -974,7 +977,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 __host__ __device__ inline size_t select_lds_bytes(int cap) {
     const size_t nwin = (cap + 63) / 64;
     // W: 2 x u32 per point | wmask u64 | wvis 4 x u64 | wexit 4 x u8 | wsel u8
-    return (size_t)cap * 8 + nwin * 8 + nwin * 32 + nwin * 4 + nwin + 64;
+    return (size_t)(cap + 8) * 8 + nwin * 8 + nwin * 32 + nwin * 4 + nwin + 64;
 }
 
 __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
@@ -992,8 +995,8 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     if (n <= P.sel_cap) {
         const int cap = P.sel_cap;
         const int nwin = (cap + 63) / 64;
-        unsigned* W = reinterpret_cast<unsigned*>(smem);
-        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(W + 2 * (size_t)cap);
+        unsigned* W = reinterpret_cast<unsigned*>(smem) + 8;  // 4 pad records in front, 4 behind
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8));
         unsigned long long* wvis = wmask + nwin;
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);
         unsigned char* wsel = wexit + 4 * nwin;
@@ -1001,9 +1004,10 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     } else {
         // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
         const size_t BNT = (size_t)P.B * P.NT;
-        unsigned* W = P.sel_scratch + 2 * base;
+        // (+8 * line + 8 words: room for the pad records of every line in front of this one)
+        unsigned* W = P.sel_scratch + 2 * base + 16 * ((size_t)b * (P.L + 2) + line + 1);
         const int nwin = (n + 63) / 64;
-        uintptr_t wp = reinterpret_cast<uintptr_t>(P.sel_scratch + 2 * BNT + 2 * base);
+        uintptr_t wp = reinterpret_cast<uintptr_t>(P.sel_scratch + 2 * BNT + 16 * (size_t)(P.L + 2) * P.B + 2 * base);
         wp = (wp + 7) & ~uintptr_t(7);
         unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wp);
         unsigned long long* wvis = wmask + nwin;
