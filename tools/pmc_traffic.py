@@ -1,0 +1,36 @@
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, as
+MI355X_MICROARCH.md prescribes: TCC slots do not fit both).  On gfx950 FETCH_SIZE counts 64 B per 128-B request for
+wide coalesced streams, i.e. half the bytes: it is doubled here (calibrated on k_undistort: 13.5 M points x 20 B
+read = 270 MB, FETCH_SIZE says 134 MB; WRITE_SIZE matches the 270 MB written).  Counters are in KiB.
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/traffic_r01.json"""
+import json
+import sys
+
+import pandas as pd
+
+STAGE = {"k_assign_init": "assign", "k_assign_a": "assign", "k_assign_b": "assign", "k_assign_c": "assign",
+         "k_stencil": "stencil", "k_select": "select", "k_crop_a": "crop_compact", "k_crop_b": "crop_compact",
+         "k_crop_c": "crop_compact", "k_undistort_prep": "undistort", "k_undistort": "undistort",
+         "k_voxel": "voxel_downsample", "k_assoc_prefix": "associate", "k_associate": "associate",
+         "k_associate_hard": "associate_far", "k_assoc_stats": "assoc_stats", "k_solve": "solve"}
+
+
+def per_kernel(path, counter):
+    d = pd.read_csv(path)
+    d["k"] = d["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+    d = d[d.Counter_Name == counter]
+    mx = d.groupby("k")["Grid_Size"].transform("max")
+    return d[d.Grid_Size == mx].groupby("k")["Counter_Value"].mean()
+
+
+def main(fp, wp):
+    f, w = per_kernel(fp, "FETCH_SIZE"), per_kernel(wp, "WRITE_SIZE")
+    out = {}
+    for k, st in STAGE.items():
+        b = 2.0 * float(f.get(k, 0.0)) * 1024.0 + float(w.get(k, 0.0)) * 1024.0
+        out[st] = out.get(st, 0.0) + b
+    print(json.dumps({k: round(v) for k, v in out.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
