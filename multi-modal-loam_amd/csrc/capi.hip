@@ -61,7 +61,7 @@ void mml_destroy(mml_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    void* ptrs[] = {ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
+    void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
                     ctx->cb_label, ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
@@ -158,6 +158,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->pf, B * MF);
     ALLOC(ctx->assoc_stats, B * 16);
     ALLOC(ctx->hard_list, B * MF * 2);
+    ALLOC(ctx->hard_knn, B * MF * 2 * 10);
     ALLOC(ctx->work_off, 2 * B + 2);
     for (int k = 0; k < 2; ++k) {
         ALLOC(ctx->grid[k].pts, MM);

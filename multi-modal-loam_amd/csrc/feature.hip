@@ -217,17 +217,26 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
         s_last = -1;
     }
     __syncthreads();
-    // exclusive scan over blocks, one thread per key (+ one for the valid-point count)
-    if (tid <= nkeys) {
-        const int k = tid < nkeys ? tid : MAX_LINES;
-        int acc = 0;
-        for (int blk = 0; blk < nblk; ++blk) {
-            int* c = cnt0 + (size_t)blk * (MAX_LINES + 1) + k;
-            const int v = *c;
-            *c = acc;
-            acc += v;
+    // exclusive scan over blocks: one wavefront per key (+ one for the valid-point count), 64 blocks per step
+    {
+        const int lane = tid & 63;
+        for (int kk = tid >> 6; kk <= nkeys; kk += 1024 / 64) {
+            const int k = kk < nkeys ? kk : MAX_LINES;
+            int acc = 0;
+            for (int b0 = 0; b0 < nblk; b0 += 64) {
+                const int blk = b0 + lane;
+                int* c = cnt0 + (size_t)(blk < nblk ? blk : 0) * (MAX_LINES + 1) + k;
+                const int v = blk < nblk ? *c : 0;
+                int x = v;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int y = __shfl_up(x, o);
+                    if (lane >= o) x += y;
+                }
+                if (blk < nblk) *c = acc + x - v;
+                acc += __shfl(x, 63);
+            }
+            if (lane == 0) s_tot[kk] = acc;
         }
-        s_tot[tid] = acc;
     }
     __syncthreads();
     if (sensor == 0) {

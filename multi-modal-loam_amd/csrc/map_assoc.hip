@@ -737,6 +737,7 @@ struct AssocParams {
     const int* work_off;
     int* hard_count;   // queue of features whose 5-NN search goes beyond ring 1
     int4* hard_list;
+    float* hard_knn;   // 10 floats per queued feature: the top-5 (d2, index) found in rings 0-1
 };
 
 __device__ __forceinline__ void tf_point(const double* T, double x, double y, double z, double& ox, double& oy,
@@ -956,6 +957,12 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
         if (!done && rmax >= 2) {
             const int hw = atomicAdd(P.hard_count, 1);
             P.hard_list[hw] = make_int4(slot, kind, i, 0);
+            float* hd = P.hard_knn + 10 * (size_t)hw;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                hd[j] = k.d[j];
+                hd[5 + j] = __int_as_float(k.id[j]);
+            }
             continue;  // finished by k_associate_hard
         }
     }
@@ -964,38 +971,86 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
     }
 }
 
-// pass 2: one wavefront per queued feature; the 64 lanes split the rows of every shell and merge their private
-// top-5 lists with shuffles.  Lane 0 then runs the model fit.
+// pass 2: queued features, one 16-lane group each (4 per wavefront).  The group continues from the top-5 list pass 1
+// left after ring 1: its lanes split the rows of every further shell and merge their private lists with shuffles
+// (xor 8,4,2,1 stays inside the group).  Lane 0 of the group then runs the model fit.
+__device__ __forceinline__ void group_merge5(const Knn5& local, Knn5& out) {
+    int head = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        float d;
+        int id;
+        knn_head(local, head, d, id);
+        float md = d;
+        int mid = id;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float od = __shfl_xor(md, o);
+            const int oid = __shfl_xor(mid, o);
+            const bool take = (od < md) || (od == md && oid < mid);
+            md = take ? od : md;
+            mid = take ? oid : mid;
+        }
+        out.d[r] = md;
+        out.id[r] = mid;
+        if (d == md && id == mid && md < INFINITY) head++;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * 256) >> 6;
+    const int gl = threadIdx.x & 15;
+    const int group = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int ngroups = (gridDim.x * 256) >> 4;
     const int total = *P.hard_count;
-    for (int w = wave; w < total; w += nwaves) {
-        const int4 e = P.hard_list[w];
-        const int slot = e.x, kind = e.y, i = e.z;
-        const int b = slot + P.first;
-        const double* T = P.Twl + 16 * slot;
-        const float4 f = P.ft[kind][(size_t)b * P.MF + i];
-        double wx, wy, wz;
-        tf_point(T, f.x, f.y, f.z, wx, wy, wz);
-        const float sx = wx, sy = wy, sz = wz;
-        const MmlGrid& g = P.g[kind];
-        const KnnQuery q = knn_query(g, sx, sy, sz);
-        const int rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
+    for (int w0 = 0; w0 < total; w0 += ngroups) {
+        const int w = w0 + group;
+        bool gdone = w >= total;
+        int slot = 0, kind = 0, i = 0, b = P.first;
+        float4 f = make_float4(0, 0, 0, 0);
+        float sx = 0, sy = 0, sz = 0;
         Knn5 loc, best;
         knn_init(loc);
         knn_init(best);
-        for (int r = 0; r <= rmax; ++r) {
-            const int ww = 2 * r + 1;
-            for (int t = lane; t < ww * ww; t += 64) scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc);
-            if (r == 0) continue;  // ring 0 alone rarely terminates; merge from ring 1 on
-            wave_merge5(loc, best);
-            if (knn_done(g, q.inset, r, best.d[4], P.thres)) break;
+        KnnQuery q = knn_query(P.g[0], 0.f, 0.f, 0.f);
+        int rmax = 0;
+        if (!gdone) {
+            const int4 e = P.hard_list[w];
+            slot = e.x;
+            kind = e.y;
+            i = e.z;
+            b = slot + P.first;
+            f = P.ft[kind][(size_t)b * P.MF + i];
+            double wx, wy, wz;
+            tf_point(P.Twl + 16 * slot, f.x, f.y, f.z, wx, wy, wz);
+            sx = wx;
+            sy = wy;
+            sz = wz;
+            q = knn_query(P.g[kind], sx, sy, sz);
+            rmax = (int)ceilf(sqrtf(P.thres) * P.g[kind].inv_cell) + 1;
+            if (gl == 0) {
+                const float* hd = P.hard_knn + 10 * (size_t)w;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    loc.d[j] = hd[j];
+                    loc.id[j] = __float_as_int(hd[5 + j]);
+                }
+            }
         }
-        if (lane == 0) {
+        for (int r = 2;; ++r) {
+            if (!gdone && r > rmax) gdone = true;
+            if (__all(gdone)) break;
+            if (!gdone) {
+                const int ww = 2 * r + 1;
+                for (int t = gl; t < ww * ww; t += 16)
+                    scan_shell_row(P.g[kind], q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc);
+            }
+            group_merge5(loc, best);
+            if (!gdone && knn_done(P.g[kind], q.inset, r, best.d[4], P.thres)) gdone = true;
+        }
+        if (w < total && gl == 0) {
+            if (rmax < 2) best = loc;
             const bool ok = (double)best.d[4] < P.thres_d;
-            fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, best);
+            fit_and_store(P, kind, b, i, f, P.Twl + 16 * slot, sx, sy, sz, ok, best);
         }
     }
 }
@@ -1152,6 +1207,7 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     P.thres_d = thres_dist;
     P.hard_count = ctx->d_misc + 32;
     P.hard_list = ctx->hard_list;
+    P.hard_knn = ctx->hard_knn;
     MML_HIP(hipMemsetAsync(P.hard_count, 0, sizeof(int), ctx->stream));
     P.count = count;
     P.work_off = ctx->work_off;

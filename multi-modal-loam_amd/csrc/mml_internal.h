@@ -104,6 +104,7 @@ struct mml_ctx {
     MmlLineFactor* lf = nullptr;   // B * MF
     MmlPlaneFactor* pf = nullptr;  // B * MF
     int* work_off = nullptr;       // 2 * B + 1 chunk offsets for k_associate
+    float* hard_knn = nullptr;     // 10 floats per queued feature
     int4* hard_list = nullptr;     // B * MF * 2 queued (slot, kind, feature) triples
     double* assoc_stats = nullptr; // B * 16: n_line, n_plane, n_line_used, n_plane_used, gram[9], ...
 
