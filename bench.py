@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="scans per step per GPU")
     ap.add_argument("--map-points", type=int, default=200000)
     ap.add_argument("--gn-iters", type=int, default=10)
     ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")

@@ -2,6 +2,7 @@
 // No compute lives here; every entry point validates, stages small parameter blocks through a pinned ring and
 // enqueues the kernels of feature.hip / undistort_voxel.hip / map_assoc.hip / solve.hip on the ctx stream.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -22,7 +23,7 @@ constexpr size_t kStageDoubles = 1u << 19;  // 4 MiB
 
 double* stage_alloc(mml_ctx* ctx, size_t doubles) {
     if (ctx->stage_cursor + doubles > ctx->h_stage_doubles) {
-        hipStreamSynchronize(ctx->stream);
+        mml_sync_all(ctx);
         ctx->stage_cursor = 0;
     }
     double* p = ctx->h_stage + ctx->stage_cursor;
@@ -60,7 +61,8 @@ const char* mml_last_error(const mml_ctx* ctx) { return ctx ? ctx->err.c_str() :
 void mml_destroy(mml_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
+        if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
@@ -78,7 +80,8 @@ void mml_destroy(mml_ctx* ctx) {
         hipEventDestroy(pe.b);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
+        if (ctx->streams[l]) hipStreamDestroy(ctx->streams[l]);
     delete ctx;
 }
 
@@ -115,12 +118,18 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
-        return fail(e, "hipStreamCreate");
+    ctx->n_lanes = mml_ctx::MAX_LANES;
+    if (const char* e_l = getenv("MML_LANES")) {  // tuning knob: number of stream lanes mml_step pipelines over
+        int v = atoi(e_l);
+        if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;
+    }
+    for (int l = 0; l < ctx->n_lanes; ++l)
+        if ((e = hipStreamCreateWithFlags(&ctx->streams[l], hipStreamNonBlocking)) != hipSuccess)
+            return fail(e, "hipStreamCreate");
     const size_t B = ctx->B, NV = ctx->NV, NL = ctx->NL, NT = ctx->NT, L = ctx->L, MF = ctx->MF, MM = ctx->MM;
 #define ALLOC(ptr, n)                                                  \
     if ((e = dalloc(&(ptr), (n))) != hipSuccess) return fail(e, #ptr); \
-    if ((e = hipMemsetAsync((ptr), 0, sizeof(*(ptr)) * ((n) ? (n) : 1), ctx->stream)) != hipSuccess) return fail(e, #ptr)
+    if ((e = hipMemsetAsync((ptr), 0, sizeof(*(ptr)) * ((n) ? (n) : 1), MML_STREAM(ctx))) != hipSuccess) return fail(e, #ptr)
     ALLOC(ctx->velo_in, B * NV);
     ALLOC(ctx->livox_in, B * NL);
     ALLOC(ctx->d_n_in, B * 2);
@@ -159,7 +168,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->assoc_stats, B * 16);
     ALLOC(ctx->hard_list, B * MF * 2);
     ALLOC(ctx->hard_knn, B * MF * 2 * 10);
-    ALLOC(ctx->work_off, 2 * B + 2);
+    ALLOC(ctx->work_off, 2 * B + 8);
     for (int k = 0; k < 2; ++k) {
         ALLOC(ctx->grid[k].pts, MM);
         ALLOC(ctx->grid[k].cell_start, 4 * MM + 4096 + 2);
@@ -185,15 +194,14 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
         return fail(e, "hipHostMalloc");
     ctx->stage_cursor = 0;
     if (mml_feature_init(ctx) != MML_OK) return fail(hipErrorUnknown, "mml_feature_init");
-    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    if ((e = hipStreamSynchronize(MML_STREAM(ctx))) != hipSuccess) return fail(e, "hipStreamSynchronize");
     *out = ctx;
     return MML_OK;
 }
 
 int mml_synchronize(mml_ctx* ctx) {
     if (!ctx) return MML_ERR_INVALID;
-    MML_HIP(hipStreamSynchronize(ctx->stream));
-    return MML_OK;
+    return mml_sync_all(ctx);
 }
 
 static int check_slots(mml_ctx* ctx, int first, int count) {
@@ -216,7 +224,7 @@ static int check_slots(mml_ctx* ctx, int first, int count) {
 static int upload_doubles(mml_ctx* ctx, double* d_dst, const double* h_src, size_t n) {
     double* st = stage_alloc(ctx, n);
     memcpy(st, h_src, sizeof(double) * n);
-    MML_HIP(hipMemcpyAsync(d_dst, st, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    MML_HIP(hipMemcpyAsync(d_dst, st, sizeof(double) * n, hipMemcpyHostToDevice, MML_STREAM(ctx)));
     return MML_OK;
 }
 
@@ -229,10 +237,10 @@ int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo, 
     MML_REQUIRE((n_velo == 0 || velo_xyzi) && (n_livox == 0 || livox), MML_ERR_INVALID, "null point buffer");
     if (n_velo)
         MML_HIP(hipMemcpyAsync(ctx->velo_in + (size_t)slot * ctx->NV, velo_xyzi, sizeof(float) * 4 * (size_t)n_velo,
-                               hipMemcpyHostToDevice, ctx->stream));
+                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
     if (n_livox)
         MML_HIP(hipMemcpyAsync(ctx->livox_in + (size_t)slot * ctx->NL, livox, sizeof(mml_livox_point) * (size_t)n_livox,
-                               hipMemcpyHostToDevice, ctx->stream));
+                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
     ctx->h_n_in[2 * slot] = n_velo;
     ctx->h_n_in[2 * slot + 1] = n_livox;
     // counts travel through the pinned ring as raw bytes
@@ -240,7 +248,7 @@ int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo, 
     int* sti = reinterpret_cast<int*>(st);
     sti[0] = n_velo;
     sti[1] = n_livox;
-    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * slot, sti, sizeof(int) * 2, hipMemcpyHostToDevice, ctx->stream));
+    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * slot, sti, sizeof(int) * 2, hipMemcpyHostToDevice, MML_STREAM(ctx)));
     return MML_OK;
 }
 
@@ -253,7 +261,7 @@ int mml_extract(mml_ctx* ctx, int first_slot, int count, const float* livox_extr
         if (have) {
             double* st = stage_alloc(ctx, 8);
             memcpy(st, livox_extrinsic, sizeof(float) * 16);
-            MML_HIP(hipMemcpyAsync(ctx->d_extr, st, sizeof(float) * 16, hipMemcpyHostToDevice, ctx->stream));
+            MML_HIP(hipMemcpyAsync(ctx->d_extr, st, sizeof(float) * 16, hipMemcpyHostToDevice, MML_STREAM(ctx)));
         }
     }
     return mml_launch_extract(ctx, first_slot, count, have);
@@ -263,8 +271,8 @@ int mml_scan_info_get(mml_ctx* ctx, int slot, mml_scan_info* info) {
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE(info != nullptr, MML_ERR_INVALID, "null info");
     int h[8];
-    MML_HIP(hipMemcpyAsync(h, ctx->fu_info + 8 * slot, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_HIP(hipMemcpyAsync(h, ctx->fu_info + 8 * slot, sizeof(h), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     info->n_points = h[0];
     info->n_velo = h[1];
     info->velo_corner_num = h[2];
@@ -283,11 +291,11 @@ int mml_scan_download(mml_ctx* ctx, int slot, float* xyzi, float* reltime, uint8
     MML_REQUIRE(capacity >= info.n_points, MML_ERR_CAPACITY, "download capacity too small");
     const size_t n = info.n_points, off = (size_t)slot * ctx->NT;
     if (n == 0) return MML_OK;
-    if (xyzi) MML_HIP(hipMemcpyAsync(xyzi, ctx->fu_xyzi + off, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, ctx->stream));
-    if (reltime) MML_HIP(hipMemcpyAsync(reltime, ctx->fu_rel + off, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
-    if (line) MML_HIP(hipMemcpyAsync(line, ctx->fu_line + off, n, hipMemcpyDeviceToHost, ctx->stream));
-    if (label) MML_HIP(hipMemcpyAsync(label, ctx->fu_label + off, n, hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    if (xyzi) MML_HIP(hipMemcpyAsync(xyzi, ctx->fu_xyzi + off, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    if (reltime) MML_HIP(hipMemcpyAsync(reltime, ctx->fu_rel + off, sizeof(float) * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    if (line) MML_HIP(hipMemcpyAsync(line, ctx->fu_line + off, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    if (label) MML_HIP(hipMemcpyAsync(label, ctx->fu_label + off, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     return MML_OK;
 }
 
@@ -302,16 +310,16 @@ int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sh
     for (int i = 0; i < n; ++i)
         MML_REQUIRE(std::isfinite(pts[4 * i]) && std::isfinite(pts[4 * i + 1]) && std::isfinite(pts[4 * i + 2]),
                     MML_ERR_INVALID, "detectFeaturePoints: non-finite input (reference indexes pre-compaction)");
-    MML_HIP(hipMemcpyAsync(ctx->ln_pts, pts, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    MML_HIP(hipMemcpyAsync(ctx->ln_pts, pts, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, MML_STREAM(ctx)));
     // ln_final scratch: reuse ln_ord_c of slot 0's livox region?  Use a dedicated view of raw_ori (NV floats >= n*2 bytes).
     uint16_t* d_final = reinterpret_cast<uint16_t*>(ctx->raw_ori);
     int rc = mml_launch_detect_line(ctx, n, d_final);
     if (rc != MML_OK) return rc;
     std::vector<uint8_t> lab(n);
     std::vector<uint16_t> fin(n);
-    MML_HIP(hipMemcpyAsync(lab.data(), ctx->cb_label, n, hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipMemcpyAsync(fin.data(), d_final, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_HIP(hipMemcpyAsync(lab.data(), ctx->cb_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(fin.data(), d_final, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     int ns = 0, nf = 0;
     for (int i = 0; i < n; ++i) {  // ascending i, as the emit loop at unionFeatureExtract.cpp:818-842
         if (lab[i] == 2) flat[nf++] = i;
@@ -331,8 +339,8 @@ int mml_undistort(mml_ctx* ctx, int first_slot, int count, const double* dR, con
         memcpy(st + 12 * i, dR + 9 * i, sizeof(double) * 9);
         memcpy(st + 12 * i + 9, dt + 3 * i, sizeof(double) * 3);
     }
-    double* d_par = ctx->d_pose_in;  // B*64 doubles: [0, 12*count)
-    MML_HIP(hipMemcpyAsync(d_par, st, sizeof(double) * 12 * count, hipMemcpyHostToDevice, ctx->stream));
+    double* d_par = ctx->d_pose_in + 64 * (size_t)first_slot;  // 64 doubles per slot: [0, 12*count) of this call's slice
+    MML_HIP(hipMemcpyAsync(d_par, st, sizeof(double) * 12 * count, hipMemcpyHostToDevice, MML_STREAM(ctx)));
     return mml_launch_undistort(ctx, first_slot, count, d_par);
 }
 
@@ -345,16 +353,16 @@ int mml_features_download(mml_ctx* ctx, int slot, int kind, float* xyz, int capa
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad kind");
     int h = 0;
-    MML_HIP(hipMemcpyAsync(&h, ctx->ft_n + kind * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_HIP(hipMemcpyAsync(&h, ctx->ft_n + kind * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     MML_REQUIRE(h >= 0, MML_ERR_CAPACITY, "down-sample overflowed max_features / voxel capacity");
     *n = h;
     if (!xyz || h == 0) return MML_OK;
     MML_REQUIRE(capacity >= h, MML_ERR_CAPACITY, "download capacity too small");
     std::vector<float4> tmp(h);
     MML_HIP(hipMemcpyAsync(tmp.data(), ctx->ft_xyz[kind] + (size_t)slot * ctx->MF, sizeof(float4) * h,
-                           hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+                           hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     for (int i = 0; i < h; ++i) {
         xyz[3 * i] = tmp[i].x;
         xyz[3 * i + 1] = tmp[i].y;
@@ -371,9 +379,9 @@ int mml_features_upload(mml_ctx* ctx, int slot, int kind, const float* xyz, int 
     for (int i = 0; i < n; ++i) tmp[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
     if (n)
         MML_HIP(hipMemcpyAsync(ctx->ft_xyz[kind] + (size_t)slot * ctx->MF, tmp.data(), sizeof(float4) * n,
-                               hipMemcpyHostToDevice, ctx->stream));
-    MML_HIP(hipMemcpyAsync(ctx->ft_n + kind * ctx->B + slot, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(ctx->ft_n + kind * ctx->B + slot, &n, sizeof(int), hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     return MML_OK;
 }
 
@@ -396,13 +404,13 @@ int mml_knn5(mml_ctx* ctx, int kind, const float* q, int nq, float max_d2, int* 
     MML_HIP(hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(float) * 3 * nq));
     MML_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), sizeof(int) * 5 * nq));
     MML_HIP(hipMalloc(reinterpret_cast<void**>(&d_d2), sizeof(float) * 5 * nq));
-    MML_HIP(hipMemcpyAsync(d_q, q, sizeof(float) * 3 * nq, hipMemcpyHostToDevice, ctx->stream));
+    MML_HIP(hipMemcpyAsync(d_q, q, sizeof(float) * 3 * nq, hipMemcpyHostToDevice, MML_STREAM(ctx)));
     int rc = mml_launch_knn5(ctx, kind, d_q, nq, max_d2, d_idx, d_d2);
     if (rc == MML_OK) {
-        hipMemcpyAsync(idx, d_idx, sizeof(int) * 5 * nq, hipMemcpyDeviceToHost, ctx->stream);
-        hipMemcpyAsync(d2, d_d2, sizeof(float) * 5 * nq, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(idx, d_idx, sizeof(int) * 5 * nq, hipMemcpyDeviceToHost, MML_STREAM(ctx));
+        hipMemcpyAsync(d2, d_d2, sizeof(float) * 5 * nq, hipMemcpyDeviceToHost, MML_STREAM(ctx));
     }
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipStreamSynchronize(MML_STREAM(ctx));
     hipFree(d_q);
     hipFree(d_idx);
     hipFree(d_d2);
@@ -452,7 +460,7 @@ int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, d
     CHECK_SLOTS(first_slot, count);
     MML_REQUIRE(T_wl != nullptr, MML_ERR_INVALID, "null T_wl");
     MML_REQUIRE(ctx->have_map[0] && ctx->have_map[1], MML_ERR_STATE, "mml_associate before both maps were set");
-    double* d_T = ctx->d_pose_in;
+    double* d_T = ctx->d_pose_in + 64 * (size_t)first_slot;
     int rc = upload_doubles(ctx, d_T, T_wl, 16 * (size_t)count);
     if (rc != MML_OK) return rc;
     rc = mml_launch_associate(ctx, first_slot, count, d_T, thres_dist);
@@ -460,8 +468,8 @@ int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, d
     if (stats) {
         std::vector<double> h(16 * (size_t)count);
         MML_HIP(hipMemcpyAsync(h.data(), ctx->assoc_stats + 16 * (size_t)first_slot, sizeof(double) * h.size(),
-                               hipMemcpyDeviceToHost, ctx->stream));
-        MML_HIP(hipStreamSynchronize(ctx->stream));
+                               hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+        MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
         for (int i = 0; i < count; ++i) finish_stats(h.data() + 16 * i, &stats[i]);
     }
     return MML_OK;
@@ -471,8 +479,8 @@ int mml_factors_download(mml_ctx* ctx, int slot, int kind, double* out, int* src
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad arguments");
     int nf = 0;
-    MML_HIP(hipMemcpyAsync(&nf, ctx->ft_n + kind * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_HIP(hipMemcpyAsync(&nf, ctx->ft_n + kind * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     MML_REQUIRE(nf >= 0, MML_ERR_CAPACITY, "feature stack overflowed");
     int cnt = 0;
     if (kind == 0) {
@@ -536,8 +544,8 @@ int mml_linearize(mml_ctx* ctx, int slot, const double* x, const double* T_bl, d
     int rc = mml_linearize_record(ctx, slot, x, T_bl, plan_weight_tan, huber_delta, d_rec);
     if (rc != MML_OK) return rc;
     double rec[32];
-    MML_HIP(hipMemcpyAsync(rec, d_rec, sizeof(rec), hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    MML_HIP(hipMemcpyAsync(rec, d_rec, sizeof(rec), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     int k = 0;
     for (int a = 0; a < 6; ++a)
         for (int b = a; b < 6; ++b) {
@@ -550,28 +558,34 @@ int mml_linearize(mml_ctx* ctx, int slot, const double* x, const double* T_bl, d
     return MML_OK;
 }
 
+// enqueue only: upload x and T_bl for slots [first, first+count), launch the solver on the current lane
+static int solve_enqueue(mml_ctx* ctx, int first_slot, int count, int window, const double* T_bl,
+                         const mml_solve_opts* opts, const double* x, bool want_trace) {
+    int rc = upload_doubles(ctx, ctx->d_x + 6 * (size_t)first_slot, x, 6 * (size_t)count);
+    if (rc != MML_OK) return rc;
+    double* d_Tbl = ctx->d_pose_in + 64 * (size_t)(first_slot + count) - 16;  // tail of this call's slice
+    rc = upload_doubles(ctx, d_Tbl, T_bl, 16);
+    if (rc != MML_OK) return rc;
+    return mml_launch_solve(ctx, first_slot, count, window, d_Tbl, *opts, want_trace);
+}
+
 int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double* T_bl, const mml_solve_opts* opts,
               double* x, mml_solve_summary* summaries, double* trace) {
     CHECK_SLOTS(first_slot, count);
     MML_REQUIRE(T_bl && opts && x, MML_ERR_INVALID, "null argument");
     MML_REQUIRE(opts->max_num_iterations >= 0 && opts->max_num_iterations <= 64, MML_ERR_INVALID,
                 "max_num_iterations must be in [0, 64]");
-    int rc = upload_doubles(ctx, ctx->d_x + 6 * (size_t)first_slot, x, 6 * (size_t)count);
-    if (rc != MML_OK) return rc;
-    double* d_Tbl = ctx->d_pose_in + 64 * (size_t)ctx->B - 16;
-    rc = upload_doubles(ctx, d_Tbl, T_bl, 16);
-    if (rc != MML_OK) return rc;
-    rc = mml_launch_solve(ctx, first_slot, count, window, d_Tbl, *opts, trace != nullptr);
+    int rc = solve_enqueue(ctx, first_slot, count, window, T_bl, opts, x, trace != nullptr);
     if (rc != MML_OK) return rc;
     const int nprob = count / window;
     std::vector<double> hs(8 * (size_t)nprob);
     MML_HIP(hipMemcpyAsync(x, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost,
-                           ctx->stream));
-    MML_HIP(hipMemcpyAsync(hs.data(), ctx->d_summ, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+                           MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(hs.data(), ctx->d_summ + 8 * (size_t)first_slot, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     if (trace)
-        MML_HIP(hipMemcpyAsync(trace, ctx->d_trace, sizeof(double) * (size_t)nprob * opts->max_num_iterations * 6 * window,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+        MML_HIP(hipMemcpyAsync(trace, ctx->d_trace + (size_t)first_slot * 6 * 64, sizeof(double) * (size_t)nprob * opts->max_num_iterations * 6 * window,
+                               hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     if (summaries)
         for (int p = 0; p < nprob; ++p) {
             summaries[p].iterations = (int)hs[8 * p];
@@ -724,28 +738,52 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     MML_REQUIRE(dR && dt && exTlb && x_inout, MML_ERR_INVALID, "null argument");
     MML_REQUIRE(gn_iters >= 0 && gn_iters <= 64, MML_ERR_INVALID, "gn_iters must be in [0, 64]");
     MML_REQUIRE(ctx->have_map[0] && ctx->have_map[1], MML_ERR_STATE, "mml_step before both maps were set");
-    int rc = mml_launch_extract(ctx, first_slot, count, false);
-    if (rc != MML_OK) return rc;
-    rc = mml_undistort(ctx, first_slot, count, dR, dt);
-    if (rc != MML_OK) return rc;
-    rc = mml_launch_downsample(ctx, first_slot, count);
-    if (rc != MML_OK) return rc;
     double T_bl[16];
     invert_extrinsic(exTlb, T_bl);
-    std::vector<double> Twl(16 * (size_t)count);
-    for (int i = 0; i < count; ++i) {
-        double q[4];
-        so3_exp_h(x_inout + 6 * i + 3, q);
-        pose_to_Twl(q, x_inout + 6 * i, T_bl, &Twl[16 * i]);
-    }
-    rc = mml_associate(ctx, first_slot, count, Twl.data(), thres_dist, nullptr);
-    if (rc != MML_OK) return rc;
     mml_solve_opts so;
     so.max_num_iterations = gn_iters;
     so.fixed_iterations = 1;
     so.huber_delta = 0.1 / 1.5e-3;
     so.plan_weight_tan = 0.0;
-    return mml_solve(ctx, first_slot, count, 1, T_bl, &so, x_inout, nullptr, nullptr);
+    // Sub-batches on independent streams: the latency-bound stages of one sub-batch (per-slot scans, the 10 serial
+    // solver iterations) overlap the issue-bound stages of the others.  Scans are independent, results identical.
+    const int lanes = (count >= 64 && ctx->lanes_enabled) ? ctx->n_lanes : 1;
+    const int chunk = (count + lanes - 1) / lanes;
+    std::vector<double> Twl(16 * (size_t)chunk);
+    double* h_x = stage_alloc(ctx, 6 * (size_t)count);  // pinned read-back area
+    int rc = MML_OK;
+    for (int l = 0; l < lanes && rc == MML_OK; ++l) {
+        const int f = first_slot + l * chunk;
+        const int c = std::min(chunk, first_slot + count - f);
+        if (c <= 0) break;
+        const int off = f - first_slot;
+        ctx->cur = l;
+        rc = mml_launch_extract(ctx, f, c, false);
+        if (rc == MML_OK) rc = mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
+        if (rc == MML_OK) rc = mml_launch_downsample(ctx, f, c);
+        if (rc != MML_OK) break;
+        for (int i = 0; i < c; ++i) {
+            double q[4];
+            so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
+            pose_to_Twl(q, x_inout + 6 * (size_t)(off + i), T_bl, &Twl[16 * (size_t)i]);
+        }
+        rc = mml_associate(ctx, f, c, Twl.data(), thres_dist, nullptr);
+        if (rc == MML_OK) rc = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
+        if (rc == MML_OK) {
+            hipError_t e = hipMemcpyAsync(h_x + 6 * (size_t)off, ctx->d_x + 6 * (size_t)f, sizeof(double) * 6 * c,
+                                          hipMemcpyDeviceToHost, MML_STREAM(ctx));
+            if (e != hipSuccess) {
+                ctx->err = std::string("mml_step read-back: ") + hipGetErrorString(e);
+                rc = MML_ERR_HIP;
+            }
+        }
+    }
+    ctx->cur = 0;
+    int rs = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    if (rs != MML_OK) return rs;
+    memcpy(x_inout, h_x, sizeof(double) * 6 * (size_t)count);
+    return MML_OK;
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------------
@@ -756,7 +794,8 @@ int mml_profile_enable(mml_ctx* ctx, int on) {
 }
 
 static int drain_pending(mml_ctx* ctx) {
-    MML_HIP(hipStreamSynchronize(ctx->stream));
+    int rc0 = mml_sync_all(ctx);
+    if (rc0 != MML_OK) return rc0;
     for (auto& pe : ctx->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
@@ -823,15 +862,15 @@ extern "C" int mml_copy_bandwidth(mml_ctx* ctx, size_t bytes, int reps, double* 
     float4 *a = nullptr, *b = nullptr;
     MML_HIP(hipMalloc(reinterpret_cast<void**>(&a), n * 16));
     MML_HIP(hipMalloc(reinterpret_cast<void**>(&b), n * 16));
-    MML_HIP(hipMemsetAsync(a, 1, n * 16, ctx->stream));
+    MML_HIP(hipMemsetAsync(a, 1, n * 16, MML_STREAM(ctx)));
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
-    hipEventRecord(e0, ctx->stream);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
-    hipEventRecord(e1, ctx->stream);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, MML_STREAM(ctx), a, b, n);
+    hipEventRecord(e0, MML_STREAM(ctx));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, MML_STREAM(ctx), a, b, n);
+    hipEventRecord(e1, MML_STREAM(ctx));
+    hipError_t e = hipStreamSynchronize(MML_STREAM(ctx));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0);
@@ -871,12 +910,17 @@ int mml_stage_begin(mml_ctx* ctx, const char* name) {
     };
     pe.a = get();
     pe.b = get();
-    hipEventRecord(pe.a, ctx->stream);
+    hipEventRecord(pe.a, MML_STREAM(ctx));
     ctx->pending.push_back(pe);
     return (int)ctx->pending.size() - 1;
 }
 
 void mml_stage_end(mml_ctx* ctx, int token) {
     if (token < 0) return;
-    hipEventRecord(ctx->pending[token].b, ctx->stream);
+    hipEventRecord(ctx->pending[token].b, MML_STREAM(ctx));
+}
+
+int mml_sync_all(mml_ctx* ctx) {
+    for (int l = 0; l < ctx->n_lanes; ++l) MML_HIP(hipStreamSynchronize(ctx->streams[l]));
+    return MML_OK;
 }

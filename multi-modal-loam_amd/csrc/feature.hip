@@ -1253,7 +1253,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
 int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) {
     FeatParams P = make_params(ctx, first);
     P.extr = have_extrinsic ? ctx->d_extr : nullptr;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = MML_STREAM(ctx);
     const int pblocks = (ctx->NT + 255) / 256;
     {
         MmlStageScope t(ctx, "assign");
@@ -1284,7 +1284,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     FeatParams P = make_params(ctx, 0);
     P.ln_final = d_final;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = MML_STREAM(ctx);
     const int t = (n > ctx->L ? n : ctx->L);
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
     const int pblocks = (n + 255) / 256;

@@ -1095,7 +1095,7 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
     MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
     MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "map larger than max_map_points");
     MmlGrid& g = ctx->grid[kind];
-    hipStream_t s = ctx->stream;
+    hipStream_t s = MML_STREAM(ctx);
     ctx->have_map[kind] = false;
     g.m = m;
     if (m == 0) {
@@ -1181,7 +1181,7 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
 
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2) {
     MmlStageScope t(ctx, "knn5");
-    hipLaunchKernelGGL(k_knn5, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, ctx->grid[kind], d_q, nq, max_d2,
+    hipLaunchKernelGGL(k_knn5, dim3((nq + 255) / 256), dim3(256), 0, MML_STREAM(ctx), ctx->grid[kind], d_q, nq, max_d2,
                        d_idx, d_d2);
     MML_HIP(hipGetLastError());
     return MML_OK;
@@ -1205,24 +1205,26 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     P.thres = (float)thres_dist;
     if ((double)P.thres < thres_dist) P.thres = nextafterf(P.thres, INFINITY);
     P.thres_d = thres_dist;
-    P.hard_count = ctx->d_misc + 32;
-    P.hard_list = ctx->hard_list;
-    P.hard_knn = ctx->hard_knn;
-    MML_HIP(hipMemsetAsync(P.hard_count, 0, sizeof(int), ctx->stream));
+    // queue storage is sliced by slot index (2 * MF entries per slot), the counter by lane
+    P.hard_count = ctx->d_misc + 32 + ctx->cur;
+    P.hard_list = ctx->hard_list + (size_t)first * ctx->MF * 2;
+    P.hard_knn = ctx->hard_knn + (size_t)first * ctx->MF * 2 * 10;
+    MML_HIP(hipMemsetAsync(P.hard_count, 0, sizeof(int), MML_STREAM(ctx)));
     P.count = count;
-    P.work_off = ctx->work_off;
+    int* work_off = ctx->work_off + 2 * (size_t)first + ctx->cur;
+    P.work_off = work_off;
     {
         MmlStageScope t(ctx, "associate");
-        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, ctx->stream, first, count, ctx->B, ctx->ft_n, ctx->work_off);
-        hipLaunchKernelGGL(k_associate, dim3(4096), dim3(128), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, MML_STREAM(ctx), first, count, ctx->B, ctx->ft_n, work_off);
+        hipLaunchKernelGGL(k_associate, dim3(4096), dim3(128), 0, MML_STREAM(ctx), P);
     }
     {
         MmlStageScope t(ctx, "associate_far");
-        hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P);
     }
     {
         MmlStageScope t(ctx, "assoc_stats");
-        hipLaunchKernelGGL(k_assoc_stats, dim3(count), dim3(256), 0, ctx->stream, first, ctx->B, ctx->MF, ctx->ft_n,
+        hipLaunchKernelGGL(k_assoc_stats, dim3(count), dim3(256), 0, MML_STREAM(ctx), first, ctx->B, ctx->MF, ctx->ft_n,
                            ctx->lf, ctx->pf, ctx->assoc_stats);
     }
     MML_HIP(hipGetLastError());

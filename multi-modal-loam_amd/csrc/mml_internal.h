@@ -51,7 +51,13 @@ struct MmlStageTimer {
 struct mml_ctx {
     mml_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
+    // `lanes`: independent HIP streams.  Entry points enqueue on lane `cur` (0 unless mml_step is pipelining
+    // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.
+    static constexpr int MAX_LANES = 4;
+    hipStream_t streams[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    int n_lanes = 1;
+    int cur = 0;
+    bool lanes_enabled = true;
     std::string err;
 
     int B = 0, NV = 0, NL = 0, NT = 0, L = 0, MF = 0;
@@ -145,6 +151,9 @@ struct mml_ctx {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
 };
+
+#define MML_STREAM(ctx) ((ctx)->streams[(ctx)->cur])
+int mml_sync_all(mml_ctx* ctx);
 
 #define MML_HIP(call)                                                                         \
     do {                                                                                      \

@@ -594,10 +594,10 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
     P.pf = ctx->pf;
     P.Tbl = d_Tbl;
     P.x = ctx->d_x;
-    P.summ = ctx->d_summ;
-    P.trace = want_trace ? ctx->d_trace : nullptr;
+    P.summ = ctx->d_summ + 8 * (size_t)first;
+    P.trace = want_trace ? ctx->d_trace + (size_t)first * 6 * 64 : nullptr;
     MmlStageScope t(ctx, "solve");
-    hipLaunchKernelGGL(k_solve, dim3(count / window), dim3(SOLVE_THREADS), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_solve, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
@@ -605,7 +605,7 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan, double huber,
                          double* d_record) {
     MmlStageScope t(ctx, "linearize");
-    hipLaunchKernelGGL(k_linearize, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, slot, ctx->B, ctx->MF, ctx->ft_n,
+    hipLaunchKernelGGL(k_linearize, dim3(1), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), slot, ctx->B, ctx->MF, ctx->ft_n,
                        ctx->lf, ctx->pf, d_x, d_Tbl, w_tan, huber, ctx->assoc_stats, d_record);
     MML_HIP(hipGetLastError());
     return MML_OK;

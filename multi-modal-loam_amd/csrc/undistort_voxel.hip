@@ -357,9 +357,9 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int first, int NT, int MF,
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params) {
     MmlStageScope t(ctx, "undistort");
     dim3 grid((ctx->NT + 255) / 256, count);
-    hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, count, d_params, ctx->d_und);
-    hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, ctx->stream, first, ctx->NT, ctx->fu_info, ctx->fu_xyzi,
-                       ctx->fu_rel, d_params, ctx->d_und);
+    hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, MML_STREAM(ctx), count, d_params, ctx->d_und + 8 * (size_t)first);
+    hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, MML_STREAM(ctx), first, ctx->NT, ctx->fu_info, ctx->fu_xyzi,
+                       ctx->fu_rel, d_params, ctx->d_und + 8 * (size_t)first);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
@@ -370,7 +370,7 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     int npad = 1;
     while (npad < cap) npad <<= 1;
     size_t lds = (size_t)npad * sizeof(unsigned long long);
-    hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, ctx->stream, first, ctx->NT, ctx->MF, ctx->B,
+    hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, MML_STREAM(ctx), first, ctx->NT, ctx->MF, ctx->B,
                        cap, ctx->fu_info, ctx->fu_xyzi, ctx->fu_label, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
                        ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     MML_HIP(hipGetLastError());
