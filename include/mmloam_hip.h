@@ -126,6 +126,15 @@ int mml_features_upload(mml_ctx* ctx, int slot, int kind, const float* xyz, int 
  * Uploads a map cloud (3 floats per point) and builds the radix-sorted uniform grid that replaces
  * pcl::KdTreeFLANN::setInputCloud.  kind: 0 corner, 1 surf. */
 int mml_map_set_local(mml_ctx* ctx, int kind, const float* xyz, int m);
+/* ---- a12: laserCloud{Corner,Surf}FromMap cube store (Estimator.cpp:1170-1184, Map_Manager.cpp:583-629)
+ * The reference hands Estimate() 21*11*21 = 4851 cube clouds plus one kd-tree per cube; processPointToLine /
+ * processPointToPlane look the feature's cube up (MAP_MANAGER::FindUsedMap), query THAT cube's tree when the
+ * cube holds > 100 corner / > 50 surf points, and fall back to the local map otherwise or when the cube
+ * neighbourhood fails the fit.  Here the cubes arrive as ONE concatenated cloud: xyz (3 floats per point) and
+ * cube[i] = ToIndex(i, j, k) = i + 21 j + 441 k of point i (points of one cube in the cube cloud's order, so
+ * that kd-tree tie order is preserved).  cen: laserCloudCen{Width,Height,Depth}_last (3 ints, NULL keeps
+ * the current value, default 10, 5, 10).  m = 0 removes the global map (local-only association). */
+int mml_map_set_global(mml_ctx* ctx, int kind, const float* xyz, const int* cube, int m, const int* cen);
 /* Exact 5-NN against a local map (twin of kdtree->nearestKSearch(p, 5, idx, d2), Estimator.cpp:284,704):
  * q: nq x 3 host floats (already in the map frame); idx: nq x 5 (indices into the uploaded cloud,
  * ascending d2, ties by lower index), d2: nq x 5 (float, ((dx*dx+dy*dy)+dz*dz)). max_d2: search bound

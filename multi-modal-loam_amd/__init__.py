@@ -103,6 +103,20 @@ def lib():
     return _lib
 
 
+def cube_index(xyz, cen=(10, 5, 10)):
+    """Cube of every map-frame point, MAP_MANAGER::FindUsedCornerMap / FindUsedSurfMap (Map_Manager.cpp:583-629):
+    ToIndex(i, j, k) = i + 21 j + 441 k over the 21 x 21 x 11 grid of 50 m cubes, 5000 for a point outside it.
+    cen = laserCloudCen{Width,Height,Depth}_last.  Used to tag a global map for Context.map_set_global."""
+    p = _f32(xyz).reshape(-1, 3).astype(np.float64)
+    q = (p + 25.0) / 50.0
+    with np.errstate(invalid="ignore"):
+        c = np.where(np.isfinite(q), np.trunc(q), -1.0e6).astype(np.int64)
+    c -= (p + 25.0 < 0)
+    ci, cj, ck = c[:, 0] + cen[2], c[:, 1] + cen[0], c[:, 2] + cen[1]
+    ok = (ci >= 0) & (ci < 21) & (cj >= 0) & (cj < 21) & (ck >= 0) & (ck < 11)
+    return np.where(ok, ci + 21 * cj + 441 * ck, 5000).astype(np.int32)
+
+
 def default_config(max_scans=1, **over):
     cfg = Config()
     lib().mml_config_default(C.byref(cfg), C.c_int(max_scans))
@@ -221,6 +235,15 @@ class Context:
     def map_set_local(self, kind, xyz):
         xyz = _f32(xyz).reshape(-1, 3)
         self._ck(lib().mml_map_set_local(self._h, C.c_int(kind), _p(xyz), C.c_int(len(xyz))))
+
+    def map_set_global(self, kind, xyz, cube, cen=None):
+        """Cube store of the global map (a12): xyz (m, 3) and the ToIndex cube of every point."""
+        xyz = _f32(xyz).reshape(-1, 3)
+        cube = np.ascontiguousarray(cube, dtype=np.int32).reshape(-1)
+        if len(cube) != len(xyz):
+            raise ValueError("one cube index per point")
+        cen_p = None if cen is None else _p(np.ascontiguousarray(cen, dtype=np.int32))
+        self._ck(lib().mml_map_set_global(self._h, C.c_int(kind), _p(xyz), _p(cube), C.c_int(len(xyz)), cen_p))
 
     def knn5(self, kind, q, max_d2=np.inf):
         q = _f32(q).reshape(-1, 3)

@@ -71,7 +71,9 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
                     ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_summ, ctx->d_trace, ctx->d_rec,
-                    ctx->d_extr,   ctx->d_misc};
+                    ctx->d_extr,   ctx->d_misc,   ctx->ggrid[0].pts, ctx->ggrid[1].pts, ctx->ggrid[0].cell_start,
+                    ctx->ggrid[1].cell_start, ctx->ggrid[0].tags, ctx->ggrid[1].tags, ctx->gmap_orig[0],
+                    ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -390,6 +392,14 @@ int mml_map_set_local(mml_ctx* ctx, int kind, const float* xyz, int m) {
     MML_REQUIRE(m >= 0 && (m == 0 || xyz), MML_ERR_INVALID, "bad map arguments");
     MML_HIP(hipSetDevice(ctx->device));
     return mml_build_grid(ctx, kind, xyz, m);
+}
+
+int mml_map_set_global(mml_ctx* ctx, int kind, const float* xyz, const int* cube, int m, const int* cen) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(m >= 0 && (m == 0 || (xyz && cube)), MML_ERR_INVALID, "bad global map arguments");
+    MML_HIP(hipSetDevice(ctx->device));
+    mml_sync_all(ctx);
+    return mml_build_global_grid(ctx, kind, xyz, cube, m, cen);
 }
 
 int mml_knn5(mml_ctx* ctx, int kind, const float* q, int nq, float max_d2, int* idx, float* d2) {

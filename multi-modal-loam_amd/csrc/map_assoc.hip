@@ -100,6 +100,11 @@ __global__ void k_gather_sorted(const float4* pts, const unsigned* vals, int m, 
     out[i] = p;
 }
 
+__global__ void k_gather_tags(const uint16_t* tag_orig, const unsigned* vals, int m, uint16_t* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = tag_orig[vals[i]];
+}
+
 // number of occupied cells = number of key changes in the sorted key array
 __global__ void k_count_occupied(const unsigned* keys, int m, int* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,9 +160,13 @@ __device__ __forceinline__ void knn_insert(Knn5& k, float dd, int ii) {
     }
 }
 
-__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int s, int e, float qx, float qy, float qz,
-                                           Knn5& k) {
+// tags / mytag: when the grid carries cube tags (global map, a12) only points of the query's cube take part: the
+// reference searches the kd-tree of ONE cube (Estimator.cpp:199,630).  Every point inside the visited radius is still
+// looked at, so the exactness bound of the ring search is unchanged.
+__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, const uint16_t* __restrict__ tags, int mytag,
+                                           int s, int e, float qx, float qy, float qz, Knn5& k) {
     for (int i = s; i < e; ++i) {
+        if (tags && (int)tags[i] != mytag) continue;
         float4 p = pts[i];
         float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
         float r = 0;
@@ -209,7 +218,8 @@ __device__ __forceinline__ bool knn_done(const MmlGrid& g, float inset, int r, f
 }
 
 // one row (fixed y,z) of shell r: the whole x-span on a face, the two end cells otherwise
-__device__ __forceinline__ void scan_shell_row(const MmlGrid& g, const KnnQuery& q, int r, int y, int z, Knn5& k) {
+__device__ __forceinline__ void scan_shell_row(const MmlGrid& g, const KnnQuery& q, int r, int y, int z, Knn5& k,
+                                               int mytag = -1) {
     const int DX = g.dim[0], DY = g.dim[1], DZ = g.dim[2];
     if (y < 0 || y >= DY || z < 0 || z >= DZ) return;
     const int x0 = q.hx - r, x1 = q.hx + r;
@@ -217,11 +227,13 @@ __device__ __forceinline__ void scan_shell_row(const MmlGrid& g, const KnnQuery&
     const int rowbase = DX * (y + DY * z);
     if (face) {
         const int xa = max(x0, 0), xb = min(x1, DX - 1);
-        if (xa <= xb) scan_range(g.pts, g.cell_start[rowbase + xa], g.cell_start[rowbase + xb + 1], q.qx, q.qy, q.qz, k);
+        if (xa <= xb)
+            scan_range(g.pts, g.tags, mytag, g.cell_start[rowbase + xa], g.cell_start[rowbase + xb + 1], q.qx, q.qy, q.qz, k);
     } else {
-        if (x0 >= 0 && x0 < DX) scan_range(g.pts, g.cell_start[rowbase + x0], g.cell_start[rowbase + x0 + 1], q.qx, q.qy, q.qz, k);
+        if (x0 >= 0 && x0 < DX)
+            scan_range(g.pts, g.tags, mytag, g.cell_start[rowbase + x0], g.cell_start[rowbase + x0 + 1], q.qx, q.qy, q.qz, k);
         if (x1 >= 0 && x1 < DX && x1 != x0)
-            scan_range(g.pts, g.cell_start[rowbase + x1], g.cell_start[rowbase + x1 + 1], q.qx, q.qy, q.qz, k);
+            scan_range(g.pts, g.tags, mytag, g.cell_start[rowbase + x1], g.cell_start[rowbase + x1 + 1], q.qx, q.qy, q.qz, k);
     }
 }
 
@@ -725,6 +737,12 @@ struct AssocParams {
     int first, B, MF;
     MmlGrid g[2];
     const float4* map_orig[2];  // unsorted map clouds (index = original index)
+    // global cube map (a12): tagged grids, unsorted clouds, per-cube point counts, grid centre
+    MmlGrid gg[2];
+    const float4* gmap_orig[2];
+    const int* cube_cnt[2];
+    int have_g[2];
+    int cen[3];
     const float4* ft[2];
     const int* ft_n;
     MmlLineFactor* lf;
@@ -749,9 +767,36 @@ __device__ __forceinline__ void tf_point(const double* T, double x, double y, do
 
 // one lane per feature: grid.x covers MF features, grid.y = slot, grid.z = kind
 // model fit + factor record for one feature (a14 / a15 / a16), given its exact 5 nearest map points
-__device__ __forceinline__ void fit_and_store(const AssocParams& P, int kind, int b, int i, const float4 f, const double* T,
-                                              float sx, float sy, float sz, bool ok, const Knn5& k) {
-    const float4* mp = P.map_orig[kind];
+__device__ __forceinline__ void store_none(const AssocParams& P, int kind, int b, int i) {
+    if (kind == 0) {
+        MmlLineFactor out;
+        memset(&out, 0, sizeof(out));
+        out.src = -1;
+        P.lf[(size_t)b * P.MF + i] = out;
+    } else {
+        MmlPlaneFactor out;
+        memset(&out, 0, sizeof(out));
+        out.src = -1;
+        P.pf[(size_t)b * P.MF + i] = out;
+    }
+}
+
+// Map_Manager.cpp:583-629 FindUsed{Corner,Surf}Map
+__device__ __forceinline__ int find_used_map(float x, float y, float z, const int* cen) {
+    int cubeI = int((x + 25.0) / 50.0) + cen[2];
+    int cubeJ = int((y + 25.0) / 50.0) + cen[0];
+    int cubeK = int((z + 25.0) / 50.0) + cen[1];
+    if (x + 25.0 < 0) cubeI--;
+    if (y + 25.0 < 0) cubeJ--;
+    if (z + 25.0 < 0) cubeK--;
+    if (cubeI >= 0 && cubeI < 21 && cubeJ >= 0 && cubeJ < 21 && cubeK >= 0 && cubeK < 11)
+        return cubeI + 21 * cubeJ + 21 * 21 * cubeK;  // ToIndex, Map_Manager.cpp:65-67
+    return 5000;
+}
+
+// returns true (and stores the factor) when the neighbourhood passes the gate and yields a model
+__device__ __forceinline__ bool fit_and_store(const AssocParams& P, int kind, int b, int i, const float4 f, const double* T,
+                                              float sx, float sy, float sz, bool ok, const Knn5& k, const float4* mp) {
     if (kind == 0) {
         MmlLineFactor out;
         out.src = -1;
@@ -823,7 +868,8 @@ __device__ __forceinline__ void fit_and_store(const AssocParams& P, int kind, in
                 out.error = a012 / l12;
             }
         }
-        P.lf[(size_t)b * P.MF + i] = out;
+        if (out.src >= 0) P.lf[(size_t)b * P.MF + i] = out;
+        return out.src >= 0;
     } else {
         MmlPlaneFactor out;
         out.src = -1;
@@ -876,7 +922,8 @@ __device__ __forceinline__ void fit_and_store(const AssocParams& P, int kind, in
                 out.src = i;
             }
         }
-        P.pf[(size_t)b * P.MF + i] = out;
+        if (out.src >= 0) P.pf[(size_t)b * P.MF + i] = out;
+        return out.src >= 0;
     }
 }
 
@@ -938,17 +985,27 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
     double wx, wy, wz;
     tf_point(T, f.x, f.y, f.z, wx, wy, wz);
     const float sx = wx, sy = wy, sz = wz;
-    bool ok = !(isnan(sx) || isnan(sy) || isnan(sz)) && P.map_m[kind] > 20;  // :196, :283 / :702
-    Knn5 k;
-    knn_init(k);
-    if (ok) {
-        const MmlGrid& g = P.g[kind];
+    // :192-196 / :621-625: features outside the 21 x 11 x 21 cube grid, or NaN after the transform, get no factor
+    const int cube = find_used_map(sx, sy, sz, P.cen);
+    if (cube == 5000 || isnan(sx) || isnan(sy) || isnan(sz)) {
+        store_none(P, kind, b, i);
+        continue;
+    }
+    // stage 0: the cube's own cloud when it holds > 100 corner / > 50 surf points (:198, :627); stage 1: local map
+    int stage = (P.have_g[kind] && P.cube_cnt[kind][cube] > (kind == 0 ? 100 : 50)) ? 0 : 1;
+    bool queued = false, stored = false;
+    for (; stage < 2 && !stored && !queued; ++stage) {
+        if (stage == 1 && !(P.map_m[kind] > 20)) break;  // :283 / :702
+        const MmlGrid& g = stage == 0 ? P.gg[kind] : P.g[kind];
+        const int mytag = stage == 0 ? cube : -1;
+        Knn5 k;
+        knn_init(k);
         const KnnQuery q = knn_query(g, sx, sy, sz);
         const int rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
         bool done = false;
         for (int r = 0; r <= 1 && r <= rmax; ++r) {
             for (int z = q.hz - r; z <= q.hz + r; ++z)
-                for (int y = q.hy - r; y <= q.hy + r; ++y) scan_shell_row(g, q, r, y, z, k);
+                for (int y = q.hy - r; y <= q.hy + r; ++y) scan_shell_row(g, q, r, y, z, k, mytag);
             if (knn_done(g, q.inset, r, k.d[4], P.thres)) {
                 done = true;
                 break;
@@ -956,18 +1013,20 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
         }
         if (!done && rmax >= 2) {
             const int hw = atomicAdd(P.hard_count, 1);
-            P.hard_list[hw] = make_int4(slot, kind, i, 0);
+            P.hard_list[hw] = make_int4(slot, kind, i, stage | (cube << 1));
             float* hd = P.hard_knn + 10 * (size_t)hw;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 hd[j] = k.d[j];
                 hd[5 + j] = __int_as_float(k.id[j]);
             }
-            continue;  // finished by k_associate_hard
+            queued = true;  // finished by k_associate_hard
+            break;
         }
+        const bool ok = (double)k.d[4] < P.thres_d;  // :201,285 / :631,705
+        stored = fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, k, stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]);
     }
-    ok = ok && (double)k.d[4] < P.thres_d;  // :285 / :705
-    fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, k);
+    if (!stored && !queued) store_none(P, kind, b, i);
     }
 }
 
@@ -1004,20 +1063,20 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
     const int total = *P.hard_count;
     for (int w0 = 0; w0 < total; w0 += ngroups) {
         const int w = w0 + group;
-        bool gdone = w >= total;
-        int slot = 0, kind = 0, i = 0, b = P.first;
+        const bool live = w < total;
+        int slot = 0, kind = 0, i = 0, b = P.first, stage = 1, cube = 0;
         float4 f = make_float4(0, 0, 0, 0);
         float sx = 0, sy = 0, sz = 0;
         Knn5 loc, best;
         knn_init(loc);
         knn_init(best);
-        KnnQuery q = knn_query(P.g[0], 0.f, 0.f, 0.f);
-        int rmax = 0;
-        if (!gdone) {
+        if (live) {
             const int4 e = P.hard_list[w];
             slot = e.x;
             kind = e.y;
             i = e.z;
+            stage = e.w & 1;
+            cube = e.w >> 1;
             b = slot + P.first;
             f = P.ft[kind][(size_t)b * P.MF + i];
             double wx, wy, wz;
@@ -1025,9 +1084,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
             sx = wx;
             sy = wy;
             sz = wz;
-            q = knn_query(P.g[kind], sx, sy, sz);
-            rmax = (int)ceilf(sqrtf(P.thres) * P.g[kind].inv_cell) + 1;
-            if (gl == 0) {
+            if (gl == 0) {  // the list pass 1 left after ring 1
                 const float* hd = P.hard_knn + 10 * (size_t)w;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
@@ -1036,21 +1093,48 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
                 }
             }
         }
-        for (int r = 2;; ++r) {
-            if (!gdone && r > rmax) gdone = true;
-            if (__all(gdone)) break;
-            if (!gdone) {
-                const int ww = 2 * r + 1;
-                for (int t = gl; t < ww * ww; t += 16)
-                    scan_shell_row(P.g[kind], q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc);
+        bool finished = !live;  // group-uniform
+        int r0 = 2;             // pass 1 already covered rings 0 and 1 of the queued stage
+        while (!__all(finished)) {
+            // ---- one search (current stage) ----
+            const MmlGrid& g = stage == 0 ? P.gg[kind] : P.g[kind];
+            const int mytag = stage == 0 ? cube : -1;
+            const KnnQuery q = knn_query(g, sx, sy, sz);
+            const int rmax = finished ? 0 : (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
+            bool sdone = finished;
+            if (!sdone && r0 > rmax) {
+                sdone = true;
+                group_merge5(loc, best);
             }
-            group_merge5(loc, best);
-            if (!gdone && knn_done(P.g[kind], q.inset, r, best.d[4], P.thres)) gdone = true;
-        }
-        if (w < total && gl == 0) {
-            if (rmax < 2) best = loc;
-            const bool ok = (double)best.d[4] < P.thres_d;
-            fit_and_store(P, kind, b, i, f, P.Twl + 16 * slot, sx, sy, sz, ok, best);
+            for (int r = r0;; ++r) {
+                if (!sdone && r > rmax) sdone = true;
+                if (__all(sdone)) break;
+                if (!sdone) {
+                    const int ww = 2 * r + 1;
+                    for (int t = gl; t < ww * ww; t += 16) scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc, mytag);
+                }
+                group_merge5(loc, best);
+                if (!sdone && knn_done(g, q.inset, r, best.d[4], P.thres)) sdone = true;
+            }
+            // ---- model fit on lane 0 of the group; fall back to the local map after a failed cube stage ----
+            int stored = 0;
+            if (!finished && gl == 0) {
+                const bool ok = (double)best.d[4] < P.thres_d;
+                stored = fit_and_store(P, kind, b, i, f, P.Twl + 16 * slot, sx, sy, sz, ok, best,
+                                       stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]) ? 1 : 0;
+            }
+            stored = __shfl(stored, (threadIdx.x & 63) & ~15, 64);
+            if (!finished) {
+                if (stored || stage == 1 || !(P.map_m[kind] > 20)) {
+                    if (!stored && gl == 0) store_none(P, kind, b, i);
+                    finished = true;
+                } else {
+                    stage = 1;  // :283 / :702: local cloud, searched from ring 0 by the whole group
+                    r0 = 0;
+                    knn_init(loc);
+                    knn_init(best);
+                }
+            }
         }
     }
 }
@@ -1091,12 +1175,10 @@ __global__ __launch_bounds__(256) void k_assoc_stats(int first, int B, int MF, c
 
 }  // namespace
 
-int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
-    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
-    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "map larger than max_map_points");
-    MmlGrid& g = ctx->grid[kind];
+// Builds the radix-sorted grid `g` over m points (host xyz), keeping the unsorted cloud in `orig`.
+static int build_grid_into(mml_ctx* ctx, MmlGrid& g, float4* orig, const float* h_xyz, int m, float cell,
+                           const uint16_t* d_tag_orig) {
     hipStream_t s = MML_STREAM(ctx);
-    ctx->have_map[kind] = false;
     g.m = m;
     if (m == 0) {
         g.dim[0] = g.dim[1] = g.dim[2] = 1;
@@ -1105,13 +1187,11 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
         g.inv_cell = 1.f;
         g.origin[0] = g.origin[1] = g.origin[2] = 0.f;
         MML_HIP(hipMemsetAsync(g.cell_start, 0, 2 * sizeof(int), s));
-        ctx->have_map[kind] = true;
         return MML_OK;
     }
     // host xyz (3 floats) -> device float4 (original order, w unused)
     std::vector<float4> tmp((size_t)m);
     for (int i = 0; i < m; ++i) tmp[i] = make_float4(h_xyz[3 * i], h_xyz[3 * i + 1], h_xyz[3 * i + 2], 0.f);
-    float4* orig = ctx->map_tmp + (size_t)kind * ctx->MM;
     MML_HIP(hipMemcpyAsync(orig, tmp.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, s));
     MML_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
     MmlStageScope t(ctx, "map_build");
@@ -1122,7 +1202,6 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
     float bbox[6];
     MML_HIP(hipMemcpyAsync(bbox, d_bbox, sizeof(bbox), hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));
-    float cell = kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf;
     const long long max_cells = (long long)4 * ctx->MM + 4096;
     const int blocks = (m + 255) / 256;
     int dim[3];
@@ -1172,11 +1251,67 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
         cell *= 0.5f;
     }
     hipLaunchKernelGGL(k_gather_sorted, dim3(blocks), dim3(256), 0, s, orig, ctx->map_vals2, m, g.pts);
+    if (d_tag_orig) hipLaunchKernelGGL(k_gather_tags, dim3(blocks), dim3(256), 0, s, d_tag_orig, ctx->map_vals2, m, g.tags);
     hipLaunchKernelGGL(k_cell_start, dim3((g.ncell + 1 + 255) / 256), dim3(256), 0, s, ctx->map_keys2, m, g.ncell,
                        g.cell_start);
     MML_HIP(hipGetLastError());
-    ctx->have_map[kind] = true;
     return MML_OK;
+}
+
+int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
+    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
+    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "map larger than max_map_points");
+    ctx->have_map[kind] = false;
+    ctx->grid[kind].tags = nullptr;
+    int rc = build_grid_into(ctx, ctx->grid[kind], ctx->map_tmp + (size_t)kind * ctx->MM, h_xyz, m,
+                             kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf, nullptr);
+    if (rc == MML_OK) ctx->have_map[kind] = true;
+    return rc;
+}
+
+// a12: the global map handed to Estimate() (Estimator.cpp:1170-1184) as one concatenated cloud with the cube index
+// (ToIndex) of every point.  The per-cube kd-trees become one grid whose points carry their cube as a tag.
+int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen) {
+    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
+    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "global map larger than max_map_points");
+    hipStream_t s = MML_STREAM(ctx);
+    ctx->have_gmap[kind] = false;
+    if (cen) {
+        ctx->cen[0] = cen[0];
+        ctx->cen[1] = cen[1];
+        ctx->cen[2] = cen[2];
+    }
+    MmlGrid& g = ctx->ggrid[kind];
+    if (m > ctx->gmap_cap[kind] || !ctx->cube_cnt[kind]) {
+        MML_HIP(hipStreamSynchronize(s));
+        if (g.pts) hipFree(g.pts);
+        if (g.cell_start) hipFree(g.cell_start);
+        if (g.tags) hipFree(g.tags);
+        if (ctx->gmap_orig[kind]) hipFree(ctx->gmap_orig[kind]);
+        if (ctx->gtag_orig[kind]) hipFree(ctx->gtag_orig[kind]);
+        const size_t cap = (size_t)(m > 1024 ? m : 1024);
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&g.pts), sizeof(float4) * cap));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&g.cell_start), sizeof(int) * (4 * (size_t)ctx->MM + 4096 + 2)));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&g.tags), sizeof(uint16_t) * cap));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->gmap_orig[kind]), sizeof(float4) * cap));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->gtag_orig[kind]), sizeof(uint16_t) * cap));
+        if (!ctx->cube_cnt[kind]) MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->cube_cnt[kind]), sizeof(int) * 4851));
+        ctx->gmap_cap[kind] = (int)cap;
+    }
+    std::vector<uint16_t> tags((size_t)(m ? m : 1));
+    std::vector<int> cnt(4851, 0);
+    for (int i = 0; i < m; ++i) {
+        MML_REQUIRE(h_cube[i] >= 0 && h_cube[i] < 4851, MML_ERR_INVALID, "cube index outside [0, 4851)");
+        tags[i] = (uint16_t)h_cube[i];
+        cnt[h_cube[i]]++;
+    }
+    MML_HIP(hipMemcpyAsync(ctx->cube_cnt[kind], cnt.data(), sizeof(int) * 4851, hipMemcpyHostToDevice, s));
+    if (m) MML_HIP(hipMemcpyAsync(ctx->gtag_orig[kind], tags.data(), sizeof(uint16_t) * (size_t)m, hipMemcpyHostToDevice, s));
+    MML_HIP(hipStreamSynchronize(s));
+    int rc = build_grid_into(ctx, g, ctx->gmap_orig[kind], h_xyz, m, kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf,
+                             ctx->gtag_orig[kind]);
+    if (rc == MML_OK) ctx->have_gmap[kind] = m > 0;
+    return rc;
 }
 
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2) {
@@ -1198,6 +1333,15 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
         P.ft[k] = ctx->ft_xyz[k];
         P.map_m[k] = ctx->grid[k].m;
     }
+    for (int k = 0; k < 2; ++k) {
+        P.gg[k] = ctx->ggrid[k];
+        P.gmap_orig[k] = ctx->gmap_orig[k];
+        P.cube_cnt[k] = ctx->cube_cnt[k];
+        P.have_g[k] = ctx->have_gmap[k] ? 1 : 0;
+    }
+    P.cen[0] = ctx->cen[0];
+    P.cen[1] = ctx->cen[1];
+    P.cen[2] = ctx->cen[2];
     P.ft_n = ctx->ft_n;
     P.lf = ctx->lf;
     P.pf = ctx->pf;

@@ -32,14 +32,15 @@ struct MmlPlaneFactor {  // Estimator.h:105-122 FeaturePlanVec with sqrt_info re
 };
 
 struct MmlGrid {         // radix-sorted uniform grid over one map cloud (replaces pcl::KdTreeFLANN)
-    float4* pts;         // sorted by cell key: x, y, z, original index (bit pattern)
-    int* cell_start;     // ncell + 1
-    int m;
-    float origin[3];
-    float cell;
-    float inv_cell;
-    int dim[3];
-    int ncell;
+    float4* pts = nullptr;      // sorted by cell key: x, y, z, original index (bit pattern)
+    int* cell_start = nullptr;  // ncell + 1
+    uint16_t* tags = nullptr;   // optional: cube index of every sorted point (global map), else nullptr
+    int m = 0;
+    float origin[3] = {0.f, 0.f, 0.f};
+    float cell = 1.f;
+    float inv_cell = 1.f;
+    int dim[3] = {1, 1, 1};
+    int ncell = 1;
 };
 
 struct MmlStageTimer {
@@ -117,6 +118,14 @@ struct mml_ctx {
     // maps
     MmlGrid grid[2];
     bool have_map[2] = {false, false};
+    // global cube map (a12): tagged grids over the concatenated cube clouds
+    MmlGrid ggrid[2];
+    bool have_gmap[2] = {false, false};
+    float4* gmap_orig[2] = {nullptr, nullptr};
+    uint16_t* gtag_orig[2] = {nullptr, nullptr};
+    int* cube_cnt[2] = {nullptr, nullptr};  // 4851 ints each
+    int gmap_cap[2] = {0, 0};
+    int cen[3] = {10, 5, 10};  // laserCloudCen{Width,Height,Depth}_last (Map_Manager.h:113-115)
     float4* map_tmp = nullptr;
     unsigned* map_keys = nullptr;
     unsigned* map_keys2 = nullptr;
@@ -187,6 +196,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic);
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params);
 int mml_launch_downsample(mml_ctx* ctx, int first, int count);
 int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
+int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen);
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2);
 int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,

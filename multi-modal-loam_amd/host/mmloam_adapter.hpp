@@ -180,6 +180,14 @@ class Estimator {
         n_surf_map_ = n_surf;
     }
 
+    // laserCloud{Corner,Surf}FromMap[4851] + kdtree{Corner,Surf}FromMap[4851] (Estimator.cpp:1170-1184): the cube
+    // clouds concatenated, cube[i] = index of point i's cube in the MAP_MANAGER arrays; cen = laserCloudCen*_last.
+    void setGlobalMap(const float* corner_xyz, const int* corner_cube, int n_corner, const float* surf_xyz,
+                      const int* surf_cube, int n_surf, const int cen[3]) {
+        check(ctx_.get(), mml_map_set_global(ctx_.get(), 0, corner_xyz, corner_cube, n_corner, cen), "global corner");
+        check(ctx_.get(), mml_map_set_global(ctx_.get(), 1, surf_xyz, surf_cube, n_surf, cen), "global surf");
+    }
+
     // EstimateLidarPose(std::list<LidarFrame>&, exTlb, gravity, lidarMode) (Estimator.h:211-214, Estimator.cpp:967-1140).
     // Live 1-frame mode: every frame of the list is registered independently against the local map.
     // Poses are updated in place; failureDetected() reports the degeneracy flag (:1139).

@@ -262,140 +262,241 @@ static double line_error(const Vec3& po, const Vec3& a, const Vec3& b, const dou
     return a012 / l12;
 }
 
-// a14  Estimator.cpp:283-361 (local-map branch of processPointToLine; the global-cube branch :198-281 is
-// arithmetically identical on a different cloud)
-extern "C" int mmlo_associate_lines(const float* feat, int n_feat, const float* map, int m,
-                                    const mmlo_kdtree* tree, const double* T, double thres_dist,
-                                    mmlo_line_factor* out, int* out_src) {
+// a14  line model of processPointToLine (Estimator.cpp:204-277 for the cube cloud, :288-358 for the local cloud:
+// the two copies are arithmetically identical).  nb: coordinates of the 5 neighbours in search order.
+static bool fit_line(const float* ori, const float nb[5][3], const double* T, mmlo_line_factor* f) {
+    float cx = 0, cy = 0, cz = 0;
+    for (int j = 0; j < 5; j++) {
+        cx += nb[j][0];
+        cy += nb[j][1];
+        cz += nb[j][2];
+    }
+    cx /= 5;
+    cy /= 5;
+    cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+    for (int j = 0; j < 5; j++) {
+        float ax = nb[j][0] - cx;
+        float ay = nb[j][1] - cy;
+        float az = nb[j][2] - cz;
+        a11 += ax * ax;
+        a12 += ax * ay;
+        a13 += ax * az;
+        a22 += ay * ay;
+        a23 += ay * az;
+        a33 += az * az;
+    }
+    a11 /= 5;
+    a12 /= 5;
+    a13 /= 5;
+    a22 /= 5;
+    a23 /= 5;
+    a33 /= 5;
+    double A[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33};
+    double ev[3], V[9];
+    eig3_sym(A, ev, V);
+    double ud[3] = {V[2], V[5], V[8]};  // eigenvectors().col(2)
+    if (!(ev[2] > 3 * ev[1])) return false;
+    float x1 = cx + 0.1 * ud[0];
+    float y1 = cy + 0.1 * ud[1];
+    float z1 = cz + 0.1 * ud[2];
+    float x2 = cx - 0.1 * ud[0];
+    float y2 = cy - 0.1 * ud[1];
+    float z2 = cz - 0.1 * ud[2];
+    f->point_ori[0] = ori[0];
+    f->point_ori[1] = ori[1];
+    f->point_ori[2] = ori[2];
+    f->p1[0] = x1;
+    f->p1[1] = y1;
+    f->p1[2] = z1;
+    f->p2[0] = x2;
+    f->p2[1] = y2;
+    f->p2[2] = z2;
+    f->error = line_error(mk(ori[0], ori[1], ori[2]), mk(x1, y1, z1), mk(x2, y2, z2), T);
+    return true;
+}
+
+// a15  plane model of processPointToPlanVec (Estimator.cpp:634-693 cube cloud, :708-764 local cloud).
+static bool fit_plane(const float* ori, const float* sel, const float nb[5][3], const double* T, mmlo_plane_factor* f) {
+    double A[15];
+    for (int j = 0; j < 5; j++) {
+        A[3 * j] = nb[j][0];
+        A[3 * j + 1] = nb[j][1];
+        A[3 * j + 2] = nb[j][2];
+    }
+    double X[3];
+    plane_fit5(A, X);
+    float pa = X[0];
+    float pb = X[1];
+    float pc = X[2];
+    float pd = 1;
+    float ps = std::sqrt(pa * pa + pb * pb + pc * pc);
+    pa /= ps;
+    pb /= ps;
+    pc /= ps;
+    pd /= ps;
+    for (int j = 0; j < 5; j++) {
+        if (std::fabs(pa * nb[j][0] + pb * nb[j][1] + pc * nb[j][2] + pd) > 0.2) return false;
+    }
+    double dist = pa * sel[0] + pb * sel[1] + pc * sel[2] + pd;  // float expression (:740-742)
+    Vec3 omega = mk(pa, pb, pc);
+    Vec3 proj = mk(sel[0], sel[1], sel[2]) - dist * omega;
+    f->point_ori[0] = ori[0];
+    f->point_ori[1] = ori[1];
+    f->point_ori[2] = ori[2];
+    f->point_proj[0] = proj.x;
+    f->point_proj[1] = proj.y;
+    f->point_proj[2] = proj.z;
+    f->omega[0] = pa;
+    f->omega[1] = pb;
+    f->omega[2] = pc;
+    Vec3 P = transform_d(T, mk(ori[0], ori[1], ori[2]));
+    f->error = norm(P - proj);  // Estimator.h:118-121
+    return true;
+}
+
+// Map_Manager.cpp:583-629 FindUsed{Corner,Surf}Map: cube index of a (float) map-frame point, 5000 outside the grid.
+// cen = {laserCloudCenWidth_last, laserCloudCenHeight_last, laserCloudCenDepth_last}.
+static int find_used_map(const float* p, const int* cen) {
+    int cubeI = int((p[0] + 25.0) / 50.0) + cen[2];
+    int cubeJ = int((p[1] + 25.0) / 50.0) + cen[0];
+    int cubeK = int((p[2] + 25.0) / 50.0) + cen[1];
+    if (p[0] + 25.0 < 0) cubeI--;
+    if (p[1] + 25.0 < 0) cubeJ--;
+    if (p[2] + 25.0 < 0) cubeK--;
+    if (cubeI >= 0 && cubeI < 21 && cubeJ >= 0 && cubeJ < 21 && cubeK >= 0 && cubeK < 11)
+        return cubeI + 21 * cubeJ + 21 * 21 * cubeK;  // ToIndex, Map_Manager.cpp:65-67
+    return 5000;
+}
+extern "C" int mmlo_find_used_map(const float* p, const int* cen) { return find_used_map(p, cen); }
+
+// The global map as Estimate() sees it (Estimator.cpp:1170-1184): per-cube clouds with their own kd-trees.
+struct mmlo_cube_map {
+    std::vector<std::vector<float>> xyz;   // 4851 clouds
+    std::vector<mmlo_kdtree*> tree;
+    int cen[3];
+    ~mmlo_cube_map() {
+        for (auto* t : tree)
+            if (t) mmlo_kdtree_free(t);
+    }
+};
+extern "C" mmlo_cube_map* mmlo_cube_map_build(const float* xyz, const int* cube, int m, const int* cen) {
+    mmlo_cube_map* g = new mmlo_cube_map();
+    g->xyz.resize(4851);
+    g->tree.assign(4851, nullptr);
+    for (int c = 0; c < 3; ++c) g->cen[c] = cen[c];
+    for (int i = 0; i < m; ++i) {
+        if (cube[i] < 0 || cube[i] >= 4851) continue;
+        auto& v = g->xyz[cube[i]];
+        v.push_back(xyz[3 * i]);
+        v.push_back(xyz[3 * i + 1]);
+        v.push_back(xyz[3 * i + 2]);
+    }
+    for (int c = 0; c < 4851; ++c)
+        if (!g->xyz[c].empty()) g->tree[c] = mmlo_kdtree_build(g->xyz[c].data(), (int)g->xyz[c].size() / 3);
+    return g;
+}
+extern "C" void mmlo_cube_map_free(mmlo_cube_map* g) { delete g; }
+
+// processPointToLine (Estimator.cpp:148-365): cube cloud first (> 100 points), local cloud as fall-back.
+// gmap may be null (no global map: every cube is empty).  from_global (optional): 1 where the cube cloud was used.
+extern "C" int mmlo_associate_lines2(const float* feat, int n_feat, const mmlo_cube_map* gmap, const float* map, int m,
+                                     const mmlo_kdtree* tree, const double* T, double thres_dist,
+                                     mmlo_line_factor* out, int* out_src, int* from_global) {
     int nout = 0;
-    if (!(m > 20)) return 0;  // :283
+    static const int cen_default[3] = {10, 5, 10};
     for (int i = 0; i < n_feat; ++i) {
         const float* ori = feat + 3 * i;
         float sel[3];
         point_associate_to_map(ori, sel, T);
+        int id = find_used_map(sel, gmap ? gmap->cen : cen_default);
+        if (id == 5000) continue;                                                        // :194
         if (std::isnan(sel[0]) || std::isnan(sel[1]) || std::isnan(sel[2])) continue;  // :196
         int ind[5];
         float sq[5];
-        mmlo_kdtree_knn5(tree, sel, ind, sq);
-        if (sq[4] < thres_dist) {
-            float cx = 0, cy = 0, cz = 0;
-            for (int j = 0; j < 5; j++) {
-                cx += map[3 * ind[j]];
-                cy += map[3 * ind[j] + 1];
-                cz += map[3 * ind[j] + 2];
+        float nb[5][3];
+        if (gmap && gmap->xyz[id].size() / 3 > 100) {  // :198
+            mmlo_kdtree_knn5(gmap->tree[id], sel, ind, sq);
+            if (sq[4] < thres_dist) {
+                for (int j = 0; j < 5; ++j)
+                    for (int c = 0; c < 3; ++c) nb[j][c] = gmap->xyz[id][3 * ind[j] + c];
+                if (fit_line(ori, nb, T, &out[nout])) {
+                    if (out_src) out_src[nout] = i;
+                    if (from_global) from_global[nout] = 1;
+                    ++nout;
+                    continue;  // :276
+                }
             }
-            cx /= 5;
-            cy /= 5;
-            cz /= 5;
-            float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
-            for (int j = 0; j < 5; j++) {
-                float ax = map[3 * ind[j]] - cx;
-                float ay = map[3 * ind[j] + 1] - cy;
-                float az = map[3 * ind[j] + 2] - cz;
-                a11 += ax * ax;
-                a12 += ax * ay;
-                a13 += ax * az;
-                a22 += ay * ay;
-                a23 += ay * az;
-                a33 += az * az;
-            }
-            a11 /= 5;
-            a12 /= 5;
-            a13 /= 5;
-            a22 /= 5;
-            a23 /= 5;
-            a33 /= 5;
-            double A[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33};
-            double ev[3], V[9];
-            eig3_sym(A, ev, V);
-            double ud[3] = {V[2], V[5], V[8]};  // eigenvectors().col(2)
-            if (ev[2] > 3 * ev[1]) {
-                float x1 = cx + 0.1 * ud[0];
-                float y1 = cy + 0.1 * ud[1];
-                float z1 = cz + 0.1 * ud[2];
-                float x2 = cx - 0.1 * ud[0];
-                float y2 = cy - 0.1 * ud[1];
-                float z2 = cz - 0.1 * ud[2];
-                mmlo_line_factor& f = out[nout];
-                f.point_ori[0] = ori[0];
-                f.point_ori[1] = ori[1];
-                f.point_ori[2] = ori[2];
-                f.p1[0] = x1;
-                f.p1[1] = y1;
-                f.p1[2] = z1;
-                f.p2[0] = x2;
-                f.p2[1] = y2;
-                f.p2[2] = z2;
-                f.error = line_error(mk(ori[0], ori[1], ori[2]), mk(x1, y1, z1), mk(x2, y2, z2), T);
-                if (out_src) out_src[nout] = i;
-                ++nout;
+        }
+        if (m > 20) {  // :283
+            mmlo_kdtree_knn5(tree, sel, ind, sq);
+            if (sq[4] < thres_dist) {
+                for (int j = 0; j < 5; ++j)
+                    for (int c = 0; c < 3; ++c) nb[j][c] = map[3 * ind[j] + c];
+                if (fit_line(ori, nb, T, &out[nout])) {
+                    if (out_src) out_src[nout] = i;
+                    if (from_global) from_global[nout] = 0;
+                    ++nout;
+                }
             }
         }
     }
     return nout;
 }
 
-// a15  Estimator.cpp:702-767 (local-map branch of processPointToPlanVec)
-extern "C" int mmlo_associate_planes(const float* feat, int n_feat, const float* map, int m,
-                                     const mmlo_kdtree* tree, const double* T, double thres_dist,
-                                     mmlo_plane_factor* out, int* out_src) {
+// processPointToPlanVec (Estimator.cpp:573-777): cube cloud first (> 50 points), local cloud as fall-back.
+extern "C" int mmlo_associate_planes2(const float* feat, int n_feat, const mmlo_cube_map* gmap, const float* map, int m,
+                                      const mmlo_kdtree* tree, const double* T, double thres_dist,
+                                      mmlo_plane_factor* out, int* out_src, int* from_global) {
     int nout = 0;
-    if (!(m > 20)) return 0;  // :702
+    static const int cen_default[3] = {10, 5, 10};
     for (int i = 0; i < n_feat; ++i) {
         const float* ori = feat + 3 * i;
         float sel[3];
         point_associate_to_map(ori, sel, T);
-        if (std::isnan(sel[0]) || std::isnan(sel[1]) || std::isnan(sel[2])) continue;
+        int id = find_used_map(sel, gmap ? gmap->cen : cen_default);
+        if (id == 5000) continue;                                                        // :623
+        if (std::isnan(sel[0]) || std::isnan(sel[1]) || std::isnan(sel[2])) continue;  // :625
         int ind[5];
         float sq[5];
-        mmlo_kdtree_knn5(tree, sel, ind, sq);
-        if (sq[4] < thres_dist) {
-            double A[15];
-            for (int j = 0; j < 5; j++) {
-                A[3 * j] = map[3 * ind[j]];
-                A[3 * j + 1] = map[3 * ind[j] + 1];
-                A[3 * j + 2] = map[3 * ind[j] + 2];
-            }
-            double X[3];
-            plane_fit5(A, X);
-            float pa = X[0];
-            float pb = X[1];
-            float pc = X[2];
-            float pd = 1;
-            float ps = std::sqrt(pa * pa + pb * pb + pc * pc);
-            pa /= ps;
-            pb /= ps;
-            pc /= ps;
-            pd /= ps;
-            bool planeValid = true;
-            for (int j = 0; j < 5; j++) {
-                if (std::fabs(pa * map[3 * ind[j]] + pb * map[3 * ind[j] + 1] + pc * map[3 * ind[j] + 2] + pd) > 0.2) {
-                    planeValid = false;
-                    break;
+        float nb[5][3];
+        if (gmap && gmap->xyz[id].size() / 3 > 50) {  // :627
+            mmlo_kdtree_knn5(gmap->tree[id], sel, ind, sq);
+            if (sq[4] < thres_dist) {
+                for (int j = 0; j < 5; ++j)
+                    for (int c = 0; c < 3; ++c) nb[j][c] = gmap->xyz[id][3 * ind[j] + c];
+                if (fit_plane(ori, sel, nb, T, &out[nout])) {
+                    if (out_src) out_src[nout] = i;
+                    if (from_global) from_global[nout] = 1;
+                    ++nout;
+                    continue;  // :694
                 }
             }
-            if (planeValid) {
-                double dist = pa * sel[0] + pb * sel[1] + pc * sel[2] + pd;  // float expression (:740-742)
-                Vec3 omega = mk(pa, pb, pc);
-                Vec3 proj = mk(sel[0], sel[1], sel[2]) - dist * omega;
-                mmlo_plane_factor& f = out[nout];
-                f.point_ori[0] = ori[0];
-                f.point_ori[1] = ori[1];
-                f.point_ori[2] = ori[2];
-                f.point_proj[0] = proj.x;
-                f.point_proj[1] = proj.y;
-                f.point_proj[2] = proj.z;
-                f.omega[0] = pa;
-                f.omega[1] = pb;
-                f.omega[2] = pc;
-                Vec3 P = transform_d(T, mk(ori[0], ori[1], ori[2]));
-                f.error = norm(P - proj);  // Estimator.h:118-121
-                if (out_src) out_src[nout] = i;
-                ++nout;
+        }
+        if (m > 20) {  // :702
+            mmlo_kdtree_knn5(tree, sel, ind, sq);
+            if (sq[4] < thres_dist) {
+                for (int j = 0; j < 5; ++j)
+                    for (int c = 0; c < 3; ++c) nb[j][c] = map[3 * ind[j] + c];
+                if (fit_plane(ori, sel, nb, T, &out[nout])) {
+                    if (out_src) out_src[nout] = i;
+                    if (from_global) from_global[nout] = 0;
+                    ++nout;
+                }
             }
         }
     }
     return nout;
+}
+
+// local-map-only entry points (the global cubes empty): kept as the API used throughout the tests
+extern "C" int mmlo_associate_lines(const float* feat, int n_feat, const float* map, int m, const mmlo_kdtree* tree,
+                                    const double* T, double thres_dist, mmlo_line_factor* out, int* out_src) {
+    return mmlo_associate_lines2(feat, n_feat, nullptr, map, m, tree, T, thres_dist, out, out_src, nullptr);
+}
+extern "C" int mmlo_associate_planes(const float* feat, int n_feat, const float* map, int m, const mmlo_kdtree* tree,
+                                     const double* T, double thres_dist, mmlo_plane_factor* out, int* out_src) {
+    return mmlo_associate_planes2(feat, n_feat, nullptr, map, m, tree, T, thres_dist, out, out_src, nullptr);
 }
 
 // Estimator.cpp:536-565 checkLocalizability: JacobiSVD singular values of the M x 3 normal matrix;

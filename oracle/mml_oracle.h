@@ -98,6 +98,19 @@ int mmlo_associate_lines(const float* feat_xyz, int n_feat, const float* map_xyz
 int mmlo_associate_planes(const float* feat_xyz, int n_feat, const float* map_xyz, int m,
                           const mmlo_kdtree* tree, const double* T_wl, double thres_dist,
                           mmlo_plane_factor* out, int* out_src);
+/* a12 + two-level association: the global map of 21x11x21 cubes of 50 m (Map_Manager.h:117-146) as Estimate() copies
+ * it (Estimator.cpp:1170-1184).  cube[i]: ToIndex value of map point i; cen: laserCloudCen{Width,Height,Depth}_last.
+ * Features whose cube index is 5000 (outside the grid) are skipped altogether, as in the reference (:194, :623). */
+typedef struct mmlo_cube_map mmlo_cube_map;
+mmlo_cube_map* mmlo_cube_map_build(const float* xyz, const int* cube, int m, const int* cen);
+void mmlo_cube_map_free(mmlo_cube_map*);
+int mmlo_find_used_map(const float* p_xyz, const int* cen); /* Map_Manager.cpp:583-629 */
+int mmlo_associate_lines2(const float* feat_xyz, int n_feat, const mmlo_cube_map* gmap, const float* map_xyz, int m,
+                          const mmlo_kdtree* tree, const double* T_wl, double thres_dist, mmlo_line_factor* out,
+                          int* out_src, int* from_global);
+int mmlo_associate_planes2(const float* feat_xyz, int n_feat, const mmlo_cube_map* gmap, const float* map_xyz, int m,
+                           const mmlo_kdtree* tree, const double* T_wl, double thres_dist, mmlo_plane_factor* out,
+                           int* out_src, int* from_global);
 /* checkLocalizability, Estimator.cpp:536-565: smallest singular value of the M x 3 normal
  * matrix (= sqrt(lambda_min(N^T N))); -1 when M <= 10. */
 double mmlo_check_localizability(const mmlo_plane_factor* f, int n);

@@ -56,6 +56,7 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.mmlo_kdtree_build.restype = C.c_void_p
         _lib.mmlo_check_localizability.restype = C.c_double
+        _lib.mmlo_cube_map_build.restype = C.c_void_p
     return _lib
 
 
@@ -173,6 +174,52 @@ def associate_planes(feat, tree, T_wl, thres):
     m = lib().mmlo_associate_planes(_p(feat), C.c_int(len(feat)), _p(tree.xyz), C.c_int(len(tree.xyz)), tree.h,
                                     _p(_f64(T_wl).reshape(16)), C.c_double(thres), _p(out), _p(src))
     return out[:m].copy(), src[:m].copy()
+
+
+CUBE_W, CUBE_H, CUBE_D = 21, 11, 21  # laserCloud{Width,Height,Depth}, Map_Manager.h:116-118
+
+
+def find_used_map(p, cen=(10, 5, 10)):
+    """MAP_MANAGER::FindUsedMap (Map_Manager.cpp:583-629): cube index of a map-frame point, 5000 when outside."""
+    cen = np.ascontiguousarray(cen, dtype=np.int32)
+    return lib().mmlo_find_used_map(_p(_f32(p).reshape(3)), _p(cen))
+
+
+class CubeMap:
+    """laserCloud{Corner,Surf}FromMap[4851] + one kd-tree per cube (Estimator.cpp:1170-1184)."""
+
+    def __init__(self, xyz, cube, cen=(10, 5, 10)):
+        self.xyz = _f32(xyz).reshape(-1, 3)
+        self.cube = np.ascontiguousarray(cube, dtype=np.int32)
+        self.cen = np.ascontiguousarray(cen, dtype=np.int32)
+        self.h = C.c_void_p(lib().mmlo_cube_map_build(_p(self.xyz), _p(self.cube), C.c_int(len(self.xyz)), _p(self.cen)))
+
+    def __del__(self):
+        try:
+            lib().mmlo_cube_map_free(self.h)
+        except Exception:
+            pass
+
+
+def _associate2(fn, dt, feat, gmap, tree, T_wl, thres):
+    feat = _f32(feat).reshape(-1, 3)
+    out = np.zeros(max(len(feat), 1), dt)
+    src = np.zeros(max(len(feat), 1), np.int32)
+    fg = np.zeros(max(len(feat), 1), np.int32)
+    xyz = tree.xyz if tree is not None else np.zeros((0, 3), np.float32)
+    m = fn(_p(feat), C.c_int(len(feat)), gmap.h if gmap is not None else None, _p(xyz), C.c_int(len(xyz)),
+           tree.h if tree is not None else None, _p(_f64(T_wl).reshape(16)), C.c_double(thres), _p(out), _p(src), _p(fg))
+    return out[:m].copy(), src[:m].copy(), fg[:m].copy()
+
+
+def associate_lines2(feat, gmap, tree, T_wl, thres):
+    """processPointToLine with the cube map first and the local map as fall-back (Estimator.cpp:148-365)."""
+    return _associate2(lib().mmlo_associate_lines2, LINE_DT, feat, gmap, tree, T_wl, thres)
+
+
+def associate_planes2(feat, gmap, tree, T_wl, thres):
+    """processPointToPlane, same two-level look-up (Estimator.cpp:567-778)."""
+    return _associate2(lib().mmlo_associate_planes2, PLANE_DT, feat, gmap, tree, T_wl, thres)
 
 
 def check_localizability(pf):

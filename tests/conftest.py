@@ -72,6 +72,32 @@ def scene(O, synth):
     return dict(corner_map=cm, surf_map=sm, frames=frames)
 
 
+CUBE_SHIFT = np.array([22.0, 24.0, 60.0])  # puts the room across the 4 cubes that meet at x = y = 25, one cube up
+
+
+@pytest.fixture(scope="session")
+def cube_scene(scene, M):
+    """The scene moved onto a cube corner: a thinned, cube-tagged global map plus the full local map (a12)."""
+    rng = np.random.default_rng(5)
+    sh = CUBE_SHIFT.astype(np.float32)
+    out = dict(frames=scene["frames"], shift=CUBE_SHIFT)
+    for name, keep in (("corner", 0.9), ("surf", 0.35)):
+        loc = scene[name + "_map"] + sh
+        glob = loc[rng.random(len(loc)) < keep]
+        cube = M.cube_index(glob)
+        order = np.argsort(cube, kind="stable")  # any order keeping each cube's points in sequence is equivalent
+        out[name + "_local"] = loc
+        out[name + "_global"] = glob[order] if name == "corner" else glob
+        out[name + "_cube"] = M.cube_index(out[name + "_global"])
+    return out
+
+
+def shifted(T, shift):
+    T2 = T.copy()
+    T2[:3, 3] += shift
+    return T2
+
+
 def perturbed(T, dt=(0.03, -0.02, 0.01), rotvec=(0.002, -0.001, 0.004)):
     from scipy.spatial.transform import Rotation as Rsc
     T2 = T.copy()

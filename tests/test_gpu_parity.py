@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation as Rsc
 
-from conftest import GOLDEN, perturbed, pose_to_x
+from conftest import GOLDEN, perturbed, pose_to_x, shifted
 
 pytestmark = pytest.mark.gpu
 
@@ -283,6 +283,52 @@ def test_association_matches_oracle(ctx, O, scene, thres):
         ms = O.check_localizability(pf)
         assert abs(st[k].min_singular - ms) < 1e-9 * max(1.0, abs(ms))
         assert st[k].is_degenerate == int(ms < 3.0)
+
+
+@pytest.mark.parametrize("tight", [False, True])
+def test_two_level_association_matches_oracle(M, O, cube_scene, tight):
+    """a12: cube cloud first, local map as fall-back (Estimator.cpp:198-281 / :627-699), incl. a cube below the
+    point-count gate, fits that fail in the cube and succeed locally, and features outside the cube grid."""
+    cs = cube_scene
+    c2 = M.Context(max_scans=4)
+    try:
+        c2.map_set_local(0, cs["corner_local"])
+        c2.map_set_local(1, cs["surf_local"])
+        c2.map_set_global(0, cs["corner_global"], cs["corner_cube"])
+        c2.map_set_global(1, cs["surf_global"], cs["surf_cube"])
+        gm = [O.CubeMap(cs["corner_global"], cs["corner_cube"]), O.CubeMap(cs["surf_global"], cs["surf_cube"])]
+        tr = [O.KdTree(cs["corner_local"]), O.KdTree(cs["surf_local"])]
+        T = np.stack([shifted(perturbed(fr["T_gt"]), cs["shift"]) for fr in cs["frames"]])
+        T[3, :3, 3] += [0.0, 600.0, 0.0]  # slot 3 sits outside the 21 x 21 x 11 cube grid: FindUsedMap == 5000 -> no factors
+        for k, fr in enumerate(cs["frames"]):
+            c2.features_upload(k, 0, fr["corner"])
+            c2.features_upload(k, 1, fr["surf"])
+        for thres in ([25.0] if not tight else [1.5, 0.12]):
+            st = c2.associate(0, 4, T, thres)
+            tot_g = tot_l = 0
+            for k, fr in enumerate(cs["frames"]):
+                lf, lsrc, lfg = O.associate_lines2(fr["corner"], gm[0], tr[0], T[k], thres)
+                pf, psrc, pfg = O.associate_planes2(fr["surf"], gm[1], tr[1], T[k], thres)
+                gl, glsrc = c2.factors_download(k, 0)
+                gp, gpsrc = c2.factors_download(k, 1)
+                assert np.array_equal(glsrc, lsrc) and np.array_equal(gpsrc, psrc)
+                ol, op = _factor_arrays(lf, pf)
+                assert np.allclose(gl, ol, rtol=0, atol=1e-9) and np.allclose(gp, op, rtol=0, atol=1e-9)
+                assert st[k].n_line == len(lf) and st[k].n_plane == len(pf)
+                tot_g += int(lfg.sum() + pfg.sum())
+                tot_l += int((1 - lfg).sum() + (1 - pfg).sum())
+            assert st[3].n_line == 0 and st[3].n_plane == 0
+            assert tot_g > 100 and tot_l > 50  # both levels exercised
+        # dropping the global map again restores the single-level behaviour
+        c2.map_set_global(0, np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+        c2.map_set_global(1, np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+        c2.associate(0, 4, T, 25.0)
+        pf, psrc = O.associate_planes(cs["frames"][0]["surf"], tr[1], T[0], 25.0)
+        gp, gpsrc = c2.factors_download(0, 1)
+        op = np.concatenate([pf["point_ori"], pf["point_proj"], pf["omega"], pf["error"][:, None]], axis=1)
+        assert np.array_equal(gpsrc, psrc) and np.allclose(gp, op, rtol=0, atol=1e-9)
+    finally:
+        c2.close()
 
 
 def test_association_golden(ctx):

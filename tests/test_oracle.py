@@ -9,7 +9,7 @@ from scipy.spatial import cKDTree
 from scipy.spatial.transform import Rotation as Rsc
 from scipy.spatial.transform import Slerp
 
-from conftest import GOLDEN, perturbed, pose_to_x
+from conftest import GOLDEN, perturbed, pose_to_x, shifted
 
 
 def load(name):
@@ -315,6 +315,65 @@ def test_association_geometry(O, scene):
     sv = np.linalg.svd(pf["omega"], compute_uv=False)
     assert abs(O.check_localizability(pf) - sv[-1]) < 1e-9 * sv[0]
     assert O.check_localizability(pf[:10]) == -1
+
+
+def test_find_used_map_and_host_cube_index(O, M):
+    """a12: cube look-up (Map_Manager.cpp:583-629) incl. negative coordinates, cube edges and the 5000 sentinel."""
+    rng = np.random.default_rng(0)
+    p = np.concatenate([rng.uniform(-600, 600, (4000, 3)), rng.uniform(-30, 30, (2000, 3)),
+                        [[25.0, -25.0, 0.0], [-25.0, 25.0, -25.0], [-25.000002, 24.999998, 274.9], [0, 0, 275.0],
+                         [-525.0, 0, 0], [-525.1, 0, 0], [524.9, 524.9, 0], [525.0, 0, 0], [np.nan, 0, 0]]]).astype(np.float32)
+    for cen in [(10, 5, 10), (9, 6, 12)]:
+        ref = np.array([O.find_used_map(q, cen) for q in p])
+        assert np.array_equal(ref, M.cube_index(p, cen))
+        assert (ref == 5000).sum() > 100 and (ref != 5000).sum() > 1000
+    assert O.find_used_map([0, 0, 0]) == 10 + 21 * 10 + 441 * 5
+
+
+@pytest.mark.parametrize("tight", [False, True])
+def test_two_level_association_semantics(O, cube_scene, tight):
+    """a12: cube cloud first (> 100 corner / > 50 surf points), local map when the cube is thin or its fit fails
+    (Estimator.cpp:198-281 / :627-699) -- checked against the single-level association run on each cloud alone."""
+    cs = cube_scene
+    fr = cs["frames"][1]
+    T = shifted(perturbed(fr["T_gt"]), cs["shift"])
+    for name, assoc2, assoc1, need in (("corner", O.associate_lines2, O.associate_lines, 100),
+                                       ("surf", O.associate_planes2, O.associate_planes, 50)):
+        thres = 25.0 if not tight else (1.5 if name == "corner" else 0.12)
+        feat = fr[name]
+        gmap = O.CubeMap(cs[name + "_global"], cs[name + "_cube"])
+        tree = O.KdTree(cs[name + "_local"])
+        f2, src2, fg = assoc2(feat, gmap, tree, T, thres)
+        loc, loc_src = assoc1(feat, tree, T, thres)
+        loc_of = {int(s): loc[j] for j, s in enumerate(loc_src)}
+        world = (feat.astype(np.float64) @ T[:3, :3].T + T[:3, 3])
+        cube_of = [O.find_used_map(q) for q in O.point_associate_to_map(feat, T)] if hasattr(O, "point_associate_to_map") \
+            else [O.find_used_map(q.astype(np.float32)) for q in world]
+        per_cube = {}
+        for c in np.unique(cs[name + "_cube"]):
+            pts = cs[name + "_global"][cs[name + "_cube"] == c]
+            if len(pts) > need:
+                g1, g1_src = assoc1(feat, O.KdTree(pts), T, thres)
+                per_cube[int(c)] = {int(s): g1[j] for j, s in enumerate(g1_src)}
+        got = {int(s): (f2[j], int(fg[j])) for j, s in enumerate(src2)}
+        n_glob = n_fall = 0
+        for i in range(len(feat)):
+            c = cube_of[i]
+            in_cube = per_cube.get(c, {}).get(i)
+            want = in_cube if in_cube is not None else loc_of.get(i)
+            if want is None:
+                assert i not in got
+                continue
+            f, g = got[i]
+            assert g == (in_cube is not None) and f.tobytes() == want.tobytes()
+            n_glob += g
+            n_fall += (not g) and c in per_cube
+        assert n_glob > 20 and len(per_cube) >= 3
+        if tight:
+            assert n_fall > 0  # some cube fits failed and the local map rescued them
+    # no global map at all == the single-level association
+    f2, src2, fg = O.associate_planes2(fr["surf"], None, tree, T, thres)
+    assert f2.tobytes() == loc.tobytes() and np.array_equal(src2, loc_src) and not fg.any()
 
 
 def test_jacobians_against_finite_differences(O, scene):
