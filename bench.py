@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="scans per step per GPU")
     ap.add_argument("--map-points", type=int, default=200000)
     ap.add_argument("--gn-iters", type=int, default=10)
+    ap.add_argument("--kernel-steps", type=int, default=4, help="single-stream steps after the timed region (per-kernel timing)")
     ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans cycled through the batch")
     ap.add_argument("--cell-corner", type=float, default=0.0, help="kNN grid cell edge for the corner map (0: library default)")
@@ -131,14 +132,21 @@ def main():
 
     for _ in range(args.warmup):
         ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x = ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
     barrier()
     elapsed = time.perf_counter() - t0
+    # Per-kernel durations for the roofline object: the timed region overlaps sub-batches on 4 streams, so kernel
+    # time there is shared between concurrent kernels.  The same step is therefore repeated on ONE stream (every
+    # kernel covers the whole batch and owns the device) with HIP events around each stage on that stream; these
+    # are the launches of grid size `B scans` in the rocprofv3 summary under profiles/.
+    ctx.set_lanes(1)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(args.kernel_steps):
+        ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
     prof = ctx.profile_get()
     ctx.profile_enable(False)
     if dist is not None:
@@ -162,7 +170,10 @@ def main():
     tr_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tr_file):
         try:
-            traffic = json.load(open(tr_file)).get(dom)
+            tr = json.load(open(tr_file))
+            traffic = tr.get(dom)
+            if traffic is not None:
+                traffic = traffic * B / float(tr.get("scans_per_launch", 256))
         except Exception:
             traffic = None
     bytes_per_scan = 48 * (n_v + n_l) / B + 112 * nf / B + 72 * nf / B * args.gn_iters
@@ -224,6 +235,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "avg_launch_ms": stage_ms[dom], "algorithmic_bytes_per_launch": alg_bytes,
+                         "scans_per_launch": B, "timing": "HIP events, %d single-stream steps after the timed region" % args.kernel_steps,
                          "whole_path_frac": bytes_per_scan * value / world / 1e9 / HBM_PEAK_GBPS,
                          "stage_ms_per_launch": stage_ms},
             "cpu_baseline": cpu,

@@ -231,6 +231,9 @@ typedef struct {
     double total_ms[MML_MAX_STAGES];
     long launches[MML_MAX_STAGES];
 } mml_profile;
+/* Number of HIP streams mml_step pipelines its sub-batches over (1..4, default 4 or $MML_LANES).  With 1 every
+ * kernel covers the whole batch and runs alone on the device, which is what per-kernel timing wants. */
+int mml_set_lanes(mml_ctx* ctx, int lanes);
 int mml_profile_enable(mml_ctx* ctx, int on);
 int mml_profile_reset(mml_ctx* ctx);
 int mml_profile_get(mml_ctx* ctx, mml_profile* out);

@@ -307,6 +307,9 @@ class Context:
         return x
 
     # ---- measurement ----
+    def set_lanes(self, lanes):
+        self._ck(lib().mml_set_lanes(self._h, C.c_int(lanes)))
+
     def profile_enable(self, on=True):
         self._ck(lib().mml_profile_enable(self._h, C.c_int(1 if on else 0)))
 

@@ -125,7 +125,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
         int v = atoi(e_l);
         if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;
     }
-    for (int l = 0; l < ctx->n_lanes; ++l)
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
         if ((e = hipStreamCreateWithFlags(&ctx->streams[l], hipStreamNonBlocking)) != hipSuccess)
             return fail(e, "hipStreamCreate");
     const size_t B = ctx->B, NV = ctx->NV, NL = ctx->NL, NT = ctx->NT, L = ctx->L, MF = ctx->MF, MM = ctx->MM;
@@ -796,6 +796,15 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     return MML_OK;
 }
 
+int mml_set_lanes(mml_ctx* ctx, int lanes) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(lanes >= 1 && lanes <= mml_ctx::MAX_LANES, MML_ERR_INVALID, "lanes must be in [1, 4]");
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    ctx->n_lanes = lanes;
+    return MML_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------------------------
 int mml_profile_enable(mml_ctx* ctx, int on) {
     if (!ctx) return MML_ERR_INVALID;
@@ -931,6 +940,6 @@ void mml_stage_end(mml_ctx* ctx, int token) {
 }
 
 int mml_sync_all(mml_ctx* ctx) {
-    for (int l = 0; l < ctx->n_lanes; ++l) MML_HIP(hipStreamSynchronize(ctx->streams[l]));
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l) MML_HIP(hipStreamSynchronize(ctx->streams[l]));
     return MML_OK;
 }

@@ -394,24 +394,23 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
 __device__ __forceinline__ bool find_line(const FeatParams& P, int b, int p, int& line, int& i, int& n, int& start) {
     const int* ls = P.line_start + (size_t)b * P.L;
     const int* ll = P.line_len + (size_t)b * P.L;
-    int lo, hi;
-    if (p < P.NV) {
-        lo = 0;
-        hi = P.n_rings;
-    } else {
-        lo = P.n_rings;
-        hi = P.L;
-    }
-    // line_start is non-decreasing inside each region: last line with start <= p
+    // line_start is non-decreasing inside each region (rings | Livox lines): last line with start <= p.
+    // The lanes of a wavefront hold consecutive p, so the search runs once per wavefront on scalar registers for
+    // the first lane and every lane then steps forward from there (0 or 1 steps unless a line is very short).
+    const int p0 = __builtin_amdgcn_readfirstlane(p);
+    const bool velo0 = p0 < P.NV;
+    int lo = velo0 ? 0 : P.n_rings, hi = velo0 ? P.n_rings : P.L;
     while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (ls[mid] <= p)
+        const int mid = (lo + hi) >> 1;
+        if (ls[mid] <= p0)
             lo = mid;
         else
             hi = mid;
     }
-    // skip back over empty lines that share the same start
-    line = lo;
+    const bool velo = p < P.NV;
+    const int end = velo ? P.n_rings : P.L;
+    line = (velo == velo0) ? lo : P.n_rings;  // a wavefront that straddles NV: its Livox lanes start at their region
+    while (line + 1 < end && ls[line + 1] <= p) ++line;
     start = ls[line];
     n = ll[line];
     i = p - start;
@@ -462,19 +461,37 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         float diffX = 0, diffY = 0, diffZ = 0;
         const float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
         const float dis = sqrtf(dis2);  // == (float)sqrt((double)dis2): IEEE float sqrt
-        const D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
-        const D3 dl = d3((double)PT(-1).x - pt_cur.x, (double)PT(-1).y - pt_cur.y, (double)PT(-1).z - pt_cur.z);
-        const D3 dn = d3((double)PT(1).x - pt_cur.x, (double)PT(1).y - pt_cur.y, (double)PT(1).z - pt_cur.z);
-        const double n0 = ddot(pt_cur, pt_cur);
-        bool c1, c2;
-        bool gl = abs_cos_gt(ddot(dl, pt_cur), ddot(dl, dl), n0, 0.966 * 0.966, c1);
-        bool gn = abs_cos_gt(ddot(dn, pt_cur), ddot(dn, dn), n0, 0.966 * 0.966, c2);
-        if (!(c1 && c2)) {  // reference expression (:421-422)
-            const double ncur = dnorm(pt_cur);
-            const double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
-            const double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
-            gl = fabs(angle_last) > 0.966;
-            gn = fabs(angle_next) > 0.966;
+        // :421-422 fabs(cos) > 0.966 for both neighbours.  Float pre-decision (error ~1e-6 of the cosine, accepted only
+        // when the squared form is more than 1e-3 away from the threshold), then the double squared form, then the
+        // reference expression.
+        bool gl, gn;
+        {
+            const float lx = PT(-1).x - PT(0).x, ly = PT(-1).y - PT(0).y, lz = PT(-1).z - PT(0).z;
+            const float nx = PT(1).x - PT(0).x, ny = PT(1).y - PT(0).y, nz = PT(1).z - PT(0).z;
+            const float dotl = (lx * PT(0).x + ly * PT(0).y) + lz * PT(0).z, dotn = (nx * PT(0).x + ny * PT(0).y) + nz * PT(0).z;
+            const float rl = (0.966f * 0.966f) * (((lx * lx + ly * ly) + lz * lz) * dis2);
+            const float rn = (0.966f * 0.966f) * (((nx * nx + ny * ny) + nz * nz) * dis2);
+            const float el = dotl * dotl - rl, en = dotn * dotn - rn;
+            gl = el > 0.f;
+            gn = en > 0.f;
+            const bool sure = (fabsf(el) > 1e-3f * rl) & (fabsf(en) > 1e-3f * rn) & (rl < 1e30f) & (rn < 1e30f) &
+                              (rl > 1e-30f) & (rn > 1e-30f);
+            if (!sure) {
+                const D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
+                const D3 dl = d3((double)PT(-1).x - pt_cur.x, (double)PT(-1).y - pt_cur.y, (double)PT(-1).z - pt_cur.z);
+                const D3 dn = d3((double)PT(1).x - pt_cur.x, (double)PT(1).y - pt_cur.y, (double)PT(1).z - pt_cur.z);
+                const double n0 = ddot(pt_cur, pt_cur);
+                bool c1, c2;
+                gl = abs_cos_gt(ddot(dl, pt_cur), ddot(dl, dl), n0, 0.966 * 0.966, c1);
+                gn = abs_cos_gt(ddot(dn, pt_cur), ddot(dn, dn), n0, 0.966 * 0.966, c2);
+                if (!(c1 && c2)) {  // reference expression (:421-422)
+                    const double ncur = dnorm(pt_cur);
+                    const double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
+                    const double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
+                    gl = fabs(angle_last) > 0.966;
+                    gn = fabs(angle_next) > 0.966;
+                }
+            }
         }
         const bool grazing = gl && gn;
         int thNumCurvSize;
@@ -549,7 +566,45 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
             if (lflat) attr |= A_LFLAT;
             if (rflat) attr |= A_RFLAT;
             if (lflat && rflat) {
-                // fast form of :615-644
+                // :615-644: cc = |cos| between the weighted sums of the unit vectors to the four neighbours on either
+                // side; flag 150 needs cc < 0.5 and both outermost neighbours farther than 5 cm.
+                // (1) float pre-decision of cc >= 0.5 (the common case on a plane: cc ~ 1), accepted only when the
+                //     squared form is 1e-3 away from the threshold and neither sum nearly cancels;
+                // (2) the same squared form in double (v_rsq_f64 + Newton) with a 1e-10 band;
+                // (3) the reference expression.
+                bool c150 = false, decided = false;
+                {
+                    float lx = 0.f, ly = 0.f, lz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, za4 = 0.f, zb4 = 0.f;
+#pragma unroll
+                    for (int k = 1; k < 5; k++) {
+                        const float ax = PT(-k).x - PT(0).x, ay = PT(-k).y - PT(0).y, az = PT(-k).z - PT(0).z;
+                        const float bx = PT(k).x - PT(0).x, by = PT(k).y - PT(0).y, bz = PT(k).z - PT(0).z;
+                        const float za = (ax * ax + ay * ay) + az * az, zb = (bx * bx + by * by) + bz * bz;
+                        const float wa = (k / 10.0f) * (za > 0.f ? __builtin_amdgcn_rsqf(za) : 1.f);
+                        const float wb = (k / 10.0f) * (zb > 0.f ? __builtin_amdgcn_rsqf(zb) : 1.f);
+                        lx += wa * ax;
+                        ly += wa * ay;
+                        lz += wa * az;
+                        rx += wb * bx;
+                        ry += wb * by;
+                        rz += wb * bz;
+                        if (k == 4) {
+                            za4 = za;
+                            zb4 = zb;
+                        }
+                    }
+                    const float dt = (lx * rx + ly * ry) + lz * rz;
+                    const float n1 = (lx * lx + ly * ly) + lz * lz, n2 = (rx * rx + ry * ry) + rz * rz;
+                    const float rhs = 0.25f * (n1 * n2), df = dt * dt - rhs;
+                    const bool inr = (n1 > 0.25f) & (n2 > 0.25f) & (n1 < 4.f) & (n2 < 4.f);
+                    // cc >= 0.5 for sure: not a 150 point.  cc < 0.5 for sure: the 5 cm test on the outermost
+                    // neighbours decides, in float when neither squared distance is within 1e-5 of 0.0025.
+                    const bool ge = (df > 1e-3f * rhs) & inr, lt = (df < -1e-3f * rhs) & inr;
+                    const bool k4 = (fabsf(za4 - 0.0025f) > 2.5e-8f) & (fabsf(zb4 - 0.0025f) > 2.5e-8f);
+                    decided = ge | (lt & k4);
+                    c150 = lt & (za4 > 0.0025f) & (zb4 > 0.0025f);
+                }
+                if (!decided) {
                 D3 nl = d3(0, 0, 0), nr = d3(0, 0, 0);
                 double last2 = 0, cur2 = 0;
 #pragma unroll
@@ -573,7 +628,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
                 bool ca;
                 const bool cc_ge = abs_cos_gt(ddot(nl, nr), ddot(nl, nl), ddot(nr, nr), 0.25, ca);  // cc > 0.5
                 const bool cl = fabs(last2 - 0.0025) > 1e-12, cr = fabs(cur2 - 0.0025) > 1e-12;
-                bool c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
+                c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
                 if (!(ca && cl && cr)) {  // reference expression (:615-644)
                     D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
 #pragma unroll
@@ -599,17 +654,25 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
                     double current_dis = dnorm(current_tmp);
                     c150 = cc < 0.5 && last_dis > 0.05 && current_dis > 0.05;
                 }
+                }
                 if (c150) attr |= A_C150;
             }
         }
         // ---- :651-806 break points ----
         {
             float dX1 = PT(1).x - PT(0).x, dY1 = PT(1).y - PT(0).y, dZ1 = PT(1).z - PT(0).z;
-            float diff_right0 = sqrtf(dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1);
             float dX2 = PT(-1).x - PT(0).x, dY2 = PT(-1).y - PT(0).y, dZ2 = PT(-1).z - PT(0).z;
-            float diff_left0 = sqrtf(dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2);
+            const float sq_right = dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1, sq_left = dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2;
             bool f100 = false;
-            if (fabsf(diff_right0 - diff_left0) > thBreakCornerDis) {
+            // two distances below 1 m cannot differ by more than thBreakCornerDis = 1 (sqrtf is monotone and
+            // sqrtf(x) <= 1 for x < 1): the square roots are only taken when a neighbour is farther away than that
+            float diff_right0 = 0.f, diff_left0 = 0.f;
+            const bool may_break = !(sq_right < 1.f && sq_left < 1.f);
+            if (may_break) {
+                diff_right0 = sqrtf(sq_right);
+                diff_left0 = sqrtf(sq_left);
+            }
+            if (may_break && fabsf(diff_right0 - diff_left0) > thBreakCornerDis) {
                 float depth_right = sqrtf(PT(1).x * PT(1).x + PT(1).y * PT(1).y + PT(1).z * PT(1).z);
                 float depth_left = sqrtf(PT(-1).x * PT(-1).x + PT(-1).y * PT(-1).y + PT(-1).z * PT(-1).z);
                 if (diff_right0 > diff_left0) {
@@ -723,20 +786,97 @@ __device__ __forceinline__ bool visits_before(unsigned info_j, unsigned key_j, i
     return j < i;
 }
 __device__ __forceinline__ unsigned st_of(unsigned w) { return (w >> I_ST_SHIFT) & 3u; }
+// the six {key, info} records at distance -3,-2,-1,1,2,3 of point i, fetched together (one wait instead of six)
+template <typename WP>
+__device__ __forceinline__ void load_nb(WP W, int i, uint2 (&o)[6]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int d = q < 3 ? q - 3 : q - 2;
+        o[q].x = W[2 * (i + d)];
+        o[q].y = W[2 * (i + d) + 1];
+    }
+}
+template <typename WP>
+__device__ __forceinline__ void load_nb_info(WP W, int i, unsigned (&o)[6]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int d = q < 3 ? q - 3 : q - 2;
+        o[q] = W[2 * (i + d) + 1];
+    }
+}
 
-// W: interleaved {key, W1} pairs (8 bytes per point).
-template <typename WP, typename U64P, typename ByteP>
-__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, WP W, U64P wmask, U64P wvis,
-                                            ByteP wexit, ByteP wsel, int* s_sp, unsigned long long (*s_pm)[3],
-                                            unsigned long long* s_minE, unsigned long long* s_minG,
-                                            unsigned char* s_bfirst) {
+#ifdef MML_SEL_TIMING
+__device__ unsigned long long g_sel_dbg[64];
+#define SEL_MARK(id)                                                                  \
+    do {                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[id] = clock64(); \
+    } while (0)
+extern "C" int mml_debug_sel_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sel_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define SEL_MARK(id)
+#endif
+
+// W: interleaved {key, W1} pairs (8 bytes per point).  R: reflect order keys (4 bytes per point).
+// K > 0: the line fits the LDS budget (n <= K * SELP_THREADS).  Point i = tid + k * SELP_THREADS belongs to the same
+// thread in every phase, so its attribute word and fused-cloud index are fetched ONCE, all loads in flight together,
+// and live in registers afterwards: the kernel is bound by the latency of dependent phases, not by bytes, and every
+// global load removed from a phase removes a full HBM round trip from the critical path of the workgroup.
+// K == 0: any length, per-point state in a global scratch, attributes re-read where needed.
+template <int K, typename WP, typename U64P, typename ByteP>
+__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, WP W, WP R, U64P wmask,
+                                            U64P wvis, ByteP wexit, ByteP wsel, int* s_sp,
+                                            unsigned long long (*s_pm)[3], unsigned long long* s_minE,
+                                            unsigned long long* s_minG, unsigned char* s_bfirst,
+                                            unsigned char* s_list, int* s_cnt) {
+    constexpr bool CACHED = K > 0;
+    constexpr int KK = CACHED ? K : 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint16_t* attr = P.ln_attr + base;
     const float* curv = P.ln_curv + base;
     const float* refl = P.ln_refl + base;
+    const int* gidx = P.ln_gidx + base;
+    unsigned r_attr[KK];
+    int r_gidx[KK];
+    (void)r_attr;
+    (void)r_gidx;
+// every point of the line, always by the same thread; `k` is a compile-time constant in the cached form
+#define FOR_POINTS(...)                                          \
+    if constexpr (CACHED) {                                      \
+        _Pragma("unroll") for (int k = 0; k < KK; ++k) {         \
+            const int i = tid + k * SELP_THREADS;                \
+            if (i >= n) break;                                   \
+            __VA_ARGS__                                          \
+        }                                                        \
+    } else {                                                     \
+        for (int i = tid; i < n; i += SELP_THREADS) {            \
+            constexpr int k = 0;                                 \
+            (void)k;                                             \
+            __VA_ARGS__                                          \
+        }                                                        \
+    }
+#define ATTR(i, k) (CACHED ? r_attr[k] : (unsigned)attr[i])
+#define RKEY(i) (CACHED ? (unsigned)R[i] : refl_key(refl[i]))
 
+    SEL_MARK(0);
     int T = 2;  // thNumCurvSize as the last stencil iteration (i = n-6) left it (:492,505)
-    if (n >= 11) T = (attr[n - 6] & A_W2) ? 2 : 3;
+    unsigned at_last = 0;
+    if (n >= 11) at_last = attr[n - 6];
+    float r_curv[KK], r_refl[KK];
+    (void)r_curv;
+    (void)r_refl;
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int i = min(tid + k * SELP_THREADS, n - 1);  // clamped: unconditional, independent loads
+            r_attr[k] = attr[i];
+            r_curv[k] = curv[i];
+            r_refl[k] = refl[i];
+            r_gidx[k] = gidx[i];
+        }
+    }
+    if (n >= 11) T = (at_last & A_W2) ? 2 : 3;
     const int range = n - 11;
     for (int j = tid; j <= 50; j += SELP_THREADS) {
         int sp, ep;
@@ -748,14 +888,16 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         s_minE[t] = ~0ull;
         s_minG[t] = ~0ull;
     }
+    if (tid == 0) *s_cnt = 0;
     __syncthreads();
 
+    SEL_MARK(1);
     // ---- phase 0: per-point record --------------------------------------------------------------------------
     const float inv_m = range >= 1 ? 50.0f / (float)range : 0.f;
-    for (int i = tid; i < n; i += SELP_THREADS) {
-        unsigned inf = 0, k = 0;
+    FOR_POINTS(
+        unsigned inf = 0, kk = 0;
         if (range >= 1 && i >= 5 && i <= n - 7) {
-            const unsigned at = attr[i];
+            const unsigned at = ATTR(i, k);
             int j = (int)((float)(i - 5) * inv_m);
             j = j < 0 ? 0 : (j > 49 ? 49 : j);
             while (i >= s_sp[j + 1]) ++j;  // partitions tile [5, n-7]; empty ones have sp[j+1] == sp[j]
@@ -765,12 +907,13 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             if (at & A_ANGLE) inf |= I_ANGLE;
             if (at & A_FAR) inf |= I_FAR;
             if (at & A_REFL) inf |= I_REFL;
-            k = __float_as_uint(curv[i]);
+            kk = __float_as_uint(CACHED ? r_curv[k] : curv[i]);
             if (at & A_CAND3) inf |= I_CAND | (ST_U << I_ST_SHIFT);
         }
-        W[2 * i] = k;
+        W[2 * i] = kk;
         W[2 * i + 1] = inf;
-    }
+        if constexpr (CACHED) R[i] = refl_key(r_refl[k]);
+    )
     if (tid < 6) {  // three zero records on either side of the line: neighbour reads need no bounds checks
         const int j = tid < 3 ? tid - 3 : n + tid - 3;
         W[2 * j] = 0;
@@ -778,65 +921,82 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     }
     __syncthreads();
 
+    SEL_MARK(2);
     // ---- phase 1: which neighbours can suppress me (static); points nobody can suppress are picked at once ------
-    for (int i = tid; i < n; i += SELP_THREADS) {
-        const unsigned me = W[2 * i + 1];
+    FOR_POINTS(
+        const uint2 rec = make_uint2(W[2 * i], W[2 * i + 1]);
+        const unsigned me = rec.y;
         if (!(me & I_CAND)) continue;
-        const unsigned mk = W[2 * i];
+        const unsigned mk = rec.x;
+        uint2 o[6];
+        load_nb(W, i, o);
         unsigned m = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) {
             const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
-            const int j = i + d;
-            const unsigned o = W[2 * j + 1];
-            if ((o & I_CAND) && covers(o, -d) && visits_before(o, W[2 * j], j, me, mk, i)) m |= 1u << q;
+            const bool c = ((o[q].y & I_CAND) != 0) & covers(o[q].y, -d) & visits_before(o[q].y, o[q].x, i + d, me, mk, i);
+            m |= c ? 1u << q : 0u;
         }
         W[2 * i + 1] = m ? (me | (m << I_MASK_SHIFT)) : ((me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT));
-    }
+    )
     __syncthreads();
+    SEL_MARK(3);
+    unsigned pend = 0;  // cached form: which of my points are still undecided (skips the LDS read of the others)
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int i = tid + k * SELP_THREADS;
+            if (i < n && st_of(W[2 * i + 1]) == ST_U) pend |= 1u << k;
+        }
+    }
     for (;;) {
         int undecided = 0;
-        for (int i = tid; i < n; i += SELP_THREADS) {
+        FOR_POINTS(
+            if (CACHED && !(pend & (1u << k))) continue;
             const unsigned me = W[2 * i + 1];
             if (st_of(me) != ST_U) continue;
             const unsigned m = (me >> I_MASK_SHIFT) & 63u;
+            unsigned o[6];
+            load_nb_info(W, i, o);
             bool anyS = false, anyU = false;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                if (!(m & (1u << q))) continue;
-                const int d = q < 3 ? q - 3 : q - 2;
-                const unsigned s = st_of(W[2 * (i + d) + 1]);
-                anyS |= (s == ST_S);
-                anyU |= (s == ST_U);
+            _Pragma("unroll") for (int q = 0; q < 6; ++q) {
+                const bool on = (m >> q) & 1u;
+                const unsigned s = st_of(o[q]);
+                anyS |= on & (s == ST_S);
+                anyU |= on & (s == ST_U);
             }
-            if (anyS)
+            if (anyS) {
                 W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_N << I_ST_SHIFT);
-            else if (!anyU)
+                pend &= ~(1u << k);
+            } else if (!anyU) {
                 W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT);
-            else
+                pend &= ~(1u << k);
+            } else {
                 undecided = 1;
-        }
+            }
+        )
+#ifdef MML_SEL_TIMING
+        if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[20] += 1;
+#endif
         if (!__syncthreads_or(undecided)) break;
     }
 
+    SEL_MARK(4);
     // ---- phase 2: value held when :521-539 runs (f3a) + "a later partition marks me" ------------------------------
-    for (int i = tid; i < n; i += SELP_THREADS) {
-        const unsigned me = W[2 * i + 1];
-        const unsigned mk = W[2 * i];
+    FOR_POINTS(
+        const uint2 rec = make_uint2(W[2 * i], W[2 * i + 1]);
+        const unsigned me = rec.y;
+        const unsigned mk = rec.x;
         const bool sel = st_of(me) == ST_S;
         const int mypart = (me & I_INPART) ? (int)(me & I_PART_MASK) : (i < 5 ? -1 : 64);
+        uint2 o[6];
+        load_nb(W, i, o);
         bool covL = false, covLater = false;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) {
             const int d = q < 3 ? q - 3 : q - 2;
-            const int j = i + d;
-            const unsigned o = W[2 * j + 1];
-            if (st_of(o) != ST_S || !covers(o, -d)) continue;
-            const int pj = (int)(o & I_PART_MASK);
-            if (pj > mypart)
-                covLater = true;
-            else if (!sel || visits_before(me, mk, i, o, W[2 * j], j))
-                covL = true;
+            const bool hit = (st_of(o[q].y) == ST_S) & covers(o[q].y, -d);
+            const bool later = (int)(o[q].y & I_PART_MASK) > mypart;
+            covLater |= hit & later;
+            covL |= hit & !later & (!sel | visits_before(me, mk, i, o[q].y, o[q].x, i + d));
         }
         const unsigned f3a = covL ? 1u : (sel ? 3u : 0u);
         const unsigned f = f3a | (covLater ? 4u : 0u);
@@ -844,36 +1004,49 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         W[2 * i + 1] = me | (f << I_F_SHIFT);
         // (a) first round of the reflect-candidate minimum
         if ((me & I_REFL) && (me & I_INPART))
-            atomicMin(&s_pm[me & I_PART_MASK][0], ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i);
-    }
+            atomicMin(&s_pm[me & I_PART_MASK][0], ((unsigned long long)RKEY(i) << 32) | (unsigned)i);
+    )
     __syncthreads();
 
+    SEL_MARK(5);
     // ---- phase 3: :521-539 in closed form ---------------------------------------------------------------------------
     // (a) the three first reflect candidates in reflect order, per partition (rounds 2 and 3)
     for (int round = 1; round < 3; ++round) {
-        for (int i = tid; i < n; i += SELP_THREADS) {
+        FOR_POINTS(
             const unsigned me = W[2 * i + 1];
             if (!(me & I_REFL) || !(me & I_INPART)) continue;
             const int j = me & I_PART_MASK;
-            const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
+            const unsigned long long rk = ((unsigned long long)RKEY(i) << 32) | (unsigned)i;
             if (rk <= s_pm[j][round - 1]) continue;
             atomicMin(&s_pm[j][round], rk);
-        }
+        )
         __syncthreads();
     }
+    SEL_MARK(6);
     // (a2) for each of the <= 3 reflect picks of a partition: does its reflect visit (B_k, k = reflect rank) come
     //      before its own curvature visit (A_k)?  One wavefront per pick counts both ranks over the partition.
-    for (int t = (tid >> 6); t < 150; t += SELP_THREADS / 64) {
+    //      b_first is only read for a pick that holds flag 3 or is a grazing point (see (b) and phase 5): those few
+    //      are listed first, one lane per pick.
+    if (tid < 150) {
+        const unsigned long long e = s_pm[tid / 3][tid % 3];
+        if (e != ~0ull) {
+            const unsigned wi = W[2 * (int)(unsigned)e + 1];
+            if (((wi >> I_F_SHIFT) & 3u) == 3u || (wi & I_ANGLE)) s_list[atomicAdd(s_cnt, 1)] = (unsigned char)tid;
+        }
+    }
+    __syncthreads();
+    const int n_need = *s_cnt;
+    for (int u = (tid >> 6); u < n_need; u += SELP_THREADS / 64) {
+        const int t = s_list[u];
         const int j = t / 3, r = t % 3;
         const unsigned long long e = s_pm[j][r];
-        if (e == ~0ull) continue;  // wave-uniform
         const int i = (int)(unsigned)e;
         const int sp = s_sp[j], ep = s_sp[j + 1] - 1;
         const unsigned mk = W[2 * i];
         const unsigned mr = (unsigned)(e >> 32);
         int rc = 0, rr = 0;
         for (int q = sp + lane; q <= ep; q += 64) {
-            const unsigned kq = W[2 * q], rq = refl_key(refl[q]);
+            const unsigned kq = W[2 * q], rq = RKEY(q);
             rc += (kq < mk) || (kq == mk && q < i);
             rr += (rq < mr) || (rq == mr && q < i);
         }
@@ -885,19 +1058,19 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         if (lane == 0) s_bfirst[t] = (unsigned char)(rr < rc);
     }
     __syncthreads();
+    SEL_MARK(7);
     // (b) eff3 / G bits, first point of each class in curvature order per partition
-    for (int i = tid; i < n; i += SELP_THREADS) {
+    FOR_POINTS(
         const unsigned me = W[2 * i + 1];
         if (!(me & I_INPART)) continue;
         const int j = me & I_PART_MASK;
         bool inB = false, b_first = false;
         if (me & I_REFL) {
-            const unsigned long long rk = ((unsigned long long)refl_key(refl[i]) << 32) | (unsigned)i;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
+            const unsigned long long rk = ((unsigned long long)RKEY(i) << 32) | (unsigned)i;
+            _Pragma("unroll") for (int r = 0; r < 3; ++r)
                 if (rk == s_pm[j][r]) {
                     inB = true;
-                    b_first = s_bfirst[j * 3 + r];
+                    b_first = ((((me >> I_F_SHIFT) & 3u) == 3u) || (me & I_ANGLE)) && s_bfirst[j * 3 + r];
                 }
         }
         const bool eff3 = (((me >> I_F_SHIFT) & 3u) == 3u) && !(inB && b_first);
@@ -909,15 +1082,26 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             if (eff3) atomicMin(&s_minE[j], ck);
             if (G) atomicMin(&s_minG[j], ck);
         }
-    }
-    __syncthreads();
+    )
+    __syncthreads();  // R is dead from here on: the window tables of the cached form live in its storage
 
+    SEL_MARK(8);
     // ---- phase 4: stride walk of :543-650, window transfer functions ------------------------------------------------
     const int nw = (n + 63) / 64;
-    for (int w0 = (tid >> 6) * 64; w0 < n; w0 += SELP_THREADS) {
-        const int i = w0 + lane;
-        const unsigned long long m = __ballot(i < n && (attr[i] & A_RFLAT));
-        if (lane == 0) wmask[w0 >> 6] = m;
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int i = tid + k * SELP_THREADS;
+            if ((i & ~63) >= n) break;  // wave-uniform
+            const unsigned long long m = __ballot(i < n && (r_attr[k] & A_RFLAT));
+            if (lane == 0) wmask[i >> 6] = m;
+        }
+    } else {
+        for (int w0 = (tid >> 6) * 64; w0 < n; w0 += SELP_THREADS) {
+            const int i = w0 + lane;
+            const unsigned long long m = __ballot(i < n && (attr[i] & A_RFLAT));
+            if (lane == 0) wmask[w0 >> 6] = m;
+        }
     }
     __syncthreads();
     for (int t = tid; t < nw * 4; t += SELP_THREADS) {
@@ -933,21 +1117,40 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         wexit[t] = (unsigned char)(pos - 64);
     }
     __syncthreads();
-    if (tid == 0) {
-        int e = 0;
-        for (int w = 0; w < nw; ++w) {
-            wsel[w] = (unsigned char)e;
-            e = wexit[w * 4 + e];
+    SEL_MARK(9);
+    // entry offset of every window = composition of the exit tables of the windows before it: a prefix scan over
+    // maps {0..3} -> {0..3} (2 bits per entry), 64 windows per pass of the first wavefront
+    if (tid < 64) {
+        unsigned carry = 0;
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned f = 0xE4u;  // identity: e -> e
+            if (w < nw) f = (unsigned)wexit[w * 4] | ((unsigned)wexit[w * 4 + 1] << 2) | ((unsigned)wexit[w * 4 + 2] << 4) |
+                            ((unsigned)wexit[w * 4 + 3] << 6);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned g = __shfl_up(f, o);  // windows before mine, applied first
+                if (lane >= o) {
+                    unsigned h = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h |= ((f >> (2 * ((g >> (2 * e)) & 3u))) & 3u) << (2 * e);
+                    f = h;
+                }
+            }
+            const unsigned before = __shfl_up(f, 1);
+            const unsigned entry = lane == 0 ? carry : ((before >> (2 * carry)) & 3u);
+            if (w < nw) wsel[w] = (unsigned char)entry;
+            carry = (__shfl(f, 63) >> (2 * carry)) & 3u;
         }
     }
     __syncthreads();
 
+    SEL_MARK(10);
     // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
-    const int* gidx = P.ln_gidx + base;
     uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
-    for (int i = tid; i < n; i += SELP_THREADS) {
+    FOR_POINTS(
         const unsigned me = W[2 * i + 1];
-        const unsigned at = attr[i];
+        const unsigned at = ATTR(i, k);
         int f = (me >> I_F_SHIFT) & 3u;
         if (me & I_INPART) {
             const int j = me & I_PART_MASK;
@@ -975,41 +1178,47 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         }
         if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
         if (inner && !(at & A_NEAR)) {
+            const int gi = CACHED ? r_gidx[k] : gidx[i];
             if (f == 2)
-                cblab[gidx[i]] = 2;
+                cblab[gi] = 2;
             else if (f == 100 || f == 150)
-                cblab[gidx[i]] = 1;
+                cblab[gi] = 1;
         }
-    }
+    )
+    SEL_MARK(11);
+#undef FOR_POINTS
+#undef ATTR
+#undef RKEY
 }
 
-__host__ __device__ inline size_t select_lds_bytes(int cap) {
-    const size_t nwin = (cap + 63) / 64;
-    // W: 2 x u32 per point | wmask u64 | wvis 4 x u64 | wexit 4 x u8 | wsel u8
-    return (size_t)(cap + 8) * 8 + nwin * 8 + nwin * 32 + nwin * 4 + nwin + 64;
-}
+// LDS of the cached form: W pairs with 4 pad records either side | R (reflect keys; later the window tables)
+__host__ __device__ inline size_t select_lds_bytes(int cap) { return (size_t)(cap + 8) * 8 + (size_t)cap * 4; }
 
+template <int K>
 __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_pm[50][3];
     __shared__ unsigned long long s_minE[50], s_minG[50];
     __shared__ unsigned char s_bfirst[152];
     __shared__ int s_sp[52];
+    __shared__ unsigned char s_list[152];
+    __shared__ int s_cnt;
     const int b = blockIdx.y + P.first;
     const int line = blockIdx.x;
     const int n = P.line_len[(size_t)b * P.L + line];
     if (n <= 0) return;
     const int start = P.line_start[(size_t)b * P.L + line];
     const size_t base = (size_t)b * P.NT + start;
-    if (n <= P.sel_cap) {
-        const int cap = P.sel_cap;
-        const int nwin = (cap + 63) / 64;
+    constexpr int cap = K * SELP_THREADS;
+    if (n <= cap) {
+        constexpr int nwin = cap / 64;
         unsigned* W = reinterpret_cast<unsigned*>(smem) + 8;  // 4 pad records in front, 4 behind
-        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8));
+        unsigned* R = reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8);
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(R);  // tables reuse R (45 B per window)
         unsigned long long* wvis = wmask + nwin;
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);
         unsigned char* wsel = wexit + 4 * nwin;
-        select_body(P, b, n, base, W, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst);
+        select_body<K>(P, b, n, base, W, R, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt);
     } else {
         // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
         const size_t BNT = (size_t)P.B * P.NT;
@@ -1022,8 +1231,29 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
         unsigned long long* wvis = wmask + nwin;
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * (size_t)nwin);
         unsigned char* wsel = wexit + 4 * (size_t)nwin;
-        select_body(P, b, n, base, W, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst);
+        select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE,
+                       s_minG, s_bfirst, s_list, &s_cnt);
     }
+}
+
+// K (points per thread in LDS-resident lines) variants of k_select
+typedef void (*select_fn)(FeatParams);
+static select_fn select_variant(int cap) {
+    switch (cap / SELP_THREADS) {
+        case 2: return k_select<2>;
+        case 4: return k_select<4>;
+        case 6: return k_select<6>;
+        case 8: return k_select<8>;
+        case 12: return k_select<12>;
+        case 16: return k_select<16>;
+        default: return k_select<24>;
+    }
+}
+static int select_round_cap(int want) {
+    const int ks[] = {2, 4, 6, 8, 12, 16, 24};
+    for (int k : ks)
+        if (k * SELP_THREADS >= want) return k * SELP_THREADS;
+    return 24 * SELP_THREADS;
 }
 
 // ---- a8: removeNearFarPoints / removeNearPointCloud + compaction into the fused cloud ---------------------------
@@ -1268,7 +1498,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "select");
-        hipLaunchKernelGGL(k_select, dim3(ctx->L, count), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
+        hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(ctx->L, count), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     }
     {
         MmlStageScope t(ctx, "crop_compact");
@@ -1289,21 +1519,21 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
     const int pblocks = (n + 255) / 256;
     if (pblocks > 0) hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
-    hipLaunchKernelGGL(k_select, dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
+    hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
 
 int mml_feature_init(mml_ctx* ctx) {
-    // LDS budget of k_select: twice the nominal ring length / 1.25x the nominal Livox line length, <= 12288 points
+    // LDS budget of k_select: twice the nominal ring length / the nominal Livox line length + 2 %, rounded up to a
+    // whole number of points per thread (the default 16 x 1800 + 6 x 4000 layout gets 4096 points = 51.6 KB, three
+    // workgroups per CU); longer lines take the global-scratch form of the same code
     int cap = 2 * (ctx->NV / (ctx->cfg.n_rings > 0 ? ctx->cfg.n_rings : 1));
-    int capl = (5 * (ctx->NL / (ctx->cfg.n_livox_lines > 0 ? ctx->cfg.n_livox_lines : 1))) / 4;
+    int capl = (51 * (ctx->NL / (ctx->cfg.n_livox_lines > 0 ? ctx->cfg.n_livox_lines : 1))) / 50;
     if (capl > cap) cap = capl;
-    if (cap < 1024) cap = 1024;
-    if (cap > 12288) cap = 12288;
-    cap = (cap + 63) & ~63;
+    cap = select_round_cap(cap);
     ctx->sel_cap = cap;
-    MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)select_lds_bytes(cap)));
+    MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_variant(cap)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_lds_bytes(cap)));
     return MML_OK;
 }

@@ -2,7 +2,7 @@
 MI355X_MICROARCH.md prescribes: TCC slots do not fit both).  On gfx950 FETCH_SIZE counts 64 B per 128-B request for
 wide coalesced streams, i.e. half the bytes: it is doubled here (calibrated on k_undistort: 13.5 M points x 20 B
 read = 270 MB, FETCH_SIZE says 134 MB; WRITE_SIZE matches the 270 MB written).  Counters are in KiB.
-Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/traffic_r01.json"""
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <scans per launch> > profiles/traffic_r01.json"""
 import json
 import sys
 
@@ -23,14 +23,16 @@ def per_kernel(path, counter):
     return d[d.Grid_Size == mx].groupby("k")["Counter_Value"].mean()
 
 
-def main(fp, wp):
+def main(fp, wp, scans):
     f, w = per_kernel(fp, "FETCH_SIZE"), per_kernel(wp, "WRITE_SIZE")
     out = {}
     for k, st in STAGE.items():
         b = 2.0 * float(f.get(k, 0.0)) * 1024.0 + float(w.get(k, 0.0)) * 1024.0
         out[st] = out.get(st, 0.0) + b
-    print(json.dumps({k: round(v) for k, v in out.items()}, indent=1))
+    out = {k: round(v) for k, v in out.items()}
+    out["scans_per_launch"] = int(scans)
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 256)
