@@ -97,6 +97,7 @@ typedef struct {
     int n_velo;         /* leading points that came from the Velodyne */
     int velo_corner_num, velo_surf_num;   /* union_cloud.msg:16-19, set at :1299-1300 */
     int livox_corner_num, livox_surf_num; /* set at :939-940 */
+    int fused_corner_num, fused_surf_num; /* label-1 / label-2 points of the fused cloud (corner_cnt, Estimator.cpp:990-1003) */
 } mml_scan_info;
 int mml_scan_info_get(mml_ctx* ctx, int slot, mml_scan_info* info);
 /* Copies the fused labelled cloud of a slot to host (any pointer may be NULL).  Capacity must be
@@ -126,6 +127,19 @@ int mml_features_upload(mml_ctx* ctx, int slot, int kind, const float* xyz, int 
  * Uploads a map cloud (3 floats per point) and builds the radix-sorted uniform grid that replaces
  * pcl::KdTreeFLANN::setInputCloud.  kind: 0 corner, 1 surf. */
 int mml_map_set_local(mml_ctx* ctx, int kind, const float* xyz, int m);
+/* ---- Estimator::MapIncrementLocal (Estimator.cpp:1585-1643), on the device ----------
+ * Moves the down-sampled corner / surf stacks of `slot` (what mml_downsample left there) to the world frame with
+ * T_wl = transformTobeMapped (row-major 4x4; pointAssociateToMap, Map_Manager.cpp:75-89), stores them in ring slot
+ * localMapID % 50, rebuilds both local maps as pcl::VoxelGrid(concatenation of the ring) -- the clear() of
+ * :1083-1085 / :1125-1127 included -- and rebuilds the kNN grids, all in HBM.  The caller keeps the key-scan rule
+ * (pose moved by >= sqrt(0.5) m, :1082,1124).  n_*_map (optional) receive the new map sizes. */
+int mml_map_increment_local(mml_ctx* ctx, int slot, const double* T_wl, int* n_corner_map, int* n_surf_map);
+/* Empties the ring (localMapID = 0); the current local maps stay until the next set / increment. */
+int mml_map_local_reset(mml_ctx* ctx);
+/* Copies the current local map (as set or as rebuilt by mml_map_increment_local) to the host: 3 floats per point,
+ * in the order the kNN indices refer to.  xyz may be NULL to query *n only. */
+int mml_map_local_download(mml_ctx* ctx, int kind, float* xyz, int capacity, int* n);
+
 /* ---- a12: laserCloud{Corner,Surf}FromMap cube store (Estimator.cpp:1170-1184, Map_Manager.cpp:583-629)
  * The reference hands Estimate() 21*11*21 = 4851 cube clouds plus one kd-tree per cube; processPointToLine /
  * processPointToPlane look the feature's cube up (MAP_MANAGER::FindUsedMap), query THAT cube's tree when the

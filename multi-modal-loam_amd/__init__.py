@@ -43,7 +43,8 @@ class Config(C.Structure):
 
 class ScanInfo(C.Structure):
     _fields_ = [("n_points", C.c_int), ("n_velo", C.c_int), ("velo_corner_num", C.c_int), ("velo_surf_num", C.c_int),
-                ("livox_corner_num", C.c_int), ("livox_surf_num", C.c_int)]
+                ("livox_corner_num", C.c_int), ("livox_surf_num", C.c_int), ("fused_corner_num", C.c_int),
+                ("fused_surf_num", C.c_int)]
 
 
 class AssocStats(C.Structure):
@@ -235,6 +236,23 @@ class Context:
     def map_set_local(self, kind, xyz):
         xyz = _f32(xyz).reshape(-1, 3)
         self._ck(lib().mml_map_set_local(self._h, C.c_int(kind), _p(xyz), C.c_int(len(xyz))))
+
+    def map_increment_local(self, slot, T_wl):
+        """Estimator::MapIncrementLocal on the device; returns the new (corner, surf) local map sizes."""
+        nc, ns = C.c_int(0), C.c_int(0)
+        T = _f64(T_wl).reshape(16)
+        self._ck(lib().mml_map_increment_local(self._h, C.c_int(slot), _p(T), C.byref(nc), C.byref(ns)))
+        return nc.value, ns.value
+
+    def map_local_reset(self):
+        self._ck(lib().mml_map_local_reset(self._h))
+
+    def map_local_download(self, kind):
+        n = C.c_int(0)
+        self._ck(lib().mml_map_local_download(self._h, C.c_int(kind), None, C.c_int(0), C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        self._ck(lib().mml_map_local_download(self._h, C.c_int(kind), _p(out), C.c_int(n.value), C.byref(n)))
+        return out[:n.value].copy()
 
     def map_set_global(self, kind, xyz, cube, cen=None):
         """Cube store of the global map (a12): xyz (m, 3) and the ToIndex cube of every point."""

@@ -73,7 +73,8 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_summ, ctx->d_trace, ctx->d_rec,
                     ctx->d_extr,   ctx->d_misc,   ctx->ggrid[0].pts, ctx->ggrid[1].pts, ctx->ggrid[0].cell_start,
                     ctx->ggrid[1].cell_start, ctx->ggrid[0].tags, ctx->ggrid[1].tags, ctx->gmap_orig[0],
-                    ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1]};
+                    ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1],
+                    ctx->ring[0],  ctx->ring[1],  ctx->ring_cat, ctx->vox_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -281,6 +282,8 @@ int mml_scan_info_get(mml_ctx* ctx, int slot, mml_scan_info* info) {
     info->velo_surf_num = h[3];
     info->livox_corner_num = h[4];
     info->livox_surf_num = h[5];
+    info->fused_corner_num = h[6];
+    info->fused_surf_num = h[7];
     return MML_OK;
 }
 
@@ -392,6 +395,49 @@ int mml_map_set_local(mml_ctx* ctx, int kind, const float* xyz, int m) {
     MML_REQUIRE(m >= 0 && (m == 0 || xyz), MML_ERR_INVALID, "bad map arguments");
     MML_HIP(hipSetDevice(ctx->device));
     return mml_build_grid(ctx, kind, xyz, m);
+}
+
+int mml_map_increment_local(mml_ctx* ctx, int slot, const double* T_wl, int* n_corner_map, int* n_surf_map) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(T_wl, MML_ERR_INVALID, "null transform");
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    int n[2] = {0, 0};
+    rc = mml_map_upkeep_increment(ctx, slot, T_wl, n);
+    if (n_corner_map) *n_corner_map = n[0];
+    if (n_surf_map) *n_surf_map = n[1];
+    return rc;
+}
+
+int mml_map_local_reset(mml_ctx* ctx) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_HIP(hipSetDevice(ctx->device));
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    memset(ctx->ring_n, 0, sizeof(ctx->ring_n));
+    ctx->local_map_id = 0;
+    return MML_OK;
+}
+
+int mml_map_local_download(mml_ctx* ctx, int kind, float* xyz, int capacity, int* n) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad arguments");
+    MML_REQUIRE(ctx->have_map[kind], MML_ERR_STATE, "no local map");
+    MML_HIP(hipSetDevice(ctx->device));
+    const int m = ctx->grid[kind].m;
+    *n = m;
+    if (!xyz || m == 0) return MML_OK;
+    MML_REQUIRE(capacity >= m, MML_ERR_CAPACITY, "capacity below the map size");
+    std::vector<float4> tmp((size_t)m);
+    MML_HIP(hipMemcpyAsync(tmp.data(), ctx->map_tmp + (size_t)kind * ctx->MM, sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost,
+                           MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    for (int i = 0; i < m; ++i) {
+        xyz[3 * i] = tmp[i].x;
+        xyz[3 * i + 1] = tmp[i].y;
+        xyz[3 * i + 2] = tmp[i].z;
+    }
+    return MML_OK;
 }
 
 int mml_map_set_global(mml_ctx* ctx, int kind, const float* xyz, const int* cube, int m, const int* cen) {

@@ -1189,11 +1189,12 @@ static int build_grid_into(mml_ctx* ctx, MmlGrid& g, float4* orig, const float* 
         MML_HIP(hipMemsetAsync(g.cell_start, 0, 2 * sizeof(int), s));
         return MML_OK;
     }
-    // host xyz (3 floats) -> device float4 (original order, w unused)
-    std::vector<float4> tmp((size_t)m);
-    for (int i = 0; i < m; ++i) tmp[i] = make_float4(h_xyz[3 * i], h_xyz[3 * i + 1], h_xyz[3 * i + 2], 0.f);
-    MML_HIP(hipMemcpyAsync(orig, tmp.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, s));
-    MML_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
+    if (h_xyz) {  // host xyz (3 floats) -> device float4 (original order, w unused); null: `orig` is already filled
+        std::vector<float4> tmp((size_t)m);
+        for (int i = 0; i < m; ++i) tmp[i] = make_float4(h_xyz[3 * i], h_xyz[3 * i + 1], h_xyz[3 * i + 2], 0.f);
+        MML_HIP(hipMemcpyAsync(orig, tmp.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, s));
+        MML_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
+    }
     MmlStageScope t(ctx, "map_build");
     float init[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     float* d_bbox = reinterpret_cast<float*>(ctx->d_misc);
@@ -1264,6 +1265,18 @@ int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m) {
     ctx->have_map[kind] = false;
     ctx->grid[kind].tags = nullptr;
     int rc = build_grid_into(ctx, ctx->grid[kind], ctx->map_tmp + (size_t)kind * ctx->MM, h_xyz, m,
+                             kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf, nullptr);
+    if (rc == MML_OK) ctx->have_map[kind] = true;
+    return rc;
+}
+
+// Same, for a cloud that is already on the device in map_tmp + kind * MM (device-side map upkeep).
+int mml_build_grid_device(mml_ctx* ctx, int kind, int m) {
+    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
+    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "map larger than max_map_points");
+    ctx->have_map[kind] = false;
+    ctx->grid[kind].tags = nullptr;
+    int rc = build_grid_into(ctx, ctx->grid[kind], ctx->map_tmp + (size_t)kind * ctx->MM, nullptr, m,
                              kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf, nullptr);
     if (rc == MML_OK) ctx->have_map[kind] = true;
     return rc;

@@ -1,0 +1,230 @@
+// Device-side local map upkeep: Estimator::MapIncrementLocal (Estimator.cpp:1585-1643) together with the clear() of
+// laserCloud{Corner,Surf}FromLocal that precedes every call (:1083-1085, :1125-1127).
+//
+// The reference keeps the last localMapWindowSize = 50 key scans' features as 50 PCL clouds in the world frame,
+// concatenates them and runs pcl::VoxelGrid over the concatenation; kdtree->setInputCloud then rebuilds both trees on
+// the next Estimate() (:1159-1167).  Here the ring lives in HBM next to the scan slots it is fed from:
+//   k_to_world    : pointAssociateToMap (Map_Manager.cpp:75-89) of one slot's down-sampled stack into ring slot
+//                   localMapID % 50
+//   k_concat      : the ring in slot order = the cloud the filter sees
+//   voxel filter  : bounding box -> PCL voxel index -> rocPRIM radix sort of (index, position) pairs (stable, so
+//                   the points of a voxel stay in input order = the order the oracle sums them in) -> head flags ->
+//                   exclusive scan -> one lane per voxel sums its run and writes the centroid
+//   grid build    : the filtered cloud is already where mml_build_grid_device expects it
+// Nothing but the two cloud sizes crosses PCIe.  Compiled with -ffp-contract=off.
+#include <math.h>
+
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+#include "mml_internal.h"
+
+namespace {
+
+struct Tf12 {
+    double m[12];
+};
+
+__global__ void k_to_world(const float4* feat, int n, Tf12 T, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 f = feat[i];
+    const double x = f.x, y = f.y, z = f.z;
+    float4 o;
+    o.x = (float)(((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3]);
+    o.y = (float)(((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7]);
+    o.z = (float)(((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11]);
+    o.w = 0.f;
+    out[i] = o;
+}
+
+struct RingOffsets {
+    int off[mml_ctx::LOCAL_WINDOW + 1];
+};
+
+// grid.y = ring slot
+__global__ void k_concat(const float4* ring, int MF, RingOffsets R, float4* cat) {
+    const int s = blockIdx.y;
+    const int n = R.off[s + 1] - R.off[s];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        cat[R.off[s] + i] = ring[(size_t)s * MF + i];
+}
+
+__global__ void k_minmax(const float4* pts, int m, float* out /* 6: min xyz, max xyz */) {
+    __shared__ float s[6][4];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        mn[0] = fminf(mn[0], p.x);
+        mn[1] = fminf(mn[1], p.y);
+        mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x);
+        mx[1] = fmaxf(mx[1], p.y);
+        mx[2] = fmaxf(mx[2], p.z);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+        if (lane == 0) {
+            s[c][wave] = mn[c];
+            s[3 + c][wave] = mx[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float v = s[c][0];
+        for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, s[c][w]) : fmaxf(v, s[c][w]);
+        // min / max of floats through their order-preserving integer image
+        int* a = reinterpret_cast<int*>(out + c);
+        const int iv = __float_as_int(v);
+        const int key = iv >= 0 ? iv : (iv ^ 0x7fffffff);
+        if (c < 3)
+            atomicMin(a, key);
+        else
+            atomicMax(a, key);
+    }
+}
+__device__ __forceinline__ float unkey(int key) { return __int_as_float(key >= 0 ? key : (key ^ 0x7fffffff)); }
+
+// PCL 1.8.1 voxel_grid.hpp applyFilter: inverse leaf in float, floor, int, min_b offset (same arithmetic as k_voxel)
+__global__ void k_vox_keys(const float4* pts, int m, const int* bbox_keys, float leaf, unsigned* keys, unsigned* vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float inv = 1.0f / leaf;
+    int min_b[3], div_b[3];
+    for (int c = 0; c < 3; ++c) {
+        min_b[c] = static_cast<int>(floor(unkey(bbox_keys[c]) * inv));
+        const int max_b = static_cast<int>(floor(unkey(bbox_keys[3 + c]) * inv));
+        div_b[c] = max_b - min_b[c] + 1;
+    }
+    const float4 p = pts[i];
+    const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
+    const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
+    const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
+    keys[i] = (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
+    vals[i] = (unsigned)i;
+}
+
+__global__ void k_vox_heads(const unsigned* keys, int m, int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// one lane per voxel: AccumulatorXYZ (float sum in input order, then / n)
+__global__ void k_vox_centroid(const float4* pts, const unsigned* keys, const unsigned* vals, const int* flag,
+                               const int* pos, int m, int cap, float4* out, int* n_out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m) return;
+    if (s == m - 1) *n_out = pos[s] + flag[s];
+    if (!flag[s]) return;
+    const int dst = pos[s];
+    if (dst >= cap) return;
+    const unsigned vox = keys[s];
+    float sx = 0, sy = 0, sz = 0;
+    int e = s;
+    while (e < m && keys[e] == vox) {
+        const float4 p = pts[vals[e]];
+        sx += p.x;
+        sy += p.y;
+        sz += p.z;
+        ++e;
+    }
+    const float c = static_cast<float>(e - s);
+    out[dst] = make_float4(sx / c, sy / c, sz / c, 0.f);
+}
+
+int ensure_tmp(mml_ctx* ctx, size_t need) {
+    if (need > ctx->sort_tmp_bytes) {
+        MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+        if (ctx->sort_tmp) MML_HIP(hipFree(ctx->sort_tmp));
+        MML_HIP(hipMalloc(&ctx->sort_tmp, need));
+        ctx->sort_tmp_bytes = need;
+    }
+    return MML_OK;
+}
+
+// pcl::VoxelGrid over `m` device points; the filtered cloud goes to `out` (capacity cap), its size to *h_n
+int voxel_filter_device(mml_ctx* ctx, const float4* pts, int m, float leaf, float4* out, int cap, int* h_n) {
+    hipStream_t s = MML_STREAM(ctx);
+    *h_n = 0;
+    if (m == 0) return MML_OK;
+    MML_REQUIRE(m <= ctx->MM, MML_ERR_CAPACITY, "local map ring larger than max_map_points");
+    int* d_bbox = ctx->d_misc;
+    int* d_n = ctx->d_misc + 8;
+    const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0xff800000 ^ 0x7fffffff, (int)0xff800000 ^ 0x7fffffff,
+                         (int)0xff800000 ^ 0x7fffffff};  // +inf x3, key(-inf) x3
+    MML_HIP(hipMemcpyAsync(d_bbox, init, sizeof(init), hipMemcpyHostToDevice, s));
+    const int blocks = (m + 255) / 256;
+    hipLaunchKernelGGL(k_minmax, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, pts, m, reinterpret_cast<float*>(d_bbox));
+    hipLaunchKernelGGL(k_vox_keys, dim3(blocks), dim3(256), 0, s, pts, m, d_bbox, leaf, ctx->map_keys, ctx->map_vals);
+    size_t need = 0;
+    MML_HIP(rocprim::radix_sort_pairs(nullptr, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals, ctx->map_vals2,
+                                      (size_t)m, 0, 32, s));
+    int rc = ensure_tmp(ctx, need);
+    if (rc != MML_OK) return rc;
+    MML_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals, ctx->map_vals2,
+                                      (size_t)m, 0, 32, s));
+    int* flag = ctx->vox_flag;
+    int* pos = ctx->vox_flag + (size_t)mml_ctx::LOCAL_WINDOW * ctx->MF + 1;
+    hipLaunchKernelGGL(k_vox_heads, dim3(blocks), dim3(256), 0, s, ctx->map_keys2, m, flag);
+    need = 0;
+    MML_HIP(rocprim::exclusive_scan(nullptr, need, flag, pos, 0, (size_t)m, rocprim::plus<int>(), s));
+    rc = ensure_tmp(ctx, need);
+    if (rc != MML_OK) return rc;
+    MML_HIP(rocprim::exclusive_scan(ctx->sort_tmp, need, flag, pos, 0, (size_t)m, rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_vox_centroid, dim3(blocks), dim3(256), 0, s, pts, ctx->map_keys2, ctx->map_vals2, flag, pos, m, cap,
+                       out, d_n);
+    MML_HIP(hipMemcpyAsync(h_n, d_n, sizeof(int), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipStreamSynchronize(s));
+    MML_REQUIRE(*h_n <= cap, MML_ERR_CAPACITY, "filtered local map larger than max_map_points");
+    return MML_OK;
+}
+
+}  // namespace
+
+int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_out) {
+    hipStream_t s = MML_STREAM(ctx);
+    constexpr int W = mml_ctx::LOCAL_WINDOW;
+    const size_t ring_pts = (size_t)W * ctx->MF;
+    if (!ctx->ring[0]) {
+        for (int k = 0; k < 2; ++k) MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ring[k]), sizeof(float4) * ring_pts));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ring_cat), sizeof(float4) * ring_pts));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->vox_flag), sizeof(int) * 2 * (ring_pts + 1)));
+    }
+    int n_feat[2];
+    MML_HIP(hipMemcpyAsync(&n_feat[0], ctx->ft_n + 0 * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipMemcpyAsync(&n_feat[1], ctx->ft_n + 1 * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipStreamSynchronize(s));
+    Tf12 T;
+    memcpy(T.m, T_wl, sizeof(double) * 12);
+    const int Id = (int)(ctx->local_map_id % W);  // :1597
+    for (int kind = 0; kind < 2; ++kind) {
+        const int n = n_feat[kind];
+        MML_REQUIRE(n >= 0 && n <= ctx->MF, MML_ERR_STATE, "slot holds no down-sampled feature stack");
+        if (n)
+            hipLaunchKernelGGL(k_to_world, dim3((n + 255) / 256), dim3(256), 0, s, ctx->ft_xyz[kind] + (size_t)slot * ctx->MF,
+                               n, T, ctx->ring[kind] + (size_t)Id * ctx->MF);
+        ctx->ring_n[kind][Id] = n;
+        RingOffsets R;
+        R.off[0] = 0;
+        for (int i = 0; i < W; ++i) R.off[i + 1] = R.off[i] + ctx->ring_n[kind][i];
+        const int total = R.off[W];
+        if (total) hipLaunchKernelGGL(k_concat, dim3(8, W), dim3(256), 0, s, ctx->ring[kind], ctx->MF, R, ctx->ring_cat);
+        int m = 0;
+        int rc = voxel_filter_device(ctx, ctx->ring_cat, total, kind == 0 ? ctx->cfg.leaf_corner : ctx->cfg.leaf_surf,
+                                     ctx->map_tmp + (size_t)kind * ctx->MM, ctx->MM, &m);
+        if (rc != MML_OK) return rc;
+        rc = mml_build_grid_device(ctx, kind, m);
+        if (rc != MML_OK) return rc;
+        ctx->local_map_n[kind] = m;
+        if (n_out) n_out[kind] = m;
+    }
+    ctx->local_map_id++;  // :1642
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}

@@ -126,6 +126,14 @@ struct mml_ctx {
     int* cube_cnt[2] = {nullptr, nullptr};  // 4851 ints each
     int gmap_cap[2] = {0, 0};
     int cen[3] = {10, 5, 10};  // laserCloudCen{Width,Height,Depth}_last (Map_Manager.h:113-115)
+    // device-side local map upkeep (Estimator::MapIncrementLocal): ring of key scans' features in the world frame
+    static constexpr int LOCAL_WINDOW = 50;  // localMapWindowSize, Estimator.h:326
+    float4* ring[2] = {nullptr, nullptr};    // LOCAL_WINDOW x MF each
+    float4* ring_cat = nullptr;              // concatenation scratch, LOCAL_WINDOW x MF
+    int* vox_flag = nullptr;                 // head flags / positions, 2 x (LOCAL_WINDOW x MF + 1)
+    int ring_n[2][LOCAL_WINDOW] = {};
+    long local_map_id = 0;                   // localMapID
+    int local_map_n[2] = {0, 0};
     float4* map_tmp = nullptr;
     unsigned* map_keys = nullptr;
     unsigned* map_keys2 = nullptr;
@@ -196,6 +204,8 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic);
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params);
 int mml_launch_downsample(mml_ctx* ctx, int first, int count);
 int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
+int mml_build_grid_device(mml_ctx* ctx, int kind, int m);
+int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_out);
 int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen);
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2);
 int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);

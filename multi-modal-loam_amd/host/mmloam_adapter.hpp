@@ -189,26 +189,74 @@ class Estimator {
     }
 
     // EstimateLidarPose(std::list<LidarFrame>&, exTlb, gravity, lidarMode) (Estimator.h:211-214, Estimator.cpp:967-1140).
-    // Live 1-frame mode: every frame of the list is registered independently against the local map.
-    // Poses are updated in place; failureDetected() reports the degeneracy flag (:1139).
+    // Live 1-frame mode: the list holds one frame; it is registered against the local map, the
+    // pose is updated in place, and the key-scan rule (:1121-1135) grows the local map ON THE DEVICE
+    // (mml_map_increment_local replaces MapIncrementLocal + the two kd-tree rebuilds of the next Estimate call).
+    // failureDetected() reports the degeneracy flag (:1139).
     void EstimateLidarPose(std::list<LidarFrame>& lidarFrameList, const Matrix4d& exTlb, const Vector3d& gravity,
                            int lidarMode) {
         (void)gravity;
-        (void)lidarMode;
-        _fail_detected = false;
-        // gate of Estimator.cpp:1032-1035
-        if (!((n_corner_map_ > 0 && n_surf_map_ > 100))) return;
+        if (lidarFrameList.empty()) return;
+        // exRbl = exTlb.R^T, exPbl = -exRbl * exTlb.t (:973-974)
+        double exRbl[9], exPbl[3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) exRbl[3 * r + c] = exTlb.m[4 * c + r];
+        for (int r = 0; r < 3; ++r)
+            exPbl[r] = -1.0 * ((exRbl[3 * r] * exTlb.m[3] + exRbl[3 * r + 1] * exTlb.m[7]) + exRbl[3 * r + 2] * exTlb.m[11]);
+        auto to_be_mapped = [&](const LidarFrame& f, double* T) {
+            const double x = f.Q.x, y = f.Q.y, z = f.Q.z, w = f.Q.w;
+            const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                                 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                                 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    T[4 * r + c] = (R[3 * r] * exRbl[c] + R[3 * r + 1] * exRbl[3 + c]) + R[3 * r + 2] * exRbl[6 + c];
+                T[4 * r + 3] = ((R[3 * r] * exPbl[0] + R[3 * r + 1] * exPbl[1]) + R[3 * r + 2] * exPbl[2]) + f.P.v[r];
+            }
+            T[12] = T[13] = T[14] = 0;
+            T[15] = 1;
+        };
+        double T[16];
+        to_be_mapped(lidarFrameList.back(), T);  // :975-977
+        int corner_cnt = 0;
         for (auto& f : lidarFrameList) {
-            check(ctx_.get(), mml_downsample(ctx_.get(), f.slot, 1), "downsample");
-            double Q[4] = {f.Q.x, f.Q.y, f.Q.z, f.Q.w};
-            mml_estimate_info info;
-            check(ctx_.get(), mml_estimate(ctx_.get(), f.slot, 1, exTlb.m, f.P.v, Q, 5, 10, &info), "Estimate");
-            f.Q.x = Q[0];
-            f.Q.y = Q[1];
-            f.Q.z = Q[2];
-            f.Q.w = Q[3];
-            if (info.is_degenerate) _fail_detected = true;
+            mml_scan_info si;
+            check(ctx_.get(), mml_scan_info_get(ctx_.get(), f.slot, &si), "scan info");
+            corner_cnt += si.fused_corner_num;  // :990-996
+            check(ctx_.get(), mml_downsample(ctx_.get(), f.slot, 1), "downsample");  // :1013-1024
         }
+        bool is_degenerate = false;
+        if (n_corner_map_ > 0 && n_surf_map_ > 100) {  // :1032-1035
+            for (auto& f : lidarFrameList) {
+                double Q[4] = {f.Q.x, f.Q.y, f.Q.z, f.Q.w};
+                mml_estimate_info info;
+                check(ctx_.get(), mml_estimate(ctx_.get(), f.slot, 1, exTlb.m, f.P.v, Q, 5, 10, &info), "Estimate");
+                f.Q.x = Q[0];
+                f.Q.y = Q[1];
+                f.Q.z = Q[2];
+                f.Q.w = Q[3];
+                if (info.is_degenerate) is_degenerate = true;
+            }
+        }
+        LidarFrame& front = lidarFrameList.front();
+        if ((lidarMode == 1 && !is_degenerate && corner_cnt > 100) || (lidarMode == 2 && corner_cnt > 50)) {
+            to_be_mapped(front, T);  // :1041-1049
+        } else {                     // :1050-1066
+            T[3] = front.P.v[0];
+            T[7] = front.P.v[1];
+        }
+        if (!is_degenerate) {  // :1070-1136
+            const double dx = last_update_pose_[0] - T[3], dy = last_update_pose_[1] - T[7], dz = last_update_pose_[2] - T[11];
+            const double d2 = lidarMode == 2 ? (double)(float)(dx * dx + dy * dy + dz * dz) : (dx * dx + dy * dy + dz * dz);
+            if (d2 >= 0.5) {
+                check(ctx_.get(), mml_map_increment_local(ctx_.get(), front.slot, T, &n_corner_map_, &n_surf_map_),
+                      "MapIncrementLocal");
+                last_update_pose_[0] = T[3];
+                last_update_pose_[1] = T[7];
+                last_update_pose_[2] = T[11];
+            }
+        }
+        _fail_detected = is_degenerate;  // :1139
     }
 
     bool failureDetected() const { return _fail_detected; }  // Estimator.h:278
@@ -216,6 +264,7 @@ class Estimator {
    private:
     Context& ctx_;
     int n_corner_map_ = 0, n_surf_map_ = 0;
+    double last_update_pose_[3] = {-1.0, -1.0, -1.0};  // Estimator.h:339-340
     bool _fail_detected = false;
 };
 

@@ -112,6 +112,55 @@ extern "C" int mmlo_voxel_downsample(const float* xyz, int n, float leaf, float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Section 8(f) rank 2: Estimator::MapIncrementLocal (Estimator.cpp:1585-1643) together with the clear() of the
+// local clouds that precedes every call (:1083-1085, :1125-1127).  The local map is the voxel-filtered union of
+// the last localMapWindowSize (50, Estimator.h:326) key scans' features in the world frame.
+struct mmlo_local_map {
+    int window;
+    long id;                                   // localMapID
+    float leaf[2];                             // downSizeFilterCorner / downSizeFilterSurf leaf sizes (:78-79)
+    std::vector<std::vector<float>> ring[2];   // localCornerMap[i] / localSurfMap[i]
+    std::vector<float> map[2];                 // laserCloudCornerFromLocal / laserCloudSurfFromLocal
+};
+extern "C" mmlo_local_map* mmlo_local_map_create(int window, float leaf_corner, float leaf_surf) {
+    mmlo_local_map* h = new mmlo_local_map();
+    h->window = window;
+    h->id = 0;
+    h->leaf[0] = leaf_corner;
+    h->leaf[1] = leaf_surf;
+    for (int k = 0; k < 2; ++k) h->ring[k].resize(window);
+    return h;
+}
+extern "C" void mmlo_local_map_free(mmlo_local_map* h) { delete h; }
+extern "C" void mmlo_local_map_increment(mmlo_local_map* h, const float* corner, int nc, const float* surf, int ns,
+                                         const double* T) {
+    const size_t Id = (size_t)(h->id % h->window);  // :1597
+    const float* src[2] = {corner, surf};
+    const int cnt[2] = {nc, ns};
+    for (int k = 0; k < 2; ++k) {
+        std::vector<float>& slot = h->ring[k][Id];
+        slot.clear();  // :1600-1601
+        for (int i = 0; i < cnt[k]; ++i) {  // :1604-1612, pointAssociateToMap (Map_Manager.cpp:75-89)
+            const double x = src[k][3 * i], y = src[k][3 * i + 1], z = src[k][3 * i + 2];
+            slot.push_back((float)(((T[0] * x + T[1] * y) + T[2] * z) + T[3]));
+            slot.push_back((float)(((T[4] * x + T[5] * y) + T[6] * z) + T[7]));
+            slot.push_back((float)(((T[8] * x + T[9] * y) + T[10] * z) + T[11]));
+        }
+        std::vector<float> cat;  // :1620-1623 onto the cleared cloud
+        for (int i = 0; i < h->window; ++i) cat.insert(cat.end(), h->ring[k][i].begin(), h->ring[k][i].end());
+        std::vector<float> out(cat.size() ? cat.size() : 3);
+        const int m = mmlo_voxel_downsample(cat.data(), (int)(cat.size() / 3), h->leaf[k], out.data());  // :1630-1637
+        out.resize((size_t)m * 3);
+        h->map[k].swap(out);
+    }
+    h->id++;  // :1642
+}
+extern "C" int mmlo_local_map_size(const mmlo_local_map* h, int kind) { return (int)(h->map[kind].size() / 3); }
+extern "C" void mmlo_local_map_get(const mmlo_local_map* h, int kind, float* out_xyz) {
+    if (!h->map[kind].empty()) memcpy(out_xyz, h->map[kind].data(), h->map[kind].size() * sizeof(float));
+}
+
+// ------------------------------------------------------------------------------------------------
 // a13  exact 5-NN with FLANN L2_Simple<float> distance semantics: d2 = ((dx*dx + dy*dy) + dz*dz) in
 // float; result ascending, ties broken by lower index (FLANN's tie order is unspecified: convention).
 struct Top5 {

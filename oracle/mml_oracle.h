@@ -111,6 +111,15 @@ int mmlo_associate_lines2(const float* feat_xyz, int n_feat, const mmlo_cube_map
 int mmlo_associate_planes2(const float* feat_xyz, int n_feat, const mmlo_cube_map* gmap, const float* map_xyz, int m,
                            const mmlo_kdtree* tree, const double* T_wl, double thres_dist, mmlo_plane_factor* out,
                            int* out_src, int* from_global);
+/* Section 8(f): Estimator::MapIncrementLocal (Estimator.cpp:1585-1643) after the clear() at :1083-1085 / :1125-1127:
+ * ring of `window` (50) key scans' features moved to the world frame, local map = VoxelGrid(concatenation). */
+typedef struct mmlo_local_map mmlo_local_map;
+mmlo_local_map* mmlo_local_map_create(int window, float leaf_corner, float leaf_surf);
+void mmlo_local_map_free(mmlo_local_map*);
+void mmlo_local_map_increment(mmlo_local_map*, const float* corner_xyz, int n_corner, const float* surf_xyz, int n_surf,
+                              const double* T_wl);
+int mmlo_local_map_size(const mmlo_local_map*, int kind);
+void mmlo_local_map_get(const mmlo_local_map*, int kind, float* out_xyz);
 /* checkLocalizability, Estimator.cpp:536-565: smallest singular value of the M x 3 normal
  * matrix (= sqrt(lambda_min(N^T N))); -1 when M <= 10. */
 double mmlo_check_localizability(const mmlo_plane_factor* f, int n);

@@ -57,6 +57,7 @@ def lib():
         _lib.mmlo_kdtree_build.restype = C.c_void_p
         _lib.mmlo_check_localizability.restype = C.c_double
         _lib.mmlo_cube_map_build.restype = C.c_void_p
+        _lib.mmlo_local_map_create.restype = C.c_void_p
     return _lib
 
 
@@ -220,6 +221,31 @@ def associate_lines2(feat, gmap, tree, T_wl, thres):
 def associate_planes2(feat, gmap, tree, T_wl, thres):
     """processPointToPlane, same two-level look-up (Estimator.cpp:567-778)."""
     return _associate2(lib().mmlo_associate_planes2, PLANE_DT, feat, gmap, tree, T_wl, thres)
+
+
+class LocalMap:
+    """Estimator::MapIncrementLocal (Estimator.cpp:1585-1643): 50-key-scan ring + VoxelGrid."""
+
+    def __init__(self, window=50, leaf_corner=0.4, leaf_surf=0.2):
+        self.h = C.c_void_p(lib().mmlo_local_map_create(C.c_int(window), C.c_float(leaf_corner), C.c_float(leaf_surf)))
+
+    def __del__(self):
+        try:
+            lib().mmlo_local_map_free(self.h)
+        except Exception:
+            pass
+
+    def increment(self, corner, surf, T_wl):
+        corner = _f32(corner).reshape(-1, 3)
+        surf = _f32(surf).reshape(-1, 3)
+        lib().mmlo_local_map_increment(self.h, _p(corner), C.c_int(len(corner)), _p(surf), C.c_int(len(surf)),
+                                       _p(_f64(T_wl).reshape(16)))
+
+    def get(self, kind):
+        n = lib().mmlo_local_map_size(self.h, C.c_int(kind))
+        out = np.zeros((max(n, 1), 3), np.float32)
+        lib().mmlo_local_map_get(self.h, C.c_int(kind), _p(out))
+        return out[:n].copy()
 
 
 def check_localizability(pf):

@@ -1,6 +1,7 @@
 """GPU suite (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same seeded inputs and
 against the committed golden vectors.  Bars: bit-exact for indices / labels / float feature arithmetic;
 pose within 1e-4 m / 1e-4 rad per iteration (we hold 1e-9)."""
+import importlib
 import os
 
 import numpy as np
@@ -331,6 +332,49 @@ def test_two_level_association_matches_oracle(M, O, cube_scene, tight):
         c2.close()
 
 
+def test_local_map_upkeep_matches_oracle(M, O, scene):
+    """Section 8(f): device-side MapIncrementLocal -- ring, wrap-around past 50 key scans, VoxelGrid, grid rebuild."""
+    c2 = M.Context(max_scans=2)
+    try:
+        lm = O.LocalMap(window=50, leaf_corner=c2.cfg.leaf_corner, leaf_surf=c2.cfg.leaf_surf)
+        rng = np.random.default_rng(3)
+        for step in range(56):
+            fr = scene["frames"][step % 4]
+            # thin the stacks after the first few key scans so 56 increments stay quick on the CPU side
+            keep_c = fr["corner"] if step < 6 else fr["corner"][rng.random(len(fr["corner"])) < 0.15]
+            keep_s = fr["surf"] if step < 6 else fr["surf"][rng.random(len(fr["surf"])) < 0.08]
+            T = perturbed(fr["T_gt"], dt=(0.07 * step, -0.03 * step, 0.002 * step), rotvec=(0.001 * step, 0.0, 0.01 * step))
+            c2.features_upload(1, 0, keep_c)
+            c2.features_upload(1, 1, keep_s)
+            nc, ns = c2.map_increment_local(1, T)
+            lm.increment(keep_c, keep_s, T)
+            if step in (0, 1, 5, 49, 50, 55):
+                for kind, n in ((0, nc), (1, ns)):
+                    want = lm.get(kind)
+                    got = c2.map_local_download(kind)
+                    assert n == len(want) and got.tobytes() == want.tobytes()
+        # the rebuilt grids serve exact neighbours and the same factors as the oracle on the oracle's map
+        fr = scene["frames"][2]
+        T = perturbed(fr["T_gt"], dt=(0.07 * 55, -0.03 * 55, 0.002 * 55), rotvec=(0.055, 0.0, 0.55))
+        c2.features_upload(0, 0, fr["corner"])
+        c2.features_upload(0, 1, fr["surf"])
+        c2.associate(0, 1, T[None], 25.0)
+        lf, lsrc = O.associate_lines(fr["corner"], O.KdTree(lm.get(0)), T, 25.0)
+        pf, psrc = O.associate_planes(fr["surf"], O.KdTree(lm.get(1)), T, 25.0)
+        gl, glsrc = c2.factors_download(0, 0)
+        gp, gpsrc = c2.factors_download(0, 1)
+        assert len(pf) > 100 and np.array_equal(glsrc, lsrc) and np.array_equal(gpsrc, psrc)
+        ol, op = _factor_arrays(lf, pf)
+        assert np.allclose(gl, ol, rtol=0, atol=1e-9) and np.allclose(gp, op, rtol=0, atol=1e-9)
+        c2.map_local_reset()
+        nc, ns = c2.map_increment_local(1, T)
+        lm2 = O.LocalMap(window=50, leaf_corner=c2.cfg.leaf_corner, leaf_surf=c2.cfg.leaf_surf)
+        lm2.increment(keep_c, keep_s, T)
+        assert c2.map_local_download(1).tobytes() == lm2.get(1).tobytes()
+    finally:
+        c2.close()
+
+
 def test_association_golden(ctx):
     g = load("estimate_small.npz")
     ctx.map_set_local(0, g["corner_map"])
@@ -444,3 +488,73 @@ def test_full_size_step_properties(M, O, scene, synth):
         d = c.scan_download(s)
         assert np.array_equal(d["label"], frames[s % 4]["label"])
     c.close()
+
+
+def test_odometry_replay_matches_oracle_loop(M, O, synth):
+    """BASELINE config 3 shape, synthetic: scans replayed one by one through the whole loop -- extract, undistort,
+    down-sample, Estimate (5 outer x 10 inner) against the local map, key-scan rule, MapIncrementLocal -- with the
+    map resident on the device.  The oracle runs the same loop on the CPU; both start from the same predictions."""
+    odometry = importlib.import_module("multi-modal-loam_amd.odometry")
+    c = M.Context(max_scans=1)
+    try:
+        odo = odometry.LidarOdometry(c, lidar_mode=2)
+        lm = O.LocalMap(window=50, leaf_corner=c.cfg.leaf_corner, leaf_surf=c.cfg.leaf_surf)
+        last_update = np.array([-1.0, -1.0, -1.0])
+        ks = list(range(20, 20 + 4 * 14, 4))
+        T_prev_gpu = T_prev_cpu = T_prev_gt = None
+        n_key = 0
+        worst = 0.0
+        for step, k in enumerate(ks):
+            v, l = synth.velo_scan(k, motion=True), synth.livox_scan(k, motion=True)
+            dR, dt = synth.sweep_motion(k)
+            T_gt = synth.pose_matrix(k)
+            # prediction: previous estimate advanced by the true relative motion plus an IMU-sized error
+            def predict(T_prev):
+                if T_prev is None:
+                    return T_gt.copy()
+                return perturbed(T_prev @ np.linalg.inv(T_prev_gt) @ T_gt, dt=(0.02, -0.015, 0.01), rotvec=(0.002, -0.001, 0.003))
+            # ---- product path ----
+            Tp = predict(T_prev_gpu)
+            c.scan_upload(0, v, l)
+            c.extract(0, 1)
+            c.undistort(0, 1, dR.reshape(1, 9), dt.reshape(1, 3))
+            Pg, Qg, grew = odo.estimate_lidar_pose(0, Tp[:3, 3], Rsc.from_matrix(Tp[:3, :3]).as_quat())
+            T_gpu = np.eye(4)
+            T_gpu[:3, :3] = Rsc.from_quat(Qg).as_matrix()
+            T_gpu[:3, 3] = Pg
+            # ---- oracle loop ----
+            To = predict(T_prev_cpu)
+            ev, el = O.extract_velo(v), O.extract_livox(l)
+            xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+            rel = np.concatenate([ev["reltime"], el["reltime"]])
+            lab = np.concatenate([ev["label"], el["label"]])
+            und = O.undistort(xyz, rel, dR, dt)
+            cf, sf = O.voxel_downsample(und[lab == 1], 0.4), O.voxel_downsample(und[lab == 2], 0.2)
+            Po, Qo = To[:3, 3].copy(), Rsc.from_matrix(To[:3, :3]).as_quat()
+            cm, sm = lm.get(0), lm.get(1)
+            deg = False
+            if len(cm) > 0 and len(sm) > 100:
+                Po, Qo, _, deg, _ = O.estimate_single(cf, sf, cm, sm, np.eye(4), Po, Qo, 5, 10)
+            T_cpu = np.eye(4)
+            T_cpu[:3, :3] = Rsc.from_quat(Qo).as_matrix()
+            T_cpu[:3, 3] = Po
+            grew_cpu = False
+            if not deg:
+                d = last_update - T_cpu[:3, 3]
+                if float(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) >= 0.5:
+                    lm.increment(cf, sf, T_cpu)
+                    last_update = T_cpu[:3, 3].copy()
+                    grew_cpu = True
+            assert grew == grew_cpu and odo.fail_detected == deg
+            n_key += grew
+            dpos = np.abs(T_gpu[:3, 3] - T_cpu[:3, 3]).max()
+            drot = np.abs(Rsc.from_matrix(T_gpu[:3, :3].T @ T_cpu[:3, :3]).as_rotvec()).max()
+            worst = max(worst, dpos, drot)
+            assert dpos < 1e-6 and drot < 1e-6, (step, dpos, drot)          # target of BASELINE.json: 1e-4
+            if step > 0:
+                assert np.abs(T_gpu[:3, 3] - T_gt[:3, 3]).max() < 0.05      # and the loop actually tracks the motion
+            T_prev_gpu, T_prev_cpu, T_prev_gt = T_gpu, T_cpu, T_gt
+        assert n_key >= 3 and odo.key_scans == n_key
+        assert odo.n_surf_local == len(lm.get(1)) and odo.n_corner_local == len(lm.get(0))
+    finally:
+        c.close()

@@ -376,6 +376,31 @@ def test_two_level_association_semantics(O, cube_scene, tight):
     assert f2.tobytes() == loc.tobytes() and np.array_equal(src2, loc_src) and not fg.any()
 
 
+def test_local_map_increment_semantics(O, scene, synth):
+    """Section 8(f): MapIncrementLocal (Estimator.cpp:1585-1643) = VoxelGrid over the ring of world-frame key scans, the
+    oldest slot overwritten once the window is full."""
+    W = 3
+    lm = O.LocalMap(window=W, leaf_corner=0.4, leaf_surf=0.2)
+    ring = {0: [None] * W, 1: [None] * W}
+    for step in range(5):
+        fr = scene["frames"][step % 4]
+        T = perturbed(fr["T_gt"], dt=(0.1 * step, 0.0, 0.0))
+        lm.increment(fr["corner"], fr["surf"], T)
+        for kind, feat, leaf in ((0, fr["corner"], 0.4), (1, fr["surf"], 0.2)):
+            world = (feat.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+            ring[kind][step % W] = world
+            cat = np.concatenate([r for r in ring[kind] if r is not None])
+            want = O.voxel_downsample(cat, leaf)
+            got = lm.get(kind)
+            assert got.shape == want.shape and np.abs(got - want).max() < 1e-6
+            # the transform is evaluated in double with the reference's association order and rounded once
+            x, y, z = (feat[:, c].astype(np.float64) for c in range(3))
+            exact = np.stack([(((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]).astype(np.float32) for r in range(3)], 1)
+            ring[kind][step % W] = exact
+            cat = np.concatenate([r for r in ring[kind] if r is not None])
+            assert lm.get(kind).tobytes() == O.voxel_downsample(cat, leaf).tobytes()
+
+
 def test_jacobians_against_finite_differences(O, scene):
     lf, pf, T = _assoc(O, scene)
     rng = np.random.default_rng(7)
