@@ -111,7 +111,9 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ctx->L = cfg->n_rings + cfg->n_livox_lines;
     ctx->MF = ctx->cfg.max_features;
     ctx->MM = ctx->cfg.max_map_points;
-    ctx->VX_CAP = 8192;
+    // label lists per (slot, kind): 8192 entries feed the LDS sort of k_voxel; scans beyond 64k points (e.g. 128 x 2048
+    // rings) list every point and take the global-sort filter (mml_downsample_big)
+    ctx->VX_CAP = ctx->NT > 65536 ? (int)ctx->NT : 8192;
     ctx->h_n_in.assign((size_t)ctx->B * 2, 0);
     auto fail = [&](hipError_t e, const char* what) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);

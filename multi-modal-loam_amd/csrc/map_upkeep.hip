@@ -153,7 +153,7 @@ int voxel_filter_device(mml_ctx* ctx, const float4* pts, int m, float leaf, floa
     hipStream_t s = MML_STREAM(ctx);
     *h_n = 0;
     if (m == 0) return MML_OK;
-    MML_REQUIRE(m <= ctx->MM, MML_ERR_CAPACITY, "local map ring larger than max_map_points");
+    MML_REQUIRE(m <= ctx->MM && (size_t)m <= ctx->vox_cap, MML_ERR_CAPACITY, "cloud larger than max_map_points");
     int* d_bbox = ctx->d_misc;
     int* d_n = ctx->d_misc + 8;
     const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0xff800000 ^ 0x7fffffff, (int)0xff800000 ^ 0x7fffffff,
@@ -170,7 +170,7 @@ int voxel_filter_device(mml_ctx* ctx, const float4* pts, int m, float leaf, floa
     MML_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp, need, ctx->map_keys, ctx->map_keys2, ctx->map_vals, ctx->map_vals2,
                                       (size_t)m, 0, 32, s));
     int* flag = ctx->vox_flag;
-    int* pos = ctx->vox_flag + (size_t)mml_ctx::LOCAL_WINDOW * ctx->MF + 1;
+    int* pos = ctx->vox_flag + ctx->vox_cap + 1;
     hipLaunchKernelGGL(k_vox_heads, dim3(blocks), dim3(256), 0, s, ctx->map_keys2, m, flag);
     need = 0;
     MML_HIP(rocprim::exclusive_scan(nullptr, need, flag, pos, 0, (size_t)m, rocprim::plus<int>(), s));
@@ -187,14 +187,62 @@ int voxel_filter_device(mml_ctx* ctx, const float4* pts, int m, float leaf, floa
 
 }  // namespace
 
+namespace {
+__global__ void k_gather_list(const float4* pts, const unsigned* list, int n, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pts[list[i]];
+}
+int ensure_vox_scratch(mml_ctx* ctx, size_t pts) {
+    if (pts <= ctx->vox_cap) return MML_OK;
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    if (ctx->ring_cat) MML_HIP(hipFree(ctx->ring_cat));
+    if (ctx->vox_flag) MML_HIP(hipFree(ctx->vox_flag));
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ring_cat), sizeof(float4) * pts));
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->vox_flag), sizeof(int) * 2 * (pts + 1)));
+    ctx->vox_cap = pts;
+    return MML_OK;
+}
+}  // namespace
+
+// a10 for scans whose labelled clouds do not fit the LDS sort of k_voxel (max_velo_points + max_livox_points > 65536,
+// e.g. 128 x 2048 rings): the same filter through the global radix sort, one (slot, kind) at a time.
+int mml_downsample_big(mml_ctx* ctx, int first, int count) {
+    hipStream_t s = MML_STREAM(ctx);
+    std::vector<int> info(8 * (size_t)count);
+    MML_HIP(hipMemcpyAsync(info.data(), ctx->fu_info + 8 * (size_t)first, sizeof(int) * info.size(), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipStreamSynchronize(s));
+    int rc = ensure_vox_scratch(ctx, (size_t)ctx->NT);
+    if (rc != MML_OK) return rc;
+    const unsigned* lists = reinterpret_cast<const unsigned*>(ctx->vx_keys);
+    for (int c = 0; c < count; ++c) {
+        const int b = first + c;
+        for (int kind = 0; kind < 2; ++kind) {
+            const int n = info[8 * c + 6 + kind];
+            MML_REQUIRE(n <= ctx->VX_CAP && n <= ctx->MM, MML_ERR_CAPACITY, "labelled cloud larger than the voxel scratch");
+            int m = 0;
+            if (n) {
+                hipLaunchKernelGGL(k_gather_list, dim3((n + 255) / 256), dim3(256), 0, s, ctx->fu_xyzi + (size_t)b * ctx->NT,
+                                   lists + ((size_t)b * 2 + kind) * ctx->VX_CAP, n, ctx->ring_cat);
+                rc = voxel_filter_device(ctx, ctx->ring_cat, n, kind == 0 ? ctx->cfg.leaf_corner : ctx->cfg.leaf_surf,
+                                         ctx->ft_xyz[kind] + (size_t)b * ctx->MF, ctx->MF, &m);
+                if (rc != MML_OK) return rc;
+            }
+            MML_HIP(hipMemcpyAsync(ctx->ft_n + kind * ctx->B + b, &m, sizeof(int), hipMemcpyHostToDevice, s));
+            MML_HIP(hipStreamSynchronize(s));
+        }
+    }
+    return MML_OK;
+}
+
 int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_out) {
     hipStream_t s = MML_STREAM(ctx);
     constexpr int W = mml_ctx::LOCAL_WINDOW;
     const size_t ring_pts = (size_t)W * ctx->MF;
-    if (!ctx->ring[0]) {
+    if (!ctx->ring[0])
         for (int k = 0; k < 2; ++k) MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ring[k]), sizeof(float4) * ring_pts));
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ring_cat), sizeof(float4) * ring_pts));
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->vox_flag), sizeof(int) * 2 * (ring_pts + 1)));
+    {
+        int rc0 = ensure_vox_scratch(ctx, ring_pts);
+        if (rc0 != MML_OK) return rc0;
     }
     int n_feat[2];
     MML_HIP(hipMemcpyAsync(&n_feat[0], ctx->ft_n + 0 * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -130,7 +130,8 @@ struct mml_ctx {
     static constexpr int LOCAL_WINDOW = 50;  // localMapWindowSize, Estimator.h:326
     float4* ring[2] = {nullptr, nullptr};    // LOCAL_WINDOW x MF each
     float4* ring_cat = nullptr;              // concatenation scratch, LOCAL_WINDOW x MF
-    int* vox_flag = nullptr;                 // head flags / positions, 2 x (LOCAL_WINDOW x MF + 1)
+    int* vox_flag = nullptr;                 // head flags / positions, 2 x (vox_cap + 1)
+    size_t vox_cap = 0;                      // points ring_cat / vox_flag are sized for
     int ring_n[2][LOCAL_WINDOW] = {};
     long local_map_id = 0;                   // localMapID
     int local_map_n[2] = {0, 0};
@@ -205,6 +206,7 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
 int mml_launch_downsample(mml_ctx* ctx, int first, int count);
 int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
 int mml_build_grid_device(mml_ctx* ctx, int kind, int m);
+int mml_downsample_big(mml_ctx* ctx, int first, int count);
 int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_out);
 int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen);
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2);

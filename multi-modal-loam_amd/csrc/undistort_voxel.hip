@@ -366,6 +366,7 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
 
 int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     MmlStageScope t(ctx, "voxel_downsample");
+    if (ctx->VX_CAP > 8192) return mml_downsample_big(ctx, first, count);  // labelled clouds beyond the LDS sort
     const int cap = ctx->VX_CAP;
     int npad = 1;
     while (npad < cap) npad <<= 1;
