@@ -123,7 +123,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-    ctx->n_lanes = mml_ctx::MAX_LANES;
+    ctx->n_lanes = 4;
     if (const char* e_l = getenv("MML_LANES")) {  // tuning knob: number of stream lanes mml_step pipelines over
         int v = atoi(e_l);
         if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;
@@ -846,7 +846,7 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
 
 int mml_set_lanes(mml_ctx* ctx, int lanes) {
     if (!ctx) return MML_ERR_INVALID;
-    MML_REQUIRE(lanes >= 1 && lanes <= mml_ctx::MAX_LANES, MML_ERR_INVALID, "lanes must be in [1, 4]");
+    MML_REQUIRE(lanes >= 1 && lanes <= mml_ctx::MAX_LANES, MML_ERR_INVALID, "lanes must be in [1, 8]");
     int rc = mml_sync_all(ctx);
     if (rc != MML_OK) return rc;
     ctx->n_lanes = lanes;

@@ -54,8 +54,8 @@ struct mml_ctx {
     int device = 0;
     // `lanes`: independent HIP streams.  Entry points enqueue on lane `cur` (0 unless mml_step is pipelining
     // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.
-    static constexpr int MAX_LANES = 4;
-    hipStream_t streams[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int MAX_LANES = 8;
+    hipStream_t streams[MAX_LANES] = {};
     int n_lanes = 1;
     int cur = 0;
     bool lanes_enabled = true;

@@ -94,15 +94,16 @@ __device__ __forceinline__ double rsqrt_nr(double z) {
     y = y * (1.5 - (0.5 * z) * (y * y));
     return y;
 }
-// distance from v to the nearest float rounding boundary around (float)v; small => the float result is not safe
-__device__ __forceinline__ double round_margin(double v) {
-    const float f = (float)v;
-    const float fa = fabsf(f);
-    const int bi = __float_as_int(fa);
-    const double up = 0.5 * ((double)__int_as_float(bi + 1) - (double)fa);
-    const double dn = bi > 0 ? 0.5 * ((double)fa - (double)__int_as_float(bi - 1)) : up;
-    const double r = fabs(v) - (double)fa;
-    return r >= 0.0 ? up - r : dn + r;
+// Is the double v farther than tol from every float rounding boundary (the midpoints between adjacent floats)?  A float
+// keeps the top 23 of the 52 mantissa bits; the midpoint of v's float cell is the low 29 bits == 2^28, so the distance
+// is |low29 - 2^28| units of 2^(e-52), read straight from the bit pattern.  Values below the normal float range are
+// never declared safe.
+__device__ __forceinline__ bool float_round_safe(double v, double tol) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const int ef = (int)((hi >> 20) & 0x7ffu);
+    const int d = abs((int)(lo & 0x1fffffffu) - 0x10000000);
+    const double unit = __hiloint2double((ef - 52) << 20, 0);
+    return (ef >= 1023 - 126) && ((double)d * unit > tol);
 }
 
 // The per-point arithmetic of RemoveLidarDistortion in double, written exactly as the reference (slerp with two
@@ -154,22 +155,56 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int*
     const float s = fu_rel[(size_t)b * NT + i];
     const double t = s;
     const double qx = dv[0], qy = dv[1], qz = dv[2], qw = dv[3];
-    double scale0, scale1;
-    if (dv[7] != 0.0) {
-        scale0 = 1.0 - t;
-        scale1 = t;
+    double ax, ay, az, aw;
+    const double theta = dv[4];
+    if (dv[7] == 0.0 && theta < 0.5) {
+        // slerp(Identity, q, t) of a unit quaternion q = (sin(theta) n, +-cos(theta)) is (+-sin(t theta) n, cos(t theta)),
+        // already of unit length: the two sines, the divisions and the normalisation of the reference expression
+        // collapse to one sine / cosine of a small angle (theta = half the rotation over one sweep), evaluated here by
+        // their Taylor polynomials (truncation < 1e-18 for theta < 0.5).  Like the other fast forms the result is
+        // only trusted away from float rounding boundaries (below).
+        const double x = t * theta, z = x * x;
+        double ps = -1.0 / 1307674368000.0;
+        ps = __builtin_fma(ps, z, 1.0 / 6227020800.0);
+        ps = __builtin_fma(ps, z, -1.0 / 39916800.0);
+        ps = __builtin_fma(ps, z, 1.0 / 362880.0);
+        ps = __builtin_fma(ps, z, -1.0 / 5040.0);
+        ps = __builtin_fma(ps, z, 1.0 / 120.0);
+        ps = __builtin_fma(ps, z, -1.0 / 6.0);
+        const double sn = __builtin_fma(x * z, ps, x);
+        double pc = -1.0 / 87178291200.0;
+        pc = __builtin_fma(pc, z, 1.0 / 479001600.0);
+        pc = __builtin_fma(pc, z, -1.0 / 3628800.0);
+        pc = __builtin_fma(pc, z, 1.0 / 40320.0);
+        pc = __builtin_fma(pc, z, -1.0 / 720.0);
+        pc = __builtin_fma(pc, z, 1.0 / 24.0);
+        pc = __builtin_fma(pc, z, -0.5);
+        aw = __builtin_fma(z, pc, 1.0);
+        const double k = (qw < 0.0 ? -dv[6] : dv[6]) * sn;
+        ax = k * qx;
+        ay = k * qy;
+        az = k * qz;
     } else {
-        const double theta = dv[4], inv = dv[6];
-        scale0 = sin((1.0 - t) * theta) * inv;
-        scale1 = sin((t * theta)) * inv;
+        double scale0, scale1;
+        if (dv[7] != 0.0) {
+            scale0 = 1.0 - t;
+            scale1 = t;
+        } else {
+            const double inv = dv[6];
+            scale0 = sin((1.0 - t) * theta) * inv;
+            scale1 = sin((t * theta)) * inv;
+        }
+        if (qw < 0.0) scale1 = -scale1;
+        ax = scale1 * qx;
+        ay = scale1 * qy;
+        az = scale1 * qz;
+        aw = scale0 + scale1 * qw;
+        const double inv_n = rsqrt_nr((ax * ax + az * az) + (ay * ay + aw * aw));
+        ax *= inv_n;
+        ay *= inv_n;
+        az *= inv_n;
+        aw *= inv_n;
     }
-    if (qw < 0.0) scale1 = -scale1;
-    double ax = scale1 * qx, ay = scale1 * qy, az = scale1 * qz, aw = scale0 + scale1 * qw;
-    const double inv_n = rsqrt_nr((ax * ax + az * az) + (ay * ay + aw * aw));
-    ax *= inv_n;
-    ay *= inv_n;
-    az *= inv_n;
-    aw *= inv_n;
     const double vx = p.x, vy = p.y, vz = p.z;
     double ux = ay * vz - az * vy, uy = az * vx - ax * vz, uz = ax * vy - ay * vx;
     ux += ux;
@@ -183,7 +218,7 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int*
     const double oy = (dR[1] * wx + dR[4] * wy) + dR[7] * wz;
     const double oz = (dR[2] * wx + dR[5] * wy) + dR[8] * wz;
     const double tol = 1e-11 * (((fabs(vx) + fabs(vy)) + fabs(vz)) + ((fabs(dt[0]) + fabs(dt[1])) + fabs(dt[2])) + 1e-30);
-    if (round_margin(ox) > tol && round_margin(oy) > tol && round_margin(oz) > tol) {
+    if (float_round_safe(ox, tol) & float_round_safe(oy, tol) & float_round_safe(oz, tol)) {
         p.x = ox;
         p.y = oy;
         p.z = oz;
