@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--window-demo", action="store_true", help="run the joint window solve section on one GPU as well")
     ap.add_argument("--kernel-steps", type=int, default=4, help="single-stream steps after the timed region (per-kernel timing)")
     ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
+    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the scan-parallel CPU leg (-1: all cores up to 64, 0: skip)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans cycled through the batch")
     ap.add_argument("--cell-corner", type=float, default=0.0, help="kNN grid cell edge for the corner map (0: library default)")
     ap.add_argument("--cell-surf", type=float, default=0.0, help="kNN grid cell edge for the surf map (0: library default)")
@@ -260,7 +261,7 @@ def main():
         t1 = time.perf_counter()
         xs = cpu_scan(0)
         one = time.perf_counter() - t1
-        n_cpu = args.cpu_scans if args.cpu_scans > 0 else int(max(8, min(512, 12.0 / max(one, 1e-3))))
+        n_cpu = args.cpu_scans if args.cpu_scans > 0 else int(max(8, min(2048, 15.0 / max(one, 1e-3))))
         t1 = time.perf_counter()
         for k in range(n_cpu):
             xs = cpu_scan(k)
@@ -269,6 +270,17 @@ def main():
                "sample": "%d fused 52.8k-pt scans (cycled over %d distinct), same map / poses / 10 fixed iterations, "
                          "single thread of %d host cores, kd-tree build excluded" % (n_cpu, nd, os.cpu_count()),
                "pose_diff_vs_gpu": float(np.abs(xs[0] - x[(n_cpu - 1) % B]).max())}
+        # the same port with one scan per host thread (the C++ calls release the GIL): an upper bound for what the
+        # reference's 6-thread layout (unionFeatureExtract.cpp:1008-1015, Estimator.cpp:1271-1297,1430) could reach here
+        if args.cpu_threads != 0:
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64)
+            n_mt = int(max(2 * nthr, min(4096, 10.0 * nthr / max(one, 1e-3))))
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(cpu_scan, range(n_mt)))
+            mt_t = time.perf_counter() - t1
+            cpu["all_threads"] = {"value": n_mt / mt_t, "unit": "scans/s", "cores": nthr, "sample": "%d scans, one scan per thread" % n_mt}
 
     if rank == 0:
         out = {
