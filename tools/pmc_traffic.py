@@ -17,7 +17,8 @@ STAGE = {"k_assign_init": "assign", "k_assign_a": "assign", "k_assign_b": "assig
 
 def per_kernel(path, counter):
     d = pd.read_csv(path)
-    d["k"] = d["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+    d["k"] = (d["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace("void ", "", regex=False)
+              .str.split("(").str[0].str.split("<").str[0])
     d = d[d.Counter_Name == counter]
     mx = d.groupby("k")["Grid_Size"].transform("max")
     return d[d.Grid_Size == mx].groupby("k")["Counter_Value"].mean()
