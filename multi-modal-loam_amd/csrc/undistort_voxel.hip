@@ -248,8 +248,79 @@ __device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float
     return r;
 }
 
+// Bitonic sort of npad = KPT * VX_THREADS keys, ascending, element e = tid + VX_THREADS * k held by thread tid in
+// key[k].  The partner of element e at distance j is e ^ j: for j >= VX_THREADS that is another register of the same
+// thread, for j < 64 another lane of the same wavefront (two 32-bit shuffles), and only the four distances in between
+// go through LDS -- 22 barrier-separated exchanges for 8192 keys instead of 91.
+template <int KPT, int DK>
+__device__ __forceinline__ void bitonic_reg_step(unsigned long long (&key)[KPT], int k, int tid) {
+    if constexpr (DK < KPT) {
+#pragma unroll
+        for (int a = 0; a < KPT; ++a) {
+            constexpr int dk = DK;
+            const int c = a ^ dk;
+            if (c > a) {
+                const bool up = ((tid + VX_THREADS * a) & k) == 0;
+                const unsigned long long x = key[a], y = key[c];
+                const bool sw = (x > y) == up;
+                key[a] = sw ? y : x;
+                key[c] = sw ? x : y;
+            }
+        }
+    }
+}
+template <int KPT>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT], unsigned long long* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int NP = KPT * VX_THREADS;
+#pragma unroll 1
+    for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= VX_THREADS) {
+                const int dk = j / VX_THREADS;  // 1, 2 or 4: register distance (compile-time in each branch)
+                if (dk == 1)
+                    bitonic_reg_step<KPT, 1>(key, k, tid);
+                else if (dk == 2)
+                    bitonic_reg_step<KPT, 2>(key, k, tid);
+                else
+                    bitonic_reg_step<KPT, 4>(key, k, tid);
+            } else if (j < 64) {
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) {
+                    const unsigned long long x = key[a];
+                    const unsigned lo = __shfl_xor((unsigned)x, j), hi = __shfl_xor((unsigned)(x >> 32), j);
+                    const unsigned long long y = ((unsigned long long)hi << 32) | lo;
+                    const bool up = ((tid + VX_THREADS * a) & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const unsigned long long mn = x < y ? x : y, mx = x < y ? y : x;
+                    key[a] = (lower == up) ? mn : mx;
+                }
+            } else {
+                __syncthreads();  // the previous LDS round has been read
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) lds[tid + VX_THREADS * a] = key[a];
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) {
+                    const int e = tid + VX_THREADS * a;
+                    const unsigned long long x = key[a], y = lds[e ^ j];
+                    const bool up = (e & k) == 0;
+                    const bool lower = (e & j) == 0;
+                    const unsigned long long mn = x < y ? x : y, mx = x < y ? y : x;
+                    key[a] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < KPT; ++a) lds[tid + VX_THREADS * a] = key[a];
+    __syncthreads();
+}
+
 // One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
-__global__ __launch_bounds__(VX_THREADS) void k_voxel(int first, int NT, int MF, int B, int cap, const int* fu_info,
+__global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int MF, int B, int cap, const int* fu_info,
                                                      const float4* fu_xyzi, const uint8_t* fu_label,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
@@ -306,38 +377,35 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int first, int NT, int MF,
         div_b[c] = max_b - min_b[c] + 1;
     }
     const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
-    // pad to a power of two for the bitonic network
-    int npad = 1;
-    while (npad < cnt) npad <<= 1;
-    for (int s = tid; s < npad; s += VX_THREADS) {
-        unsigned long long key = ~0ull;
-        if (s < cnt) {
-            float4 p = px[seq2idx[s]];
-            int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
-            int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
-            int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
-            int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
-            key = ((unsigned long long)(unsigned)idx << 32) | (unsigned)s;
-        }
-        keys[s] = key;
-    }
-    __syncthreads();
+    // keys (voxel idx, sequence) of my elements e = tid + VX_THREADS * k; padding sorts to the end
+    auto make_key = [&](int sidx) -> unsigned long long {
+        if (sidx >= cnt) return ~0ull;
+        const float4 p = px[seq2idx[sidx]];
+        const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
+        const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
+        const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
+        const int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
+        return ((unsigned long long)(unsigned)idx << 32) | (unsigned)sidx;
+    };
     // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < npad; t += VX_THREADS) {
-                int ixj = t ^ j;
-                if (ixj > t) {
-                    unsigned long long a = keys[t], c = keys[ixj];
-                    bool up = (t & k) == 0;
-                    if ((a > c) == up) {
-                        keys[t] = c;
-                        keys[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    if (cnt <= VX_THREADS) {
+        unsigned long long k1[1] = {make_key(tid)};
+        bitonic_sort_regs<1>(k1, keys);
+    } else if (cnt <= 2 * VX_THREADS) {
+        unsigned long long k2[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) k2[a] = make_key(tid + VX_THREADS * a);
+        bitonic_sort_regs<2>(k2, keys);
+    } else if (cnt <= 4 * VX_THREADS) {
+        unsigned long long k4[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) k4[a] = make_key(tid + VX_THREADS * a);
+        bitonic_sort_regs<4>(k4, keys);
+    } else {
+        unsigned long long k8[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) k8[a] = make_key(tid + VX_THREADS * a);
+        bitonic_sort_regs<8>(k8, keys);
     }
     // 4. one lane per voxel head: centroid in input order (AccumulatorXYZ: float sum, then / n)
     if (tid == 0) {
