@@ -65,8 +65,8 @@ void mml_destroy(mml_ctx* ctx) {
         if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
-                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux,  ctx->cb_xyzi,  ctx->cb_rel,   ctx->cb_line,
-                    ctx->cb_label, ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
+                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux,
+                    ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
@@ -150,14 +150,10 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->sel_scratch, 4 * B * NT + 16 * B * (L + 2) + 64);
     {
         const size_t nblk = ((NV > NL ? NV : NL) + 255) / 256;
-        ALLOC(ctx->blk_cnt, B * 2 * nblk * 161);
+        ALLOC(ctx->blk_cnt, B * 2 * nblk * 162);
     }
     ALLOC(ctx->assign_aux, B * 8);
     ALLOC(ctx->crop_cnt, B * ((NT + 255) / 256) * 8);
-    ALLOC(ctx->cb_xyzi, B * NT);
-    ALLOC(ctx->cb_rel, B * NT);
-    ALLOC(ctx->cb_line, B * NT);
-    ALLOC(ctx->cb_label, B * NT);
     ALLOC(ctx->cb_n, B * 2);
     ALLOC(ctx->fu_xyzi, B * NT);
     ALLOC(ctx->fu_rel, B * NT);
@@ -324,7 +320,7 @@ int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sh
     if (rc != MML_OK) return rc;
     std::vector<uint8_t> lab(n);
     std::vector<uint16_t> fin(n);
-    MML_HIP(hipMemcpyAsync(lab.data(), ctx->cb_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(lab.data(), ctx->fu_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipMemcpyAsync(fin.data(), d_final, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     int ns = 0, nf = 0;

@@ -54,7 +54,7 @@ struct FeatParams {
     float* ln_curv;
     float* ln_refl;
     uint16_t* ln_attr;
-    int* blk_cnt;        // [B][2][nblk_max][MAX_LINES + 1] per-block histograms / exclusive offsets
+    int* blk_cnt;        // [B][2][nblk_max][BLK_STRIDE] per-block histograms / exclusive offsets
     int* assign_aux;     // AssignAux per slot
     int nblk_v, nblk_l, nblk_max, ring_bits, line_bits;
     CropBlk* crop_cnt;   // [B][nblk_t] per-block counts / exclusive offsets of the crop passes
@@ -64,10 +64,6 @@ struct FeatParams {
     int sel_cap;            // points per line k_select keeps in LDS
     int B;
     uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
-    float4* cb_xyzi;
-    float* cb_rel;
-    uint8_t* cb_line;
-    uint8_t* cb_label;
     int* cb_n;
     float4* fu_xyzi;
     float* fu_rel;
@@ -96,6 +92,7 @@ __device__ __forceinline__ void dnormalize(D3& a) {
 constexpr int ASSIGN_THREADS = 1024;
 constexpr int ASSIGN_WAVES = ASSIGN_THREADS / MML_WAVE;
 constexpr int MAX_LINES = 160;  // n_rings + n_livox_lines upper bound
+constexpr int BLK_STRIDE = MAX_LINES + 2;  // per-block record: key histogram | valid points | points kept by the crop
 
 // ---- a1 / a2: ring / line assignment + order-preserving bucketing, three fully parallel passes ------------------
 //   pass A (one point per lane) : validity, ring / line id, raw azimuth; per-256-point-block histograms
@@ -118,10 +115,17 @@ __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int
 }
 
 struct AssignAux {  // per slot, written by passes A / B
-    int first_finite, last_finite, trig, pad;
+    int first_finite, last_finite, trig, kept_velo;
     float startOri, endOri;
-    int pad2[2];
+    int kept_livox, pad;
 };
+// lidars_extrinsic_cali.h:424-477: removeNearFarPoints keeps near <= |p|^2 <= far, removeNearPointCloud only tests near
+__device__ __forceinline__ void crop_test(const FeatParams& P, float x, float y, float z, bool& keep, bool& near_ok) {
+    const float near2 = P.near_th * P.near_th, far2 = P.far_th * P.far_th;
+    const float dis = x * x + y * y + z * z;
+    keep = !(dis < near2 || dis > far2);
+    near_ok = !(dis < near2);
+}
 
 __global__ void k_assign_init(FeatParams P, int count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,6 +134,9 @@ __global__ void k_assign_init(FeatParams P, int count) {
         a->first_finite = 0x7fffffff;
         a->last_finite = -1;
         a->trig = 0x7fffffff;
+        int* info = P.fu_info + 8 * (P.first + t);
+        info[4] = 0;  // livox corner / surf: k_select adds the labelled points beyond far_th, k_crop_b the kept ones
+        info[5] = 0;
     }
 }
 
@@ -151,7 +158,7 @@ __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pit
 
 __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __shared__ int s_bcnt[MAX_LINES];
-    __shared__ int s_valid;
+    __shared__ int s_valid, s_keep;
     const int b = blockIdx.y + P.first;
     const int sensor = blockIdx.z;  // 0 velodyne, 1 livox
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,9 +169,12 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
     for (int k = tid; k < nkeys; k += AB_THREADS) s_bcnt[k] = 0;
-    if (tid == 0) s_valid = 0;
+    if (tid == 0) {
+        s_valid = 0;
+        s_keep = 0;
+    }
     __syncthreads();
-    bool valid = false;
+    bool valid = false, keep = false, near_ok = false;
     int key = 0;
     if (i < n) {
         if (sensor == 0) {
@@ -181,28 +191,34 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
             P.raw_ori[(size_t)b * P.NV + i] = ori;
             valid = ring < 254;
             key = valid ? ring : 0;
+            if (valid) crop_test(P, p.x, p.y, p.z, keep, near_ok);
         } else {
             const mml_livox_point p = P.livox_in[(size_t)b * P.NL + i];
             const int line_num = (int)p.line;
             valid = !(line_num > nkeys - 1) && !(p.x < 0.01);
             key = valid ? line_num : 0;
             P.raw_line[(size_t)b * P.NT + P.NV + i] = (uint8_t)(valid ? line_num : 255);
+            if (valid) crop_test(P, p.x, p.y, p.z, keep, near_ok);
         }
     }
     const unsigned long long eq = match_key(valid, key, nbits);
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (valid && (eq & lt) == 0) atomicAdd(&s_bcnt[key], __popcll(eq));  // first lane of each key group
-    const unsigned long long vm = __ballot(valid);
+    const unsigned long long vm = __ballot(valid), km = __ballot(keep);
     if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
+    if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
     __syncthreads();
-    int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * (MAX_LINES + 1);
+    int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
     for (int k = tid; k < nkeys; k += AB_THREADS) cnt[k] = s_bcnt[k];
-    if (tid == 0) cnt[MAX_LINES] = s_valid;
+    if (tid == 0) {
+        cnt[MAX_LINES] = s_valid;
+        cnt[MAX_LINES + 1] = s_keep;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
     __shared__ int s_trig, s_first, s_last;
-    __shared__ int s_tot[MAX_LINES];
+    __shared__ int s_tot[MAX_LINES + 2];
     const int b = blockIdx.x + P.first;
     const int sensor = blockIdx.y;
     const int tid = threadIdx.x;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
     const int nblk = (n + AB_THREADS - 1) / AB_THREADS;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
-    int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * (MAX_LINES + 1);
+    int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * BLK_STRIDE;
     if (tid == 0) {
         s_trig = 0x7fffffff;
         s_first = 0x7fffffff;
@@ -220,12 +236,12 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
     // exclusive scan over blocks: one wavefront per key (+ one for the valid-point count), 64 blocks per step
     {
         const int lane = tid & 63;
-        for (int kk = tid >> 6; kk <= nkeys; kk += 1024 / 64) {
-            const int k = kk < nkeys ? kk : MAX_LINES;
+        for (int kk = tid >> 6; kk <= nkeys + 1; kk += 1024 / 64) {
+            const int k = kk < nkeys ? kk : MAX_LINES + (kk - nkeys);
             int acc = 0;
             for (int b0 = 0; b0 < nblk; b0 += 64) {
                 const int blk = b0 + lane;
-                int* c = cnt0 + (size_t)(blk < nblk ? blk : 0) * (MAX_LINES + 1) + k;
+                int* c = cnt0 + (size_t)(blk < nblk ? blk : 0) * BLK_STRIDE + k;
                 const int v = blk < nblk ? *c : 0;
                 int x = v;
                 for (int o = 1; o < 64; o <<= 1) {
@@ -308,6 +324,10 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
             acc += s_tot[r];
         }
         P.cb_n[2 * b + sensor] = s_tot[nkeys];
+        if (sensor == 0)
+            a->kept_velo = s_tot[nkeys + 1];
+        else
+            a->kept_livox = s_tot[nkeys + 1];
     }
 }
 
@@ -335,28 +355,49 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     if (i < n) key = P.raw_line[(size_t)b * P.NT + region + i];
     const bool valid = key < 254;
     if (!valid) key = 0;
+    // the crop decision is geometric (lidars_extrinsic_cali.h:424-477), so the position of a point in the fused cloud
+    // [velo kept ; livox kept] is known before any label is: the point goes straight there
+    bool keep = false, near_ok = false;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 praw = out;
+    uint32_t off_time = 0;
+    if (valid) {
+        if (sensor == 0) {
+            praw = P.velo_in[(size_t)b * P.NV + i];
+            out = make_float4(praw.x, praw.y, praw.z, 0.f);  // intensity zeroed, :1254-1256
+        } else {
+            const mml_livox_point q = P.livox_in[(size_t)b * P.NL + i];
+            out = make_float4(q.x, q.y, q.z, (float)q.reflectivity);
+            praw = out;
+            off_time = q.offset_time;
+        }
+        crop_test(P, out.x, out.y, out.z, keep, near_ok);
+    }
     const unsigned long long eq = match_key(valid, key, nbits);
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long vm = __ballot(valid);
+    const unsigned long long km = __ballot(keep);
     if (valid && (eq & lt) == 0) s_wcnt[wave][key] = __popcll(eq);
-    if (lane == 0) s_wvalid[wave] = __popcll(vm);
+    if (lane == 0) s_wvalid[wave] = __popcll(km);
     __syncthreads();
     if (!valid) return;
-    const int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * (MAX_LINES + 1);
+    const int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
+    const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
     int pos = cnt[key] + __popcll(eq & lt);
-    int gidx = cnt[MAX_LINES] + __popcll(vm & lt);
+    int fdst = (sensor == 0 ? 0 : a->kept_velo) + cnt[MAX_LINES + 1] + __popcll(km & lt);
     for (int w = 0; w < wave; ++w) {
         pos += s_wcnt[w][key];
-        gidx += s_wvalid[w];
+        fdst += s_wvalid[w];
     }
     const int line = (sensor == 0 ? 0 : P.n_rings) + key;
     const int dst = P.line_start[(size_t)b * P.L + line] + pos;
-    float4 out;
+    P.ln_pts[(size_t)b * P.NT + dst] = praw;
+    // where the label of this point goes: its fused index, or -2 for a Livox point that only fails the far test (its
+    // label still counts towards livox_corner_num / livox_surf_num, :925-940), or -1
+    P.ln_gidx[(size_t)b * P.NT + dst] = keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1);
+    if (!keep) return;
     float rel;
     if (sensor == 0) {
-        const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
         const float startOri = a->startOri, endOri = a->endOri;
-        const float4 p = P.velo_in[(size_t)b * P.NV + i];
         float ori = P.raw_ori[(size_t)b * P.NV + i];
         if (i <= a->trig) {  // :1169-1177
             if (ori < startOri - M_PI / 2)
@@ -371,23 +412,16 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
                 ori -= 2 * M_PI;
         }
         rel = (ori - startOri) / (endOri - startOri);  // :1186
-        P.ln_pts[(size_t)b * P.NT + dst] = p;
-        out = make_float4(p.x, p.y, p.z, 0.f);  // intensity zeroed, :1254-1256
     } else {
         const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
-        const mml_livox_point p = in[i];
         const double timeSpan = livox_to_sec(in[n - 1].offset_time);  // :985
-        const float inten = p.reflectivity;
-        rel = livox_to_sec(p.offset_time) / timeSpan;  // :995
-        out = make_float4(p.x, p.y, p.z, inten);
-        P.ln_pts[(size_t)b * P.NT + dst] = out;
+        rel = livox_to_sec(off_time) / timeSpan;                       // :995
     }
-    const size_t g = (size_t)b * P.NT + region + gidx;
-    P.ln_gidx[(size_t)b * P.NT + dst] = region + gidx;
-    P.cb_xyzi[g] = out;
-    P.cb_rel[g] = rel;
-    P.cb_line[g] = (uint8_t)key;
-    P.cb_label[g] = 0;
+    const size_t g = (size_t)b * P.NT + fdst;
+    P.fu_xyzi[g] = out;
+    P.fu_rel[g] = rel;
+    P.fu_line[g] = (uint8_t)key;
+    P.fu_label[g] = 0;
 }
 
 // locate the scan line that owns bucketed position p of slot b
@@ -829,7 +863,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
                                             U64P wvis, ByteP wexit, ByteP wsel, int* s_sp,
                                             unsigned long long (*s_pm)[3], unsigned long long* s_minE,
                                             unsigned long long* s_minG, unsigned char* s_bfirst,
-                                            unsigned char* s_list, int* s_cnt) {
+                                            unsigned char* s_list, int* s_cnt, int* s_flag) {
     constexpr bool CACHED = K > 0;
     constexpr int KK = CACHED ? K : 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -889,6 +923,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         s_minG[t] = ~0ull;
     }
     if (tid == 0) *s_cnt = 0;
+    if (tid < 3) s_flag[tid] = 0;
     __syncthreads();
 
     SEL_MARK(1);
@@ -948,6 +983,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             if (i < n && st_of(W[2 * i + 1]) == ST_U) pend |= 1u << k;
         }
     }
+    int rnd = 0;
     for (;;) {
         int undecided = 0;
         FOR_POINTS(
@@ -977,7 +1013,14 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 #ifdef MML_SEL_TIMING
         if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[20] += 1;
 #endif
-        if (!__syncthreads_or(undecided)) break;
+        // one barrier per round: any wavefront with an undecided point raises the round's flag (three slots, the one
+        // two rounds ahead is cleared after the barrier, when nobody reads or writes it)
+        if (__any(undecided) && lane == 0) s_flag[rnd % 3] = 1;
+        __syncthreads();
+        const int again = s_flag[rnd % 3];
+        if (tid == 0) s_flag[(rnd + 2) % 3] = 0;
+        ++rnd;
+        if (!again) break;
     }
 
     SEL_MARK(4);
@@ -1147,7 +1190,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 
     SEL_MARK(10);
     // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
-    uint8_t* cblab = P.cb_label + (size_t)b * P.NT;
+    uint8_t* fulab = P.fu_label + (size_t)b * P.NT;
     FOR_POINTS(
         const unsigned me = W[2 * i + 1];
         const unsigned at = ATTR(i, k);
@@ -1178,11 +1221,14 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         }
         if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
         if (inner && !(at & A_NEAR)) {
-            const int gi = CACHED ? r_gidx[k] : gidx[i];
-            if (f == 2)
-                cblab[gi] = 2;
-            else if (f == 100 || f == 150)
-                cblab[gi] = 1;
+            const int lab = (f == 2) ? 2 : ((f == 100 || f == 150) ? 1 : 0);
+            if (lab) {
+                const int gi = CACHED ? r_gidx[k] : gidx[i];
+                if (gi >= 0)
+                    fulab[gi] = (uint8_t)lab;
+                else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940
+                    atomicAdd(&P.fu_info[8 * b + 3 + lab], 1);
+            }
         }
     )
     SEL_MARK(11);
@@ -1203,6 +1249,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     __shared__ int s_sp[52];
     __shared__ unsigned char s_list[152];
     __shared__ int s_cnt;
+    __shared__ int s_flag[3];
     const int b = blockIdx.y + P.first;
     const int line = blockIdx.x;
     const int n = P.line_len[(size_t)b * P.L + line];
@@ -1218,7 +1265,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
         unsigned long long* wvis = wmask + nwin;
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);
         unsigned char* wsel = wexit + 4 * nwin;
-        select_body<K>(P, b, n, base, W, R, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt);
+        select_body<K>(P, b, n, base, W, R, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag);
     } else {
         // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
         const size_t BNT = (size_t)P.B * P.NT;
@@ -1232,7 +1279,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * (size_t)nwin);
         unsigned char* wsel = wexit + 4 * (size_t)nwin;
         select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE,
-                       s_minG, s_bfirst, s_list, &s_cnt);
+                       s_minG, s_bfirst, s_list, &s_cnt, s_flag);
     }
 }
 
@@ -1257,153 +1304,111 @@ static int select_round_cap(int want) {
 }
 
 // ---- a8: removeNearFarPoints / removeNearPointCloud + compaction into the fused cloud ---------------------------
-// Three parallel passes like the bucketing: per-block counts, one scan per slot, scatter.  Besides the fused cloud
-// the scatter also emits the index lists of the corner- and surf-labelled points (the label split of
-// Estimator.cpp:992-1011), so the voxel down-sampler does not have to re-scan the whole cloud.
-struct CropBlk {
-    int keep, kc, ks, lc_near, ls_near, keep_velo, pad0, pad1;
-};
-
-__device__ __forceinline__ void crop_classify(const FeatParams& P, int b, int p, bool& keep, int& lab, bool& isv,
-                                              bool& near_ok, float4& pt) {
-    keep = false;
-    lab = 0;
-    near_ok = false;
-    isv = p < P.NV;
-    const int nv = P.cb_n[2 * b], nl = P.cb_n[2 * b + 1];
-    const bool valid = isv ? (p < nv) : (p - P.NV < nl);
-    if (!valid) return;
-    pt = P.cb_xyzi[(size_t)b * P.NT + p];
-    lab = P.cb_label[(size_t)b * P.NT + p];
-    const float near2 = P.near_th * P.near_th, far2 = P.far_th * P.far_th;
-    const float dis = pt.x * pt.x + pt.y * pt.y + pt.z * pt.z;
-    keep = !(dis < near2 || dis > far2);          // lidars_extrinsic_cali.h:451-477
-    near_ok = !(dis < near2);                      // lidars_extrinsic_cali.h:424-449
-}
-
-__global__ __launch_bounds__(256) void k_crop_a(FeatParams P) {
-    __shared__ int s_c[6];
-    const int b = blockIdx.y + P.first;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 6) s_c[threadIdx.x] = 0;
-    __syncthreads();
-    bool keep = false, isv = true, near_ok = false;
-    int lab = 0;
-    float4 pt;
-    if (p < P.NT) crop_classify(P, b, p, keep, lab, isv, near_ok, pt);
-    const bool c[6] = {keep, keep && lab == 1, keep && lab == 2, !isv && near_ok && lab == 1, !isv && near_ok && lab == 2,
-                       keep && isv};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const unsigned long long m = __ballot(c[k]);
-        if (lane == 0 && m) atomicAdd(&s_c[k], __popcll(m));
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) reinterpret_cast<int*>(P.crop_cnt + ((size_t)b * P.nblk_t + blockIdx.x))[threadIdx.x] = s_c[threadIdx.x];
-}
-
-__global__ __launch_bounds__(64) void k_crop_b(FeatParams P) {
+// The crop is geometric, so k_assign_c has already written every kept point to its place in the fused cloud and
+// k_select has written the labels there.  What is left: the label counts of union_cloud.msg, the index lists of the
+// corner- and surf-labelled points (the label split of Estimator.cpp:992-1011, consumed by the voxel down-sampler) and
+// the Livox extrinsic, which the reference applies only once livox_corner_num is known (:302-318).
+// One workgroup per slot: labels are 1 byte per fused point, so a whole scan is a few tens of KB -- counting, the scan of
+// the counts and the emission of the two index lists fit one launch (two sweeps over the label bytes).
+constexpr int CROP_THREADS = 1024;
+__global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap) {
+    __shared__ int s_w[CROP_THREADS / 64][4];
+    __shared__ int s_tot[4];
     const int b = blockIdx.x + P.first;
-    const int lane = threadIdx.x;
-    CropBlk* cb = P.crop_cnt + (size_t)b * P.nblk_t;
-    int tot[6] = {0, 0, 0, 0, 0, 0};
-    // wave-wide exclusive scan over the blocks, 64 at a time
-    for (int b0 = 0; b0 < P.nblk_t; b0 += 64) {
-        const int blk = b0 + lane;
-        int v[6];
-        const int* src = reinterpret_cast<const int*>(cb + (blk < P.nblk_t ? blk : 0));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
+    const int nv = a->kept_velo, n = nv + a->kept_livox;
+    const size_t o = (size_t)b * P.NT;
+    const uint8_t* lab = P.fu_label + o;
+    // consecutive chunk of whole 4-byte words per thread
+    const int words = (n + 3) / 4;
+    const int per = (words + CROP_THREADS - 1) / CROP_THREADS;
+    const int w0 = tid * per, w1 = min(words, w0 + per);
+    int c[4] = {0, 0, 0, 0};  // corner, surf, velo corner, velo surf
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lab);
+    for (int w = w0; w < w1; ++w) {
+        const uint32_t v = lw[w];
+        if (v == 0) continue;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = blk < P.nblk_t ? src[k] : 0;
-        int inc[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int x = v[k];
-            for (int o = 1; o < 64; o <<= 1) {
-                const int y = __shfl_up(x, o);
-                if (lane >= o) x += y;
+        for (int q = 0; q < 4; ++q) {
+            const int p = 4 * w + q;
+            const int l = (v >> (8 * q)) & 255u;
+            if (p < n && l) {
+                c[l == 1 ? 0 : 1] += 1;
+                if (p < nv) c[l == 1 ? 2 : 3] += 1;
             }
-            inc[k] = x;
         }
-        if (blk < P.nblk_t) {
-            int* dst = reinterpret_cast<int*>(cb + blk);
-            dst[0] = tot[0] + inc[0] - v[0];
-            dst[1] = tot[1] + inc[1] - v[1];
-            dst[2] = tot[2] + inc[2] - v[2];
-        }
+    }
+    // exclusive scan over threads (corner, surf) + totals (all four)
+    int inc[4];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) tot[k] += __shfl(inc[k], 63);
-    }
-    if (lane == 0) {
-        int* info = P.fu_info + 8 * b;
-        info[0] = tot[0];  // fused points
-        info[1] = tot[5];  // ... of which velodyne
-        // velo corner / surf after near+far crop (:1287-1300) = kept labelled points of the velodyne part: accumulated
-        // by pass C; livox corner / surf after near crop only (:925-940)
-        info[2] = 0;
-        info[3] = 0;
-        info[6] = tot[1];  // all kept corner-labelled points (label split, Estimator.cpp:995-999)
-        info[7] = tot[2];
-        info[4] = tot[3];
-        info[5] = tot[4];
-    }
-}
-
-// velo corner / surf counters need the velodyne-only share of kc / ks: counted in pass C of the velodyne blocks
-__global__ __launch_bounds__(256) void k_crop_c(FeatParams P, int cap) {
-    __shared__ int s_w[4][3];
-    __shared__ int s_velo[2];
-    const int b = blockIdx.y + P.first;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 2) s_velo[threadIdx.x] = 0;
-    bool keep = false, isv = true, near_ok = false;
-    int lab = 0;
-    float4 pt = make_float4(0, 0, 0, 0);
-    if (p < P.NT) crop_classify(P, b, p, keep, lab, isv, near_ok, pt);
-    const bool c1 = keep && lab == 1, c2 = keep && lab == 2;
-    const unsigned long long m0 = __ballot(keep), m1 = __ballot(c1), m2 = __ballot(c2);
-    if (lane == 0) {
-        s_w[wave][0] = __popcll(m0);
-        s_w[wave][1] = __popcll(m1);
-        s_w[wave][2] = __popcll(m2);
+    for (int k = 0; k < 4; ++k) {
+        int x = c[k];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        inc[k] = x;
+        if (lane == 63) s_w[wave][k] = x;
     }
     __syncthreads();
-    const unsigned long long mv1 = __ballot(c1 && isv), mv2 = __ballot(c2 && isv);
-    if (lane == 0) {
-        if (mv1) atomicAdd(&s_velo[0], __popcll(mv1));
-        if (mv2) atomicAdd(&s_velo[1], __popcll(mv2));
+    int base[2] = {0, 0};
+    for (int w = 0; w < wave; ++w) {
+        base[0] += s_w[w][0];
+        base[1] += s_w[w][1];
     }
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const CropBlk* cb = P.crop_cnt + (size_t)b * P.nblk_t + blockIdx.x;
-    if (keep) {
-        int dst = cb->keep + __popcll(m0 & lt);
-        int d1 = cb->kc + __popcll(m1 & lt), d2 = cb->ks + __popcll(m2 & lt);
-        for (int w = 0; w < wave; ++w) {
-            dst += s_w[w][0];
-            d1 += s_w[w][1];
-            d2 += s_w[w][2];
+    if (tid < 4) {
+        int t = 0;
+        for (int w = 0; w < CROP_THREADS / 64; ++w) t += s_w[w][tid];
+        s_tot[tid] = t;
+    }
+    __syncthreads();
+    int d1 = base[0] + inc[0] - c[0], d2 = base[1] + inc[1] - c[1];
+    if (c[0] | c[1]) {
+        for (int w = w0; w < w1; ++w) {
+            const uint32_t v = lw[w];
+            if (v == 0) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = 4 * w + q;
+                const int l = (v >> (8 * q)) & 255u;
+                if (p < n && l == 1) {
+                    if (d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)p;
+                    ++d1;
+                } else if (p < n && l == 2) {
+                    if (d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)p;
+                    ++d2;
+                }
+            }
         }
-        if (!isv && P.extr != nullptr && P.fu_info[8 * b + 4] > 100) {  // :302-318
-            // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float
-            const float* e = P.extr;
+    }
+    int* info = P.fu_info + 8 * b;
+    const int livox_corner = info[4] + s_tot[0] - s_tot[2];  // info[4/5] hold k_select's count of labelled points beyond far_th
+    __syncthreads();
+    if (tid == 0) {
+        info[0] = n;          // fused points
+        info[1] = nv;         // ... of which velodyne
+        info[2] = s_tot[2];   // velo corner / surf after near+far crop (:1287-1300)
+        info[3] = s_tot[3];
+        info[4] = livox_corner;                      // livox corner / surf after the near crop only (:925-940)
+        info[5] = info[5] + s_tot[1] - s_tot[3];
+        info[6] = s_tot[0];   // all kept corner- / surf-labelled points (label split, Estimator.cpp:995-1003)
+        info[7] = s_tot[1];
+    }
+    if (P.extr != nullptr && livox_corner > 100) {  // :302-318
+        // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float
+        const float* e = P.extr;
+        for (int p = nv + tid; p < n; p += CROP_THREADS) {
+            float4 pt = P.fu_xyzi[o + p];
             const float x = e[0] * pt.x + e[1] * pt.y + e[2] * pt.z + e[3];
             const float y = e[4] * pt.x + e[5] * pt.y + e[6] * pt.z + e[7];
             const float z = e[8] * pt.x + e[9] * pt.y + e[10] * pt.z + e[11];
             pt.x = x;
             pt.y = y;
             pt.z = z;
+            P.fu_xyzi[o + p] = pt;
         }
-        const size_t o = (size_t)b * P.NT;
-        P.fu_xyzi[o + dst] = pt;
-        P.fu_rel[o + dst] = P.cb_rel[o + p];
-        P.fu_line[o + dst] = P.cb_line[o + p];
-        P.fu_label[o + dst] = (uint8_t)lab;
-        if (c1 && d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)dst;
-        if (c2 && d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)dst;
     }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_velo[threadIdx.x]) atomicAdd(&P.fu_info[8 * b + 2 + threadIdx.x], s_velo[threadIdx.x]);
 }
 
 // single-line setup for mml_detect_line: slot 0 holds one line (ring 0) of n points already in ln_pts
@@ -1415,7 +1420,7 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
     }
     if (t < n) {
         P.ln_gidx[t] = t;
-        P.cb_label[t] = 0;
+        P.fu_label[t] = 0;
     }
     if (t == 0) {
         P.cb_n[0] = n;
@@ -1464,10 +1469,6 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.sel_cap = ctx->sel_cap;
     P.B = ctx->B;
     P.ln_final = nullptr;
-    P.cb_xyzi = ctx->cb_xyzi;
-    P.cb_rel = ctx->cb_rel;
-    P.cb_line = ctx->cb_line;
-    P.cb_label = ctx->cb_label;
     P.cb_n = ctx->cb_n;
     P.fu_xyzi = ctx->fu_xyzi;
     P.fu_rel = ctx->fu_rel;
@@ -1502,15 +1503,13 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "crop_compact");
-        hipLaunchKernelGGL(k_crop_a, dim3(P.nblk_t, count), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(k_crop_b, dim3(count), dim3(64), 0, s, P);
-        hipLaunchKernelGGL(k_crop_c, dim3(P.nblk_t, count), dim3(256), 0, s, P, ctx->VX_CAP);
+        hipLaunchKernelGGL(k_crop, dim3(count), dim3(CROP_THREADS), 0, s, P, ctx->VX_CAP);
     }
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
 
-// mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in cb_label[0..n) and ln_final.
+// mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in fu_label[0..n) and ln_final.
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     FeatParams P = make_params(ctx, 0);
     P.ln_final = d_final;

@@ -88,10 +88,6 @@ struct mml_ctx {
     int sel_cap = 0;
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
-    float4* cb_xyzi = nullptr;
-    float* cb_rel = nullptr;
-    uint8_t* cb_line = nullptr;
-    uint8_t* cb_label = nullptr;
     int* cb_n = nullptr;  // B * 2
 
     // fused cropped cloud

@@ -157,6 +157,47 @@ def test_extract_other_ring_layout(M, O, synth):
     c.close()
 
 
+def test_extract_livox_extrinsic_and_far_labels(M, O, synth):
+    """unionFeatureExtract.cpp:302-318: the Livox part is moved by the extrinsic (pcl::transformPointCloud, float)
+    only when livox_corner_num > 100; :925-940: that count includes labelled points beyond far_th, which are not
+    part of the fused cloud."""
+    fr_v, fr_l = synth.velo_scan(12), synth.livox_scan(12)
+    E = np.eye(4, dtype=np.float32)
+    E[:3, :3] = Rsc.from_rotvec([0.01, -0.02, 0.03]).as_matrix().astype(np.float32)
+    E[:3, 3] = [0.05, -0.11, 0.02]
+    small = synth.livox_scan(12, n=600)
+    for far, fr_l, expect_moved in ((50.0, fr_l, True), (6.0, fr_l, True), (50.0, small, False)):
+        c = M.Context(max_scans=1, far_th=far)
+        try:
+            c.scan_upload(0, fr_v, fr_l)
+            c.extract(0, 1)
+            plain = c.scan_download(0)
+            c.extract(0, 1, livox_extrinsic=E)
+            moved = c.scan_download(0)
+            info = moved["info"]
+            ev, el = O.extract_velo(fr_v, far=far), O.extract_livox(fr_l, far=far)
+            assert info.n_velo == len(ev["label"]) and info.n_points == len(ev["label"]) + len(el["label"])
+            assert np.array_equal(plain["label"], np.concatenate([ev["label"], el["label"]]))
+            assert info.velo_corner_num == int((ev["label"] == 1).sum()) and info.velo_surf_num == int((ev["label"] == 2).sum())
+            # labelled Livox points, near-cropped only: run the oracle without a far limit and keep the near test
+            el_all = O.extract_livox(fr_l, far=1e9)
+            assert info.livox_corner_num == int((el_all["label"] == 1).sum())
+            assert info.livox_surf_num == int((el_all["label"] == 2).sum())
+            if far < 50.0:
+                assert info.livox_corner_num > int((el["label"] == 1).sum())     # some labelled points lie beyond far_th
+            assert (info.livox_corner_num > 100) == expect_moved
+            nv = info.n_velo
+            assert np.array_equal(moved["xyzi"][:nv], plain["xyzi"][:nv]) and np.array_equal(moved["label"], plain["label"])
+            p = plain["xyzi"][nv:, :3]
+            if expect_moved:
+                want = np.stack([((E[r, 0] * p[:, 0] + E[r, 1] * p[:, 1]) + E[r, 2] * p[:, 2]) + E[r, 3] for r in range(3)], 1)
+                assert want.dtype == np.float32 and np.array_equal(moved["xyzi"][nv:, :3], want)
+            else:
+                assert np.array_equal(moved["xyzi"][nv:, :3], p)
+        finally:
+            c.close()
+
+
 def test_extract_is_deterministic(ctx, scene):
     fr = scene["frames"][0]
     outs = []
