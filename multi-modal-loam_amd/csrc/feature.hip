@@ -156,6 +156,50 @@ __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pit
     return (scanID > (R - 1) || scanID < 0) ? 255 : scanID;
 }
 
+// float(-atan2((double)y, (double)x)) of :1154.  Fast form: octant reduction + a degree-9 minimax polynomial in t^2
+// (|error| < 1e-15 over the reduced range; two divisions through v_rcp_f64 + Newton); accepted only when the double
+// lies farther than 1e-12 from a float rounding boundary, otherwise -- about one point in 1e5 -- libm atan2 decides.
+__device__ __forceinline__ double fast_div(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ float neg_atan2_f(float yf, float xf) {
+    const double x = xf, y = yf;
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    if (mx > 1e-300 && mx < 1e300) {
+        const double a = fast_div(mn, mx);
+        const bool big = a > 0.41421356237309503;
+        const double t = big ? fast_div(a - 1.0, a + 1.0) : a;
+        const double z = t * t;
+        double p = 2.25838847748916528e-02;
+        p = __builtin_fma(p, z, -4.46976301461388392e-02);
+        p = __builtin_fma(p, z, 5.73167296507084492e-02);
+        p = __builtin_fma(p, z, -6.64873778438867108e-02);
+        p = __builtin_fma(p, z, 7.69095714550778464e-02);
+        p = __builtin_fma(p, z, -9.09084591627817573e-02);
+        p = __builtin_fma(p, z, 1.11111093716489140e-01);
+        p = __builtin_fma(p, z, -1.42857142603585840e-01);
+        p = __builtin_fma(p, z, 1.99999999998416944e-01);
+        p = __builtin_fma(p, z, -3.33333333333330928e-01);
+        double r = (big ? 0.78539816339744831 : 0.0) + __builtin_fma(t * z, p, t);
+        if (ay > ax) r = 1.5707963267948966 - r;
+        if (x < 0.0) r = 3.141592653589793 - r;
+        if (y < 0.0) r = -r;
+        const double v = -r;
+        // float rounding boundary test on the bit pattern (see undistort_voxel.hip): low 29 mantissa bits vs 2^28
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const int ef = (int)((hi >> 20) & 0x7ffu);
+        const int d = abs((int)(lo & 0x1fffffffu) - 0x10000000);
+        const double unit = __hiloint2double((ef - 52) << 20, 0);
+        if (ef >= 1023 - 126 && (double)d * unit > 1e-12) return (float)v;
+    }
+    return (float)(-atan2(y, x));
+}
+
 __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __shared__ int s_bcnt[MAX_LINES];
     __shared__ int s_valid, s_keep;
@@ -185,7 +229,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
             if (fin) {
                 ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
                 if (ring == 255) ring = 254;
-                ori = -atan2((double)p.y, (double)p.x);
+                ori = neg_atan2_f(p.y, p.x);
             }
             P.raw_line[(size_t)b * P.NT + i] = (uint8_t)ring;
             P.raw_ori[(size_t)b * P.NV + i] = ori;
