@@ -531,6 +531,60 @@ def test_full_size_step_properties(M, O, scene, synth):
     c.close()
 
 
+def test_fused_step_equals_staged_path_with_motion(M, O, synth):
+    """mml_step pipelines sub-batches over several streams; the staged entry points (extract, undistort, down-sample,
+    associate, solve) must leave bit-identical clouds, stacks and poses on scans with intra-sweep motion."""
+    B = 4
+    c = M.Context(max_scans=B)
+    try:
+        ks = [30, 31, 32, 33]
+        cm, sm = [], []
+        for k in range(22, 30):
+            ev, el = O.extract_velo(synth.velo_scan(k)), O.extract_livox(synth.livox_scan(k))
+            xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+            lab = np.concatenate([ev["label"], el["label"]])
+            T = synth.pose_matrix(k)
+            cm.append(synth.transform(T, O.voxel_downsample(xyz[lab == 1], 0.4).astype(np.float64)).astype(np.float32))
+            sm.append(synth.transform(T, O.voxel_downsample(xyz[lab == 2], 0.2).astype(np.float64)).astype(np.float32))
+        c.map_set_local(0, O.voxel_downsample(np.concatenate(cm), 0.4))
+        c.map_set_local(1, O.voxel_downsample(np.concatenate(sm), 0.2))
+        dR = np.zeros((B, 9))
+        dt = np.zeros((B, 3))
+        for s, k in enumerate(ks):
+            c.scan_upload(s, synth.velo_scan(k, motion=True), synth.livox_scan(k, motion=True))
+            mR, mt = synth.sweep_motion(k)
+            dR[s], dt[s] = mR.reshape(9), mt
+        x0 = np.stack([pose_to_x(perturbed(synth.pose_matrix(k))) for k in ks])
+        x_step = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
+        fused_step = [c.scan_download(s) for s in range(B)]
+        feats_step = [(c.features_download(s, 0), c.features_download(s, 1)) for s in range(B)]
+        # staged
+        c.extract(0, B)
+        c.undistort(0, B, dR, dt)
+        c.downsample(0, B)
+        Tw = np.stack([perturbed(synth.pose_matrix(k)) for k in ks])
+        c.associate(0, B, Tw, 25.0)
+        x_staged, _, _ = c.solve(0, B, x0, np.eye(4), max_iters=10, fixed=True, huber=0.1 / 1.5e-3, w_tan=0.0)
+        for s in range(B):
+            d = c.scan_download(s)
+            for key in ("xyzi", "reltime", "ring", "label"):
+                assert np.array_equal(d[key], fused_step[s][key]), key
+            assert np.all(d["reltime"] == 1.0)
+            assert c.features_download(s, 0).tobytes() == feats_step[s][0].tobytes()
+            assert c.features_download(s, 1).tobytes() == feats_step[s][1].tobytes()
+        assert np.array_equal(x_step, x_staged)
+        # and the undistorted cloud is the oracle's
+        v, l = synth.velo_scan(ks[1], motion=True), synth.livox_scan(ks[1], motion=True)
+        ev, el = O.extract_velo(v), O.extract_livox(l)
+        xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+        rel = np.concatenate([ev["reltime"], el["reltime"]])
+        und = O.undistort(xyz, rel, dR[1].reshape(3, 3), dt[1])
+        assert np.array_equal(fused_step[1]["xyzi"][:, :3], und)
+        assert np.abs(x_step[:, :3] - np.stack([synth.pose_matrix(k)[:3, 3] for k in ks])).max() < 0.03
+    finally:
+        c.close()
+
+
 def test_odometry_replay_matches_oracle_loop(M, O, synth):
     """BASELINE config 3 shape, synthetic: scans replayed one by one through the whole loop -- extract, undistort,
     down-sample, Estimate (5 outer x 10 inner) against the local map, key-scan rule, MapIncrementLocal -- with the
