@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="scans per step per GPU")
     ap.add_argument("--map-points", type=int, default=200000)
     ap.add_argument("--gn-iters", type=int, default=10)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the N > 1 code path)")
     ap.add_argument("--window-demo", action="store_true", help="run the joint window solve section on one GPU as well")
     ap.add_argument("--kernel-steps", type=int, default=4, help="single-stream steps after the timed region (per-kernel timing)")
     ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
@@ -69,7 +70,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
