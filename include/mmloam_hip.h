@@ -245,6 +245,53 @@ typedef struct {
     double total_ms[MML_MAX_STAGES];
     long launches[MML_MAX_STAGES];
 } mml_profile;
+/* ---- IMU factor, marginalization prior, full-window solve (host side) --------------
+ * O(W) dense work on <= 8 frames x 15 parameters; the per-frame lidar normal equations come from the device
+ * (mml_linearize_record / the all-gather of section 8(e)).  No device is needed for these entry points. */
+typedef struct {
+    double dp[3], dv[3];
+    double dq[4];             /* x, y, z, w */
+    double dtime;
+    double bg[3], ba[3];      /* linearized_bg / linearized_ba */
+    double jacobian[225];     /* 15 x 15 row-major, order P R V BG BA (IMUIntegrator.h:86-93) */
+    double covariance[225];
+} mml_imu_preint;
+/* IMUIntegrator::PreIntegration (IMUIntegrator.cpp:108-166).  samples: n x 7 doubles = angular_velocity xyz,
+ * linear_acceleration xyz as in the message (multiplied by gnorm = 9.805 inside, :119-121), dt to the previous
+ * sample (:122). */
+int mml_imu_preintegrate(const double* samples, int n, const double* bg, const double* ba, mml_imu_preint* out);
+/* Cost_NavState_PRV_Bias (ceresfunc.h:321-393) with sqrt_information = LLT(covariance^-1).matrixL()^T
+ * (Estimator.cpp:1240-1242).  pr*: [P(3), rotation vector(3)], vb*: [V(3), bg(3), ba(3)].  residual: 15;
+ * jacobian (may be NULL): 15 x 30 row-major, columns [pr_i | vb_i | pr_j | vb_j]. */
+int mml_imu_factor(const mml_imu_preint* pre, const double* gravity, const double* pr_i, const double* vb_i,
+                   const double* pr_j, const double* vb_j, double* residual, double* jacobian);
+/* MarginalizationFactor living on (para_PR[0], para_VBias[0]) (ceresfunc.h:244-303): residual =
+ * r0 + J * dx(x, x0) with the reference's dx (translation / velocity / bias differences, rotation part
+ * log(exp(x)^-1 exp(x0)), :274-283); J is handed to the solver unchanged. */
+typedef struct {
+    double J[225];            /* linearized_jacobians, 15 x 15 row-major, columns [PR 6 | VBias 9] */
+    double r0[15];            /* linearized_residuals */
+    double x0[15];            /* keep_block_data */
+} mml_prior;
+typedef struct mml_fullwindow mml_fullwindow;
+/* Estimator::Estimate in full-window mode (Estimator.cpp:1226-1254,1425-1432): W frames x [PR 6 | VBias 9]. */
+mml_fullwindow* mml_fullwindow_create(int W, const mml_solve_opts* opts);
+void mml_fullwindow_destroy(mml_fullwindow*);
+/* IMU factor between frames f-1 and f (1 <= f < W), Estimator.cpp:1235-1248. */
+int mml_fullwindow_set_imu(mml_fullwindow*, int f, const mml_imu_preint* pre, const double* gravity);
+/* last_marginalization_info (NULL: none), Estimator.cpp:1249-1254. */
+int mml_fullwindow_set_prior(mml_fullwindow*, const mml_prior* prior);
+/* One trust-region evaluation, same protocol as mml_window_solver_step: records = W x 32 lidar records evaluated at
+ * x_eval (W x 15, in/out).  Returns 1 when finished, 0 when x_eval holds the next point to evaluate, < 0 on error. */
+int mml_fullwindow_step(mml_fullwindow*, const double* records, double* x_eval);
+int mml_fullwindow_summary(const mml_fullwindow*, mml_solve_summary* out);
+/* The dense normal equations of the whole window at x (W x 15): H (15W x 15W row-major), g, cost. */
+int mml_fullwindow_normal_equations(const mml_fullwindow*, const double* records, const double* x, double* H, double* g,
+                                    double* cost);
+/* MarginalizationInfo::marginalize for the factor set of Estimator.cpp:1453-1546 (previous prior, IMU factor 0-1,
+ * lidar factors of frame 0 as their loss-free normal equations).  x: W x 15.  out: the prior for the slid window. */
+int mml_fullwindow_marginalize(const mml_fullwindow*, const double* lidar_record0, const double* x, mml_prior* out);
+
 /* Number of HIP streams mml_step pipelines its sub-batches over (1..4, default 4 or $MML_LANES).  With 1 every
  * kernel covers the whole batch and runs alone on the device, which is what per-kernel timing wants. */
 int mml_set_lanes(mml_ctx* ctx, int lanes);

@@ -352,6 +352,95 @@ class Context:
         return g.value
 
 
+class ImuPreint(C.Structure):
+    _fields_ = [("dp", C.c_double * 3), ("dv", C.c_double * 3), ("dq", C.c_double * 4), ("dtime", C.c_double),
+                ("bg", C.c_double * 3), ("ba", C.c_double * 3), ("jacobian", C.c_double * 225),
+                ("covariance", C.c_double * 225)]
+
+
+class Prior(C.Structure):
+    _fields_ = [("J", C.c_double * 225), ("r0", C.c_double * 15), ("x0", C.c_double * 15)]
+
+
+def imu_preintegrate(samples, bg, ba):
+    """IMUIntegrator::PreIntegration: samples (n, 7) = gyro xyz, accel xyz (message units), dt."""
+    smp = _f64(samples).reshape(-1, 7)
+    out = ImuPreint()
+    rc = lib().mml_imu_preintegrate(_p(smp), C.c_int(len(smp)), _p(_f64(bg)), _p(_f64(ba)), C.byref(out))
+    if rc != MML_OK:
+        raise MmlError(rc, "mml_imu_preintegrate")
+    return out
+
+
+def imu_factor(pre, gravity, pr_i, vb_i, pr_j, vb_j, jac=True):
+    """Cost_NavState_PRV_Bias: weighted residual (15) and Jacobian (15, 30) [pr_i | vb_i | pr_j | vb_j]."""
+    r = np.zeros(15)
+    J = np.zeros((15, 30)) if jac else None
+    rc = lib().mml_imu_factor(C.byref(pre), _p(_f64(gravity)), _p(_f64(pr_i)), _p(_f64(vb_i)), _p(_f64(pr_j)),
+                              _p(_f64(vb_j)), _p(r), _p(J))
+    if rc != MML_OK:
+        raise MmlError(rc, "mml_imu_factor")
+    return r, J
+
+
+class FullWindowSolver:
+    """Estimator::Estimate in full-window mode on the host: W x [PR 6 | VBias 9], lidar records from the device,
+    IMU factors between consecutive frames, optional marginalization prior on frame 0."""
+
+    def __init__(self, W, max_iters=10, fixed=False, huber=0.0, w_tan=3e-4):
+        self.W = W
+        self._opts = SolveOpts(max_iters, 1 if fixed else 0, huber, w_tan)
+        lib().mml_fullwindow_create.restype = C.c_void_p
+        self._h = C.c_void_p(lib().mml_fullwindow_create(C.c_int(W), C.byref(self._opts)))
+        if not self._h:
+            raise MmlError(MML_ERR_INVALID, "mml_fullwindow_create failed")
+
+    def _ck(self, rc, what):
+        if rc < 0:
+            raise MmlError(rc, what)
+        return rc
+
+    def set_imu(self, f, pre, gravity):
+        self._ck(lib().mml_fullwindow_set_imu(self._h, C.c_int(f), C.byref(pre), _p(_f64(gravity))), "set_imu")
+
+    def set_prior(self, prior):
+        self._ck(lib().mml_fullwindow_set_prior(self._h, C.byref(prior) if prior is not None else None), "set_prior")
+
+    def step(self, records, x_eval):
+        rec = _f64(records).reshape(self.W, NEQ_RECORD_DOUBLES)
+        x = _f64(x_eval).reshape(self.W, 15).copy()
+        rc = self._ck(lib().mml_fullwindow_step(self._h, _p(rec), _p(x)), "mml_fullwindow_step")
+        return rc == 1, x
+
+    def summary(self):
+        s = SolveSummary()
+        lib().mml_fullwindow_summary(self._h, C.byref(s))
+        return s
+
+    def normal_equations(self, records, x):
+        n = 15 * self.W
+        H = np.zeros((n, n))
+        g = np.zeros(n)
+        c = C.c_double(0)
+        self._ck(lib().mml_fullwindow_normal_equations(self._h, _p(_f64(records).reshape(self.W, NEQ_RECORD_DOUBLES)),
+                                                       _p(_f64(x).reshape(self.W, 15)), _p(H), _p(g), C.byref(c)), "normal_equations")
+        return H, g, c.value
+
+    def marginalize(self, lidar_record0, x):
+        out = Prior()
+        self._ck(lib().mml_fullwindow_marginalize(self._h, _p(_f64(lidar_record0).reshape(NEQ_RECORD_DOUBLES)),
+                                                  _p(_f64(x).reshape(self.W, 15)), C.byref(out)), "marginalize")
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mml_fullwindow_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class WindowSolver:
     """Host-side joint dogleg over W all-gathered 32-double records; needs no device."""
 

@@ -1,0 +1,912 @@
+// window_imu.hip -- SURVEY.md section 8(f) rank 1: the IMU side of the joint window solve.  Pure host code (W <= 8
+// frames, 15 parameters each: O(W) tiny dense work next to the per-frame lidar normal equations that come from the
+// device), compiled into the same library so that it sits behind the same C-ABI.
+//   * IMUIntegrator::PreIntegration            mm-loam/src/lio/IMUIntegrator.cpp:108-166  -> mml_imu_preintegrate
+//   * Cost_NavState_PRV_Bias (15 residuals)    mm-loam/include/utils/ceresfunc.h:321-393   -> mml_imu_factor
+//     Jacobians: the reference lets Ceres autodiff the functor; here they are analytic (checked against central
+//     differences of the residual in tests/test_imu.py)
+//   * MarginalizationInfo / MarginalizationFactor  ceresfunc.h:92-317, hookup Estimator.cpp:1448-1567
+//                                                                                          -> mml_fullwindow_marginalize
+//   * the full-window problem of Estimator::Estimate (Estimator.cpp:1226-1254,1425-1432): lidar blocks on para_PR[f],
+//     IMU factors between consecutive frames on (para_PR, para_VBias), the marginalization prior on frame 0, solved
+//     with the same trust-region dogleg iteration as mml_solve but on the dense 15 W system     -> mml_fullwindow_*
+// Rotation blocks are rotation VECTORS in a plain Euclidean parameter block (Estimator.cpp:1228), R = Sophus exp.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/mmloam_hip.h"
+
+namespace {
+
+// ---- small dense helpers (row-major) -------------------------------------------------------------------------------
+struct M3 {
+    double a[9];
+};
+inline M3 m3_identity() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+inline M3 m3_mul(const M3& A, const M3& B) {
+    M3 C;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C.a[3 * r + c] = (A.a[3 * r] * B.a[c] + A.a[3 * r + 1] * B.a[3 + c]) + A.a[3 * r + 2] * B.a[6 + c];
+    return C;
+}
+inline M3 m3_t(const M3& A) { return M3{{A.a[0], A.a[3], A.a[6], A.a[1], A.a[4], A.a[7], A.a[2], A.a[5], A.a[8]}}; }
+inline void m3_vec(const M3& A, const double* v, double* o) {
+    for (int r = 0; r < 3; ++r) o[r] = (A.a[3 * r] * v[0] + A.a[3 * r + 1] * v[1]) + A.a[3 * r + 2] * v[2];
+}
+inline M3 hat(const double* v) { return M3{{0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}}; }
+inline M3 m3_scale(const M3& A, double s) {
+    M3 C;
+    for (int i = 0; i < 9; ++i) C.a[i] = A.a[i] * s;
+    return C;
+}
+inline M3 m3_add(const M3& A, const M3& B) {
+    M3 C;
+    for (int i = 0; i < 9; ++i) C.a[i] = A.a[i] + B.a[i];
+    return C;
+}
+
+// Sophus::SO3d::exp (so3.hpp:585-622, epsilon 1e-10 on theta^2): rotation vector -> unit quaternion (x, y, z, w)
+inline void so3_exp_q(const double* w, double* q) {
+    const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+    double imag, real;
+    if (th2 < 1e-10 * 1e-10) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1.0 - 0.125 * th2 + (1.0 / 384.0) * th4;
+    } else {
+        const double th = sqrt(th2), h = 0.5 * th;
+        imag = sin(h) / th;
+        real = cos(h);
+    }
+    q[0] = imag * w[0];
+    q[1] = imag * w[1];
+    q[2] = imag * w[2];
+    q[3] = real;
+}
+inline M3 quat_to_m3(const double* q) {  // Eigen::Quaterniond::toRotationMatrix
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+                 tzz = tz * z;
+    return M3{{1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)}};
+}
+inline M3 so3_exp(const double* w) {
+    double q[4];
+    so3_exp_q(w, q);
+    return quat_to_m3(q);
+}
+// Eigen quaternionbase_assign_impl<Matrix3d>
+inline void m3_to_quat(const M3& M, double* q) {
+    const double* m = M.a;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+// Sophus::SO3d::log of a unit quaternion (so3.hpp logAndTheta)
+inline void so3_log_q(const double* q, double* w) {
+    const double n2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    const double qw = q[3];
+    double two_atan;
+    if (n2 < 1e-10 * 1e-10) {
+        two_atan = 2.0 / qw - (2.0 / 3.0) * n2 / (qw * qw * qw);
+    } else {
+        const double n = sqrt(n2);
+        if (fabs(qw) < 1e-10)
+            two_atan = (qw > 0 ? M_PI : -M_PI) / n;
+        else
+            two_atan = 2.0 * atan(n / qw) / n;
+    }
+    w[0] = two_atan * q[0];
+    w[1] = two_atan * q[1];
+    w[2] = two_atan * q[2];
+}
+inline void so3_log(const M3& R, double* w) {
+    double q[4];
+    m3_to_quat(R, q);
+    const double n = sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+    so3_log_q(q, w);
+}
+// right Jacobian of SO(3) and its inverse
+inline M3 so3_Jr(const double* w) {
+    const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+    const M3 K = hat(w), K2 = m3_mul(K, K);
+    double a, b;
+    if (th2 < 1e-8) {
+        a = 0.5 - th2 / 24.0;
+        b = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        const double th = sqrt(th2);
+        a = (1.0 - cos(th)) / th2;
+        b = (th - sin(th)) / (th2 * th);
+    }
+    return m3_add(m3_add(m3_identity(), m3_scale(K, -a)), m3_scale(K2, b));
+}
+inline M3 so3_Jr_inv(const double* w) {
+    const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+    const M3 K = hat(w), K2 = m3_mul(K, K);
+    double c;
+    if (th2 < 1e-8) {
+        c = 1.0 / 12.0 + th2 / 720.0;
+    } else {
+        const double th = sqrt(th2);
+        c = 1.0 / th2 - (1.0 + cos(th)) / (2.0 * th * sin(th));
+    }
+    return m3_add(m3_add(m3_identity(), m3_scale(K, 0.5)), m3_scale(K2, c));
+}
+
+// in-place Cholesky A = L L^T (lower, row-major n x n); false when not positive definite
+bool cholesky(double* A, int n) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+        if (!(d > 0.0) || !isfinite(d)) return false;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = s / d;
+        }
+    }
+    return true;
+}
+void chol_solve(const double* L, int n, double* b) {
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * n + k] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+}
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix: A = V diag(ev) V^T, eigenvalues ascending
+void sym_eig(const double* Ain, int n, double* ev, double* V) {
+    std::vector<double> A(Ain, Ain + n * n);
+    for (int i = 0; i < n * n; ++i) V[i] = 0;
+    for (int i = 0; i < n; ++i) V[i * n + i] = 1;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]]) {
+                int t = order[i];
+                order[i] = order[j];
+                order[j] = t;
+            }
+    std::vector<double> Vs(n * n);
+    for (int c = 0; c < n; ++c) {
+        ev[c] = A[order[c] * n + order[c]];
+        for (int r = 0; r < n; ++r) Vs[r * n + c] = V[r * n + order[c]];
+    }
+    memcpy(V, Vs.data(), sizeof(double) * n * n);
+}
+
+constexpr double kGnorm = 9.805;                                        // IMUIntegrator.h:84
+constexpr double kAccN = 0.08, kGyrN = 0.004, kAccW = 2.0e-4, kGyrW = 2.0e-5;  // IMUIntegrator.h:79-82
+
+inline void set_block(double* M, int ld, int r0, int c0, const M3& B, double s = 1.0) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[(r0 + r) * ld + c0 + c] = s * B.a[3 * r + c];
+}
+
+// sqrt information of one pre-integration: LLT(covariance^-1).matrixL().transpose() (Estimator.cpp:1240-1242)
+bool imu_sqrt_info(const mml_imu_preint* pre, double* U /*15x15 upper*/) {
+    double L[225];
+    memcpy(L, pre->covariance, sizeof(L));
+    if (!cholesky(L, 15)) return false;
+    double inv[225];
+    for (int c = 0; c < 15; ++c) {
+        double e[15] = {0};
+        e[c] = 1.0;
+        chol_solve(L, 15, e);
+        for (int r = 0; r < 15; ++r) inv[r * 15 + c] = e[r];
+    }
+    for (int r = 0; r < 15; ++r)
+        for (int c = r + 1; c < 15; ++c) inv[r * 15 + c] = inv[c * 15 + r] = 0.5 * (inv[r * 15 + c] + inv[c * 15 + r]);
+    if (!cholesky(inv, 15)) return false;
+    for (int r = 0; r < 15; ++r)
+        for (int c = 0; c < 15; ++c) U[r * 15 + c] = (c >= r) ? inv[c * 15 + r] : 0.0;  // U = L^T
+    return true;
+}
+
+// residual (15) and Jacobian (15 x 30, columns [PR_i 6 | VBias_i 9 | PR_j 6 | VBias_j 9]) BEFORE the sqrt information
+void imu_raw(const mml_imu_preint* pre, const double* g, const double* pri, const double* vbi, const double* prj,
+             const double* vbj, double* r, double* J) {
+    const double dt = pre->dtime, dt2 = dt * dt;
+    const M3 Ri = so3_exp(pri + 3), Rj = so3_exp(prj + 3), RiT = m3_t(Ri);
+    const double dbg[3] = {vbi[3] - pre->bg[0], vbi[4] - pre->bg[1], vbi[5] - pre->bg[2]};
+    const double dba[3] = {vbi[6] - pre->ba[0], vbi[7] - pre->ba[1], vbi[8] - pre->ba[2]};
+    auto Jb = [&](int r0, int c0) {
+        M3 B;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) B.a[3 * a + b] = pre->jacobian[(r0 + a) * 15 + c0 + b];
+        return B;
+    };
+    const M3 Jpbg = Jb(0, 9), Jpba = Jb(0, 12), Jrbg = Jb(3, 9), Jvbg = Jb(6, 9), Jvba = Jb(6, 12);
+    double a[3], b[3];
+    for (int k = 0; k < 3; ++k) {
+        a[k] = prj[k] - pri[k] - vbi[k] * dt - 0.5 * g[k] * dt2;
+        b[k] = vbj[k] - vbi[k] - g[k] * dt;
+    }
+    double Ra[3], Rb[3], t1[3], t2[3];
+    m3_vec(RiT, a, Ra);
+    m3_vec(RiT, b, Rb);
+    m3_vec(Jpbg, dbg, t1);
+    m3_vec(Jpba, dba, t2);
+    for (int k = 0; k < 3; ++k) r[k] = Ra[k] - (pre->dp[k] + t1[k] + t2[k]);
+    m3_vec(Jvbg, dbg, t1);
+    m3_vec(Jvba, dba, t2);
+    for (int k = 0; k < 3; ++k) r[6 + k] = Rb[k] - (pre->dv[k] + t1[k] + t2[k]);
+    double jd[3];
+    m3_vec(Jrbg, dbg, jd);
+    const M3 dR = quat_to_m3(pre->dq);
+    const M3 C = m3_mul(dR, so3_exp(jd));
+    const M3 E = m3_mul(m3_t(C), m3_mul(RiT, Rj));
+    so3_log(E, r + 3);
+    for (int k = 0; k < 6; ++k) r[9 + k] = vbj[3 + k] - vbi[3 + k];
+    if (!J) return;
+    memset(J, 0, sizeof(double) * 15 * 30);
+    const M3 Jri = so3_Jr(pri + 3), Jrj = so3_Jr(prj + 3), JrInv = so3_Jr_inv(r + 3);
+    // position rows
+    set_block(J, 30, 0, 0, RiT, -1.0);
+    set_block(J, 30, 0, 3, m3_mul(hat(Ra), Jri));
+    set_block(J, 30, 0, 6, RiT, -dt);
+    set_block(J, 30, 0, 9, Jpbg, -1.0);
+    set_block(J, 30, 0, 12, Jpba, -1.0);
+    set_block(J, 30, 0, 15, RiT);
+    // rotation rows
+    set_block(J, 30, 3, 3, m3_mul(JrInv, m3_mul(m3_mul(m3_t(Rj), Ri), Jri)), -1.0);
+    set_block(J, 30, 3, 9, m3_mul(JrInv, m3_mul(m3_t(E), m3_mul(so3_Jr(jd), Jrbg))), -1.0);
+    set_block(J, 30, 3, 18, m3_mul(JrInv, Jrj));
+    // velocity rows
+    set_block(J, 30, 6, 3, m3_mul(hat(Rb), Jri));
+    set_block(J, 30, 6, 6, RiT, -1.0);
+    set_block(J, 30, 6, 9, Jvbg, -1.0);
+    set_block(J, 30, 6, 12, Jvba, -1.0);
+    set_block(J, 30, 6, 21, RiT);
+    // bias rows
+    for (int k = 0; k < 6; ++k) {
+        J[(9 + k) * 30 + 9 + k] = -1.0;
+        J[(9 + k) * 30 + 24 + k] = 1.0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mml_imu_preintegrate(const double* samples, int n, const double* bg, const double* ba, mml_imu_preint* out) {
+    if (!out || n < 0 || (n > 0 && !samples) || !bg || !ba) return MML_ERR_INVALID;
+    // Reset() (:49-58)
+    memset(out, 0, sizeof(*out));
+    out->dq[3] = 1.0;
+    for (int i = 0; i < 15; ++i) out->jacobian[i * 15 + i] = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        out->bg[k] = bg[k];
+        out->ba[k] = ba[k];
+    }
+    double noise[12] = {kGyrN * kGyrN, kGyrN* kGyrN, kGyrN* kGyrN, kAccN* kAccN, kAccN* kAccN, kAccN* kAccN,
+                        kGyrW* kGyrW, kGyrW* kGyrW, kGyrW* kGyrW, kAccW* kAccW, kAccW* kAccW, kAccW* kAccW};  // :33-37 (diagonal)
+    std::vector<double> A(225), B(15 * 12), T(225), T2(225);
+    for (int s = 0; s < n; ++s) {
+        const double* m = samples + 7 * s;
+        double gyr[3] = {m[0] - bg[0], m[1] - bg[1], m[2] - bg[2]};
+        double acc[3] = {m[3] * kGnorm - ba[0], m[4] * kGnorm - ba[1], m[5] * kGnorm - ba[2]};
+        const double dt = m[6], dt2 = dt * dt;
+        double gdt[3] = {gyr[0] * dt, gyr[1] * dt, gyr[2] * dt};
+        const M3 dR = so3_exp(gdt);
+        M3 Jr = m3_identity();
+        const double nrm = sqrt((gdt[0] * gdt[0] + gdt[1] * gdt[1]) + gdt[2] * gdt[2]);
+        if (nrm > 0.00001) {  // :129-135
+            double k[3] = {gdt[0] / nrm, gdt[1] / nrm, gdt[2] / nrm};
+            const M3 K = hat(k);
+            Jr = m3_add(m3_add(m3_identity(), m3_scale(K, -(1 - cos(nrm)) / nrm)), m3_scale(m3_mul(K, K), 1 - sin(nrm) / nrm));
+        }
+        const M3 Rq = quat_to_m3(out->dq);
+        const M3 RqA = m3_mul(Rq, hat(acc));
+        for (int i = 0; i < 225; ++i) A[i] = 0;
+        for (int i = 0; i < 15; ++i) A[i * 15 + i] = 1.0;
+        set_block(A.data(), 15, 0, 3, RqA, -0.5 * dt2);
+        set_block(A.data(), 15, 0, 6, m3_identity(), dt);
+        set_block(A.data(), 15, 0, 12, Rq, -0.5 * dt2);
+        set_block(A.data(), 15, 3, 3, m3_t(dR));
+        set_block(A.data(), 15, 3, 9, Jr, -dt);
+        set_block(A.data(), 15, 6, 3, RqA, -dt);
+        set_block(A.data(), 15, 6, 12, Rq, -dt);
+        for (int i = 0; i < 15 * 12; ++i) B[i] = 0;
+        set_block(B.data(), 12, 0, 3, Rq, 0.5 * dt2);
+        set_block(B.data(), 12, 3, 0, Jr, dt);
+        set_block(B.data(), 12, 6, 3, Rq, dt);
+        set_block(B.data(), 12, 9, 6, m3_identity(), dt);
+        set_block(B.data(), 12, 12, 9, m3_identity(), dt);
+        // jacobian = A * jacobian
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) {
+                double acc_ = 0;
+                for (int k = 0; k < 15; ++k) acc_ += A[r * 15 + k] * out->jacobian[k * 15 + c];
+                T[r * 15 + c] = acc_;
+            }
+        memcpy(out->jacobian, T.data(), sizeof(double) * 225);
+        // covariance = A * covariance * A^T + B * noise * B^T
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) {
+                double acc_ = 0;
+                for (int k = 0; k < 15; ++k) acc_ += A[r * 15 + k] * out->covariance[k * 15 + c];
+                T[r * 15 + c] = acc_;
+            }
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) {
+                double acc_ = 0;
+                for (int k = 0; k < 15; ++k) acc_ += T[r * 15 + k] * A[c * 15 + k];
+                double bn = 0;
+                for (int k = 0; k < 12; ++k) bn += B[r * 12 + k] * noise[k] * B[c * 12 + k];
+                T2[r * 15 + c] = acc_ + bn;
+            }
+        memcpy(out->covariance, T2.data(), sizeof(double) * 225);
+        // dp += dv*dt + 0.5*dq*acc*dt2 ; dv += dq*acc*dt   (:159-160)
+        double Ra[3];
+        m3_vec(Rq, acc, Ra);
+        for (int k = 0; k < 3; ++k) out->dp[k] += out->dv[k] * dt + 0.5 * Ra[k] * dt2;
+        for (int k = 0; k < 3; ++k) out->dv[k] += Ra[k] * dt;
+        // dq = normalized(Quaterniond(dq.matrix() * dR)), w >= 0  (:161-165)
+        double q[4];
+        m3_to_quat(m3_mul(Rq, dR), q);
+        if (q[3] < 0)
+            for (int k = 0; k < 4; ++k) q[k] = -q[k];
+        const double nq = sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+        for (int k = 0; k < 4; ++k) out->dq[k] = q[k] / nq;
+        out->dtime += dt;
+    }
+    return MML_OK;
+}
+
+int mml_imu_factor(const mml_imu_preint* pre, const double* gravity, const double* pri, const double* vbi, const double* prj,
+                   const double* vbj, double* residual, double* jacobian) {
+    if (!pre || !gravity || !pri || !vbi || !prj || !vbj || !residual) return MML_ERR_INVALID;
+    double U[225];
+    if (!imu_sqrt_info(pre, U)) return MML_ERR_STATE;
+    double r[15], J[15 * 30];
+    imu_raw(pre, gravity, pri, vbi, prj, vbj, r, jacobian ? J : nullptr);
+    for (int i = 0; i < 15; ++i) {  // eResiduals.applyOnTheLeft(sqrt_information)
+        double s = 0;
+        for (int k = i; k < 15; ++k) s += U[i * 15 + k] * r[k];
+        residual[i] = s;
+    }
+    if (jacobian)
+        for (int i = 0; i < 15; ++i)
+            for (int c = 0; c < 30; ++c) {
+                double s = 0;
+                for (int k = i; k < 15; ++k) s += U[i * 15 + k] * J[k * 30 + c];
+                jacobian[i * 30 + c] = s;
+            }
+    return MML_OK;
+}
+
+}  // extern "C"
+
+// ---- the full-window problem -------------------------------------------------------------------------------------------
+namespace {
+
+struct Prior {            // MarginalizationFactor on (para_PR[0], para_VBias[0]) after the address shift (:1552-1562)
+    bool valid = false;
+    int nres = 15;
+    double J[15 * 15];    // linearized_jacobians, columns [PR 6 | VBias 9]
+    double r0[15];        // linearized_residuals
+    double x0[15];        // keep_block_data
+};
+
+// MarginalizationFactor::Evaluate (ceresfunc.h:262-301): residual at x, the (constant) Jacobian is P.J
+void prior_residual(const Prior& P, const double* x15, double* r) {
+    double dx[15];
+    for (int k = 0; k < 3; ++k) dx[k] = x15[k] - P.x0[k];
+    const M3 E = m3_mul(m3_t(so3_exp(x15 + 3)), so3_exp(P.x0 + 3));  // exp(x)^-1 * exp(x0)  (:279)
+    so3_log(E, dx + 3);
+    for (int k = 6; k < 15; ++k) dx[k] = x15[k] - P.x0[k];
+    for (int i = 0; i < 15; ++i) {
+        double s = P.r0[i];
+        for (int k = 0; k < 15; ++k) s += P.J[i * 15 + k] * dx[k];
+        r[i] = s;
+    }
+}
+
+struct Eval {  // dense normal equations of the whole window at one x
+    std::vector<double> H, g;
+    double cost = 0;
+};
+
+}  // namespace
+
+struct mml_fullwindow {
+    int W = 0, n = 0;
+    mml_solve_opts opts;
+    std::vector<mml_imu_preint> imu;   // imu[f]: between frame f-1 and f (f >= 1)
+    std::vector<char> have_imu;
+    double gravity[3] = {0, 0, 0};
+    Prior prior;
+    // trust-region state (Ceres 2.1 TRADITIONAL_DOGLEG, same constants as mml_solve / tr_propose / tr_decide)
+    std::vector<double> x, xc, scale, diag, grad, gn, step;
+    Eval cur, cand;
+    double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0, x_norm = 0, model_change = 0, step_norm = 0;
+    int reuse = 0, num_invalid = 0, iter = 0, successful = 0, termination = 0, started = 0, done = 0;
+    double initial_cost = 0;
+};
+
+namespace {
+
+// adds the IMU factors and the prior, evaluated at x (W x 15: PR 6 | VBias 9), to the lidar records (W x 32)
+int assemble(const mml_fullwindow* s, const double* records, const double* x, Eval& e) {
+    const int W = s->W, n = s->n;
+    e.H.assign((size_t)n * n, 0.0);
+    e.g.assign(n, 0.0);
+    e.cost = 0;
+    for (int f = 0; f < W; ++f) {
+        const double* rec = records + 32 * f;
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) {
+                const double v = rec[k++];
+                e.H[(size_t)(15 * f + a) * n + 15 * f + b] += v;
+                if (b != a) e.H[(size_t)(15 * f + b) * n + 15 * f + a] += v;
+            }
+        for (int a = 0; a < 6; ++a) e.g[15 * f + a] += rec[21 + a];
+        e.cost += rec[27];
+    }
+    for (int f = 1; f < W; ++f) {
+        if (!s->have_imu[f]) continue;
+        double r[15], J[15 * 30];
+        const double* xi = x + 15 * (f - 1);
+        const double* xj = x + 15 * f;
+        int rc = mml_imu_factor(&s->imu[f], s->gravity, xi, xi + 6, xj, xj + 6, r, J);
+        if (rc != MML_OK) return rc;
+        const int base = 15 * (f - 1);  // the 30 columns are exactly the two consecutive frames
+        for (int a = 0; a < 30; ++a) {
+            double ga = 0;
+            for (int i = 0; i < 15; ++i) ga += J[i * 30 + a] * r[i];
+            e.g[base + a] += ga;
+            for (int b = 0; b < 30; ++b) {
+                double h = 0;
+                for (int i = 0; i < 15; ++i) h += J[i * 30 + a] * J[i * 30 + b];
+                e.H[(size_t)(base + a) * n + base + b] += h;
+            }
+        }
+        double c = 0;
+        for (int i = 0; i < 15; ++i) c += r[i] * r[i];
+        e.cost += 0.5 * c;
+    }
+    if (s->prior.valid) {
+        double r[15];
+        prior_residual(s->prior, x, r);
+        for (int a = 0; a < 15; ++a) {
+            double ga = 0;
+            for (int i = 0; i < 15; ++i) ga += s->prior.J[i * 15 + a] * r[i];
+            e.g[a] += ga;
+            for (int b = 0; b < 15; ++b) {
+                double h = 0;
+                for (int i = 0; i < 15; ++i) h += s->prior.J[i * 15 + a] * s->prior.J[i * 15 + b];
+                e.H[(size_t)a * n + b] += h;
+            }
+        }
+        double c = 0;
+        for (int i = 0; i < 15; ++i) c += r[i] * r[i];
+        e.cost += 0.5 * c;
+    }
+    return MML_OK;
+}
+
+double quad(const mml_fullwindow* s, const std::vector<double>& v) {  // v^T (S H S) v
+    const int n = s->n;
+    double q = 0;
+    for (int a = 0; a < n; ++a) {
+        double row = 0;
+        for (int b = 0; b < n; ++b) row += s->cur.H[(size_t)a * n + b] * s->scale[b] * v[b];
+        q += v[a] * s->scale[a] * row;
+    }
+    return q;
+}
+
+// one proposal: returns 1 when s->xc holds a candidate to evaluate, 0 when the step was invalid (propose again),
+// -1 when the minimiser has stopped
+int propose(mml_fullwindow* s) {
+    const int n = s->n;
+    if (s->iter >= s->opts.max_num_iterations || s->radius < 1e-32 || s->num_invalid > 5) return -1;
+    s->iter++;
+    bool solve_ok = true;
+    if (!s->reuse) {
+        s->reuse = 1;
+        for (int i = 0; i < n; ++i) {
+            double d = s->cur.H[(size_t)i * n + i] * s->scale[i] * s->scale[i];
+            d = fmin(fmax(d, 1e-6), 1e32);
+            s->diag[i] = sqrt(d);
+        }
+        double gg = 0;
+        std::vector<double> sg(n);
+        for (int i = 0; i < n; ++i) {
+            s->grad[i] = s->cur.g[i] * s->scale[i] / s->diag[i];
+            sg[i] = s->grad[i] / s->diag[i];
+            gg += s->grad[i] * s->grad[i];
+        }
+        s->alpha = gg / quad(s, sg);
+        solve_ok = false;
+        std::vector<double> A((size_t)n * n), b(n);
+        while (s->mu < 1.0) {
+            for (int a = 0; a < n; ++a) {
+                for (int c = 0; c < n; ++c) A[(size_t)a * n + c] = s->cur.H[(size_t)a * n + c] * s->scale[a] * s->scale[c];
+                A[(size_t)a * n + a] += s->mu * s->diag[a] * s->diag[a];
+                b[a] = s->cur.g[a] * s->scale[a];
+            }
+            bool ok = cholesky(A.data(), n);
+            if (ok) {
+                chol_solve(A.data(), n, b.data());
+                for (int a = 0; a < n; ++a)
+                    if (!isfinite(b[a])) ok = false;
+            }
+            if (!ok) {
+                s->mu *= 10.0;
+                continue;
+            }
+            for (int a = 0; a < n; ++a) s->gn[a] = -s->diag[a] * b[a];
+            solve_ok = true;
+            break;
+        }
+    }
+    bool step_valid = solve_ok;
+    if (solve_ok) {
+        double gradient_norm = 0, gn_norm = 0;
+        for (int i = 0; i < n; ++i) {
+            gradient_norm += s->grad[i] * s->grad[i];
+            gn_norm += s->gn[i] * s->gn[i];
+        }
+        gradient_norm = sqrt(gradient_norm);
+        gn_norm = sqrt(gn_norm);
+        if (gn_norm <= s->radius) {
+            for (int i = 0; i < n; ++i) s->step[i] = s->gn[i];
+            s->dogleg_norm = gn_norm;
+        } else if (gradient_norm * s->alpha >= s->radius) {
+            for (int i = 0; i < n; ++i) s->step[i] = -(s->radius / gradient_norm) * s->grad[i];
+            s->dogleg_norm = s->radius;
+        } else {
+            double gdot = 0;
+            for (int i = 0; i < n; ++i) gdot += s->grad[i] * s->gn[i];
+            const double b_dot_a = -s->alpha * gdot;
+            const double a_sq = (s->alpha * gradient_norm) * (s->alpha * gradient_norm);
+            const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+            const double c = b_dot_a - a_sq;
+            const double d = sqrt(c * c + bma_sq * (s->radius * s->radius - a_sq));
+            const double beta = (c <= 0) ? (d - c) / bma_sq : (s->radius * s->radius - a_sq) / (d + c);
+            double sn = 0;
+            for (int i = 0; i < n; ++i) {
+                s->step[i] = (-s->alpha * (1.0 - beta)) * s->grad[i] + beta * s->gn[i];
+                sn += s->step[i] * s->step[i];
+            }
+            s->dogleg_norm = sqrt(sn);
+        }
+        for (int i = 0; i < n; ++i) s->step[i] /= s->diag[i];
+        double sgd = 0;
+        for (int i = 0; i < n; ++i) sgd += s->step[i] * s->cur.g[i] * s->scale[i];
+        s->model_change = -(sgd + 0.5 * quad(s, s->step));
+        if (!(s->model_change > 0.0)) step_valid = false;
+    }
+    if (!step_valid) {
+        s->num_invalid++;
+        s->mu *= 10.0;
+        s->reuse = 0;
+        return 0;
+    }
+    s->num_invalid = 0;
+    double sn = 0;
+    for (int i = 0; i < n; ++i) {
+        const double delta = s->step[i] * s->scale[i];
+        s->xc[i] = s->x[i] + delta;
+        sn += delta * delta;
+    }
+    s->step_norm = sqrt(sn);
+    return 1;
+}
+
+// after the candidate has been evaluated into s->cand: accept / reject; returns true when the minimiser stops
+bool decide(mml_fullwindow* s) {
+    const int n = s->n;
+    const bool fixed = s->opts.fixed_iterations != 0;
+    const double cand = s->cand.cost;
+    if (!fixed) {
+        if (s->step_norm <= 1e-8 * (s->x_norm + 1e-8)) {
+            s->termination = 2;
+            return true;
+        }
+        if (fabs(s->cur.cost - cand) <= 1e-6 * s->cur.cost) {
+            s->termination = 3;
+            return true;
+        }
+    }
+    const double rel = (s->cur.cost - cand) / s->model_change;
+    if (rel > 1e-3) {
+        double xn = 0;
+        for (int i = 0; i < n; ++i) {
+            s->x[i] = s->xc[i];
+            xn += s->x[i] * s->x[i];
+        }
+        s->x_norm = sqrt(xn);
+        s->cur = s->cand;
+        s->successful++;
+        if (!fixed) {
+            double gm = 0;
+            for (int i = 0; i < n; ++i) gm = fmax(gm, fabs(s->cur.g[i]));
+            if (gm <= 1e-10) {
+                s->termination = 1;
+                return true;
+            }
+        }
+        if (rel < 0.25) s->radius *= 0.5;
+        if (rel > 0.75) s->radius = fmax(s->radius, 3.0 * s->dogleg_norm);
+        s->mu = fmax(1e-8, 2.0 * s->mu / 10.0);
+        s->reuse = 0;
+    } else {
+        s->radius *= 0.5;
+        s->reuse = 1;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+mml_fullwindow* mml_fullwindow_create(int W, const mml_solve_opts* opts) {
+    if (W < 1 || W > 8 || !opts) return nullptr;
+    mml_fullwindow* s = new mml_fullwindow();
+    s->W = W;
+    s->n = 15 * W;
+    s->opts = *opts;
+    s->imu.resize(W);
+    s->have_imu.assign(W, 0);
+    const int n = s->n;
+    s->x.assign(n, 0);
+    s->xc.assign(n, 0);
+    s->scale.assign(n, 1);
+    s->diag.assign(n, 1);
+    s->grad.assign(n, 0);
+    s->gn.assign(n, 0);
+    s->step.assign(n, 0);
+    return s;
+}
+
+void mml_fullwindow_destroy(mml_fullwindow* s) { delete s; }
+
+int mml_fullwindow_set_imu(mml_fullwindow* s, int f, const mml_imu_preint* pre, const double* gravity) {
+    if (!s || !pre || !gravity || f < 1 || f >= s->W) return MML_ERR_INVALID;
+    s->imu[f] = *pre;
+    s->have_imu[f] = 1;
+    for (int k = 0; k < 3; ++k) s->gravity[k] = gravity[k];
+    return MML_OK;
+}
+
+int mml_fullwindow_set_prior(mml_fullwindow* s, const mml_prior* p) {
+    if (!s) return MML_ERR_INVALID;
+    if (!p) {
+        s->prior.valid = false;
+        return MML_OK;
+    }
+    s->prior.valid = true;
+    memcpy(s->prior.J, p->J, sizeof(s->prior.J));
+    memcpy(s->prior.r0, p->r0, sizeof(s->prior.r0));
+    memcpy(s->prior.x0, p->x0, sizeof(s->prior.x0));
+    return MML_OK;
+}
+
+// Protocol of mml_window_solver_step: `records` are the lidar normal equations (W x 32, from mml_linearize_record /
+// the all-gather) evaluated at x_eval (W x 15).  Returns 1 when finished (x_eval holds the solution), 0 when x_eval
+// holds the next point to evaluate, < 0 on error.
+int mml_fullwindow_step(mml_fullwindow* s, const double* records, double* x_eval) {
+    if (!s || !records || !x_eval) return MML_ERR_INVALID;
+    const int n = s->n;
+    if (s->done) {
+        memcpy(x_eval, s->x.data(), sizeof(double) * n);
+        return 1;
+    }
+    if (!s->started) {
+        s->started = 1;
+        memcpy(s->x.data(), x_eval, sizeof(double) * n);
+        int rc = assemble(s, records, s->x.data(), s->cur);
+        if (rc != MML_OK) return rc;
+        s->initial_cost = s->cur.cost;
+        double xn = 0;
+        for (int i = 0; i < n; ++i) xn += s->x[i] * s->x[i];
+        s->x_norm = sqrt(xn);
+        for (int i = 0; i < n; ++i) s->scale[i] = 1.0 / (1.0 + sqrt(s->cur.H[(size_t)i * n + i]));  // Jacobi scaling
+        if (!s->opts.fixed_iterations) {
+            double gm = 0;
+            for (int i = 0; i < n; ++i) gm = fmax(gm, fabs(s->cur.g[i]));
+            if (gm <= 1e-10) {
+                s->termination = 1;
+                s->done = 1;
+                return 1;
+            }
+        }
+    } else {
+        int rc = assemble(s, records, s->xc.data(), s->cand);
+        if (rc != MML_OK) return rc;
+        if (decide(s)) {
+            s->done = 1;
+            memcpy(x_eval, s->x.data(), sizeof(double) * n);
+            return 1;
+        }
+    }
+    for (;;) {
+        const int p = propose(s);
+        if (p < 0) {
+            s->done = 1;
+            memcpy(x_eval, s->x.data(), sizeof(double) * n);
+            return 1;
+        }
+        if (p == 1) break;
+    }
+    memcpy(x_eval, s->xc.data(), sizeof(double) * n);
+    return 0;
+}
+
+// The dense normal equations Ceres would assemble at x: H = sum J^T J (n x n row-major, n = 15 W), g = sum J^T r,
+// cost = 1/2 sum r^2 over the lidar blocks (from `records`), the IMU factors and the prior.
+int mml_fullwindow_normal_equations(const mml_fullwindow* s, const double* records, const double* x, double* H, double* g,
+                                    double* cost) {
+    if (!s || !records || !x || !H || !g || !cost) return MML_ERR_INVALID;
+    Eval e;
+    int rc = assemble(s, records, x, e);
+    if (rc != MML_OK) return rc;
+    memcpy(H, e.H.data(), sizeof(double) * e.H.size());
+    memcpy(g, e.g.data(), sizeof(double) * e.g.size());
+    *cost = e.cost;
+    return MML_OK;
+}
+
+int mml_fullwindow_summary(const mml_fullwindow* s, mml_solve_summary* out) {
+    if (!s || !out) return MML_ERR_INVALID;
+    out->iterations = s->iter;
+    out->successful = s->successful;
+    out->initial_cost = s->initial_cost;
+    out->final_cost = s->cur.cost;
+    out->termination = s->termination;
+    return MML_OK;
+}
+
+// MarginalizationInfo::preMarginalize + marginalize (ceresfunc.h:132-228) for the factor set of Estimator.cpp:1453-1546:
+// the previous prior (all of its blocks are dropped: it lives on frame 0), the IMU factor between frames 0 and 1, and
+// the lidar factors of frame 0 given as their normal equations `lidar_record0` (32 doubles, evaluated WITHOUT a loss
+// function at x[0..6)).  x: W x 15 current values.  Result: the prior on (PR, VBias) of frame 1, i.e. of frame 0 once
+// the window has slid (:1552-1562).
+int mml_fullwindow_marginalize(const mml_fullwindow* s, const double* lidar_record0, const double* x, mml_prior* out) {
+    if (!s || !lidar_record0 || !x || !out || s->W < 2 || !s->have_imu[1]) return MML_ERR_INVALID;
+    const int m = 15, n = 15, N = 30;
+    std::vector<double> A((size_t)N * N, 0.0), b(N, 0.0);
+    if (s->prior.valid) {
+        double r[15];
+        prior_residual(s->prior, x, r);
+        for (int a = 0; a < 15; ++a) {
+            for (int i = 0; i < 15; ++i) b[a] += s->prior.J[i * 15 + a] * r[i];
+            for (int c = 0; c < 15; ++c)
+                for (int i = 0; i < 15; ++i) A[(size_t)a * N + c] += s->prior.J[i * 15 + a] * s->prior.J[i * 15 + c];
+        }
+    }
+    {
+        double r[15], J[15 * 30];
+        int rc = mml_imu_factor(&s->imu[1], s->gravity, x, x + 6, x + 15, x + 21, r, J);
+        if (rc != MML_OK) return rc;
+        for (int a = 0; a < 30; ++a) {
+            for (int i = 0; i < 15; ++i) b[a] += J[i * 30 + a] * r[i];
+            for (int c = 0; c < 30; ++c)
+                for (int i = 0; i < 15; ++i) A[(size_t)a * N + c] += J[i * 30 + a] * J[i * 30 + c];
+        }
+    }
+    {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int c = a; c < 6; ++c) {
+                const double v = lidar_record0[k++];
+                A[(size_t)a * N + c] += v;
+                if (c != a) A[(size_t)c * N + a] += v;
+            }
+        for (int a = 0; a < 6; ++a) b[a] += lidar_record0[21 + a];
+    }
+    const double eps = 1e-8;
+    // Amm^-1 through the eigen-decomposition of its symmetric part, eigenvalues <= eps dropped (:203-206)
+    double Amm[225], ev[15], V[225], Ainv[225];
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < m; ++c) Amm[r * m + c] = 0.5 * (A[(size_t)r * N + c] + A[(size_t)c * N + r]);
+    sym_eig(Amm, m, ev, V);
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < m; ++c) {
+            double sum = 0;
+            for (int k = 0; k < m; ++k)
+                if (ev[k] > eps) sum += V[r * m + k] * (1.0 / ev[k]) * V[c * m + k];
+            Ainv[r * m + c] = sum;
+        }
+    // Schur complement (:208-214)
+    double T[225];  // Arm * Amm_inv
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < m; ++c) {
+            double sum = 0;
+            for (int k = 0; k < m; ++k) sum += A[(size_t)(m + r) * N + k] * Ainv[k * m + c];
+            T[r * m + c] = sum;
+        }
+    double Ar[225], br[15];
+    for (int r = 0; r < n; ++r) {
+        for (int c = 0; c < n; ++c) {
+            double sum = 0;
+            for (int k = 0; k < m; ++k) sum += T[r * m + k] * A[(size_t)k * N + m + c];
+            Ar[r * n + c] = A[(size_t)(m + r) * N + m + c] - sum;
+        }
+        double sb = 0;
+        for (int k = 0; k < m; ++k) sb += T[r * m + k] * b[k];
+        br[r] = b[m + r] - sb;
+    }
+    for (int r = 0; r < n; ++r)
+        for (int c = r + 1; c < n; ++c) Ar[r * n + c] = Ar[c * n + r] = 0.5 * (Ar[r * n + c] + Ar[c * n + r]);
+    // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b  (:216-227)
+    double ev2[15], V2[225];
+    sym_eig(Ar, n, ev2, V2);
+    for (int i = 0; i < n; ++i) {
+        const double sv = ev2[i] > eps ? sqrt(ev2[i]) : 0.0;
+        const double si = ev2[i] > eps ? sqrt(1.0 / ev2[i]) : 0.0;
+        double vb = 0;
+        for (int k = 0; k < n; ++k) {
+            out->J[i * 15 + k] = sv * V2[k * n + i];
+            vb += V2[k * n + i] * br[k];
+        }
+        out->r0[i] = si * vb;
+    }
+    memcpy(out->x0, x + 15, sizeof(double) * 15);  // parameter_block_data of the kept blocks = their current values
+    return MML_OK;
+}
+
+}  // extern "C"
