@@ -68,3 +68,95 @@ class LidarOdometry:
                 grew = True
         self.fail_detected = is_degenerate                              # :1139
         return P, Q, grew
+
+
+def _rotvec_from_quat(q):
+    """Sophus::SO3d(Q).log() (vector2double, Estimator.cpp:942)."""
+    x, y, z, w = q
+    n = np.sqrt(x * x + y * y + z * z)
+    if n < 1e-10:
+        k = 2.0 / w - (2.0 / 3.0) * n * n / (w * w * w)
+    elif abs(w) < 1e-10:
+        k = (np.pi if w > 0 else -np.pi) / n
+    else:
+        k = 2.0 * np.arctan(n / w) / n
+    return np.array([k * x, k * y, k * z])
+
+
+def _quat_from_rotvec(phi):
+    """Sophus::SO3d::exp(phi).unit_quaternion() (double2vector, Estimator.cpp:958)."""
+    th = np.linalg.norm(phi)
+    if th * th < 1e-20:
+        im, re = 0.5 - th * th / 48.0, 1.0 - th * th / 8.0
+    else:
+        im, re = np.sin(0.5 * th) / th, np.cos(0.5 * th)
+    return np.array([im * phi[0], im * phi[1], im * phi[2], re])
+
+
+class WindowEstimator:
+    """Estimator::Estimate in full-window mode (windowSize == SLIDEWINDOWSIZE, Estimator.cpp:1143-1581): lidar factors
+    of every frame (associated once, thres_dist 1, plan_weight_tan 3e-4, no loss), IMU factors between consecutive
+    frames, the marginalization prior of the previous call.  Association and the per-frame normal equations run on
+    the device; the 15 W dense trust-region iteration, the IMU factors and the marginalization are host code behind
+    the same C-ABI (mml_fullwindow_*)."""
+
+    def __init__(self, ctx, exTlb=None, gravity=(0.0, 0.0, -9.805), max_outer=5, inner_iters=10):
+        import importlib
+        self.M = importlib.import_module(__package__)
+        self.ctx = ctx
+        self.exTlb = np.eye(4) if exTlb is None else np.asarray(exTlb, dtype=np.float64)
+        self.T_bl = np.linalg.inv(self.exTlb)
+        self.exRbl = self.exTlb[:3, :3].T.copy()
+        self.exPbl = -1.0 * self.exRbl @ self.exTlb[:3, 3]
+        self.gravity = np.asarray(gravity, dtype=np.float64)
+        self.max_outer, self.inner_iters = max_outer, inner_iters
+        self.prior = None                 # last_marginalization_info
+        self.plan_weight_tan = 0.0003     # :1203
+        self.thres_dist = 1.0             # :1204
+
+    def _T_wl(self, x15):
+        R = _quat_to_matrix(_quat_from_rotvec(x15[3:6]))
+        T = np.eye(4)
+        T[:3, :3] = R @ self.exRbl
+        T[:3, 3] = R @ self.exPbl + x15[:3]
+        return T
+
+    def _records(self, slots, x):
+        M = self.M
+        return np.stack([M.pack_record(*self.ctx.linearize(s, x[f][:6], self.T_bl, self.plan_weight_tan, 0.0))
+                         for f, s in enumerate(slots)])
+
+    def estimate(self, slots, frames, preints):
+        """slots: scan slot of every frame (already down-sampled); frames: list of dicts with P, Q (x,y,z,w), V, bg, ba
+        (updated in place); preints[f] (f >= 1): mml_imu_preint between frames f-1 and f.  Returns the new prior."""
+        M, ctx, W = self.M, self.ctx, len(slots)
+        info = dict(outer=0, summaries=[])
+        for it in range(self.max_outer):
+            x = np.stack([np.concatenate([fr["P"], _rotvec_from_quat(fr["Q"]), fr["V"], fr["bg"], fr["ba"]]) for fr in frames])
+            if it == 0:                                        # vLineFeatures / vPlanFeatures are empty only here
+                for f, s in enumerate(slots):
+                    ctx.associate(s, 1, self._T_wl(x[f])[None], self.thres_dist)
+            q_before, t_before = frames[-1]["Q"].copy(), frames[-1]["P"].copy()
+            fw = M.FullWindowSolver(W, max_iters=self.inner_iters, fixed=False, huber=0.0, w_tan=self.plan_weight_tan)
+            for f in range(1, W):
+                fw.set_imu(f, preints[f], self.gravity)
+            if self.prior is not None:
+                fw.set_prior(self.prior)
+            for _ in range(20 * self.inner_iters):
+                done, x = fw.step(self._records(slots, x), x)
+                if done:
+                    break
+            info["summaries"].append(fw.summary())
+            for f, fr in enumerate(frames):                    # double2vector
+                fr["P"], fr["Q"] = x[f][0:3].copy(), _quat_from_rotvec(x[f][3:6])
+                fr["V"], fr["bg"], fr["ba"] = x[f][6:9].copy(), x[f][9:12].copy(), x[f][12:15].copy()
+            info["outer"] = it + 1
+            d = abs(float(np.dot(q_before, frames[-1]["Q"])))
+            deltaR = 2.0 * np.arccos(min(1.0, d)) * 180.0 / np.pi      # angularDistance, :1443
+            deltaT = float(np.linalg.norm(t_before - frames[-1]["P"]))
+            if (deltaR < 0.05 and deltaT < 0.05) or it + 1 == self.max_outer:
+                # marginalize frame 0 (:1453-1546): previous prior, IMU factor 0-1, the stored lidar factors of frame 0
+                rec0 = M.pack_record(*ctx.linearize(slots[0], x[0][:6], self.T_bl, self.plan_weight_tan, 0.0))
+                self.prior = fw.marginalize(rec0, x) if W >= 2 else None
+                break
+        return info

@@ -36,6 +36,30 @@ def pose_at(k, dt=0.1, v=0.5, w=0.2):
     return R, np.array([x, y, 1.0])
 
 
+GRAVITY = np.array([0.0, 0.0, -9.805])  # the vector of Cost_NavState_PRV_Bias: P_j = P_i + V_i dt + g dt^2 / 2 + R_i dP
+
+
+def velocity_at(k, dt=0.1, v=0.5, w=0.2):
+    """World-frame velocity of the sensor at scan time k (constant-twist motion of pose_at)."""
+    R, _ = pose_at(k, dt, v, w)
+    return R @ np.array([v, 0.0, 0.0])
+
+
+def imu_samples(k0, k1, rate=200, dt=0.1, v=0.5, w=0.2, gnorm=9.805):
+    """IMU messages between scan times k0 and k1 for the motion of pose_at: rows of (angular_velocity xyz,
+    linear_acceleration xyz in units of g as the Livox IMU reports it, dt to the previous message).  Each sample
+    holds over the following dt (the forward-Euler convention of IMUIntegrator::PreIntegration)."""
+    n = int(round((k1 - k0) * dt * rate))
+    h = (k1 - k0) * dt / n
+    out = np.zeros((n, 7))
+    for i in range(n):
+        out[i, 0:3] = [0.0, 0.0, w]
+        # body-frame specific force: centripetal acceleration (0, v w, 0) minus gravity, both constant in the body frame
+        out[i, 3:6] = (np.array([0.0, v * w, 0.0]) - GRAVITY) / gnorm
+        out[i, 6] = h
+    return out
+
+
 def _raycast(origin, dirs):
     """Nearest hit range for unit directions `dirs` (n,3) from `origin` ((3,) or (n,3)) inside the room."""
     with np.errstate(divide="ignore", invalid="ignore"):

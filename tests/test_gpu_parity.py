@@ -3,6 +3,7 @@ against the committed golden vectors.  Bars: bit-exact for indices / labels / fl
 pose within 1e-4 m / 1e-4 rad per iteration (we hold 1e-9)."""
 import importlib
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -651,5 +652,127 @@ def test_odometry_replay_matches_oracle_loop(M, O, synth):
             T_prev_gpu, T_prev_cpu, T_prev_gt = T_gpu, T_cpu, T_gt
         assert n_key >= 3 and odo.key_scans == n_key
         assert odo.n_surf_local == len(lm.get(1)) and odo.n_corner_local == len(lm.get(0))
+    finally:
+        c.close()
+
+
+def test_full_window_estimate_with_imu_matches_oracle_loop(M, O, synth, scene):
+    """SURVEY section 8(f) rank 1 at system level: Estimator::Estimate in full-window mode (5 frames, lidar factors from
+    the device, IMU factors, marginalization prior carried into the next call) against the same control flow driven by
+    the CPU oracle (C++ lidar restatement + numpy IMU / marginalization / trust region)."""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import imu_oracle as IO
+    odometry = importlib.import_module("multi-modal-loam_amd.odometry")
+    W = 5
+    G = synth.GRAVITY
+    c = M.Context(max_scans=W + 1)
+    try:
+        c.map_set_local(0, scene["corner_map"])
+        c.map_set_local(1, scene["surf_map"])
+        tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
+        west = odometry.WindowEstimator(c, gravity=G)
+        prior_np = None
+        rng = np.random.default_rng(17)
+        for call, k0 in enumerate((10, 11)):               # two consecutive windows: the second consumes the prior
+            ks = list(range(k0, k0 + W))
+            feats, frames_g, frames_o, pres, pres_np = [], [], [], [None], [None]
+            for f, k in enumerate(ks):
+                v, l = synth.velo_scan(k), synth.livox_scan(k)
+                c.scan_upload(f, v, l)
+                c.extract(f, 1)
+                c.undistort(f, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+                c.downsample(f, 1)
+                feats.append((c.features_download(f, 0), c.features_download(f, 1)))
+                T = perturbed(synth.pose_matrix(k), dt=rng.normal(0, 0.02, 3), rotvec=rng.normal(0, 0.003, 3))
+                fr = dict(P=T[:3, 3].copy(), Q=Rsc.from_matrix(T[:3, :3]).as_quat(), V=synth.velocity_at(k) + rng.normal(0, 0.02, 3),
+                          bg=np.zeros(3), ba=np.zeros(3))
+                if fr["Q"][3] < 0:
+                    fr["Q"] = -fr["Q"]
+                frames_g.append({kk: vv.copy() for kk, vv in fr.items()})
+                frames_o.append({kk: vv.copy() for kk, vv in fr.items()})
+                if f > 0:
+                    smp = synth.imu_samples(k - 1, k)
+                    pres.append(M.imu_preintegrate(smp, np.zeros(3), np.zeros(3)))
+                    pres_np.append(IO.preintegrate(smp, np.zeros(3), np.zeros(3)))
+            info = west.estimate(list(range(W)), frames_g, pres)
+            # ---- oracle loop ----
+            x = np.stack([np.concatenate([fr["P"], Rsc.from_quat(fr["Q"]).as_rotvec(), fr["V"], fr["bg"], fr["ba"]]) for fr in frames_o])
+            facs = None
+            outer = 0
+            for it in range(5):
+                if it == 0:
+                    facs = []
+                    for f in range(W):
+                        Twl = np.eye(4)
+                        Twl[:3, :3] = Rsc.from_rotvec(x[f][3:6]).as_matrix()
+                        Twl[:3, 3] = x[f][:3]
+                        facs.append((O.associate_lines(feats[f][0], tc, Twl, 1.0)[0], O.associate_planes(feats[f][1], ts, Twl, 1.0)[0]))
+                back_before = x[-1].copy()
+
+                def evaluate(z):
+                    xx = z.reshape(W, 15)
+                    n = 15 * W
+                    H, g, cost = np.zeros((n, n)), np.zeros(n), 0.0
+                    for f in range(W):
+                        Hf, gf, cf = O.linearize(facs[f][0], facs[f][1], xx[f][:6], np.eye(4), 3e-4, 0.0)
+                        H[15 * f:15 * f + 6, 15 * f:15 * f + 6] += Hf
+                        g[15 * f:15 * f + 6] += gf
+                        cost += cf
+                    for f in range(1, W):
+                        fun = lambda q: IO.imu_residual(pres_np[f], G, q[:6], q[6:15], q[15:21], q[21:30])
+                        q = np.concatenate([xx[f - 1], xx[f]])
+                        r = fun(q)
+                        J = IO.numeric_jacobian(fun, q, h=1e-6)
+                        sl = slice(15 * (f - 1), 15 * (f + 1))
+                        H[sl, sl] += J.T @ J
+                        g[sl] += J.T @ r
+                        cost += 0.5 * r @ r
+                    if prior_np is not None:
+                        r = IO.prior_residual(prior_np, xx[0])
+                        H[:15, :15] += prior_np["J"].T @ prior_np["J"]
+                        g[:15] += prior_np["J"].T @ r
+                        cost += 0.5 * r @ r
+                    return H, g, cost
+
+                z, trace, iters, term = IO.dense_trust_region(evaluate, x, max_iters=10, fixed=False)
+                x = z.reshape(W, 15)
+                outer = it + 1
+                Rb = Rsc.from_rotvec(back_before[3:6]).inv() * Rsc.from_rotvec(x[-1][3:6])
+                deltaR = np.degrees(np.linalg.norm(Rb.as_rotvec()))
+                deltaT = np.linalg.norm(back_before[:3] - x[-1][:3])
+                sm = info["summaries"][it]
+                assert sm.iterations == iters and sm.termination == term
+                assert abs(sm.final_cost - trace[-1]) < 1e-6 * max(trace[-1], 1e-12)
+                if (deltaR < 0.05 and deltaT < 0.05) or it == 4:
+                    A = np.zeros((30, 30))
+                    b = np.zeros(30)
+                    if prior_np is not None:
+                        r = IO.prior_residual(prior_np, x[0])
+                        A[:15, :15] += prior_np["J"].T @ prior_np["J"]
+                        b[:15] += prior_np["J"].T @ r
+                    fun = lambda q: IO.imu_residual(pres_np[1], G, q[:6], q[6:15], q[15:21], q[21:30])
+                    q = np.concatenate([x[0], x[1]])
+                    J = IO.numeric_jacobian(fun, q, h=1e-6)
+                    A += J.T @ J
+                    b += J.T @ fun(q)
+                    H0, g0, _ = O.linearize(facs[0][0], facs[0][1], x[0][:6], np.eye(4), 3e-4, 0.0)
+                    A[:6, :6] += H0
+                    b[:6] += g0
+                    Jn, rn, Ar, br = IO.marginalize(A, b, 15)
+                    prior_np = dict(J=Jn, r0=rn, x0=x[1].copy())
+                    break
+            assert info["outer"] == outer
+            xg = np.stack([np.concatenate([fr["P"], Rsc.from_quat(fr["Q"]).as_rotvec(), fr["V"], fr["bg"], fr["ba"]]) for fr in frames_g])
+            assert np.abs(xg - x).max() < 1e-6, np.abs(xg - x).max(0)
+            Jp, rp = np.array(west.prior.J).reshape(15, 15), np.array(west.prior.r0)
+            assert np.allclose(Jp.T @ Jp, prior_np["J"].T @ prior_np["J"], rtol=1e-4, atol=1e-6 * np.abs(Ar).max())
+            assert np.allclose(Jp.T @ rp, prior_np["J"].T @ prior_np["r0"], rtol=1e-4, atol=1e-5 * np.abs(br).max())
+            assert np.allclose(np.array(west.prior.x0), prior_np["x0"], atol=1e-6)
+            # the joint solve keeps the lidar-observed poses near the ground truth and estimates plausible velocities
+            for f, k in enumerate(ks):
+                assert np.abs(xg[f][:3] - synth.pose_matrix(k)[:3, 3]).max() < 0.03
+                assert np.abs(xg[f][6:9] - synth.velocity_at(k)).max() < 0.25
     finally:
         c.close()
