@@ -259,10 +259,154 @@ class Estimator {
         _fail_detected = is_degenerate;  // :1139
     }
 
+    // Estimate(lidarFrameList, exTlb, gravity, is_degenerate) in full-window mode (windowSize == SLIDEWINDOWSIZE,
+    // Estimator.cpp:1143-1581, IMU_Mode = 2): lidar factors of every frame associated once (thres_dist 1,
+    // plan_weight_tan 3e-4, no loss) and linearised on the device, IMU factors (LidarFrame::imu) between consecutive
+    // frames, the marginalization prior of the previous call; 5 outer x 10 inner iterations, then frame 0 is
+    // marginalized (:1448-1567).  imu[f] (f >= 1) = the pre-integration between frames f-1 and f
+    // (mml_imu_preintegrate replaces IMUIntegrator::PreIntegration).
+    void EstimateFullWindow(std::vector<LidarFrame*>& frames, const std::vector<mml_imu_preint>& imu, const Matrix4d& exTlb,
+                            const Vector3d& gravity) {
+        const int W = (int)frames.size();
+        if (W < 1 || W > 8 || (int)imu.size() < W) throw std::runtime_error("EstimateFullWindow: bad window");
+        double T_bl[16];  // inverse of exTlb
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) T_bl[4 * r + c] = exTlb.m[4 * c + r];
+            T_bl[4 * r + 3] = -((exTlb.m[r] * exTlb.m[3] + exTlb.m[4 + r] * exTlb.m[7]) + exTlb.m[8 + r] * exTlb.m[11]);
+        }
+        T_bl[12] = T_bl[13] = T_bl[14] = 0;
+        T_bl[15] = 1;
+        const double w_tan = 0.0003, thres_dist = 1.0;  // :1203-1204
+        std::vector<double> x(15 * (size_t)W), rec(32 * (size_t)W);
+        for (int it = 0; it < 5; ++it) {
+            for (int f = 0; f < W; ++f) {  // vector2double (:937-950)
+                const LidarFrame& l = *frames[f];
+                double* xf = &x[15 * (size_t)f];
+                for (int k = 0; k < 3; ++k) {
+                    xf[k] = l.P.v[k];
+                    xf[6 + k] = l.V.v[k];
+                    xf[9 + k] = l.bg.v[k];
+                    xf[12 + k] = l.ba.v[k];
+                }
+                quat_log(l.Q, xf + 3);
+            }
+            if (it == 0)
+                for (int f = 0; f < W; ++f) {
+                    double T_wl[16];
+                    body_to_lidar_world(*frames[f], exTlb, T_wl);
+                    check(ctx_.get(), mml_associate(ctx_.get(), frames[f]->slot, 1, T_wl, thres_dist, nullptr), "associate");
+                }
+            const Quaterniond q_before = frames[W - 1]->Q;
+            const Vector3d t_before = frames[W - 1]->P;
+            mml_solve_opts so{10, 0, 0.0, w_tan};
+            mml_fullwindow* fw = mml_fullwindow_create(W, &so);
+            if (!fw) throw std::runtime_error("mml_fullwindow_create");
+            for (int f = 1; f < W; ++f) mml_fullwindow_set_imu(fw, f, &imu[f], gravity.v);
+            if (have_prior_) mml_fullwindow_set_prior(fw, &prior_);
+            auto lidar_records = [&]() {
+                for (int f = 0; f < W; ++f) {
+                    double H[36], g[6], c;
+                    check(ctx_.get(), mml_linearize(ctx_.get(), frames[f]->slot, &x[15 * (size_t)f], T_bl, w_tan, 0.0, H, g, &c),
+                          "linearize");
+                    double* r = &rec[32 * (size_t)f];
+                    int k = 0;
+                    for (int a = 0; a < 6; ++a)
+                        for (int b = a; b < 6; ++b) r[k++] = H[6 * a + b];
+                    for (int a = 0; a < 6; ++a) r[21 + a] = g[a];
+                    r[27] = c;
+                    r[28] = r[29] = r[30] = r[31] = 0;
+                }
+            };
+            for (int guard = 0; guard < 200; ++guard) {
+                lidar_records();
+                const int rc = mml_fullwindow_step(fw, rec.data(), x.data());
+                if (rc < 0) {
+                    mml_fullwindow_destroy(fw);
+                    throw std::runtime_error("mml_fullwindow_step");
+                }
+                if (rc == 1) break;
+            }
+            for (int f = 0; f < W; ++f) {  // double2vector (:952-964)
+                LidarFrame& l = *frames[f];
+                const double* xf = &x[15 * (size_t)f];
+                for (int k = 0; k < 3; ++k) {
+                    l.P.v[k] = xf[k];
+                    l.V.v[k] = xf[6 + k];
+                    l.bg.v[k] = xf[9 + k];
+                    l.ba.v[k] = xf[12 + k];
+                }
+                quat_exp(xf + 3, l.Q);
+            }
+            const Quaterniond& qa = frames[W - 1]->Q;
+            const double dot = std::fabs(q_before.x * qa.x + q_before.y * qa.y + q_before.z * qa.z + q_before.w * qa.w);
+            const double deltaR = 2.0 * std::acos(dot > 1.0 ? 1.0 : dot) * 180.0 / M_PI;
+            double dT = 0;
+            for (int k = 0; k < 3; ++k) dT += (t_before.v[k] - frames[W - 1]->P.v[k]) * (t_before.v[k] - frames[W - 1]->P.v[k]);
+            const bool last = (deltaR < 0.05 && std::sqrt(dT) < 0.05) || it == 4;
+            if (last && W >= 2) {  // :1453-1546
+                lidar_records();
+                have_prior_ = mml_fullwindow_marginalize(fw, rec.data(), x.data(), &prior_) == MML_OK;
+            }
+            mml_fullwindow_destroy(fw);
+            if (last) break;
+        }
+    }
+
     bool failureDetected() const { return _fail_detected; }  // Estimator.h:278
 
    private:
+    // Sophus::SO3d(Q).log() / SO3d::exp(phi).unit_quaternion()
+    static void quat_log(const Quaterniond& q, double* w) {
+        const double n2 = q.x * q.x + q.y * q.y + q.z * q.z, n = std::sqrt(n2);
+        double k;
+        if (n2 < 1e-20)
+            k = 2.0 / q.w - (2.0 / 3.0) * n2 / (q.w * q.w * q.w);
+        else if (std::fabs(q.w) < 1e-10)
+            k = (q.w > 0 ? M_PI : -M_PI) / n;
+        else
+            k = 2.0 * std::atan(n / q.w) / n;
+        w[0] = k * q.x;
+        w[1] = k * q.y;
+        w[2] = k * q.z;
+    }
+    static void quat_exp(const double* w, Quaterniond& q) {
+        const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        double im, re;
+        if (th2 < 1e-20) {
+            im = 0.5 - th2 / 48.0;
+            re = 1.0 - th2 / 8.0;
+        } else {
+            const double th = std::sqrt(th2);
+            im = std::sin(0.5 * th) / th;
+            re = std::cos(0.5 * th);
+        }
+        q.x = im * w[0];
+        q.y = im * w[1];
+        q.z = im * w[2];
+        q.w = re;
+    }
+    // transformTobeMapped = [Q exRbl | Q exPbl + P] (:1266-1268)
+    static void body_to_lidar_world(const LidarFrame& f, const Matrix4d& exTlb, double* T) {
+        const double x = f.Q.x, y = f.Q.y, z = f.Q.z, w = f.Q.w;
+        const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+        double exRbl[9], exPbl[3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) exRbl[3 * r + c] = exTlb.m[4 * c + r];
+        for (int r = 0; r < 3; ++r)
+            exPbl[r] = -1.0 * ((exRbl[3 * r] * exTlb.m[3] + exRbl[3 * r + 1] * exTlb.m[7]) + exRbl[3 * r + 2] * exTlb.m[11]);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c)
+                T[4 * r + c] = (R[3 * r] * exRbl[c] + R[3 * r + 1] * exRbl[3 + c]) + R[3 * r + 2] * exRbl[6 + c];
+            T[4 * r + 3] = ((R[3 * r] * exPbl[0] + R[3 * r + 1] * exPbl[1]) + R[3 * r + 2] * exPbl[2]) + f.P.v[r];
+        }
+        T[12] = T[13] = T[14] = 0;
+        T[15] = 1;
+    }
     Context& ctx_;
+    mml_prior prior_;
+    bool have_prior_ = false;
     int n_corner_map_ = 0, n_surf_map_ = 0;
     double last_update_pose_[3] = {-1.0, -1.0, -1.0};  // Estimator.h:339-340
     bool _fail_detected = false;

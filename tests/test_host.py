@@ -58,6 +58,41 @@ def test_no_device_is_a_loud_error(M, has_gpu):
     assert e.value.code == M.MML_ERR_NO_DEVICE
 
 
+def test_cpp_adapter_compiles_links_and_runs_host_side(M, tmp_path):
+    """multi-modal-loam_amd/host/mmloam_adapter.hpp (the reference-language mirror of feature_extraction / Estimator)
+    builds against include/mmloam_hip.h and the shared library; the IMU pre-integration it forwards to needs no
+    device, and creating a context without one is the documented loud error."""
+    src = tmp_path / "adapter_probe.cpp"
+    src.write_text(textwrap.dedent(r"""
+        #include <cstdio>
+        #include "mmloam_adapter.hpp"
+        int main() {
+            double smp[7 * 20];
+            for (int i = 0; i < 20; ++i) { double* m = smp + 7 * i; m[0] = 0; m[1] = 0; m[2] = 0.2; m[3] = 0; m[4] = 0.01; m[5] = 1.0; m[6] = 0.005; }
+            const double z[3] = {0, 0, 0};
+            mml_imu_preint pre;
+            if (mml_imu_preintegrate(smp, 20, z, z, &pre) != MML_OK) return 2;
+            std::printf("dtime %.3f dv_z %.4f\n", pre.dtime, pre.dv[2]);
+            try {
+                mml::Context ctx(1, 0);
+                mml::Estimator est(ctx, 0.4f, 0.2f);
+                std::printf("context ok\n");
+            } catch (const std::exception& e) {
+                std::printf("no device: %s\n", e.what());
+            }
+            return 0;
+        }"""))
+    exe = tmp_path / "adapter_probe"
+    libdir = os.path.join(ROOT, "multi-modal-loam_amd")
+    cmd = ["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "host"), str(src), "-o", str(exe),
+           "-L", libdir, "-lmmloam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "dtime 0.100" in run.stdout and ("no device" in run.stdout or "context ok" in run.stdout)
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "multi-modal-loam_amd")
     for dp, _, files in os.walk(pkg):
