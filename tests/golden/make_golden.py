@@ -81,6 +81,31 @@ def main():
                         cost=c, solve_x=xs, solve_trace=trace, solve_summary=np.array([summ["iterations"], summ["successful"],
                         summ["termination"]]), solve_costs=np.array([summ["initial_cost"], summ["final_cost"]]),
                         est_P=P, est_Q=Q, est_outer=it, est_trace=otrace, knn_q=q, knn_idx=ki, knn_d2=kd)
+    # 5. IMU pre-integration, IMU factor, marginalization, local-map upkeep, numpy / C++ oracle
+    import imu_oracle as IO
+    smp = synth.imu_samples(30, 31)
+    smp[:, 0:3] += np.random.default_rng(8).normal(0, 0.02, (len(smp), 3))
+    bg, ba = np.array([0.002, -0.001, 0.003]), np.array([0.02, -0.01, 0.015])
+    pre = IO.preintegrate(smp, bg, ba)
+    rng = np.random.default_rng(9)
+    Ti, Tj = synth.pose_matrix(30), synth.pose_matrix(31)
+    xi = np.concatenate([Ti[:3, 3], Rsc.from_matrix(Ti[:3, :3]).as_rotvec(), synth.velocity_at(30), bg, ba]) + rng.normal(0, 0.01, 15) * np.r_[np.ones(9), 0.1 * np.ones(6)]
+    xj = np.concatenate([Tj[:3, 3], Rsc.from_matrix(Tj[:3, :3]).as_rotvec(), synth.velocity_at(31), bg, ba]) + rng.normal(0, 0.01, 15) * np.r_[np.ones(9), 0.1 * np.ones(6)]
+    res = IO.imu_residual(pre, synth.GRAVITY, xi[:6], xi[6:], xj[:6], xj[6:])
+    jac = IO.numeric_jacobian(lambda z: IO.imu_residual(pre, synth.GRAVITY, z[:6], z[6:15], z[15:21], z[21:30]), np.concatenate([xi, xj]))
+    A = jac.T @ jac + np.diag(np.r_[1e4 * np.ones(6), np.zeros(24)])
+    b = jac.T @ res
+    Jm, rm, Ar, br = IO.marginalize(A, b, 15)
+    lm = O.LocalMap(window=3, leaf_corner=0.4, leaf_surf=0.2)
+    for k in (22, 23, 24, 25):
+        Tk = synth.pose_matrix(k)
+        lm.increment(cf, sf, Tk)
+    np.savez_compressed(os.path.join(OUT, "imu_map_small.npz"), imu_samples=smp, bg=bg, ba=ba, dp=pre["dp"], dv=pre["dv"],
+                        dR=pre["dR"], dtime=pre["dtime"], jacobian=pre["jacobian"], covariance=pre["covariance"], xi=xi, xj=xj,
+                        gravity=synth.GRAVITY, residual=res, residual_jacobian=jac, marg_A=A, marg_b=b, marg_JtJ=Jm.T @ Jm,
+                        marg_Jtr=Jm.T @ rm, local_corner_feat=cf, local_surf_feat=sf,
+                        local_poses=np.stack([synth.pose_matrix(k) for k in (22, 23, 24, 25)]), local_corner_map=lm.get(0),
+                        local_surf_map=lm.get(1))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -417,6 +417,22 @@ def test_local_map_upkeep_matches_oracle(M, O, scene):
         c2.close()
 
 
+def test_local_map_golden(M):
+    g = load("imu_map_small.npz")
+    c2 = M.Context(max_scans=1)
+    try:
+        c2.features_upload(0, 0, g["local_corner_feat"])
+        c2.features_upload(0, 1, g["local_surf_feat"])
+        # the fixture's ring has 3 slots and saw 4 key scans: it ends as [pose 3, pose 1, pose 2] in slot order, which is
+        # the order the filter sums in; the device ring (50 slots) is fed in that order
+        for T in g["local_poses"][[3, 1, 2]]:
+            c2.map_increment_local(0, T)
+        assert c2.map_local_download(0).tobytes() == g["local_corner_map"].tobytes()
+        assert c2.map_local_download(1).tobytes() == g["local_surf_map"].tobytes()
+    finally:
+        c2.close()
+
+
 def test_association_golden(ctx):
     g = load("estimate_small.npz")
     ctx.map_set_local(0, g["corner_map"])

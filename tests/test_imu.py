@@ -263,3 +263,24 @@ def test_marginalization_prior_matches_numpy_and_preserves_the_estimate(M):
     fwp = M.FullWindowSolver(1, max_iters=1)
     pr = dict(J=Jp, r0=r0, x0=xk)
     assert np.allclose(IO.prior_residual(pr, xt)[:3], r0[:3] + (Jp @ np.r_[xt[:3] - xk[:3], IO.log_so3(IO.exp_so3(xt[3:6]).T @ IO.exp_so3(xk[3:6])), xt[6:] - xk[6:]])[:3])
+
+
+def test_golden_imu_fixture(M):
+    """tests/golden/imu_map_small.npz pins the numpy oracle; the product is held to the same numbers."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "imu_map_small.npz"))
+    ref = IO.preintegrate(g["imu_samples"], g["bg"], g["ba"])
+    for k in ("dp", "dv", "dR", "jacobian", "covariance"):
+        assert np.allclose(ref[k], g[k], rtol=1e-12, atol=1e-15), k
+    pre = M.imu_preintegrate(g["imu_samples"], g["bg"], g["ba"])
+    assert np.allclose(np.array(pre.dp), g["dp"], atol=1e-12) and np.allclose(np.array(pre.dv), g["dv"], atol=1e-12)
+    assert np.allclose(Rsc.from_quat(np.array(pre.dq)).as_matrix(), g["dR"], atol=1e-12)
+    assert np.allclose(np.array(pre.covariance).reshape(15, 15), g["covariance"], rtol=1e-9, atol=1e-20)
+    xi, xj = g["xi"], g["xj"]
+    assert np.allclose(IO.imu_residual(ref, g["gravity"], xi[:6], xi[6:], xj[:6], xj[6:]), g["residual"], rtol=1e-9, atol=1e-9)
+    r, J = M.imu_factor(pre, g["gravity"], xi[:6], xi[6:], xj[:6], xj[6:])
+    assert np.allclose(r, g["residual"], rtol=1e-6, atol=1e-6 * np.abs(g["residual"]).max())
+    assert np.abs(J - g["residual_jacobian"]).max() < 1e-5 * np.abs(g["residual_jacobian"]).max()
+    Jm, rm, _, _ = IO.marginalize(g["marg_A"], g["marg_b"], 15)
+    assert np.allclose(Jm.T @ Jm, g["marg_JtJ"], rtol=1e-9, atol=1e-9 * np.abs(g["marg_JtJ"]).max())
+    assert np.allclose(Jm.T @ rm, g["marg_Jtr"], rtol=1e-8, atol=1e-9 * np.abs(g["marg_Jtr"]).max())

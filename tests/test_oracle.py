@@ -401,6 +401,14 @@ def test_local_map_increment_semantics(O, scene, synth):
             assert lm.get(kind).tobytes() == O.voxel_downsample(cat, leaf).tobytes()
 
 
+def test_golden_local_map(O):
+    g = load("imu_map_small.npz")
+    lm = O.LocalMap(window=3, leaf_corner=0.4, leaf_surf=0.2)
+    for T in g["local_poses"]:
+        lm.increment(g["local_corner_feat"], g["local_surf_feat"], T)
+    assert lm.get(0).tobytes() == g["local_corner_map"].tobytes() and lm.get(1).tobytes() == g["local_surf_map"].tobytes()
+
+
 def test_jacobians_against_finite_differences(O, scene):
     lf, pf, T = _assoc(O, scene)
     rng = np.random.default_rng(7)
