@@ -83,6 +83,18 @@ int mml_synchronize(mml_ctx* ctx);
 int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo,
                     const mml_livox_point* livox, int n_livox);
 
+/* Same, with the Velodyne part taken straight from a sensor_msgs/PointCloud2 payload (SURVEY section 8(f) rank 3;
+ * replaces pcl::fromROSMsg at unionFeatureExtract.cpp:1119-1121): data = msg.data.data(), n_points = width * height,
+ * point_step and the byte offsets of the float32 fields x, y, z, intensity as listed in msg.fields
+ * (off_intensity < 0: no such field, 0 is used).  The records are decoded on the device. */
+int mml_scan_upload_pointcloud2(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x,
+                                int off_y, int off_z, int off_intensity, const mml_livox_point* livox, int n_livox);
+/* The fused labelled cloud of a slot as the payload pcl::toROSMsg(pcl::PointCloud<PointXYZINormal>) produces for
+ * velo_combine / livox_combine (unionFeatureExtract.cpp:918, :1287-1293): 48-byte records, float32 fields x 0, y 4,
+ * z 8, normal_x 16 (in-sweep time), normal_y 20 (ring / line), normal_z 24 (label 0/1/2), intensity 32,
+ * curvature 36; packed on the device.  out may be NULL to query *n_points only. */
+int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int capacity_points, int* n_points);
+
 /* ---- a1..a8: feature extraction -----------------------------------------------------------------
  * feature_extraction::unionCloudHandler minus the PCL GICP refresh (unionFeatureExtract.cpp:266-321):
  * getVeloFeature (:1113-1317) + getHoriFeature/getHoriFeatureExtract (:891-1035) with

@@ -179,6 +179,24 @@ class Context:
             self.synchronize()
             self._keep = self._keep[-self.cfg.max_scans:]
 
+    def scan_upload_pointcloud2(self, slot, data, n_points, point_step, off_x, off_y, off_z, off_intensity, livox):
+        """Velodyne part as a sensor_msgs/PointCloud2 payload (bytes / uint8 array), decoded on the device."""
+        raw = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        lv = np.ascontiguousarray(livox) if livox is not None else None
+        nl = 0 if lv is None else len(lv)
+        self._ck(lib().mml_scan_upload_pointcloud2(self._h, C.c_int(slot), _p(raw), C.c_int(n_points), C.c_int(point_step),
+                                                   C.c_int(off_x), C.c_int(off_y), C.c_int(off_z), C.c_int(off_intensity),
+                                                   _p(lv) if nl else None, C.c_int(nl)))
+        self.synchronize()
+
+    def scan_download_pointxyzinormal(self, slot):
+        """The fused labelled cloud as 48-byte PointXYZINormal records (the velo_combine / livox_combine payload)."""
+        n = C.c_int(0)
+        self._ck(lib().mml_scan_download_pointxyzinormal(self._h, C.c_int(slot), None, C.c_int(0), C.byref(n)))
+        out = np.zeros((max(n.value, 1), 12), np.float32)
+        self._ck(lib().mml_scan_download_pointxyzinormal(self._h, C.c_int(slot), _p(out), C.c_int(n.value), C.byref(n)))
+        return out[:n.value]
+
     def extract(self, first=0, count=1, livox_extrinsic=None):
         e = _f32(livox_extrinsic).reshape(16) if livox_extrinsic is not None else None
         self._ck(lib().mml_extract(self._h, C.c_int(first), C.c_int(count), _p(e)))

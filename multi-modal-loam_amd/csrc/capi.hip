@@ -74,7 +74,7 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->d_extr,   ctx->d_misc,   ctx->ggrid[0].pts, ctx->ggrid[1].pts, ctx->ggrid[0].cell_start,
                     ctx->ggrid[1].cell_start, ctx->ggrid[0].tags, ctx->ggrid[1].tags, ctx->gmap_orig[0],
                     ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1],
-                    ctx->ring[0],  ctx->ring[1],  ctx->ring_cat, ctx->vox_flag};
+                    ctx->ring[0],  ctx->ring[1],  ctx->ring_cat, ctx->vox_flag, ctx->wire_stage};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -250,6 +250,112 @@ int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo, 
     sti[0] = n_velo;
     sti[1] = n_livox;
     MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * slot, sti, sizeof(int) * 2, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    return MML_OK;
+}
+
+// ---- wire formats ---------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float load_f32_unaligned(const uint8_t* p) {
+    const unsigned u = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24);
+    return __uint_as_float(u);
+}
+// pcl::fromROSMsg<PointXYZI> on the device: fields located by byte offset inside point_step-sized records
+__global__ void k_decode_pointcloud2(const uint8_t* raw, int n, int step, int ox, int oy, int oz, int oi, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = raw + (size_t)i * step;
+    float4 v;
+    v.x = load_f32_unaligned(p + ox);
+    v.y = load_f32_unaligned(p + oy);
+    v.z = load_f32_unaligned(p + oz);
+    v.w = oi >= 0 ? load_f32_unaligned(p + oi) : 0.f;
+    out[i] = v;
+}
+// pcl::toROSMsg<PointXYZINormal> payload: 48-byte records, x y z 1 | normal_x normal_y normal_z 0 | intensity curvature 0 0
+__global__ void k_encode_xyzinormal(const float4* xyzi, const float* rel, const uint8_t* line, const uint8_t* label, int n,
+                                    float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = xyzi[i];
+    float* o = out + 12 * (size_t)i;
+    o[0] = p.x;
+    o[1] = p.y;
+    o[2] = p.z;
+    o[3] = 1.0f;
+    o[4] = rel[i];             // normal_x: in-sweep time (unionFeatureExtract.cpp:1186)
+    o[5] = (float)line[i];     // normal_y: ring / Livox line
+    o[6] = (float)label[i];    // normal_z: 0 none, 1 corner, 2 surf (:1018-1021)
+    o[7] = 0.f;
+    o[8] = p.w;                // intensity
+    o[9] = 0.f;                // curvature
+    o[10] = 0.f;
+    o[11] = 0.f;
+}
+int ensure_wire_stage(mml_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->wire_stage_bytes) return MML_OK;
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    if (ctx->wire_stage) MML_HIP(hipFree(ctx->wire_stage));
+    MML_HIP(hipMalloc(&ctx->wire_stage, bytes));
+    ctx->wire_stage_bytes = bytes;
+    return MML_OK;
+}
+}  // namespace
+
+int mml_scan_upload_pointcloud2(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x,
+                                int off_y, int off_z, int off_intensity, const mml_livox_point* livox, int n_livox) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(n_points >= 0 && n_livox >= 0, MML_ERR_INVALID, "negative point count");
+    MML_REQUIRE(n_points <= ctx->cfg.max_velo_points && n_livox <= ctx->cfg.max_livox_points, MML_ERR_CAPACITY,
+                "scan exceeds max_velo_points / max_livox_points");
+    MML_REQUIRE((n_points == 0 || data) && (n_livox == 0 || livox), MML_ERR_INVALID, "null point buffer");
+    MML_REQUIRE(point_step >= 12 && point_step <= 256, MML_ERR_INVALID, "point_step out of range");
+    const int offs[4] = {off_x, off_y, off_z, off_intensity};
+    for (int k = 0; k < 4; ++k)
+        MML_REQUIRE((k == 3 && offs[k] < 0) || (offs[k] >= 0 && offs[k] + 4 <= point_step), MML_ERR_INVALID,
+                    "field offset outside the point record");
+    if (n_points) {
+        const size_t bytes = (size_t)n_points * point_step;
+        int rc = ensure_wire_stage(ctx, bytes);
+        if (rc != MML_OK) return rc;
+        MML_HIP(hipMemcpyAsync(ctx->wire_stage, data, bytes, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+        hipLaunchKernelGGL(k_decode_pointcloud2, dim3((n_points + 255) / 256), dim3(256), 0, MML_STREAM(ctx),
+                           reinterpret_cast<const uint8_t*>(ctx->wire_stage), n_points, point_step, off_x, off_y, off_z,
+                           off_intensity, ctx->velo_in + (size_t)slot * ctx->NV);
+        MML_HIP(hipGetLastError());
+    }
+    // the Livox part and the two counts travel as in mml_scan_upload
+    if (n_livox)
+        MML_HIP(hipMemcpyAsync(ctx->livox_in + (size_t)slot * ctx->NL, livox, sizeof(mml_livox_point) * (size_t)n_livox,
+                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    ctx->h_n_in[2 * slot] = n_points;
+    ctx->h_n_in[2 * slot + 1] = n_livox;
+    double* st = stage_alloc(ctx, 1);
+    int* sti = reinterpret_cast<int*>(st);
+    sti[0] = n_points;
+    sti[1] = n_livox;
+    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * slot, sti, sizeof(int) * 2, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    return MML_OK;
+}
+
+int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int capacity_points, int* n_points) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(n_points != nullptr, MML_ERR_INVALID, "null n_points");
+    mml_scan_info info;
+    int rc = mml_scan_info_get(ctx, slot, &info);
+    if (rc != MML_OK) return rc;
+    *n_points = info.n_points;
+    if (!out || info.n_points == 0) return MML_OK;
+    MML_REQUIRE(capacity_points >= info.n_points, MML_ERR_CAPACITY, "download capacity too small");
+    const size_t bytes = (size_t)info.n_points * 48;
+    rc = ensure_wire_stage(ctx, bytes);
+    if (rc != MML_OK) return rc;
+    const size_t off = (size_t)slot * ctx->NT;
+    hipLaunchKernelGGL(k_encode_xyzinormal, dim3((info.n_points + 255) / 256), dim3(256), 0, MML_STREAM(ctx), ctx->fu_xyzi + off,
+                       ctx->fu_rel + off, ctx->fu_line + off, ctx->fu_label + off, info.n_points,
+                       reinterpret_cast<float*>(ctx->wire_stage));
+    MML_HIP(hipGetLastError());
+    MML_HIP(hipMemcpyAsync(out, ctx->wire_stage, bytes, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     return MML_OK;
 }
 

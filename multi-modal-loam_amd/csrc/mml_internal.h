@@ -130,6 +130,8 @@ struct mml_ctx {
     size_t vox_cap = 0;                      // points ring_cat / vox_flag are sized for
     int ring_n[2][LOCAL_WINDOW] = {};
     long local_map_id = 0;                   // localMapID
+    void* wire_stage = nullptr;              // raw message bytes on their way in / out (one slot at a time)
+    size_t wire_stage_bytes = 0;
     int local_map_n[2] = {0, 0};
     float4* map_tmp = nullptr;
     unsigned* map_keys = nullptr;

@@ -199,6 +199,46 @@ def test_extract_livox_extrinsic_and_far_labels(M, O, synth):
             c.close()
 
 
+def test_wire_formats_pointcloud2_in_pointxyzinormal_out(M, O, synth):
+    """the Velodyne cloud straight from a sensor_msgs/PointCloud2 payload (velodyne driver
+    layout: x y z intensity float32, ring uint16, time float32 -- 22-byte unaligned records) and the fused cloud
+    back as PointXYZINormal records, both (de)serialised on the device."""
+    v, l = synth.velo_scan(14), synth.livox_scan(14)
+    step = 22
+    raw = np.zeros((len(v), step), np.uint8)
+    raw[:, 0:16] = v.view(np.uint8).reshape(len(v), 16)                        # x y z intensity
+    raw[:, 16:18] = (np.arange(len(v)) % 16).astype("<u2").view(np.uint8).reshape(-1, 2)
+    raw[:, 18:22] = np.linspace(0, 0.1, len(v)).astype("<f4").view(np.uint8).reshape(-1, 4)
+    c = M.Context(max_scans=2)
+    try:
+        c.scan_upload(0, v, l)
+        c.scan_upload_pointcloud2(1, raw.reshape(-1), len(v), step, 0, 4, 8, 12, l)
+        c.extract(0, 2)
+        a, b = c.scan_download(0), c.scan_download(1)
+        for key in ("xyzi", "reltime", "ring", "label"):
+            assert np.array_equal(a[key], b[key]), key
+        rec = c.scan_download_pointxyzinormal(1)
+        assert rec.shape == (len(b["label"]), 12)
+        assert np.array_equal(rec[:, 0:3], b["xyzi"][:, :3]) and np.all(rec[:, 3] == 1.0)
+        assert np.array_equal(rec[:, 4], b["reltime"]) and np.array_equal(rec[:, 5], b["ring"].astype(np.float32))
+        assert np.array_equal(rec[:, 6], b["label"].astype(np.float32)) and np.array_equal(rec[:, 8], b["xyzi"][:, 3])
+        assert not rec[:, [7, 9, 10, 11]].any()
+        # a payload without an intensity field
+        c.scan_upload_pointcloud2(1, np.ascontiguousarray(raw[:, :12]).reshape(-1), len(v), 12, 0, 4, 8, -1, l)
+        c.extract(1, 1)
+        d = c.scan_download(1)
+        v0 = v.copy()
+        v0[:, 3] = 0.0
+        ev0 = O.extract_velo(v0)
+        nv = d["info"].n_velo
+        assert nv == len(ev0["label"]) and np.array_equal(d["xyzi"][:nv, :3], ev0["xyzi"][:, :3])
+        assert np.array_equal(d["label"][:nv], ev0["label"])
+        with pytest.raises(M.MmlError):
+            c.scan_upload_pointcloud2(1, raw.reshape(-1), len(v), step, 0, 4, 20, 12, l)   # z field past the record
+    finally:
+        c.close()
+
+
 def test_extract_is_deterministic(ctx, scene):
     fr = scene["frames"][0]
     outs = []
