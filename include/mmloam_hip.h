@@ -152,6 +152,22 @@ int mml_map_local_reset(mml_ctx* ctx);
  * in the order the kNN indices refer to.  xyz may be NULL to query *n only. */
 int mml_map_local_download(mml_ctx* ctx, int kind, float* xyz, int capacity, int* n);
 
+/* ---- SURVEY section 8(f) rank 2, global half: the MAP_MANAGER cube stores on the device ----------------------------
+ * mml_map_global_append   = MAP_MANAGER::featureAssociateToMap (Map_Manager.cpp:91-117): the down-sampled stacks of
+ *                           `slot` moved to the world frame with T_wl and appended to the pending clouds
+ *                           (laserCloud*_to_map of Estimator::threadMapIncrement, Estimator.cpp:120-122);
+ * mml_map_global_increment = MAP_MANAGER::MapIncrement(pending, T_wl) (:125-281) incl. MapMove (:288-581): the cube
+ *                           grid follows the sensor, new points go to their cubes, cubes that received points and hold
+ *                           > 300 are voxel-filtered (leaf 0.4).  As in the reference (:136-149) the map Estimate()
+ *                           matches against becomes the store as it was BEFORE this call (cubes, trees and centre):
+ *                           the a12 grids and laserCloudCen*_last are rebuilt from it.  n_* (optional): live store
+ *                           sizes after the update.
+ * mml_map_global_download: the LIVE store (xyz: 3 floats per point, cube: its index, cen: 3 ints; any may be NULL). */
+int mml_map_global_append(mml_ctx* ctx, int slot, const double* T_wl);
+int mml_map_global_increment(mml_ctx* ctx, const double* T_wl, int* n_corner, int* n_surf);
+int mml_map_global_download(mml_ctx* ctx, int kind, float* xyz, int* cube, int capacity, int* n, int* cen);
+int mml_map_global_reset(mml_ctx* ctx);
+
 /* ---- a12: laserCloud{Corner,Surf}FromMap cube store (Estimator.cpp:1170-1184, Map_Manager.cpp:583-629)
  * The reference hands Estimate() 21*11*21 = 4851 cube clouds plus one kd-tree per cube; processPointToLine /
  * processPointToPlane look the feature's cube up (MAP_MANAGER::FindUsedMap), query THAT cube's tree when the

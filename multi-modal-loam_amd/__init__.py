@@ -272,6 +272,27 @@ class Context:
         self._ck(lib().mml_map_local_download(self._h, C.c_int(kind), _p(out), C.c_int(n.value), C.byref(n)))
         return out[:n.value].copy()
 
+    def map_global_append(self, slot, T_wl):
+        self._ck(lib().mml_map_global_append(self._h, C.c_int(slot), _p(_f64(T_wl).reshape(16))))
+
+    def map_global_increment(self, T_wl):
+        """MAP_MANAGER::MapIncrement on the device; returns the live (corner, surf) store sizes."""
+        nc, ns = C.c_int(0), C.c_int(0)
+        self._ck(lib().mml_map_global_increment(self._h, _p(_f64(T_wl).reshape(16)), C.byref(nc), C.byref(ns)))
+        return nc.value, ns.value
+
+    def map_global_download(self, kind):
+        n = C.c_int(0)
+        cen = np.zeros(3, np.int32)
+        self._ck(lib().mml_map_global_download(self._h, C.c_int(kind), None, None, C.c_int(0), C.byref(n), _p(cen)))
+        xyz = np.zeros((max(n.value, 1), 3), np.float32)
+        cube = np.zeros(max(n.value, 1), np.int32)
+        self._ck(lib().mml_map_global_download(self._h, C.c_int(kind), _p(xyz), _p(cube), C.c_int(n.value), C.byref(n), _p(cen)))
+        return xyz[:n.value].copy(), cube[:n.value].copy(), cen
+
+    def map_global_reset(self):
+        self._ck(lib().mml_map_global_reset(self._h))
+
     def map_set_global(self, kind, xyz, cube, cen=None):
         """Cube store of the global map (a12): xyz (m, 3) and the ToIndex cube of every point."""
         xyz = _f32(xyz).reshape(-1, 3)

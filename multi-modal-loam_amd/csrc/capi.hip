@@ -74,7 +74,9 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->d_extr,   ctx->d_misc,   ctx->ggrid[0].pts, ctx->ggrid[1].pts, ctx->ggrid[0].cell_start,
                     ctx->ggrid[1].cell_start, ctx->ggrid[0].tags, ctx->ggrid[1].tags, ctx->gmap_orig[0],
                     ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1],
-                    ctx->ring[0],  ctx->ring[1],  ctx->ring_cat, ctx->vox_flag, ctx->wire_stage};
+                    ctx->ring[0],  ctx->ring[1],  ctx->ring_cat, ctx->vox_flag, ctx->wire_stage, ctx->gs_pts[0], ctx->gs_pts[1], ctx->gs_tag[0],
+                    ctx->gs_tag[1], ctx->gs_pts2[0], ctx->gs_pts2[1], ctx->gs_tag2[0], ctx->gs_tag2[1], ctx->gp_pts[0],
+                    ctx->gp_pts[1], ctx->gs_work, ctx->gs_keys};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -542,6 +544,42 @@ int mml_map_local_download(mml_ctx* ctx, int kind, float* xyz, int capacity, int
         xyz[3 * i + 2] = tmp[i].z;
     }
     return MML_OK;
+}
+
+int mml_map_global_append(mml_ctx* ctx, int slot, const double* T_wl) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(T_wl, MML_ERR_INVALID, "null transform");
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    return mml_cube_store_append(ctx, slot, T_wl);
+}
+
+int mml_map_global_increment(mml_ctx* ctx, const double* T_wl, int* n_corner, int* n_surf) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(T_wl, MML_ERR_INVALID, "null transform");
+    MML_HIP(hipSetDevice(ctx->device));
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    int n[2] = {0, 0};
+    rc = mml_cube_store_increment(ctx, T_wl, n);
+    if (n_corner) *n_corner = n[0];
+    if (n_surf) *n_surf = n[1];
+    return rc;
+}
+
+int mml_map_global_download(mml_ctx* ctx, int kind, float* xyz, int* cube, int capacity, int* n, int* cen) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad arguments");
+    MML_HIP(hipSetDevice(ctx->device));
+    return mml_cube_store_download(ctx, kind, xyz, cube, capacity, n, cen);
+}
+
+int mml_map_global_reset(mml_ctx* ctx) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_HIP(hipSetDevice(ctx->device));
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    return mml_cube_store_reset(ctx);
 }
 
 int mml_map_set_global(mml_ctx* ctx, int kind, const float* xyz, const int* cube, int m, const int* cen) {

@@ -1284,16 +1284,8 @@ int mml_build_grid_device(mml_ctx* ctx, int kind, int m) {
 
 // a12: the global map handed to Estimate() (Estimator.cpp:1170-1184) as one concatenated cloud with the cube index
 // (ToIndex) of every point.  The per-cube kd-trees become one grid whose points carry their cube as a tag.
-int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen) {
-    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
-    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "global map larger than max_map_points");
+static int ensure_global_capacity(mml_ctx* ctx, int kind, int m) {
     hipStream_t s = MML_STREAM(ctx);
-    ctx->have_gmap[kind] = false;
-    if (cen) {
-        ctx->cen[0] = cen[0];
-        ctx->cen[1] = cen[1];
-        ctx->cen[2] = cen[2];
-    }
     MmlGrid& g = ctx->ggrid[kind];
     if (m > ctx->gmap_cap[kind] || !ctx->cube_cnt[kind]) {
         MML_HIP(hipStreamSynchronize(s));
@@ -1311,6 +1303,21 @@ int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int*
         if (!ctx->cube_cnt[kind]) MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->cube_cnt[kind]), sizeof(int) * 4851));
         ctx->gmap_cap[kind] = (int)cap;
     }
+    return MML_OK;
+}
+
+int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen) {
+    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
+    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "global map larger than max_map_points");
+    hipStream_t s = MML_STREAM(ctx);
+    ctx->have_gmap[kind] = false;
+    if (cen) {
+        ctx->cen[0] = cen[0];
+        ctx->cen[1] = cen[1];
+        ctx->cen[2] = cen[2];
+    }
+    int rc = ensure_global_capacity(ctx, kind, m);
+    if (rc != MML_OK) return rc;
     std::vector<uint16_t> tags((size_t)(m ? m : 1));
     std::vector<int> cnt(4851, 0);
     for (int i = 0; i < m; ++i) {
@@ -1321,8 +1328,31 @@ int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int*
     MML_HIP(hipMemcpyAsync(ctx->cube_cnt[kind], cnt.data(), sizeof(int) * 4851, hipMemcpyHostToDevice, s));
     if (m) MML_HIP(hipMemcpyAsync(ctx->gtag_orig[kind], tags.data(), sizeof(uint16_t) * (size_t)m, hipMemcpyHostToDevice, s));
     MML_HIP(hipStreamSynchronize(s));
-    int rc = build_grid_into(ctx, g, ctx->gmap_orig[kind], h_xyz, m, kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf,
-                             ctx->gtag_orig[kind]);
+    rc = build_grid_into(ctx, ctx->ggrid[kind], ctx->gmap_orig[kind], h_xyz, m,
+                         kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf, ctx->gtag_orig[kind]);
+    if (rc == MML_OK) ctx->have_gmap[kind] = m > 0;
+    return rc;
+}
+
+// Same from device arrays (device-side cube store, map_global.hip): points, their cube tags and the 4851 cube counts.
+int mml_build_global_grid_device(mml_ctx* ctx, int kind, const float4* d_pts, const uint16_t* d_tags, const int* d_cnt, int m,
+                                 const int* cen) {
+    MML_REQUIRE(kind == 0 || kind == 1, MML_ERR_INVALID, "map kind must be 0 (corner) or 1 (surf)");
+    MML_REQUIRE(m >= 0 && m <= ctx->MM, MML_ERR_CAPACITY, "global map larger than max_map_points");
+    hipStream_t s = MML_STREAM(ctx);
+    ctx->have_gmap[kind] = false;
+    ctx->cen[0] = cen[0];
+    ctx->cen[1] = cen[1];
+    ctx->cen[2] = cen[2];
+    int rc = ensure_global_capacity(ctx, kind, m);
+    if (rc != MML_OK) return rc;
+    MML_HIP(hipMemcpyAsync(ctx->cube_cnt[kind], d_cnt, sizeof(int) * 4851, hipMemcpyDeviceToDevice, s));
+    if (m) {
+        MML_HIP(hipMemcpyAsync(ctx->gmap_orig[kind], d_pts, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, s));
+        MML_HIP(hipMemcpyAsync(ctx->gtag_orig[kind], d_tags, sizeof(uint16_t) * (size_t)m, hipMemcpyDeviceToDevice, s));
+    }
+    rc = build_grid_into(ctx, ctx->ggrid[kind], ctx->gmap_orig[kind], nullptr, m,
+                         kind == 0 ? ctx->cfg.cell_corner : ctx->cfg.cell_surf, ctx->gtag_orig[kind]);
     if (rc == MML_OK) ctx->have_gmap[kind] = m > 0;
     return rc;
 }

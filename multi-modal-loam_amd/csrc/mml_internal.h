@@ -130,6 +130,18 @@ struct mml_ctx {
     size_t vox_cap = 0;                      // points ring_cat / vox_flag are sized for
     int ring_n[2][LOCAL_WINDOW] = {};
     long local_map_id = 0;                   // localMapID
+    // device-side MAP_MANAGER cube stores (map_global.hip): live points + cube tags, pending world-frame features
+    float4* gs_pts[2] = {nullptr, nullptr};
+    uint16_t* gs_tag[2] = {nullptr, nullptr};
+    float4* gs_pts2[2] = {nullptr, nullptr};   // ping-pong for compaction
+    uint16_t* gs_tag2[2] = {nullptr, nullptr};
+    int gs_n[2] = {0, 0};
+    float4* gp_pts[2] = {nullptr, nullptr};    // laserCloud{Corner,Surf}_to_map
+    int gp_n[2] = {0, 0};
+    int gp_cap = 0;
+    int gs_cen[3] = {10, 5, 10};               // laserCloudCen{Width,Height,Depth} of the live store
+    int* gs_work = nullptr;                    // histograms / flags / bbox keys / scan scratch
+    unsigned long long* gs_keys = nullptr;     // 64-bit sort keys, 2 x MM
     void* wire_stage = nullptr;              // raw message bytes on their way in / out (one slot at a time)
     size_t wire_stage_bytes = 0;
     int local_map_n[2] = {0, 0};
@@ -207,6 +219,12 @@ int mml_build_grid_device(mml_ctx* ctx, int kind, int m);
 int mml_downsample_big(mml_ctx* ctx, int first, int count);
 int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_out);
 int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen);
+int mml_build_global_grid_device(mml_ctx* ctx, int kind, const float4* d_pts, const uint16_t* d_tags, const int* d_cnt, int m,
+                                 const int* cen);
+int mml_cube_store_append(mml_ctx* ctx, int slot, const double* T_wl);
+int mml_cube_store_increment(mml_ctx* ctx, const double* T_wl, int* n_out);
+int mml_cube_store_download(mml_ctx* ctx, int kind, float* xyz, int* cube, int capacity, int* n, int* cen);
+int mml_cube_store_reset(mml_ctx* ctx);
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2);
 int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,

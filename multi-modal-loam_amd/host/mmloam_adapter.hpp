@@ -188,6 +188,15 @@ class Estimator {
         check(ctx_.get(), mml_map_set_global(ctx_.get(), 1, surf_xyz, surf_cube, n_surf, cen), "global surf");
     }
 
+    // Estimator::threadMapIncrement (Estimator.cpp:92-145) with the MAP_MANAGER cube stores on the device:
+    // featureAssociateToMap -> mml_map_global_append, MapIncrement (+ MapMove) -> mml_map_global_increment.
+    void appendToGlobalMap(const LidarFrame& f, const Matrix4d& transformForMap) {
+        check(ctx_.get(), mml_map_global_append(ctx_.get(), f.slot, transformForMap.m), "featureAssociateToMap");
+    }
+    void incrementGlobalMap(const Matrix4d& transform) {
+        check(ctx_.get(), mml_map_global_increment(ctx_.get(), transform.m, nullptr, nullptr), "MapIncrement");
+    }
+
     // EstimateLidarPose(std::list<LidarFrame>&, exTlb, gravity, lidarMode) (Estimator.h:211-214, Estimator.cpp:967-1140).
     // Live 1-frame mode: the list holds one frame; it is registered against the local map, the
     // pose is updated in place, and the key-scan rule (:1121-1135) grows the local map ON THE DEVICE

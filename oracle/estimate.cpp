@@ -161,6 +161,145 @@ extern "C" void mmlo_local_map_get(const mmlo_local_map* h, int kind, float* out
 }
 
 // ------------------------------------------------------------------------------------------------
+// Section 8(f) rank 2, global half: MAP_MANAGER::MapIncrement + MapMove (Map_Manager.cpp:125-581) for the corner and
+// surf cube stores (21 x 21 x 11 cubes of 50 m, index i + 21 j + 441 k).  What Estimate() matches against is the state
+// copied at the START of the last MapIncrement (laserCloud*_for_match, laserCloudCen*_last, :136-149): one update behind.
+struct mmlo_cube_store {
+    int cen[3] = {10, 5, 10};        // laserCloudCen{Width,Height,Depth}
+    int cen_last[3] = {10, 5, 10};
+    float leaf[2];
+    std::vector<std::vector<float>> cube[2];        // laserCloud{Corner,Surf}Array
+    std::vector<std::vector<float>> for_match[2];   // laserCloud{Corner,Surf}_for_match
+};
+extern "C" mmlo_cube_store* mmlo_cube_store_create(float leaf_corner, float leaf_surf) {
+    mmlo_cube_store* h = new mmlo_cube_store();
+    h->leaf[0] = leaf_corner;
+    h->leaf[1] = leaf_surf;
+    for (int k = 0; k < 2; ++k) {
+        h->cube[k].resize(4851);
+        h->for_match[k].resize(4851);
+    }
+    return h;
+}
+extern "C" void mmlo_cube_store_free(mmlo_cube_store* h) { delete h; }
+static inline int cs_index(int i, int j, int k) { return i + 21 * j + 441 * k; }  // ToIndex (:65-67)
+// MapMove (:288-581): keep the sensor's cube at least 8 cubes from every face; each step rotates one layer out
+static void cs_map_move(mmlo_cube_store* h, const double* T) {
+    const double t[3] = {T[3], T[7], T[11]};
+    int cI = int((t[0] + 25.0) / 50.0) + h->cen[2];
+    int cJ = int((t[1] + 25.0) / 50.0) + h->cen[0];
+    int cK = int((t[2] + 25.0) / 50.0) + h->cen[1];
+    if (t[0] + 25.0 < 0) cI--;
+    if (t[1] + 25.0 < 0) cJ--;
+    if (t[2] + 25.0 < 0) cK--;
+    const int D = 21, Wd = 21, Hh = 11;
+    auto shift = [&](int axis, int dir) {  // dir +1: contents move towards higher index, the lowest layer is emptied
+        const int n[3] = {D, Wd, Hh};
+        for (int kind = 0; kind < 2; ++kind) {
+            auto& c = h->cube[kind];
+            for (int a = 0; a < n[(axis + 1) % 3]; ++a)
+                for (int b = 0; b < n[(axis + 2) % 3]; ++b) {
+                    auto idx = [&](int v) {
+                        int ijk[3];
+                        ijk[axis] = v;
+                        ijk[(axis + 1) % 3] = a;
+                        ijk[(axis + 2) % 3] = b;
+                        return cs_index(ijk[0], ijk[1], ijk[2]);
+                    };
+                    if (dir > 0) {
+                        for (int v = n[axis] - 1; v >= 1; --v) c[idx(v)].swap(c[idx(v - 1)]);
+                        c[idx(0)].clear();
+                    } else {
+                        for (int v = 0; v < n[axis] - 1; ++v) c[idx(v)].swap(c[idx(v + 1)]);
+                        c[idx(n[axis] - 1)].clear();
+                    }
+                }
+        }
+    };
+    while (cI < 8) {
+        shift(0, +1);
+        cI++;
+        h->cen[2]++;
+    }
+    while (cI >= D - 8) {
+        shift(0, -1);
+        cI--;
+        h->cen[2]--;
+    }
+    while (cJ < 8) {
+        shift(1, +1);
+        cJ++;
+        h->cen[0]++;
+    }
+    while (cJ >= Wd - 8) {
+        shift(1, -1);
+        cJ--;
+        h->cen[0]--;
+    }
+    while (cK < 8) {
+        shift(2, +1);
+        cK++;
+        h->cen[1]++;
+    }
+    while (cK >= Hh - 8) {
+        shift(2, -1);
+        cK--;
+        h->cen[1]--;
+    }
+}
+// MapIncrement (:125-281): world-frame feature points (already through featureAssociateToMap), pose of the scan
+extern "C" void mmlo_cube_store_increment(mmlo_cube_store* h, const float* corner, int nc, const float* surf, int ns,
+                                          const double* T) {
+    for (int k = 0; k < 2; ++k) h->for_match[k] = h->cube[k];  // :136-143
+    for (int c = 0; c < 3; ++c) h->cen_last[c] = h->cen[c];     // :145-147
+    cs_map_move(h, T);
+    const float* src[2] = {corner, surf};
+    const int cnt[2] = {nc, ns};
+    for (int k = 0; k < 2; ++k) {
+        std::vector<char> changed(4851, 0);
+        for (int i = 0; i < cnt[k]; ++i) {
+            const float* p = src[k] + 3 * i;
+            int cI = int((p[0] + 25.0) / 50.0) + h->cen[2];
+            int cJ = int((p[1] + 25.0) / 50.0) + h->cen[0];
+            int cK = int((p[2] + 25.0) / 50.0) + h->cen[1];
+            if (p[0] + 25.0 < 0) cI--;
+            if (p[1] + 25.0 < 0) cJ--;
+            if (p[2] + 25.0 < 0) cK--;
+            if (cI >= 0 && cI < 21 && cJ >= 0 && cJ < 21 && cK >= 0 && cK < 11) {
+                const int id = cs_index(cI, cJ, cK);
+                h->cube[k][id].insert(h->cube[k][id].end(), p, p + 3);
+                changed[id] = 1;
+            }
+        }
+        for (int id = 0; id < 4851; ++id) {
+            if (!changed[id]) continue;
+            std::vector<float>& c = h->cube[k][id];
+            if (c.size() / 3 > 300) {  // :225-233
+                std::vector<float> out(c.size());
+                const int m = mmlo_voxel_downsample(c.data(), (int)(c.size() / 3), h->leaf[k], out.data());
+                out.resize((size_t)m * 3);
+                c.swap(out);
+            }
+        }
+    }
+}
+// which: 0 the live store, 1 the copy Estimate() matches against.  Returns the number of points; xyz / cube may be null.
+extern "C" int mmlo_cube_store_get(const mmlo_cube_store* h, int which, int kind, float* xyz, int* cube, int* cen) {
+    const auto& c = which ? h->for_match[kind] : h->cube[kind];
+    int n = 0;
+    for (int id = 0; id < 4851; ++id) {
+        const int m = (int)(c[id].size() / 3);
+        if (xyz && m) memcpy(xyz + 3 * (size_t)n, c[id].data(), sizeof(float) * 3 * (size_t)m);
+        if (cube)
+            for (int i = 0; i < m; ++i) cube[n + i] = id;
+        n += m;
+    }
+    if (cen)
+        for (int k = 0; k < 3; ++k) cen[k] = which ? h->cen_last[k] : h->cen[k];
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a13  exact 5-NN with FLANN L2_Simple<float> distance semantics: d2 = ((dx*dx + dy*dy) + dz*dz) in
 // float; result ascending, ties broken by lower index (FLANN's tie order is unspecified: convention).
 struct Top5 {

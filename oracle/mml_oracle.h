@@ -120,6 +120,13 @@ void mmlo_local_map_increment(mmlo_local_map*, const float* corner_xyz, int n_co
                               const double* T_wl);
 int mmlo_local_map_size(const mmlo_local_map*, int kind);
 void mmlo_local_map_get(const mmlo_local_map*, int kind, float* out_xyz);
+/* Section 8(f): MAP_MANAGER::MapIncrement + MapMove (Map_Manager.cpp:125-581), corner and surf cube stores. */
+typedef struct mmlo_cube_store mmlo_cube_store;
+mmlo_cube_store* mmlo_cube_store_create(float leaf_corner, float leaf_surf);
+void mmlo_cube_store_free(mmlo_cube_store*);
+void mmlo_cube_store_increment(mmlo_cube_store*, const float* corner_world, int n_corner, const float* surf_world, int n_surf,
+                               const double* T_wl);
+int mmlo_cube_store_get(const mmlo_cube_store*, int which, int kind, float* xyz, int* cube, int* cen);
 /* checkLocalizability, Estimator.cpp:536-565: smallest singular value of the M x 3 normal
  * matrix (= sqrt(lambda_min(N^T N))); -1 when M <= 10. */
 double mmlo_check_localizability(const mmlo_plane_factor* f, int n);

@@ -58,6 +58,7 @@ def lib():
         _lib.mmlo_check_localizability.restype = C.c_double
         _lib.mmlo_cube_map_build.restype = C.c_void_p
         _lib.mmlo_local_map_create.restype = C.c_void_p
+        _lib.mmlo_cube_store_create.restype = C.c_void_p
     return _lib
 
 
@@ -246,6 +247,34 @@ class LocalMap:
         out = np.zeros((max(n, 1), 3), np.float32)
         lib().mmlo_local_map_get(self.h, C.c_int(kind), _p(out))
         return out[:n].copy()
+
+
+class CubeStore:
+    """MAP_MANAGER corner / surf cube stores: MapIncrement + MapMove (Map_Manager.cpp:125-581).  The map leaf sizes of
+    the manager are 0.4 for both kinds (Map_Manager.cpp:58-61)."""
+
+    def __init__(self, leaf_corner=0.4, leaf_surf=0.4):
+        self.h = C.c_void_p(lib().mmlo_cube_store_create(C.c_float(leaf_corner), C.c_float(leaf_surf)))
+
+    def __del__(self):
+        try:
+            lib().mmlo_cube_store_free(self.h)
+        except Exception:
+            pass
+
+    def increment(self, corner_world, surf_world, T_wl):
+        c = _f32(corner_world).reshape(-1, 3)
+        s = _f32(surf_world).reshape(-1, 3)
+        lib().mmlo_cube_store_increment(self.h, _p(c), C.c_int(len(c)), _p(s), C.c_int(len(s)), _p(_f64(T_wl).reshape(16)))
+
+    def get(self, kind, match=False):
+        """(xyz, cube index of every point, cen) of the live store or of the copy Estimate() matches against."""
+        cen = np.zeros(3, np.int32)
+        n = lib().mmlo_cube_store_get(self.h, C.c_int(1 if match else 0), C.c_int(kind), None, None, _p(cen))
+        xyz = np.zeros((max(n, 1), 3), np.float32)
+        cube = np.zeros(max(n, 1), np.int32)
+        lib().mmlo_cube_store_get(self.h, C.c_int(1 if match else 0), C.c_int(kind), _p(xyz), _p(cube), _p(cen))
+        return xyz[:n].copy(), cube[:n].copy(), cen
 
 
 def check_localizability(pf):

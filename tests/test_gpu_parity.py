@@ -473,6 +473,80 @@ def test_local_map_golden(M):
         c2.close()
 
 
+def test_global_cube_store_matches_oracle(M, O, scene):
+    """Section 8(f): device-side MAP_MANAGER::MapIncrement / MapMove.  Per cube the stored points (order included) equal
+    the oracle's after every increment; the map the association sees lags one increment, as in the reference."""
+    c2 = M.Context(max_scans=2)
+    cs = O.CubeStore()
+    sh = np.array([22.0, 24.0, 0.0])
+
+    def per_cube(xyz, cube):
+        order = np.argsort(cube, kind="stable")
+        return xyz[order], cube[order]
+
+    try:
+        steps = [(k, 1) for k in range(4)] + [(0, 2), (1, 2), ("far", 0), (2, 1), ("gone", 0), (3, 1)]
+        for step, (k, reps) in enumerate(steps):
+            if k == "far":
+                T = np.eye(4)
+                T[:3, 3] = [182.0, 24.0, 1.0]
+                feats = []
+            elif k == "gone":
+                T = np.eye(4)
+                T[:3, 3] = [900.0, -500.0, 1.0]
+                feats = []
+            else:
+                fr = scene["frames"][k]
+                feats = []
+                for r in range(reps):       # several frames accumulated between two map updates (map_skip_frame)
+                    Tr = shifted(perturbed(fr["T_gt"], dt=(0.13 * step + 0.05 * r, -0.07 * step, 0.0), rotvec=(0.0, 0.0, 0.01 * step)), sh)
+                    feats.append((fr["corner"], fr["surf"], Tr))
+                T = feats[-1][2]
+            cw, sw = [np.zeros((0, 3), np.float32)], [np.zeros((0, 3), np.float32)]
+            for cf, sf, Tr in feats:
+                c2.features_upload(0, 0, cf)
+                c2.features_upload(0, 1, sf)
+                c2.map_global_append(0, Tr)
+                x, y, z = (cf[:, i].astype(np.float64) for i in range(3))
+                cw.append(np.stack([(((Tr[r, 0] * x + Tr[r, 1] * y) + Tr[r, 2] * z) + Tr[r, 3]).astype(np.float32) for r in range(3)], 1))
+                x, y, z = (sf[:, i].astype(np.float64) for i in range(3))
+                sw.append(np.stack([(((Tr[r, 0] * x + Tr[r, 1] * y) + Tr[r, 2] * z) + Tr[r, 3]).astype(np.float32) for r in range(3)], 1))
+            nc, ns = c2.map_global_increment(T)
+            cs.increment(np.concatenate(cw), np.concatenate(sw), T)
+            for kind, n in ((0, nc), (1, ns)):
+                gx, gc, gcen = c2.map_global_download(kind)
+                ox, oc, ocen = cs.get(kind)
+                assert n == len(ox) and np.array_equal(gcen, ocen)
+                gxs, gcs = per_cube(gx, gc)
+                assert np.array_equal(gcs, oc) and gxs.tobytes() == ox.tobytes(), (step, kind)
+            # association goes against the copy taken at the start of this increment
+            if step in (2, 5, 7):
+                fr = scene["frames"][1]
+                Tq = shifted(perturbed(fr["T_gt"]), sh)
+                c2.map_set_local(0, scene["corner_map"] + sh.astype(np.float32))
+                c2.map_set_local(1, scene["surf_map"] + sh.astype(np.float32))
+                c2.features_upload(1, 0, fr["corner"])
+                c2.features_upload(1, 1, fr["surf"])
+                c2.associate(1, 1, Tq[None], 1.0)
+                gm = []
+                for kind in range(2):
+                    mx, mc, mcen = cs.get(kind, match=True)
+                    gm.append(O.CubeMap(mx, mc, mcen))
+                tr = [O.KdTree(scene["corner_map"] + sh.astype(np.float32)), O.KdTree(scene["surf_map"] + sh.astype(np.float32))]
+                lf, lsrc, lfg = O.associate_lines2(fr["corner"], gm[0], tr[0], Tq, 1.0)
+                pf, psrc, pfg = O.associate_planes2(fr["surf"], gm[1], tr[1], Tq, 1.0)
+                gl, glsrc = c2.factors_download(1, 0)
+                gp, gpsrc = c2.factors_download(1, 1)
+                assert np.array_equal(glsrc, lsrc) and np.array_equal(gpsrc, psrc)
+                ol, op = _factor_arrays(lf, pf)
+                assert np.allclose(gl, ol, rtol=0, atol=1e-9) and np.allclose(gp, op, rtol=0, atol=1e-9)
+                if step == 5:
+                    assert pfg.sum() > 50        # the cube map is actually used once it holds enough points
+        assert len(c2.map_global_download(1)[0]) > 0
+    finally:
+        c2.close()
+
+
 def test_association_golden(ctx):
     g = load("estimate_small.npz")
     ctx.map_set_local(0, g["corner_map"])

@@ -409,6 +409,57 @@ def test_golden_local_map(O):
     assert lm.get(0).tobytes() == g["local_corner_map"].tobytes() and lm.get(1).tobytes() == g["local_surf_map"].tobytes()
 
 
+def _world(feat, T):
+    x, y, z = (feat[:, c].astype(np.float64) for c in range(3))
+    return np.stack([(((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]).astype(np.float32) for r in range(3)], 1)
+
+
+def test_cube_store_increment_and_move_semantics(O, M, scene):
+    """Section 8(f): MAP_MANAGER::MapIncrement / MapMove (Map_Manager.cpp:125-581) -- cube assignment, the > 300-point
+    filter of changed cubes, the one-update lag of the copy Estimate() matches against, the layer shifts."""
+    cs = O.CubeStore()
+    sh = np.array([22.0, 24.0, 0.0])
+    seen = {0: [], 1: []}
+    prev_live = None
+    for step in range(4):
+        fr = scene["frames"][step % 4]
+        T = shifted(perturbed(fr["T_gt"], dt=(0.2 * step, 0.1 * step, 0.0)), sh)
+        cw, sw = _world(fr["corner"], T), _world(fr["surf"], T)
+        cs.increment(cw, sw, T)
+        xyz, cube, cen = cs.get(1)
+        # the first MapMove pulls the height centre from 5 to 2 (the >= Height - 8 = 3 loop undoes more than the < 8 loop adds)
+        assert list(cen) == [10, 2, 10]
+        assert np.array_equal(cube, M.cube_index(xyz, cen)) and len(np.unique(cube)) == 4
+        mx, mc, mcen = cs.get(1, match=True)
+        if prev_live is None:
+            assert len(mx) == 0 and list(mcen) == [10, 5, 10]
+        else:
+            assert mx.tobytes() == prev_live[0].tobytes() and np.array_equal(mc, prev_live[1]) and np.array_equal(mcen, prev_live[2])
+        prev_live = (xyz, cube, cen)
+        seen[1].append(sw)
+        if step == 0:
+            # nothing was filtered yet unless a cube already holds > 300 points: each cube = its points in input order,
+            # or the VoxelGrid (leaf 0.4) of them
+            tags = M.cube_index(sw, cen)
+            for c in np.unique(tags):
+                pts = sw[tags == c]
+                got = xyz[cube == c]
+                want = O.voxel_downsample(pts, 0.4) if len(pts) > 300 else pts
+                assert got.tobytes() == want.tobytes()
+    assert all((cube == c).sum() <= 700 for c in np.unique(cube))      # filtered down to the 0.4 m lattice
+    n_before = len(xyz)
+    # a pose 160 m further along x: the grid follows (cen depth 10 -> 9 -> ...), everything stays, indices shift
+    Tfar = np.eye(4)
+    Tfar[:3, 3] = [182.0, 24.0, 1.0]
+    cs.increment(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), Tfar)
+    xyz2, cube2, cen2 = cs.get(1)
+    assert cen2[2] < 10 and len(xyz2) == n_before and np.array_equal(cube2, M.cube_index(xyz2, cen2))
+    # 600 m away: the old cubes leave the 21-cube window and are dropped
+    Tfar[:3, 3] = [900.0, 24.0, 1.0]
+    cs.increment(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), Tfar)
+    assert len(cs.get(1)[0]) == 0 and len(cs.get(1, match=True)[0]) == n_before
+
+
 def test_jacobians_against_finite_differences(O, scene):
     lf, pf, T = _assoc(O, scene)
     rng = np.random.default_rng(7)
