@@ -284,3 +284,57 @@ def test_golden_imu_fixture(M):
     Jm, rm, _, _ = IO.marginalize(g["marg_A"], g["marg_b"], 15)
     assert np.allclose(Jm.T @ Jm, g["marg_JtJ"], rtol=1e-9, atol=1e-9 * np.abs(g["marg_JtJ"]).max())
     assert np.allclose(Jm.T @ rm, g["marg_Jtr"], rtol=1e-8, atol=1e-9 * np.abs(g["marg_Jtr"]).max())
+
+
+_GLOO_FULLWINDOW = r"""
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import test_imu as T
+M = importlib.import_module("multi-modal-loam_amd")
+dist.init_process_group("gloo")
+rank, W = dist.get_rank(), dist.get_world_size()
+Wf = 2 * W                      # two frames of the window per rank
+pres, pres_np, meas, lid, x0 = T._problem(M, Wf, 21)
+mine = [2 * rank, 2 * rank + 1]
+fw = M.FullWindowSolver(Wf, max_iters=10, fixed=False, huber=0.0, w_tan=3e-4)
+for f in range(1, Wf):
+    fw.set_imu(f, pres[f - 1], T.G)          # O(W) host data, replicated on every rank
+x = x0.copy()
+for _ in range(100):
+    full = T._records(M, lid, meas, x)                                     # stand-in for the device linearisation ...
+    local = torch.from_numpy(np.ascontiguousarray(full[mine]).reshape(-1))  # ... of THIS rank's frames only
+    out = [torch.zeros(2 * 32, dtype=torch.float64) for _ in range(W)]
+    dist.all_gather(out, local)                                            # the 32-double-per-frame exchange
+    rec = np.concatenate([t.numpy().reshape(2, 32) for t in out])
+    done, x = fw.step(rec, x)
+    if done:
+        break
+chk = [torch.zeros(15 * Wf, dtype=torch.float64) for _ in range(W)]
+dist.all_gather(chk, torch.from_numpy(x.reshape(-1).copy()))
+assert all(torch.equal(chk[0], c) for c in chk)
+if rank == 0:
+    xs, fws = T._solve(M, Wf, lid, meas, pres, x0, max_iters=10)           # single-process reference
+    assert np.array_equal(xs, x) and fw.summary().iterations == fws.summary().iterations
+    print("GLOO_FULLWINDOW_OK", fw.summary().iterations)
+dist.destroy_process_group()
+"""
+
+
+def test_full_window_two_ranks_gloo(tmp_path):
+    """world_size 2, gloo: every rank contributes the lidar records of its own frames, all ranks run the 15 W host
+    solve (IMU factors included) redundantly and end with bit-identical states."""
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_FULLWINDOW)
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "GLOO_FULLWINDOW_OK" in out.stdout
