@@ -948,7 +948,8 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     const int lanes = (count >= 64 && ctx->lanes_enabled) ? ctx->n_lanes : 1;
     const int chunk = (count + lanes - 1) / lanes;
     std::vector<double> Twl(16 * (size_t)chunk);
-    double* h_x = stage_alloc(ctx, 6 * (size_t)count);  // pinned read-back area
+    double* h_x = stage_alloc(ctx, 7 * (size_t)count + 1);  // pinned read-back area: poses, then the two stack-size arrays
+    int* h_ftn = reinterpret_cast<int*>(h_x + 6 * (size_t)count);
     int rc = MML_OK;
     for (int l = 0; l < lanes && rc == MML_OK; ++l) {
         const int f = first_slot + l * chunk;
@@ -976,10 +977,22 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
             }
         }
     }
+    // the per-slot stack sizes ride back with the poses: a negative count is the down-sampler's overflow mark
+    if (rc == MML_OK) {
+        ctx->cur = 0;
+        for (int l = 1; l < mml_ctx::MAX_LANES && rc == MML_OK; ++l)
+            if (hipStreamSynchronize(ctx->streams[l]) != hipSuccess) rc = MML_ERR_HIP;
+        for (int kind = 0; kind < 2 && rc == MML_OK; ++kind)
+            if (hipMemcpyAsync(h_ftn + (size_t)kind * count, ctx->ft_n + kind * ctx->B + first_slot, sizeof(int) * count,
+                               hipMemcpyDeviceToHost, MML_STREAM(ctx)) != hipSuccess)
+                rc = MML_ERR_HIP;
+    }
     ctx->cur = 0;
     int rs = mml_sync_all(ctx);
     if (rc != MML_OK) return rc;
     if (rs != MML_OK) return rs;
+    for (int i = 0; i < 2 * count; ++i)
+        MML_REQUIRE(h_ftn[i] >= 0, MML_ERR_CAPACITY, "down-sample overflowed max_features / the voxel sort capacity");
     memcpy(x_inout, h_x, sizeof(double) * 6 * (size_t)count);
     return MML_OK;
 }

@@ -716,6 +716,23 @@ def test_fused_step_equals_staged_path_with_motion(M, O, synth):
         c.close()
 
 
+def test_step_reports_feature_capacity_overflow(M, scene, synth):
+    """A down-sampled stack that does not fit max_features is an error of mml_step, not a silently empty problem."""
+    c = M.Context(max_scans=2, max_features=256)
+    try:
+        c.map_set_local(0, scene["corner_map"])
+        c.map_set_local(1, scene["surf_map"])
+        fr = scene["frames"][0]
+        for s in range(2):
+            c.scan_upload(s, fr["velo"], fr["livox"])
+        x0 = np.stack([pose_to_x(perturbed(fr["T_gt"]))] * 2)
+        with pytest.raises(M.MmlError) as e:
+            c.step(0, 2, np.tile(np.eye(3).reshape(1, 9), (2, 1)), np.zeros((2, 3)), np.eye(4), 25.0, 10, x0)
+        assert e.value.code == M.MML_ERR_CAPACITY
+    finally:
+        c.close()
+
+
 def test_odometry_replay_matches_oracle_loop(M, O, synth):
     """BASELINE config 3 shape, synthetic: scans replayed one by one through the whole loop -- extract, undistort,
     down-sample, Estimate (5 outer x 10 inner) against the local map, key-scan rule, MapIncrementLocal -- with the
