@@ -31,7 +31,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s ach
 # The SURVEY 8(d) figures: extraction 20 B/pt in total, undistort 28 B/pt, association 112 B/feature,
 # linearisation 72 B/factor/iteration.  The extraction chain is split over its kernels by what each must move.
 STAGE_BYTES = {
-    "assign":           lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l, # read the raw records once
+    "assign_count":     lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l, # k_assign_a: read the raw records, ring id / crop test
+    "assign_scan":      lambda n_v, n_l, nf, it: 0,                   # k_assign_b: block records only
+    "assign_scatter":   lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l + 20 * (n_v + n_l),  # k_assign_c: read again, write xyzi + label slot
     "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),    # read xyzi of every bucketed point
     "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),    # attr 2 B + 2 order keys 8 B + label 1 B
     "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),     # write the 4 B label/line/time record

@@ -1531,10 +1531,16 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     hipStream_t s = MML_STREAM(ctx);
     const int pblocks = (ctx->NT + 255) / 256;
     {
-        MmlStageScope t(ctx, "assign");
+        MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
         hipLaunchKernelGGL(k_assign_a, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "assign_scan");
         hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(1024), 0, s, P);
+    }
+    {
+        MmlStageScope t(ctx, "assign_scatter");
         hipLaunchKernelGGL(k_assign_c, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
     }
     {
