@@ -71,6 +71,8 @@ struct FeatParams {
     uint8_t* fu_label;
     int* fu_info;
     const float* extr;  // 16 floats or nullptr
+    unsigned* brk_queue;  // [B][NT] line-bucketed positions whose break-point test needs the double-precision part
+    int* brk_cnt;         // [B]
 };
 
 struct D3 {
@@ -526,6 +528,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     const float4* pt = P.ln_pts + base;
     unsigned attr = 0;
     float curv = 0.f, refl = 0.f;
+    bool brk = false;
     if (i >= 5 && i < n - 5) {
         const float thDistanceFaraway = 50.0;
         const float thFlatThreshold = 0.02;
@@ -737,6 +740,48 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
             }
         }
         // ---- :651-806 break points ----
+        // Only a range discontinuity of more than 1 m can make a break point; what follows that test (two more square
+        // roots, a double-precision angle, six double normalisations) concerns a few dozen points per scan, but a
+        // wavefront pays for it as soon as ONE of its 64 lanes qualifies.  Those points are therefore queued and
+        // finished by k_stencil_break with every lane busy.
+        {
+            float dX1 = PT(1).x - PT(0).x, dY1 = PT(1).y - PT(0).y, dZ1 = PT(1).z - PT(0).z;
+            float dX2 = PT(-1).x - PT(0).x, dY2 = PT(-1).y - PT(0).y, dZ2 = PT(-1).z - PT(0).z;
+            const float sq_right = dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1, sq_left = dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2;
+            // two distances below 1 m cannot differ by more than thBreakCornerDis = 1 (sqrtf is monotone and
+            // sqrtf(x) <= 1 for x < 1)
+            brk = !(sq_right < 1.f && sq_left < 1.f);
+        }
+        if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
+#undef PT
+    }
+    P.ln_curv[base + i] = curv;
+    P.ln_refl[base + i] = refl;
+    P.ln_attr[base + i] = (uint16_t)attr;
+    // wave-aggregated append to the slot's break-point queue
+    const unsigned long long bm = __ballot(brk);
+    if (bm) {
+        const int lane = threadIdx.x & 63;
+        int first = 0;
+        if (lane == (int)__ffsll((long long)bm) - 1) first = atomicAdd(&P.brk_cnt[b], __popcll(bm));
+        first = __shfl(first, (int)__ffsll((long long)bm) - 1);
+        if (brk) P.brk_queue[(size_t)b * P.NT + first + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(start + i);
+    }
+}
+
+// the queued break-point candidates (:651-806), one per lane
+__global__ __launch_bounds__(256) void k_stencil_break(FeatParams P) {
+    const int b = blockIdx.y + P.first;
+    const int cnt = P.brk_cnt[b];
+    const float thBreakCornerDis = 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
+        const size_t pos = (size_t)b * P.NT + P.brk_queue[(size_t)b * P.NT + e];
+        const float4* pt = P.ln_pts + pos;
+        float4 q[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q[k] = pt[k - 3];
+#define PT(o) q[3 + (o)]
+        unsigned f5 = 0;
         {
             float dX1 = PT(1).x - PT(0).x, dY1 = PT(1).y - PT(0).y, dZ1 = PT(1).z - PT(0).z;
             float dX2 = PT(-1).x - PT(0).x, dY2 = PT(-1).y - PT(0).y, dZ2 = PT(-1).z - PT(0).z;
@@ -799,15 +844,12 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
                     norm_back.z += (k / 6.0) * tmp.z;
                 }
                 double cc = fabs(ddot(norm_front, norm_back) / (dnorm(norm_front) * dnorm(norm_back)));
-                attr |= (cc < 0.95 ? 1u : 2u) << A_F5_SHIFT;
+                f5 = cc < 0.95 ? 1u : 2u;
             }
         }
-        if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
+        if (f5) P.ln_attr[pos] = (uint16_t)(P.ln_attr[pos] | (f5 << A_F5_SHIFT));
 #undef PT
     }
-    P.ln_curv[base + i] = curv;
-    P.ln_refl[base + i] = refl;
-    P.ln_attr[base + i] = (uint16_t)attr;
 }
 
 // ---- a4 + a5 + a6 walk + a8 emit: one 256-thread workgroup per scan line ---------------------------------------
@@ -1520,6 +1562,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.fu_label = ctx->fu_label;
     P.fu_info = ctx->fu_info;
     P.extr = nullptr;
+    P.brk_queue = ctx->brk_queue;
+    P.brk_cnt = ctx->brk_cnt;
     return P;
 }
 
@@ -1545,7 +1589,9 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "stencil");
+        MML_HIP(hipMemsetAsync(ctx->brk_cnt + first, 0, sizeof(int) * count, s));
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, count), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
     }
     {
         MmlStageScope t(ctx, "select");
@@ -1567,7 +1613,11 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     const int t = (n > ctx->L ? n : ctx->L);
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
     const int pblocks = (n + 255) / 256;
-    if (pblocks > 0) hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
+    MML_HIP(hipMemsetAsync(ctx->brk_cnt, 0, sizeof(int), s));
+    if (pblocks > 0) {
+        hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_stencil_break, dim3(2, 1), dim3(256), 0, s, P);
+    }
     hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     MML_HIP(hipGetLastError());
     return MML_OK;

@@ -86,6 +86,8 @@ struct mml_ctx {
     int* assign_aux = nullptr;   // 8 ints per slot
     unsigned* sel_scratch = nullptr;  // 4 x B*NT unsigned: k_select scratch for lines beyond the LDS budget
     int sel_cap = 0;
+    unsigned* brk_queue = nullptr;  // B * NT: queued break-point candidates of k_stencil
+    int* brk_cnt = nullptr;         // B
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
     int* cb_n = nullptr;  // B * 2
