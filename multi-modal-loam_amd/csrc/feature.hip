@@ -143,13 +143,13 @@ __global__ void k_assign_init(FeatParams P, int count) {
 }
 
 // getVeloFeature per-point part (:1133, :1154-1168) -- ring id through a float estimate of the pitch, the reference
-// expression (double atan) only when the estimate is within 1e-3 ring widths of a rounding boundary.
+// expression (double atan) only when the estimate is within 2e-4 ring widths of a rounding boundary.
 __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pitch_step, int R) {
     const float rxy = sqrtf(p.x * p.x + p.y * p.y);
     const float est = atanf(p.z / rxy) * 57.29577951308232f;
     const double t = (double)((est - pitch0) / pitch_step) + 0.5;
     int scanID;
-    if (fabs(t - rint(t)) > 1e-3 && fabs(t) < 1e6) {
+    if (fabs(t - rint(t)) > 2e-4 && fabs(t) < 1e6) {
         scanID = (int)t;
     } else {
         const float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;

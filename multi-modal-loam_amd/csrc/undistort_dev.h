@@ -110,7 +110,7 @@ __device__ __forceinline__ void undistort_exact(const double* dR, const double* 
 // One point.  dR / dt: the 12 per-scan doubles; dv: the 8 derived doubles of k_undistort_prep (qlc x,y,z,w | theta |
 // sinTheta | 1/sinTheta | linear-branch flag); s: the point's in-sweep time.  Fast form first (closed-form slerp of a
 // unit quaternion, small-angle sin / cos polynomials), the reference expression when a coordinate of the double
-// result lies within 1e-11 of a float rounding boundary.
+// result lies within 1e-13 (relative to the input scale) of a float rounding boundary.
 __device__ __forceinline__ void undistort_point(const double* dR, const double* dt, const double* dv, float s, float4& p) {
     const double t = s;
     const double qx = dv[0], qy = dv[1], qz = dv[2], qw = dv[3];
@@ -176,7 +176,7 @@ __device__ __forceinline__ void undistort_point(const double* dR, const double* 
     const double ox = (dR[0] * wx + dR[3] * wy) + dR[6] * wz;
     const double oy = (dR[1] * wx + dR[4] * wy) + dR[7] * wz;
     const double oz = (dR[2] * wx + dR[5] * wy) + dR[8] * wz;
-    const double tol = 1e-11 * (((fabs(vx) + fabs(vy)) + fabs(vz)) + ((fabs(dt[0]) + fabs(dt[1])) + fabs(dt[2])) + 1e-30);
+    const double tol = 1e-13 * (((fabs(vx) + fabs(vy)) + fabs(vz)) + ((fabs(dt[0]) + fabs(dt[1])) + fabs(dt[2])) + 1e-30);
     if (float_round_safe(ox, tol) & float_round_safe(oy, tol) & float_round_safe(oz, tol)) {
         p.x = ox;
         p.y = oy;

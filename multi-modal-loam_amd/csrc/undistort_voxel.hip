@@ -43,7 +43,7 @@ __global__ void k_undistort_prep(int count, const double* params, double* derive
 
 // One point per lane.  Fast form: the slerp divisions become one multiplication by the per-scan 1/sin(theta), the
 // quaternion normalisation uses v_rsq_f64 + Newton; its result differs from the reference expression by ~1e-15
-// relative, so the FLOAT it rounds to is the same unless the double lies within 1e-11 of a float rounding
+// relative, so the FLOAT it rounds to is the same unless the double lies within 1e-13 of a float rounding
 // boundary -- in that case (a few points per million) the reference expression is evaluated.
 __global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int* fu_info, float4* fu_xyzi,
                                                   float* fu_rel, const double* params, const double* derived) {
