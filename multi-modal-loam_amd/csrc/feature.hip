@@ -906,6 +906,29 @@ __device__ __forceinline__ bool visits_before(unsigned info_j, unsigned key_j, i
     return j < i;
 }
 __device__ __forceinline__ unsigned st_of(unsigned w) { return (w >> I_ST_SHIFT) & 3u; }
+// visits_before for neighbours: j = i + D with D a compile-time constant, so the index tie-break is the sign of D and
+// the rest is one 64-bit comparison of (partition, curvature bits)
+template <int D>
+__device__ __forceinline__ bool nb_visits_before_me(unsigned info_j, unsigned key_j, unsigned info_i, unsigned key_i) {
+    const unsigned long long kj = ((unsigned long long)(info_j & I_PART_MASK) << 32) | key_j;
+    const unsigned long long ki = ((unsigned long long)(info_i & I_PART_MASK) << 32) | key_i;
+    return D < 0 ? kj <= ki : kj < ki;
+}
+template <int D>
+__device__ __forceinline__ bool me_visits_before_nb(unsigned info_i, unsigned key_i, unsigned info_j, unsigned key_j) {
+    const unsigned long long kj = ((unsigned long long)(info_j & I_PART_MASK) << 32) | key_j;
+    const unsigned long long ki = ((unsigned long long)(info_i & I_PART_MASK) << 32) | key_i;
+    return D > 0 ? ki <= kj : ki < kj;
+}
+template <int Q>
+constexpr int nb_dist() {  // neighbour slot q -> distance: -3, -2, -1, 1, 2, 3
+    return Q < 3 ? Q - 3 : Q - 2;
+}
+// covers(info_j, -D): does neighbour j = i + D mark me?  (a: how far it marks towards higher indices, b: lower)
+template <int D>
+__device__ __forceinline__ bool nb_covers_me(unsigned info_j) {
+    return D < 0 ? (unsigned)(-D) <= ((info_j >> I_A_SHIFT) & 3u) : (unsigned)D <= ((info_j >> I_B_SHIFT) & 3u);
+}
 // the six {key, info} records at distance -3,-2,-1,1,2,3 of point i, fetched together (one wait instead of six)
 template <typename WP>
 __device__ __forceinline__ void load_nb(WP W, int i, uint2 (&o)[6]) {
@@ -938,6 +961,23 @@ extern "C" int mml_debug_sel_timing(unsigned long long* out) {
 #define SEL_MARK(id)
 #endif
 
+// phase 1: can neighbour slot Q suppress me?   phase 2: does picked neighbour Q mark me (before my visit / from a
+// later partition)?
+template <int Q>
+__device__ __forceinline__ unsigned p1_bit(const uint2 o, unsigned me, unsigned mk) {
+    constexpr int D = nb_dist<Q>();
+    const bool c = ((o.y & I_CAND) != 0) & nb_covers_me<D>(o.y) & nb_visits_before_me<D>(o.y, o.x, me, mk);
+    return c ? 1u << Q : 0u;
+}
+template <int Q>
+__device__ __forceinline__ void p2_acc(const uint2 o, unsigned me, unsigned mk, bool sel, int mypart, bool& covL, bool& covLater) {
+    constexpr int D = nb_dist<Q>();
+    const bool hit = (st_of(o.y) == ST_S) & nb_covers_me<D>(o.y);
+    const bool later = (int)(o.y & I_PART_MASK) > mypart;
+    covLater |= hit & later;
+    covL |= hit & !later & (!sel | me_visits_before_nb<D>(me, mk, o.y, o.x));
+}
+
 // W: interleaved {key, W1} pairs (8 bytes per point).  R: reflect order keys (4 bytes per point).
 // K > 0: the line fits the LDS budget (n <= K * SELP_THREADS).  Point i = tid + k * SELP_THREADS belongs to the same
 // thread in every phase, so its attribute word and fused-cloud index are fetched ONCE, all loads in flight together,
@@ -949,7 +989,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
                                             U64P wvis, ByteP wexit, ByteP wsel, int* s_sp,
                                             unsigned long long (*s_pm)[3], unsigned long long* s_minE,
                                             unsigned long long* s_minG, unsigned char* s_bfirst,
-                                            unsigned char* s_list, int* s_cnt, int* s_flag) {
+                                            unsigned char* s_list, int* s_cnt, int* s_flag, unsigned short* s_walk) {
     constexpr bool CACHED = K > 0;
     constexpr int KK = CACHED ? K : 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1010,6 +1050,17 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     }
     if (tid == 0) *s_cnt = 0;
     if (tid < 3) s_flag[tid] = 0;
+    // transfer table of the stride walk over 8 positions: (RFLAT byte, entry offset 0..3) -> visited byte | exit << 8
+    for (int t = tid; t < 1024; t += SELP_THREADS) {
+        const unsigned m8 = (unsigned)t >> 2;
+        int pos = t & 3;
+        unsigned v = 0;
+        while (pos < 8) {
+            v |= 1u << pos;
+            pos += ((m8 >> pos) & 1u) ? 4 : 1;
+        }
+        s_walk[t] = (unsigned short)(v | ((unsigned)(pos - 8) << 8));
+    }
     __syncthreads();
 
     SEL_MARK(1);
@@ -1051,12 +1102,8 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         const unsigned mk = rec.x;
         uint2 o[6];
         load_nb(W, i, o);
-        unsigned m = 0;
-        _Pragma("unroll") for (int q = 0; q < 6; ++q) {
-            const int d = q < 3 ? q - 3 : q - 2;  // -3,-2,-1,1,2,3  (j = i + d)
-            const bool c = ((o[q].y & I_CAND) != 0) & covers(o[q].y, -d) & visits_before(o[q].y, o[q].x, i + d, me, mk, i);
-            m |= c ? 1u << q : 0u;
-        }
+        const unsigned m = p1_bit<0>(o[0], me, mk) | p1_bit<1>(o[1], me, mk) | p1_bit<2>(o[2], me, mk) | p1_bit<3>(o[3], me, mk) |
+                           p1_bit<4>(o[4], me, mk) | p1_bit<5>(o[5], me, mk);
         W[2 * i + 1] = m ? (me | (m << I_MASK_SHIFT)) : ((me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT));
     )
     __syncthreads();
@@ -1070,32 +1117,59 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         }
     }
     int rnd = 0;
+    // one decision step for point i: returns true when the point got decided
+    auto decide = [&](int i) -> bool {
+        const unsigned me = W[2 * i + 1];
+        if (st_of(me) != ST_U) return true;
+        unsigned o[6];
+        load_nb_info(W, i, o);
+        // the six neighbour states packed 2 bits each, tested against the predecessor mask spread to the same layout
+        unsigned ps = 0;
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) ps |= ((o[q] >> I_ST_SHIFT) & 3u) << (2 * q);
+        unsigned m = (me >> I_MASK_SHIFT) & 63u;
+        m = (m | (m << 4)) & 0x0F0Fu;
+        m = (m | (m << 2)) & 0x3333u;
+        m = (m | (m << 1)) & 0x5555u;                 // bit q -> bit 2q
+        const bool anyU = (ps & m) != 0;              // ST_U = 01
+        const bool anyS = (ps & (m << 1)) != 0;       // ST_S = 10
+        if (anyS) {
+            W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_N << I_ST_SHIFT);
+            return true;
+        }
+        if (!anyU) {
+            W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT);
+            return true;
+        }
+        return false;
+    };
     for (;;) {
         int undecided = 0;
-        FOR_POINTS(
-            if (CACHED && !(pend & (1u << k))) continue;
-            const unsigned me = W[2 * i + 1];
-            if (st_of(me) != ST_U) continue;
-            const unsigned m = (me >> I_MASK_SHIFT) & 63u;
-            unsigned o[6];
-            load_nb_info(W, i, o);
-            bool anyS = false, anyU = false;
-            _Pragma("unroll") for (int q = 0; q < 6; ++q) {
-                const bool on = (m >> q) & 1u;
-                const unsigned s = st_of(o[q]);
-                anyS |= on & (s == ST_S);
-                anyU |= on & (s == ST_U);
+        if constexpr (CACHED) {
+            // The 64 lanes of a wavefront hold 64 consecutive points, and a point only waits for neighbours at most 3
+            // away: most dependency chains live inside one wavefront and are followed there, a few steps per k,
+            // without a workgroup barrier (LDS operations of one wavefront execute in program order).
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const int i = tid + k * SELP_THREADS;
+                bool mine = i < n && ((pend >> k) & 1u);
+                for (int rep = 0; rep < 4; ++rep) {
+                    if (!__any(mine)) break;
+                    bool changed = false;
+                    if (mine && decide(i)) {
+                        mine = false;
+                        changed = true;
+                        pend &= ~(1u << k);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");  // neighbours' words must be re-read in the next step
+                    if (!__any(changed)) break;
+                }
+                undecided |= mine ? 1 : 0;
             }
-            if (anyS) {
-                W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_N << I_ST_SHIFT);
-                pend &= ~(1u << k);
-            } else if (!anyU) {
-                W[2 * i + 1] = (me & ~I_ST_MASK) | (ST_S << I_ST_SHIFT);
-                pend &= ~(1u << k);
-            } else {
-                undecided = 1;
-            }
-        )
+        } else {
+            for (int i = tid; i < n; i += SELP_THREADS)
+                if (!decide(i)) undecided = 1;
+        }
 #ifdef MML_SEL_TIMING
         if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[20] += 1;
 #endif
@@ -1120,13 +1194,12 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         uint2 o[6];
         load_nb(W, i, o);
         bool covL = false, covLater = false;
-        _Pragma("unroll") for (int q = 0; q < 6; ++q) {
-            const int d = q < 3 ? q - 3 : q - 2;
-            const bool hit = (st_of(o[q].y) == ST_S) & covers(o[q].y, -d);
-            const bool later = (int)(o[q].y & I_PART_MASK) > mypart;
-            covLater |= hit & later;
-            covL |= hit & !later & (!sel | visits_before(me, mk, i, o[q].y, o[q].x, i + d));
-        }
+        p2_acc<0>(o[0], me, mk, sel, mypart, covL, covLater);
+        p2_acc<1>(o[1], me, mk, sel, mypart, covL, covLater);
+        p2_acc<2>(o[2], me, mk, sel, mypart, covL, covLater);
+        p2_acc<3>(o[3], me, mk, sel, mypart, covL, covLater);
+        p2_acc<4>(o[4], me, mk, sel, mypart, covL, covLater);
+        p2_acc<5>(o[5], me, mk, sel, mypart, covL, covLater);
         const unsigned f3a = covL ? 1u : (sel ? 3u : 0u);
         const unsigned f = f3a | (covLater ? 4u : 0u);
         // the word is only read by its owner from here on
@@ -1152,66 +1225,119 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         __syncthreads();
     }
     SEL_MARK(6);
-    // (a2) for each of the <= 3 reflect picks of a partition: does its reflect visit (B_k, k = reflect rank) come
-    //      before its own curvature visit (A_k)?  One wavefront per pick counts both ranks over the partition.
-    //      b_first is only read for a pick that holds flag 3 or is a grazing point (see (b) and phase 5): those few
-    //      are listed first, one lane per pick.
-    if (tid < 150) {
-        const unsigned long long e = s_pm[tid / 3][tid % 3];
-        if (e != ~0ull) {
-            const unsigned wi = W[2 * (int)(unsigned)e + 1];
-            if (((wi >> I_F_SHIFT) & 3u) == 3u || (wi & I_ANGLE)) s_list[atomicAdd(s_cnt, 1)] = (unsigned char)tid;
-        }
-    }
-    __syncthreads();
-    const int n_need = *s_cnt;
-    for (int u = (tid >> 6); u < n_need; u += SELP_THREADS / 64) {
-        const int t = s_list[u];
-        const int j = t / 3, r = t % 3;
-        const unsigned long long e = s_pm[j][r];
-        const int i = (int)(unsigned)e;
-        const int sp = s_sp[j], ep = s_sp[j + 1] - 1;
-        const unsigned mk = W[2 * i];
-        const unsigned mr = (unsigned)(e >> 32);
-        int rc = 0, rr = 0;
-        for (int q = sp + lane; q <= ep; q += 64) {
-            const unsigned kq = W[2 * q], rq = RKEY(q);
-            rc += (kq < mk) || (kq == mk && q < i);
-            rr += (rq < mr) || (rq == mr && q < i);
-        }
+    // (a2) + (b).  (a2): for each of the <= 3 reflect picks of a partition, does its reflect visit (B_k, k = reflect rank)
+    //      come before its own curvature visit (A_k)?  Only read for a pick that holds flag 3 or is a grazing point.
+    //      (b): eff3 / G bits, first point of each class in curvature order per partition.
+    if constexpr (CACHED) {
+        // the wavefront that owns such a pick counts both ranks over the pick's partition on the spot (two ballots per
+        // 64 points), so the answer never leaves the owner's registers: no list, no extra barriers
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            rc += __shfl_xor(rc, o);
-            rr += __shfl_xor(rr, o);
-        }
-        if (lane == 0) s_bfirst[t] = (unsigned char)(rr < rc);
-    }
-    __syncthreads();
-    SEL_MARK(7);
-    // (b) eff3 / G bits, first point of each class in curvature order per partition
-    FOR_POINTS(
-        const unsigned me = W[2 * i + 1];
-        if (!(me & I_INPART)) continue;
-        const int j = me & I_PART_MASK;
-        bool inB = false, b_first = false;
-        if (me & I_REFL) {
-            const unsigned long long rk = ((unsigned long long)RKEY(i) << 32) | (unsigned)i;
-            _Pragma("unroll") for (int r = 0; r < 3; ++r)
-                if (rk == s_pm[j][r]) {
-                    inB = true;
-                    b_first = ((((me >> I_F_SHIFT) & 3u) == 3u) || (me & I_ANGLE)) && s_bfirst[j * 3 + r];
+        for (int k = 0; k < KK; ++k) {
+            const int i = tid + k * SELP_THREADS;
+            if ((i & ~63) >= n) break;  // wave-uniform
+            const bool act = i < n;
+            const unsigned me = act ? (unsigned)W[2 * i + 1] : 0u;
+            const unsigned mk = act ? (unsigned)W[2 * i] : 0u;
+            const int j = me & I_PART_MASK;
+            bool inB = false;
+            unsigned myr = 0;
+            if ((me & I_INPART) && (me & I_REFL)) {
+                myr = R[i];
+                const unsigned long long rk = ((unsigned long long)myr << 32) | (unsigned)i;
+                inB = (rk == s_pm[j][0]) | (rk == s_pm[j][1]) | (rk == s_pm[j][2]);
+            }
+            const bool need = inB && ((((me >> I_F_SHIFT) & 3u) == 3u) || (me & I_ANGLE));
+            bool b_first = false;
+            unsigned long long bm = __ballot(need);
+            while (bm) {
+                const int src = (int)__ffsll((long long)bm) - 1;
+                bm &= bm - 1;
+                const int pj = __shfl(j, src), pi = __shfl(i, src);
+                const unsigned pk = __shfl(mk, src), pr = __shfl(myr, src);
+                const int sp = s_sp[pj], ep = s_sp[pj + 1] - 1;
+                int rc = 0, rr = 0;
+                for (int q0 = sp; q0 <= ep; q0 += 64) {
+                    const int q = q0 + lane;
+                    const bool in = q <= ep;
+                    const unsigned kq = in ? (unsigned)W[2 * q] : 0u, rq = in ? (unsigned)R[q] : 0u;
+                    rc += __popcll(__ballot(in && ((kq < pk) || (kq == pk && q < pi))));
+                    rr += __popcll(__ballot(in && ((rq < pr) || (rq == pr && q < pi))));
                 }
+                if (lane == src) b_first = rr < rc;
+            }
+            if (!(me & I_INPART)) continue;
+            const bool eff3 = (((me >> I_F_SHIFT) & 3u) == 3u) && !(inB && b_first);
+            const bool G = (me & I_ANGLE) || (eff3 && (me & I_FAR));
+            if (inB || eff3 || G) {
+                const unsigned bits = (inB ? 1u : 0u) | (eff3 ? 2u : 0u) | (G ? 4u : 0u) | (b_first ? 8u : 0u);
+                W[2 * i + 1] = me | (bits << I_X_SHIFT);
+                const unsigned long long ck = ((unsigned long long)mk << 32) | (unsigned)i;
+                if (eff3) atomicMin(&s_minE[j], ck);
+                if (G) atomicMin(&s_minG[j], ck);
+            }
         }
-        const bool eff3 = (((me >> I_F_SHIFT) & 3u) == 3u) && !(inB && b_first);
-        const bool G = (me & I_ANGLE) || (eff3 && (me & I_FAR));
-        if (inB || eff3 || G) {
-            const unsigned bits = (inB ? 1u : 0u) | (eff3 ? 2u : 0u) | (G ? 4u : 0u) | (b_first ? 8u : 0u);
-            W[2 * i + 1] = me | (bits << I_X_SHIFT);
-            const unsigned long long ck = ((unsigned long long)W[2 * i] << 32) | (unsigned)i;
-            if (eff3) atomicMin(&s_minE[j], ck);
-            if (G) atomicMin(&s_minG[j], ck);
+    } else {
+        // (a2) for each of the <= 3 reflect picks of a partition: does its reflect visit (B_k, k = reflect rank) come
+        //      before its own curvature visit (A_k)?  One wavefront per pick counts both ranks over the partition.
+        //      b_first is only read for a pick that holds flag 3 or is a grazing point (see (b) and phase 5): those few
+        //      are listed first, one lane per pick.
+        if (tid < 150) {
+            const unsigned long long e = s_pm[tid / 3][tid % 3];
+            if (e != ~0ull) {
+                const unsigned wi = W[2 * (int)(unsigned)e + 1];
+                if (((wi >> I_F_SHIFT) & 3u) == 3u || (wi & I_ANGLE)) s_list[atomicAdd(s_cnt, 1)] = (unsigned char)tid;
+            }
         }
-    )
+        __syncthreads();
+        const int n_need = *s_cnt;
+        for (int u = (tid >> 6); u < n_need; u += SELP_THREADS / 64) {
+            const int t = s_list[u];
+            const int j = t / 3, r = t % 3;
+            const unsigned long long e = s_pm[j][r];
+            const int i = (int)(unsigned)e;
+            const int sp = s_sp[j], ep = s_sp[j + 1] - 1;
+            const unsigned mk = W[2 * i];
+            const unsigned mr = (unsigned)(e >> 32);
+            int rc = 0, rr = 0;
+            for (int q = sp + lane; q <= ep; q += 64) {
+                const unsigned kq = W[2 * q], rq = RKEY(q);
+                rc += (kq < mk) || (kq == mk && q < i);
+                rr += (rq < mr) || (rq == mr && q < i);
+            }
+    #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                rc += __shfl_xor(rc, o);
+                rr += __shfl_xor(rr, o);
+            }
+            if (lane == 0) s_bfirst[t] = (unsigned char)(rr < rc);
+        }
+        __syncthreads();
+        SEL_MARK(7);
+        // (b) eff3 / G bits, first point of each class in curvature order per partition
+        FOR_POINTS(
+            const unsigned me = W[2 * i + 1];
+            if (!(me & I_INPART)) continue;
+            const int j = me & I_PART_MASK;
+            bool inB = false, b_first = false;
+            if (me & I_REFL) {
+                const unsigned long long rk = ((unsigned long long)RKEY(i) << 32) | (unsigned)i;
+                _Pragma("unroll") for (int r = 0; r < 3; ++r)
+                    if (rk == s_pm[j][r]) {
+                        inB = true;
+                        b_first = ((((me >> I_F_SHIFT) & 3u) == 3u) || (me & I_ANGLE)) && s_bfirst[j * 3 + r];
+                    }
+            }
+            const bool eff3 = (((me >> I_F_SHIFT) & 3u) == 3u) && !(inB && b_first);
+            const bool G = (me & I_ANGLE) || (eff3 && (me & I_FAR));
+            if (inB || eff3 || G) {
+                const unsigned bits = (inB ? 1u : 0u) | (eff3 ? 2u : 0u) | (G ? 4u : 0u) | (b_first ? 8u : 0u);
+                W[2 * i + 1] = me | (bits << I_X_SHIFT);
+                const unsigned long long ck = ((unsigned long long)W[2 * i] << 32) | (unsigned)i;
+                if (eff3) atomicMin(&s_minE[j], ck);
+                if (G) atomicMin(&s_minG[j], ck);
+            }
+        )
+    }
     __syncthreads();  // R is dead from here on: the window tables of the cached form live in its storage
 
     SEL_MARK(8);
@@ -1234,16 +1360,26 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     }
     __syncthreads();
     for (int t = tid; t < nw * 4; t += SELP_THREADS) {
-        const int w = t >> 2, e = t & 3;
+        const int w = t >> 2;
         const unsigned long long m = wmask[w];
         unsigned long long vis = 0;
-        int pos = (w == 0) ? 5 : e;  // the walk starts at index 5
-        while (pos < 64) {
-            vis |= 1ull << pos;
-            pos += ((m >> pos) & 1ull) ? 4 : 1;
+        int ent = t & 3, sb = 0;
+        if (w == 0) {  // the walk starts at index 5: the first byte by hand
+            int pos = 5;
+            while (pos < 8) {
+                vis |= 1ull << pos;
+                pos += ((m >> pos) & 1ull) ? 4 : 1;
+            }
+            ent = pos - 8;
+            sb = 1;
+        }
+        for (; sb < 8; ++sb) {  // one table look-up per 8 positions instead of up to 8 dependent steps
+            const unsigned tv = s_walk[(((unsigned)(m >> (8 * sb)) & 255u) << 2) + ent];
+            vis |= (unsigned long long)(tv & 255u) << (8 * sb);
+            ent = (int)(tv >> 8);
         }
         wvis[t] = vis;
-        wexit[t] = (unsigned char)(pos - 64);
+        wexit[t] = (unsigned char)ent;
     }
     __syncthreads();
     SEL_MARK(9);
@@ -1331,11 +1467,13 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_pm[50][3];
     __shared__ unsigned long long s_minE[50], s_minG[50];
-    __shared__ unsigned char s_bfirst[152];
     __shared__ int s_sp[52];
-    __shared__ unsigned char s_list[152];
     __shared__ int s_cnt;
     __shared__ int s_flag[3];
+    __shared__ unsigned short s_walk[1024];
+    // only the global-scratch form (lines beyond the LDS budget) uses these two; its dynamic LDS block is otherwise idle
+    unsigned char* s_bfirst = smem;
+    unsigned char* s_list = smem + 160;
     const int b = blockIdx.y + P.first;
     const int line = blockIdx.x;
     const int n = P.line_len[(size_t)b * P.L + line];
@@ -1351,7 +1489,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
         unsigned long long* wvis = wmask + nwin;
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);
         unsigned char* wsel = wexit + 4 * nwin;
-        select_body<K>(P, b, n, base, W, R, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag);
+        select_body<K>(P, b, n, base, W, R, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
     } else {
         // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
         const size_t BNT = (size_t)P.B * P.NT;
@@ -1365,7 +1503,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
         unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * (size_t)nwin);
         unsigned char* wsel = wexit + 4 * (size_t)nwin;
         select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE,
-                       s_minG, s_bfirst, s_list, &s_cnt, s_flag);
+                       s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
     }
 }
 
