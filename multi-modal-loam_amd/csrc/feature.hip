@@ -62,6 +62,7 @@ struct FeatParams {
     int nblk_t;
     unsigned* sel_scratch;  // global-memory scratch for lines longer than sel_cap: 4 x B*NT unsigned
     int sel_cap;            // points per line k_select keeps in LDS
+    int line0;              // first scan line of this k_select launch (rings and Livox lines are launched separately)
     int B;
     uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
     int* cb_n;
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     unsigned char* s_bfirst = smem;
     unsigned char* s_list = smem + 160;
     const int b = blockIdx.y + P.first;
-    const int line = blockIdx.x;
+    const int line = blockIdx.x + P.line0;
     const int n = P.line_len[(size_t)b * P.L + line];
     if (n <= 0) return;
     const int start = P.line_start[(size_t)b * P.L + line];
@@ -1691,6 +1692,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.nblk_t = (ctx->NT + 255) / 256;
     P.sel_scratch = ctx->sel_scratch;
     P.sel_cap = ctx->sel_cap;
+    P.line0 = 0;
     P.B = ctx->B;
     P.ln_final = nullptr;
     P.cb_n = ctx->cb_n;
@@ -1733,7 +1735,18 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "select");
-        hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(ctx->L, count), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
+        // rings and Livox lines have different nominal lengths: each group runs the variant whose LDS block fits it, so the
+        // short rings do not pay (in occupancy) for the long Livox lines
+        FeatParams Pv = P;
+        Pv.sel_cap = ctx->sel_cap_velo;
+        hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(ctx->cfg.n_rings, count), dim3(SELP_THREADS),
+                           select_lds_bytes(ctx->sel_cap_velo), s, Pv);
+        if (ctx->L > ctx->cfg.n_rings) {
+            FeatParams Pl = P;
+            Pl.line0 = ctx->cfg.n_rings;
+            hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(ctx->L - ctx->cfg.n_rings, count), dim3(SELP_THREADS),
+                               select_lds_bytes(ctx->sel_cap), s, Pl);
+        }
     }
     {
         MmlStageScope t(ctx, "crop_compact");
@@ -1765,12 +1778,17 @@ int mml_feature_init(mml_ctx* ctx) {
     // LDS budget of k_select: twice the nominal ring length / the nominal Livox line length + 2 %, rounded up to a
     // whole number of points per thread (the default 16 x 1800 + 6 x 4000 layout gets 4096 points = 51.6 KB, three
     // workgroups per CU); longer lines take the global-scratch form of the same code
-    int cap = 2 * (ctx->NV / (ctx->cfg.n_rings > 0 ? ctx->cfg.n_rings : 1));
+    const int ring_nominal = ctx->NV / (ctx->cfg.n_rings > 0 ? ctx->cfg.n_rings : 1);
     int capl = (51 * (ctx->NL / (ctx->cfg.n_livox_lines > 0 ? ctx->cfg.n_livox_lines : 1))) / 50;
-    if (capl > cap) cap = capl;
+    int cap = capl > 2 * ring_nominal ? capl : 2 * ring_nominal;  // Livox lines, and the single-line entry point
     cap = select_round_cap(cap);
     ctx->sel_cap = cap;
+    // rings: nominal length + 12 % (a 16 x 1800 scan gets 2048 points = 28.9 KB, five workgroups per CU)
+    ctx->sel_cap_velo = select_round_cap((ring_nominal * 9) / 8);
+    if (ctx->sel_cap_velo > cap) ctx->sel_cap_velo = cap;
     MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_variant(cap)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_lds_bytes(cap)));
+    MML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_variant(ctx->sel_cap_velo)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_lds_bytes(ctx->sel_cap_velo)));
     return MML_OK;
 }

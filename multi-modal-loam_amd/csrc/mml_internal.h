@@ -86,6 +86,7 @@ struct mml_ctx {
     int* assign_aux = nullptr;   // 8 ints per slot
     unsigned* sel_scratch = nullptr;  // 4 x B*NT unsigned: k_select scratch for lines beyond the LDS budget
     int sel_cap = 0;
+    int sel_cap_velo = 0;
     unsigned* brk_queue = nullptr;  // B * NT: queued break-point candidates of k_stencil
     int* brk_cnt = nullptr;         // B
 

@@ -59,8 +59,9 @@ def test_detect_line_golden_and_oracle(ctx, O, synth):
 
 def test_detect_line_edge_cases(ctx, O):
     rng = np.random.default_rng(0)
-    # 5056 = LDS capacity of k_select for the default config: longer lines take the global-scratch path
-    for n in (0, 1, 5, 10, 11, 12, 13, 25, 60, 61, 62, 64, 65, 111, 127, 128, 129, 700, 3333, 5056, 5057, 9001):
+    # 4096 (Livox lines, single-line entry) = LDS capacity of k_select for the default config: longer lines take the
+    # global-scratch path
+    for n in (0, 1, 5, 10, 11, 12, 13, 25, 60, 61, 62, 64, 65, 111, 127, 128, 129, 700, 2048, 2049, 3333, 4096, 4097, 5057, 9001):
         pts = np.zeros((n, 4), np.float32)
         if n:
             az = np.linspace(0, 1.0 + 0.001 * n, n)
