@@ -17,11 +17,13 @@ STAGE = {"k_assign_init": "assign_count", "k_assign_a": "assign_count", "k_assig
 
 def per_kernel(path, counter):
     d = pd.read_csv(path)
-    d["k"] = (d["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace("void ", "", regex=False)
-              .str.split("(").str[0].str.split("<").str[0])
+    full = d["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace("void ", "", regex=False).str.split("(").str[0]
+    d["kfull"] = full                     # template arguments kept: k_select<4> and k_select<8> are separate launches
+    d["k"] = full.str.split("<").str[0]
     d = d[d.Counter_Name == counter]
-    mx = d.groupby("k")["Grid_Size"].transform("max")
-    return d[d.Grid_Size == mx].groupby("k")["Counter_Value"].mean()
+    mx = d.groupby("kfull")["Grid_Size"].transform("max")
+    per_variant = d[d.Grid_Size == mx].groupby(["k", "kfull"])["Counter_Value"].mean()
+    return per_variant.groupby(level=0).sum()
 
 
 def main(fp, wp, scans):
