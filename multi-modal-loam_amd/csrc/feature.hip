@@ -1680,8 +1680,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.ln_attr = ctx->ln_attr;
     P.blk_cnt = ctx->blk_cnt;
     P.assign_aux = ctx->assign_aux;
-    P.nblk_v = (ctx->NV + 255) / 256;
-    P.nblk_l = (ctx->NL + 255) / 256;
+    P.nblk_v = (ctx->NV + AB_THREADS - 1) / AB_THREADS;
+    P.nblk_l = (ctx->NL + AB_THREADS - 1) / AB_THREADS;
     P.nblk_max = P.nblk_v > P.nblk_l ? P.nblk_v : P.nblk_l;
     P.ring_bits = 1;
     while ((1 << P.ring_bits) < ctx->cfg.n_rings) ++P.ring_bits;
