@@ -1056,35 +1056,45 @@ __device__ __forceinline__ void group_merge5(const Knn5& local, Knn5& out) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
+// Queue entry word: bit 0 stage (0 cube cloud, 1 local map), bits 1..14 cube, bit 30 "search again in the local map".
+constexpr int HARD_REDO = 1 << 30;
+
+// Far queries, search only: one 16-lane group per queued feature, the lanes split the rows of every shell and merge
+// their private top-5 lists with shuffles.  The result goes back to hard_knn; the model fit runs in k_associate_fit with
+// one LANE per feature -- inside this kernel it would run on one lane in sixteen.
+// round 0: every queued feature, continuing after ring 1 of the stage it was queued in.
+// round 1: the features whose cube-stage fit failed (HARD_REDO), local map from ring 0 (:283 / :702).
+__global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round) {
     const int gl = threadIdx.x & 15;
     const int group = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int ngroups = (gridDim.x * 256) >> 4;
     const int total = *P.hard_count;
     for (int w0 = 0; w0 < total; w0 += ngroups) {
         const int w = w0 + group;
-        const bool live = w < total;
+        bool live = w < total;
         int slot = 0, kind = 0, i = 0, b = P.first, stage = 1, cube = 0;
-        float4 f = make_float4(0, 0, 0, 0);
         float sx = 0, sy = 0, sz = 0;
         Knn5 loc, best;
         knn_init(loc);
         knn_init(best);
         if (live) {
             const int4 e = P.hard_list[w];
+            if (round == 1 && !(e.w & HARD_REDO)) live = false;
             slot = e.x;
             kind = e.y;
             i = e.z;
-            stage = e.w & 1;
-            cube = e.w >> 1;
+            stage = round == 1 ? 1 : (e.w & 1);
+            cube = (e.w >> 1) & 0x3fff;
             b = slot + P.first;
-            f = P.ft[kind][(size_t)b * P.MF + i];
+        }
+        if (live) {
+            const float4 f = P.ft[kind][(size_t)b * P.MF + i];
             double wx, wy, wz;
             tf_point(P.Twl + 16 * slot, f.x, f.y, f.z, wx, wy, wz);
             sx = wx;
             sy = wy;
             sz = wz;
-            if (gl == 0) {  // the list pass 1 left after ring 1
+            if (round == 0 && gl == 0) {  // the list pass 1 left after ring 1
                 const float* hd = P.hard_knn + 10 * (size_t)w;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
@@ -1093,49 +1103,66 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P) {
                 }
             }
         }
-        bool finished = !live;  // group-uniform
-        int r0 = 2;             // pass 1 already covered rings 0 and 1 of the queued stage
-        while (!__all(finished)) {
-            // ---- one search (current stage) ----
-            const MmlGrid& g = stage == 0 ? P.gg[kind] : P.g[kind];
-            const int mytag = stage == 0 ? cube : -1;
-            const KnnQuery q = knn_query(g, sx, sy, sz);
-            const int rmax = finished ? 0 : (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
-            bool sdone = finished;
-            if (!sdone && r0 > rmax) {
-                sdone = true;
-                group_merge5(loc, best);
+        const int r0 = round == 0 ? 2 : 0;
+        const MmlGrid& g = stage == 0 ? P.gg[kind] : P.g[kind];
+        const int mytag = stage == 0 ? cube : -1;
+        const KnnQuery q = knn_query(g, sx, sy, sz);
+        const int rmax = live ? (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1 : 0;
+        bool sdone = !live;
+        if (!sdone && r0 > rmax) {
+            sdone = true;
+            group_merge5(loc, best);
+        }
+        for (int r = r0;; ++r) {
+            if (!sdone && r > rmax) sdone = true;
+            if (__all(sdone)) break;
+            if (!sdone) {
+                const int ww = 2 * r + 1;
+                for (int t = gl; t < ww * ww; t += 16) scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc, mytag);
             }
-            for (int r = r0;; ++r) {
-                if (!sdone && r > rmax) sdone = true;
-                if (__all(sdone)) break;
-                if (!sdone) {
-                    const int ww = 2 * r + 1;
-                    for (int t = gl; t < ww * ww; t += 16) scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc, mytag);
-                }
-                group_merge5(loc, best);
-                if (!sdone && knn_done(g, q.inset, r, best.d[4], P.thres)) sdone = true;
-            }
-            // ---- model fit on lane 0 of the group; fall back to the local map after a failed cube stage ----
-            int stored = 0;
-            if (!finished && gl == 0) {
-                const bool ok = (double)best.d[4] < P.thres_d;
-                stored = fit_and_store(P, kind, b, i, f, P.Twl + 16 * slot, sx, sy, sz, ok, best,
-                                       stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]) ? 1 : 0;
-            }
-            stored = __shfl(stored, (threadIdx.x & 63) & ~15, 64);
-            if (!finished) {
-                if (stored || stage == 1 || !(P.map_m[kind] > 20)) {
-                    if (!stored && gl == 0) store_none(P, kind, b, i);
-                    finished = true;
-                } else {
-                    stage = 1;  // :283 / :702: local cloud, searched from ring 0 by the whole group
-                    r0 = 0;
-                    knn_init(loc);
-                    knn_init(best);
-                }
+            group_merge5(loc, best);
+            if (!sdone && knn_done(g, q.inset, r, best.d[4], P.thres)) sdone = true;
+        }
+        if (live && gl == 0) {
+            float* hd = P.hard_knn + 10 * (size_t)w;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                hd[j] = best.d[j];
+                hd[5 + j] = __int_as_float(best.id[j]);
             }
         }
+    }
+}
+
+// model fit of the far queries, one lane per queued feature (see k_associate_hard)
+__global__ __launch_bounds__(128) void k_associate_fit(AssocParams P, int round) {
+    const int total = *P.hard_count;
+    for (int w = blockIdx.x * 128 + threadIdx.x; w < total; w += gridDim.x * 128) {
+        const int4 e = P.hard_list[w];
+        if (round == 1 && !(e.w & HARD_REDO)) continue;
+        const int slot = e.x, kind = e.y, i = e.z, b = slot + P.first;
+        const int stage = round == 1 ? 1 : (e.w & 1);
+        const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+        double wx, wy, wz;
+        tf_point(P.Twl + 16 * slot, f.x, f.y, f.z, wx, wy, wz);
+        const float sx = wx, sy = wy, sz = wz;
+        Knn5 best;
+        const float* hd = P.hard_knn + 10 * (size_t)w;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            best.d[j] = hd[j];
+            best.id[j] = __float_as_int(hd[5 + j]);
+        }
+        const bool ok = (double)best.d[4] < P.thres_d;
+        const bool stored = fit_and_store(P, kind, b, i, f, P.Twl + 16 * slot, sx, sy, sz, ok, best,
+                                          stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]);
+        if (!stored) {
+            if (stage == 0 && P.map_m[kind] > 20)
+                P.hard_list[w].w = e.w | HARD_REDO;  // fall back to the local map (:283 / :702)
+            else
+                store_none(P, kind, b, i);
+        }
+        if (round == 1) P.hard_list[w].w = e.w & ~HARD_REDO;
     }
 }
 
@@ -1407,7 +1434,12 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     }
     {
         MmlStageScope t(ctx, "associate_far");
-        hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P);
+        hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, 0);
+        hipLaunchKernelGGL(k_associate_fit, dim3(512), dim3(128), 0, MML_STREAM(ctx), P, 0);
+        if (ctx->have_gmap[0] || ctx->have_gmap[1]) {  // features whose cube neighbourhood did not yield a model
+            hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, 1);
+            hipLaunchKernelGGL(k_associate_fit, dim3(512), dim3(128), 0, MML_STREAM(ctx), P, 1);
+        }
     }
     {
         MmlStageScope t(ctx, "assoc_stats");
