@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int*
 // ------------------------------------------------------------------------------------------------------------
 constexpr int VX_THREADS = 1024;
 constexpr int VX_WAVES = VX_THREADS / 64;
+constexpr int VX_TAIL = 64;
 
 __device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float* s_red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int s_wtot[VX_WAVES];
+    __shared__ float s_stage[3][VX_THREADS + VX_TAIL];
     __shared__ int s_base;
     __shared__ float s_red[VX_WAVES];
     __shared__ int s_nout;
@@ -251,6 +253,18 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
             vox = (unsigned)(keys[s] >> 32);
             head = (s == 0) || ((unsigned)(keys[s - 1] >> 32) != vox);
         }
+        // the points of this chunk (and VX_TAIL beyond it, for runs that cross into the next chunk) are fetched by their
+        // own lanes, all gathers in flight together, so that the sequential per-voxel sums below read LDS instead of
+        // chasing two dependent global loads per point
+        for (int t = tid; t < VX_THREADS + VX_TAIL; t += VX_THREADS) {
+            const int e = c0 + t;
+            if (e < cnt) {
+                const float4 p = px[seq2idx[(unsigned)(keys[e] & 0xffffffffu)]];
+                s_stage[0][t] = p.x;
+                s_stage[1][t] = p.y;
+                s_stage[2][t] = p.z;
+            }
+        }
         unsigned long long m = __ballot(head);
         if (lane == 0) s_wtot[wave] = __popcll(m);
         __syncthreads();
@@ -261,10 +275,17 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
             float sx = 0, sy = 0, sz = 0;
             int e = s;
             while (e < cnt && (unsigned)(keys[e] >> 32) == vox) {
-                float4 p = px[seq2idx[(unsigned)(keys[e] & 0xffffffffu)]];
-                sx += p.x;
-                sy += p.y;
-                sz += p.z;
+                const int t = e - c0;
+                if (t < VX_THREADS + VX_TAIL) {
+                    sx += s_stage[0][t];
+                    sy += s_stage[1][t];
+                    sz += s_stage[2][t];
+                } else {  // a voxel with more than VX_TAIL points across the chunk edge
+                    const float4 p = px[seq2idx[(unsigned)(keys[e] & 0xffffffffu)]];
+                    sx += p.x;
+                    sy += p.y;
+                    sz += p.z;
+                }
                 ++e;
             }
             float c = static_cast<float>(e - s);

@@ -1,4 +1,4 @@
-"""Dev aid: per-stage times of mml_extract alone (HIP events, one stream), for kernel experiments that may break the
+"""Dev aid: per-stage times of mml_extract / mml_undistort / mml_downsample alone (HIP events, one stream), for kernel experiments that may break the
 downstream stages.  Usage: python tools/dev_stage_time.py [batch]"""
 import importlib
 import os
@@ -18,10 +18,14 @@ ctx.synchronize()
 ctx.set_lanes(1)
 for _ in range(2):
     ctx.extract(0, B)
+    ctx.undistort(0, B, np.tile(np.eye(3).reshape(1, 9), (B, 1)), np.zeros((B, 3)))
+    ctx.downsample(0, B)
 ctx.profile_enable(True)
 ctx.profile_reset()
 for _ in range(4):
     ctx.extract(0, B)
+    ctx.undistort(0, B, np.tile(np.eye(3).reshape(1, 9), (B, 1)), np.zeros((B, 3)))
+    ctx.downsample(0, B)
 prof = ctx.profile_get()
 for k, v in prof.items():
     if v[1]:
