@@ -94,6 +94,7 @@ __device__ __forceinline__ void dnormalize(D3& a) {
 
 constexpr int ASSIGN_THREADS = 1024;
 constexpr int ASSIGN_WAVES = ASSIGN_THREADS / MML_WAVE;
+constexpr int STENCIL_PTS = 1024;  // bucketed positions per k_stencil workgroup (256 threads, 4 rounds)
 constexpr int MAX_LINES = 160;  // n_rings + n_livox_lines upper bound
 constexpr int BLK_STRIDE = MAX_LINES + 2;  // per-block record: key histogram | valid points | points kept by the crop
 
@@ -471,29 +472,64 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     P.fu_label[g] = 0;
 }
 
-// locate the scan line that owns bucketed position p of slot b
-__device__ __forceinline__ bool find_line(const FeatParams& P, int b, int p, int& line, int& i, int& n, int& start) {
+// locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
+// The line table of the slot (<= MAX_LINES starts and lengths) is read ONCE into the lanes of the wavefront - lane j
+// holds lines j, j + 64, j + 128 - and searched there with ballots and lane shuffles: one memory round trip instead of
+// a chain of dependent scalar loads in front of every wavefront's real work.
+__device__ __forceinline__ int line_tab_get(const int (&tab)[3], int idx, int L) {
+    int v = __shfl(tab[0], idx & 63);
+    if (L > 64) {
+        const int v1 = __shfl(tab[1], idx & 63);
+        v = idx >= 64 ? v1 : v;
+        if (L > 128) {
+            const int v2 = __shfl(tab[2], idx & 63);
+            v = idx >= 128 ? v2 : v;
+        }
+    }
+    return v;
+}
+struct LineTab {
+    int ls[3], ll[3];
+};
+__device__ __forceinline__ void load_line_tab(const FeatParams& P, int b, LineTab& t) {
+    static_assert(MAX_LINES <= 192, "three table registers per lane");
     const int* ls = P.line_start + (size_t)b * P.L;
     const int* ll = P.line_len + (size_t)b * P.L;
-    // line_start is non-decreasing inside each region (rings | Livox lines): last line with start <= p.
-    // The lanes of a wavefront hold consecutive p, so the search runs once per wavefront on scalar registers for
-    // the first lane and every lane then steps forward from there (0 or 1 steps unless a line is very short).
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int j = lane + 64 * r;
+        const bool in = j < P.L;
+        t.ls[r] = in ? ls[j] : 0x7fffffff;
+        t.ll[r] = in ? ll[j] : 0;
+    }
+}
+__device__ __forceinline__ bool find_line(const FeatParams& P, const LineTab& t, int p, int& line, int& i, int& n, int& start) {
+    const int lane = threadIdx.x & 63;
+    // line_start is non-decreasing inside each region (rings | Livox lines): last line of the region with start <= p.
+    // The lanes hold consecutive p: one ballot search for the first lane, then every lane steps forward from there
+    // (0 or 1 steps unless a line is very short).
     const int p0 = __builtin_amdgcn_readfirstlane(p);
     const bool velo0 = p0 < P.NV;
-    int lo = velo0 ? 0 : P.n_rings, hi = velo0 ? P.n_rings : P.L;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (ls[mid] <= p0)
-            lo = mid;
-        else
-            hi = mid;
+    const int r0 = velo0 ? 0 : P.n_rings, r1 = velo0 ? P.n_rings : P.L;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int j = lane + 64 * r;
+        cnt += __popcll(__ballot(j >= r0 && j < r1 && t.ls[r] <= p0));
     }
     const bool velo = p < P.NV;
     const int end = velo ? P.n_rings : P.L;
-    line = (velo == velo0) ? lo : P.n_rings;  // a wavefront that straddles NV: its Livox lanes start at their region
-    while (line + 1 < end && ls[line + 1] <= p) ++line;
-    start = ls[line];
-    n = ll[line];
+    line = (velo == velo0) ? r0 + cnt - 1 : P.n_rings;  // a wavefront that straddles NV: its Livox lanes start at their region
+    for (;;) {
+        const int nx = line + 1;
+        const int nxs = line_tab_get(t.ls, nx < P.L ? nx : 0, P.L);
+        const bool adv = nx < end && nxs <= p;
+        if (!__any(adv)) break;
+        if (adv) line = nx;
+    }
+    start = line_tab_get(t.ls, line, P.L);
+    n = line_tab_get(t.ll, line, P.L);
     i = p - start;
     return i >= 0 && i < n;
 }
@@ -521,23 +557,35 @@ __device__ __forceinline__ bool abs_cos_gt(double dot, double n1, double n2, dou
 
 __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     const int b = blockIdx.y + P.first;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P.NT) return;
+    // the STENCIL_PTS + 10 points this workgroup's windows cover, read once (lines are contiguous in ln_pts, so the
+    // window of position p is [p - 5, p + 5] whatever its line)
+    __shared__ float4 s_pt[STENCIL_PTS + 10];
+    const int p_first = blockIdx.x * STENCIL_PTS;
+    for (int k = threadIdx.x; k < STENCIL_PTS + 10; k += 256) {
+        const int gp = p_first - 5 + k;
+        s_pt[k] = (gp >= 0 && gp < P.NT) ? P.ln_pts[(size_t)b * P.NT + gp] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    LineTab tab;
+    load_line_tab(P, b, tab);
+    __syncthreads();
+    for (int rep = 0; rep < STENCIL_PTS / 256; ++rep) {
+    const int tp = rep * 256 + threadIdx.x, p = p_first + tp;
+    if (__builtin_amdgcn_readfirstlane(p) >= P.NT) break;
     int line, i, n, start;
-    if (!find_line(P, b, p, line, i, n, start)) return;
+    const bool found = find_line(P, tab, p < P.NT ? p : P.NT - 1, line, i, n, start);  // (whole wavefront takes part)
+    const bool live = p < P.NT && found;
     const size_t base = (size_t)b * P.NT + start;
-    const float4* pt = P.ln_pts + base;
     unsigned attr = 0;
     float curv = 0.f, refl = 0.f;
     bool brk = false;
-    if (i >= 5 && i < n - 5) {
+    if (live && i >= 5 && i < n - 5) {
         const float thDistanceFaraway = 50.0;
         const float thFlatThreshold = 0.02;
         const float thLidarNearestDis = 1.0;
         const float thBreakCornerDis = 1;
         float4 q[11];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) q[k] = pt[i - 5 + k];
+        for (int k = 0; k < 11; ++k) q[k] = s_pt[tp + k];
 #define PT(o) q[5 + (o)]
         // ---- :407-451 ----
         float diffX = 0, diffY = 0, diffZ = 0;
@@ -550,10 +598,12 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         {
             const float lx = PT(-1).x - PT(0).x, ly = PT(-1).y - PT(0).y, lz = PT(-1).z - PT(0).z;
             const float nx = PT(1).x - PT(0).x, ny = PT(1).y - PT(0).y, nz = PT(1).z - PT(0).z;
-            const float dotl = (lx * PT(0).x + ly * PT(0).y) + lz * PT(0).z, dotn = (nx * PT(0).x + ny * PT(0).y) + nz * PT(0).z;
-            const float rl = (0.966f * 0.966f) * (((lx * lx + ly * ly) + lz * lz) * dis2);
-            const float rn = (0.966f * 0.966f) * (((nx * nx + ny * ny) + nz * nz) * dis2);
-            const float el = dotl * dotl - rl, en = dotn * dotn - rn;
+            // (fused multiply-adds are fine here: this is the banded pre-decision, not the reference arithmetic)
+            const float dotl = fmaf(lz, PT(0).z, fmaf(ly, PT(0).y, lx * PT(0).x));
+            const float dotn = fmaf(nz, PT(0).z, fmaf(ny, PT(0).y, nx * PT(0).x));
+            const float rl = (0.966f * 0.966f) * (fmaf(lz, lz, fmaf(ly, ly, lx * lx)) * dis2);
+            const float rn = (0.966f * 0.966f) * (fmaf(nz, nz, fmaf(ny, ny, nx * nx)) * dis2);
+            const float el = fmaf(dotl, dotl, -rl), en = fmaf(dotn, dotn, -rn);
             gl = el > 0.f;
             gn = en > 0.f;
             const bool sure = (fabsf(el) > 1e-3f * rl) & (fabsf(en) > 1e-3f * rn) & (rl < 1e30f) & (rn < 1e30f) &
@@ -611,13 +661,17 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         if (far) attr |= A_FAR;
         if (curv < 0.7 * thFlatThreshold * dis * thFlatThreshold * dis && refl > 20.0) attr |= A_REFL;
         {
+            // the reference compares the float sum with the double 0.02 (:569, :584).  0.02f is the float just below
+            // 0.02, so for a float x: x > 0.02 <=> x > 0.02f.
+            constexpr float kTh002 = 0.02f;
+            static_assert((double)kTh002 < 0.02, "0.02f must round down");
             int a3 = 0;
 #pragma unroll
             for (int l = 1; l <= 3; l++) {
                 float dX = PT(l).x - PT(l - 1).x;
                 float dY = PT(l).y - PT(l - 1).y;
                 float dZ = PT(l).z - PT(l - 1).z;
-                if (dX * dX + dY * dY + dZ * dZ > 0.02 || far) break;
+                if (dX * dX + dY * dY + dZ * dZ > kTh002 || far) break;
                 a3 = l;
             }
             int b3 = 0;
@@ -626,7 +680,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
                 float dX = PT(l).x - PT(l + 1).x;
                 float dY = PT(l).y - PT(l + 1).y;
                 float dZ = PT(l).z - PT(l + 1).z;
-                if (dX * dX + dY * dY + dZ * dZ > 0.02 || far) break;
+                if (dX * dX + dY * dY + dZ * dZ > kTh002 || far) break;
                 b3 = -l;
             }
             attr |= (unsigned)a3 << A_A3_SHIFT;
@@ -661,23 +715,23 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
                     for (int k = 1; k < 5; k++) {
                         const float ax = PT(-k).x - PT(0).x, ay = PT(-k).y - PT(0).y, az = PT(-k).z - PT(0).z;
                         const float bx = PT(k).x - PT(0).x, by = PT(k).y - PT(0).y, bz = PT(k).z - PT(0).z;
-                        const float za = (ax * ax + ay * ay) + az * az, zb = (bx * bx + by * by) + bz * bz;
+                        const float za = fmaf(az, az, fmaf(ay, ay, ax * ax)), zb = fmaf(bz, bz, fmaf(by, by, bx * bx));
                         const float wa = (k / 10.0f) * (za > 0.f ? __builtin_amdgcn_rsqf(za) : 1.f);
                         const float wb = (k / 10.0f) * (zb > 0.f ? __builtin_amdgcn_rsqf(zb) : 1.f);
-                        lx += wa * ax;
-                        ly += wa * ay;
-                        lz += wa * az;
-                        rx += wb * bx;
-                        ry += wb * by;
-                        rz += wb * bz;
+                        lx = fmaf(wa, ax, lx);
+                        ly = fmaf(wa, ay, ly);
+                        lz = fmaf(wa, az, lz);
+                        rx = fmaf(wb, bx, rx);
+                        ry = fmaf(wb, by, ry);
+                        rz = fmaf(wb, bz, rz);
                         if (k == 4) {
                             za4 = za;
                             zb4 = zb;
                         }
                     }
-                    const float dt = (lx * rx + ly * ry) + lz * rz;
-                    const float n1 = (lx * lx + ly * ly) + lz * lz, n2 = (rx * rx + ry * ry) + rz * rz;
-                    const float rhs = 0.25f * (n1 * n2), df = dt * dt - rhs;
+                    const float dt = fmaf(lz, rz, fmaf(ly, ry, lx * rx));
+                    const float n1 = fmaf(lz, lz, fmaf(ly, ly, lx * lx)), n2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+                    const float rhs = 0.25f * (n1 * n2), df = fmaf(dt, dt, -rhs);
                     const bool inr = (n1 > 0.25f) & (n2 > 0.25f) & (n1 < 4.f) & (n2 < 4.f);
                     // cc >= 0.5 for sure: not a 150 point.  cc < 0.5 for sure: the 5 cm test on the outermost
                     // neighbours decides, in float when neither squared distance is within 1e-5 of 0.0025.
@@ -756,9 +810,11 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
 #undef PT
     }
-    P.ln_curv[base + i] = curv;
-    P.ln_refl[base + i] = refl;
-    P.ln_attr[base + i] = (uint16_t)attr;
+    if (live) {
+        P.ln_curv[base + i] = curv;
+        P.ln_refl[base + i] = refl;
+        P.ln_attr[base + i] = (uint16_t)attr;
+    }
     // wave-aggregated append to the slot's break-point queue
     const unsigned long long bm = __ballot(brk);
     if (bm) {
@@ -767,6 +823,7 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         if (lane == (int)__ffsll((long long)bm) - 1) first = atomicAdd(&P.brk_cnt[b], __popcll(bm));
         first = __shfl(first, (int)__ffsll((long long)bm) - 1);
         if (brk) P.brk_queue[(size_t)b * P.NT + first + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(start + i);
+    }
     }
 }
 
@@ -1713,7 +1770,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     FeatParams P = make_params(ctx, first);
     P.extr = have_extrinsic ? ctx->d_extr : nullptr;
     hipStream_t s = MML_STREAM(ctx);
-    const int pblocks = (ctx->NT + 255) / 256;
+    const int pblocks = (ctx->NT + STENCIL_PTS - 1) / STENCIL_PTS;
     {
         MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
@@ -1763,7 +1820,7 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     hipStream_t s = MML_STREAM(ctx);
     const int t = (n > ctx->L ? n : ctx->L);
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
-    const int pblocks = (n + 255) / 256;
+    const int pblocks = (n + STENCIL_PTS - 1) / STENCIL_PTS;
     MML_HIP(hipMemsetAsync(ctx->brk_cnt, 0, sizeof(int), s));
     if (pblocks > 0) {
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
