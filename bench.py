@@ -41,6 +41,7 @@ STAGE_BYTES = {
     "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),    # label scan + xyz of labelled points
     "associate":        lambda n_v, n_l, nf, it: 112 * nf,
     "associate_far":    lambda n_v, n_l, nf, it: 0,                   # queue of the few far queries (bytes counted in associate)
+    "associate_fit":    lambda n_v, n_l, nf, it: 0,                   # model fit of the searched features (bytes counted in associate)
     "assoc_stats":      lambda n_v, n_l, nf, it: 0,
     "solve":            lambda n_v, n_l, nf, it: 72 * nf * (it + 1),  # it iterations + the initial linearisation
 }

@@ -130,33 +130,32 @@ __global__ void k_cell_start(const unsigned* keys, int m, int ncell, int* cell_s
 
 // ---------------------------------------------------------------------------------------------------
 // exact 5-NN
+// The list is five 64-bit keys, (bits of d2) << 32 | index: d2 is a non-negative float, so its bit pattern orders like
+// its value and one unsigned compare is the reference's order "(d, index) ascending" (ties by lower index).  A NaN d2
+// has a pattern above +inf and never enters, as with the float compare.
 struct Knn5 {
-    float d[5];
-    int id[5];
+    unsigned long long key[5];
 };
+constexpr unsigned long long KNN_EMPTY = (0x7f800000ull << 32) | 0x7fffffffull;  // (INFINITY, INT_MAX)
+__device__ __forceinline__ unsigned long long knn_key(float d, int id) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
+}
+__device__ __forceinline__ float knn_d(const Knn5& k, int j) { return __uint_as_float((unsigned)(k.key[j] >> 32)); }
+__device__ __forceinline__ int knn_id(const Knn5& k, int j) { return (int)(unsigned)k.key[j]; }
 __device__ __forceinline__ void knn_init(Knn5& k) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        k.d[i] = INFINITY;
-        k.id[i] = 0x7fffffff;
-    }
+    for (int i = 0; i < 5; ++i) k.key[i] = KNN_EMPTY;
 }
-// sorted insert, order (d, id) ascending
+// sorted insert: the new key sinks to its place, the largest of the six falls off (no branches past the reject test)
 __device__ __forceinline__ void knn_insert(Knn5& k, float dd, int ii) {
-    if (!(dd < k.d[4] || (dd == k.d[4] && ii < k.id[4]))) return;
-    k.d[4] = dd;
-    k.id[4] = ii;
+    unsigned long long x = knn_key(dd, ii);
+    if (!(x < k.key[4])) return;
 #pragma unroll
-    for (int s = 4; s > 0; --s) {
-        bool sw = (k.d[s] < k.d[s - 1]) || (k.d[s] == k.d[s - 1] && k.id[s] < k.id[s - 1]);
-        if (sw) {
-            float td = k.d[s];
-            k.d[s] = k.d[s - 1];
-            k.d[s - 1] = td;
-            int ti = k.id[s];
-            k.id[s] = k.id[s - 1];
-            k.id[s - 1] = ti;
-        }
+    for (int s = 0; s < 5; ++s) {
+        const unsigned long long cur = k.key[s];
+        const bool lt = x < cur;
+        k.key[s] = lt ? x : cur;
+        x = lt ? cur : x;
     }
 }
 
@@ -165,15 +164,26 @@ __device__ __forceinline__ void knn_insert(Knn5& k, float dd, int ii) {
 // looked at, so the exactness bound of the ring search is unchanged.
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, const uint16_t* __restrict__ tags, int mytag,
                                            int s, int e, float qx, float qy, float qz, Knn5& k) {
-    for (int i = s; i < e; ++i) {
-        if (tags && (int)tags[i] != mytag) continue;
-        float4 p = pts[i];
-        float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        float r = 0;
-        r += dx * dx;
-        r += dy * dy;
-        r += dz * dz;
-        knn_insert(k, r, (int)__float_as_uint(p.w));
+    // four candidates per round, their loads issued together (one load per round leaves its whole latency exposed)
+    for (int i0 = s; i0 < e; i0 += 4) {
+        float4 p[4];
+        int tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u, e - 1);
+            p[u] = pts[i];
+            tg[u] = tags ? (int)tags[i] : mytag;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u >= e || tg[u] != mytag) continue;
+            float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+            float r = 0;
+            r += dx * dx;
+            r += dy * dy;
+            r += dz * dz;
+            knn_insert(k, r, (int)__float_as_uint(p[u].w));
+        }
     }
 }
 
@@ -189,6 +199,7 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, const
 // the cost of the rare far query (hundreds of mostly empty cells) by ~1/64 of a private walk.
 struct KnnQuery {
     float qx, qy, qz, inset;
+    float fx, fy, fz;  // the query in cell units
     int hx, hy, hz;
 };
 
@@ -199,6 +210,9 @@ __device__ __forceinline__ KnnQuery knn_query(const MmlGrid& g, float qx, float 
     q.qz = qz;
     const float fx = (qx - g.origin[0]) * g.inv_cell, fy = (qy - g.origin[1]) * g.inv_cell,
                 fz = (qz - g.origin[2]) * g.inv_cell;
+    q.fx = fx;
+    q.fy = fy;
+    q.fz = fz;
     q.hx = (int)floorf(fx);
     q.hy = (int)floorf(fy);
     q.hz = (int)floorf(fz);
@@ -217,58 +231,79 @@ __device__ __forceinline__ bool knn_done(const MmlGrid& g, float inset, int r, f
     return d5 < rho2 || rho2 >= max_d2;
 }
 
-// one row (fixed y,z) of shell r: the whole x-span on a face, the two end cells otherwise
+// one row (fixed y,z) of shell r: the whole x-span on a face, the two end cells otherwise.
+// `bound` is any upper bound of the query's final 5th squared distance (INFINITY when none is known).  Cells that
+// cannot hold a point closer than that are skipped: a point stored in cell (cx, y, z) lies, per axis, within 2e-3 cells
+// of the cell's slab (float rounding of the cell mapping at build and query time, the same allowance knn_done makes),
+// so its distance to the query is at least cell * (|gap vector| - 4e-3); a skipped point has d2 > bound * (1 + 1e-5) in
+// exact arithmetic and therefore a float d2 > bound: it could not have entered the list.
 __device__ __forceinline__ void scan_shell_row(const MmlGrid& g, const KnnQuery& q, int r, int y, int z, Knn5& k,
-                                               int mytag = -1) {
+                                               int mytag = -1, float bound = INFINITY) {
     const int DX = g.dim[0], DY = g.dim[1], DZ = g.dim[2];
     if (y < 0 || y >= DY || z < 0 || z >= DZ) return;
+    const float gy = y > q.hy ? (float)y - q.fy : (y < q.hy ? q.fy - (float)(y + 1) : 0.f);
+    const float gz = z > q.hz ? (float)z - q.fz : (z < q.hz ? q.fz - (float)(z + 1) : 0.f);
+    const float reach = sqrtf(bound * 1.00001f) * g.inv_cell + 4e-3f;  // cells; inf when bound is
+    const float w2 = reach * reach - (gy * gy + gz * gz);
+    if (w2 < 0.f) return;
+    const float w = sqrtf(w2);
+    // cells of this row whose slab comes within w cells of the query along x
+    const int xlo = (int)floorf(fmaxf(q.fx - w, -1.f)), xhi = (int)floorf(fminf(q.fx + w, (float)DX));
     const int x0 = q.hx - r, x1 = q.hx + r;
     const bool face = (z == q.hz - r || z == q.hz + r || y == q.hy - r || y == q.hy + r);
     const int rowbase = DX * (y + DY * z);
     if (face) {
-        const int xa = max(x0, 0), xb = min(x1, DX - 1);
+        const int xa = max(max(x0, 0), xlo), xb = min(min(x1, DX - 1), xhi);
         if (xa <= xb)
             scan_range(g.pts, g.tags, mytag, g.cell_start[rowbase + xa], g.cell_start[rowbase + xb + 1], q.qx, q.qy, q.qz, k);
     } else {
-        if (x0 >= 0 && x0 < DX)
+        if (x0 >= 0 && x0 < DX && x0 >= xlo)
             scan_range(g.pts, g.tags, mytag, g.cell_start[rowbase + x0], g.cell_start[rowbase + x0 + 1], q.qx, q.qy, q.qz, k);
-        if (x1 >= 0 && x1 < DX && x1 != x0)
+        if (x1 >= 0 && x1 < DX && x1 != x0 && x1 <= xhi)
             scan_range(g.pts, g.tags, mytag, g.cell_start[rowbase + x1], g.cell_start[rowbase + x1 + 1], q.qx, q.qy, q.qz, k);
     }
 }
 
-__device__ __forceinline__ void knn_head(const Knn5& k, int head, float& d, int& id) {
-    d = INFINITY;
-    id = 0x7fffffff;
-#pragma unroll
-    for (int s = 0; s < 5; ++s)
-        if (head == s) {
-            d = k.d[s];
-            id = k.id[s];
-        }
+// ring 1 rows, nearest first, so that the bound has tightened before the edge and corner rows are reached
+__device__ __constant__ const signed char kRing1Row[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+
+// rings 0 and 1 of one query, private to the lane; true when the search may stop there
+__device__ __forceinline__ bool scan_rings01(const MmlGrid& g, const KnnQuery& q, int rmax, float max_d2, Knn5& k, int mytag) {
+    scan_shell_row(g, q, 0, q.hy, q.hz, k, mytag);
+    if (knn_done(g, q.inset, 0, knn_d(k, 4), max_d2)) return true;
+    if (rmax < 1) return false;
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) scan_shell_row(g, q, 1, q.hy + kRing1Row[t][0], q.hz + kRing1Row[t][1], k, mytag, knn_d(k, 4));
+    return knn_done(g, q.inset, 1, knn_d(k, 4), max_d2);
 }
 
-// wave-wide merge of the lanes' private sorted lists (disjoint point sets) into the global top-5, same in all lanes
-__device__ __forceinline__ void wave_merge5(const Knn5& local, Knn5& out) {
+__device__ __forceinline__ unsigned long long knn_head(const Knn5& k, int head) {
+    unsigned long long key = KNN_EMPTY;
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+        if (head == s) key = k.key[s];
+    return key;
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+    const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// merge of the private sorted lists (disjoint point sets) of the lanes whose ids differ in the bits below `span` into
+// their common top-5, same in all of them
+template <int SPAN>
+__device__ __forceinline__ void lanes_merge5(const Knn5& local, Knn5& out) {
     int head = 0;
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        float d;
-        int id;
-        knn_head(local, head, d, id);
-        float md = d;
-        int mid = id;
+        const unsigned long long mine = knn_head(local, head);
+        unsigned long long m = mine;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float od = __shfl_xor(md, o);
-            const int oid = __shfl_xor(mid, o);
-            const bool take = (od < md) || (od == md && oid < mid);
-            md = take ? od : md;
-            mid = take ? oid : mid;
+        for (int o = SPAN / 2; o > 0; o >>= 1) {
+            const unsigned long long other = shfl_xor_u64(m, o);
+            m = other < m ? other : m;
         }
-        out.d[r] = md;
-        out.id[r] = mid;
-        if (d == md && id == mid && md < INFINITY) head++;
+        out.key[r] = m;
+        if (mine == m && (unsigned)(m >> 32) < 0x7f800000u) head++;
     }
 }
 
@@ -279,15 +314,7 @@ __device__ void knn5_search(const MmlGrid& g, bool valid, float qx, float qy, fl
     const int rmax = (int)ceilf(sqrtf(max_d2) * g.inv_cell) + 1;
     bool pending = false;
     if (valid) {
-        pending = true;
-        for (int r = 0; r <= 1 && r <= rmax; ++r) {
-            for (int z = q.hz - r; z <= q.hz + r; ++z)
-                for (int y = q.hy - r; y <= q.hy + r; ++y) scan_shell_row(g, q, r, y, z, k);
-            if (knn_done(g, q.inset, r, k.d[4], max_d2)) {
-                pending = false;
-                break;
-            }
-        }
+        pending = !scan_rings01(g, q, rmax, max_d2, k, -1);
         if (rmax < 2) pending = false;
     }
     unsigned long long todo = __ballot(pending);
@@ -300,6 +327,9 @@ __device__ void knn5_search(const MmlGrid& g, bool valid, float qx, float qy, fl
         s.qy = __shfl(q.qy, src);
         s.qz = __shfl(q.qz, src);
         s.inset = __shfl(q.inset, src);
+        s.fx = __shfl(q.fx, src);
+        s.fy = __shfl(q.fy, src);
+        s.fz = __shfl(q.fz, src);
         s.hx = __shfl(q.hx, src);
         s.hy = __shfl(q.hy, src);
         s.hz = __shfl(q.hz, src);
@@ -312,9 +342,11 @@ __device__ void knn5_search(const MmlGrid& g, bool valid, float qx, float qy, fl
         knn_init(best);
         for (int r = 2; r <= rmax; ++r) {
             const int w = 2 * r + 1;
-            for (int t = lane; t < w * w; t += 64) scan_shell_row(g, s, r, s.hy - r + (t % w), s.hz - r + (t / w), loc);
-            wave_merge5(loc, best);
-            if (knn_done(g, s.inset, r, best.d[4], max_d2)) break;
+            const float bnd = fminf(knn_d(best, 4), __shfl(knn_d(k, 4), src));  // both bound the final 5th distance from above
+            for (int t = lane; t < w * w; t += 64)
+                scan_shell_row(g, s, r, s.hy - r + (t % w), s.hz - r + (t / w), loc, -1, fminf(bnd, knn_d(loc, 4)));
+            lanes_merge5<64>(loc, best);
+            if (knn_done(g, s.inset, r, knn_d(best, 4), max_d2)) break;
         }
         if (lane == src) k = best;
     }
@@ -327,9 +359,9 @@ __global__ __launch_bounds__(256) void k_knn5(MmlGrid g, const float* q, int nq,
     knn5_search(g, valid, valid ? q[3 * i] : 0.f, valid ? q[3 * i + 1] : 0.f, valid ? q[3 * i + 2] : 0.f, max_d2, k);
     if (!valid) return;
     for (int j = 0; j < 5; ++j) {
-        bool ok = k.d[j] < max_d2 && k.d[4] < max_d2;
-        idx[5 * i + j] = ok ? k.id[j] : -1;
-        d2[5 * i + j] = ok ? k.d[j] : INFINITY;
+        bool ok = knn_d(k, j) < max_d2 && knn_d(k, 4) < max_d2;
+        idx[5 * i + j] = ok ? knn_id(k, j) : -1;
+        d2[5 * i + j] = ok ? knn_d(k, j) : INFINITY;
     }
 }
 
@@ -805,7 +837,7 @@ __device__ __forceinline__ bool fit_and_store(const AssocParams& P, int kind, in
             float nx[5], ny[5], nz[5];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                float4 q = mp[k.id[j]];
+                float4 q = mp[knn_id(k, j)];
                 nx[j] = q.x;
                 ny[j] = q.y;
                 nz[j] = q.z;
@@ -880,7 +912,7 @@ __device__ __forceinline__ bool fit_and_store(const AssocParams& P, int kind, in
             float nx[5], ny[5], nz[5];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                float4 q = mp[k.id[j]];
+                float4 q = mp[knn_id(k, j)];
                 nx[j] = q.x;
                 ny[j] = q.y;
                 nz[j] = q.z;
@@ -961,12 +993,18 @@ __global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int
     if (tid == 0) work_off[nitems] = acc;
 }
 
-__global__ __launch_bounds__(128) void k_associate(AssocParams P) {
-    const int nitems = 2 * P.count;
-    const int total = P.work_off[nitems];
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
-    // locate the item that owns chunk w: last item with work_off[item] <= w
-    int lo = 0, hi = nitems;
+// What pass 1 leaves for a feature, parked in the first 32 bytes of the feature's own (not yet written) factor record:
+// [0] = ids 0..3, [1] = (id 4, bits of d2[4], state | stage << 2, cube).
+constexpr int REC_NONE = 0, REC_READY = 1, REC_QUEUED = 2;
+__device__ __forceinline__ int4* assoc_rec(const AssocParams& P, int kind, int b, int i) {
+    return kind == 0 ? reinterpret_cast<int4*>(P.lf + (size_t)b * P.MF + i) : reinterpret_cast<int4*>(P.pf + (size_t)b * P.MF + i);
+}
+static_assert(sizeof(MmlLineFactor) >= 32 && sizeof(MmlLineFactor) % 16 == 0, "record parking needs 32 aligned bytes");
+static_assert(sizeof(MmlPlaneFactor) >= 32 && sizeof(MmlPlaneFactor) % 16 == 0, "record parking needs 32 aligned bytes");
+
+// locate the (kind, slot) item that owns chunk w: last item with work_off[item] <= w
+__device__ __forceinline__ int assoc_item(const AssocParams& P, int w) {
+    int lo = 0, hi = 2 * P.count;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (P.work_off[mid] <= w)
@@ -974,42 +1012,53 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
         else
             hi = mid;
     }
-    const int kind = lo / P.count, slot = lo % P.count;
-    const int b = slot + P.first;
-    const int i = (w - P.work_off[lo]) * 128 + threadIdx.x;
-    const int nf = P.ft_n[kind * P.B + b];
-    if (i >= nf) continue;
-    const double* T = P.Twl + 16 * slot;
-    const float4 f = P.ft[kind][(size_t)b * P.MF + i];
-    // Map_Manager.cpp:75-89 pointAssociateToMap: double transform stored to float
-    double wx, wy, wz;
-    tf_point(T, f.x, f.y, f.z, wx, wy, wz);
-    const float sx = wx, sy = wy, sz = wz;
-    // :192-196 / :621-625: features outside the 21 x 11 x 21 cube grid, or NaN after the transform, get no factor
-    const int cube = find_used_map(sx, sy, sz, P.cen);
-    if (cube == 5000 || isnan(sx) || isnan(sy) || isnan(sz)) {
-        store_none(P, kind, b, i);
-        continue;
-    }
-    // stage 0: the cube's own cloud when it holds > 100 corner / > 50 surf points (:198, :627); stage 1: local map
-    int stage = (P.have_g[kind] && P.cube_cnt[kind][cube] > (kind == 0 ? 100 : 50)) ? 0 : 1;
-    bool queued = false, stored = false;
-    for (; stage < 2 && !stored && !queued; ++stage) {
-        if (stage == 1 && !(P.map_m[kind] > 20)) break;  // :283 / :702
-        const MmlGrid& g = stage == 0 ? P.gg[kind] : P.g[kind];
-        const int mytag = stage == 0 ? cube : -1;
+    return lo;
+}
+
+// Search only: the model fit (double-precision eigen / QR code, ~150 registers) lives in k_associate_fit_all, so this
+// kernel keeps a small register footprint and enough wavefronts in flight to hide its dependent gathers.
+__global__ __launch_bounds__(128) void k_associate(AssocParams P) {
+    const int nitems = 2 * P.count;
+    const int total = P.work_off[nitems];
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int item = assoc_item(P, w);
+        const int kind = item / P.count, slot = item % P.count;
+        const int b = slot + P.first;
+        const int i = (w - P.work_off[item]) * 128 + threadIdx.x;
+        const int nf = P.ft_n[kind * P.B + b];
+        if (i >= nf) continue;
+        int4* rec = assoc_rec(P, kind, b, i);
+        const double* T = P.Twl + 16 * slot;
+        const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+        // Map_Manager.cpp:75-89 pointAssociateToMap: double transform stored to float
+        double wx, wy, wz;
+        tf_point(T, f.x, f.y, f.z, wx, wy, wz);
+        const float sx = wx, sy = wy, sz = wz;
+        // :192-196 / :621-625: features outside the 21 x 11 x 21 cube grid, or NaN after the transform, get no factor
+        const int cube = find_used_map(sx, sy, sz, P.cen);
+        // stage 0: the cube's own cloud when it holds > 100 corner / > 50 surf points (:198, :627); stage 1: local map
+        const int stage = (cube != 5000 && P.have_g[kind] && P.cube_cnt[kind][cube] > (kind == 0 ? 100 : 50)) ? 0 : 1;
+        if (cube == 5000 || isnan(sx) || isnan(sy) || isnan(sz) || (stage == 1 && !(P.map_m[kind] > 20))) {  // (:283 / :702)
+            rec[1] = make_int4(0, 0, REC_NONE, 0);
+            continue;
+        }
+        // one call site per stage: each names ONE grid of the (wave-uniform) kind, so the grid descriptor stays in scalar
+        // registers - selected per lane it is re-read from memory in front of every row
+        const int ukind = __builtin_amdgcn_readfirstlane(kind);
         Knn5 k;
         knn_init(k);
-        const KnnQuery q = knn_query(g, sx, sy, sz);
-        const int rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
         bool done = false;
-        for (int r = 0; r <= 1 && r <= rmax; ++r) {
-            for (int z = q.hz - r; z <= q.hz + r; ++z)
-                for (int y = q.hy - r; y <= q.hy + r; ++y) scan_shell_row(g, q, r, y, z, k, mytag);
-            if (knn_done(g, q.inset, r, k.d[4], P.thres)) {
-                done = true;
-                break;
-            }
+        int rmax = 0;
+        if (stage == 0) {
+            const MmlGrid& g = P.gg[ukind];
+            const KnnQuery q = knn_query(g, sx, sy, sz);
+            rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
+            done = scan_rings01(g, q, rmax, P.thres, k, cube);
+        } else {
+            const MmlGrid& g = P.g[ukind];
+            const KnnQuery q = knn_query(g, sx, sy, sz);
+            rmax = (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1;
+            done = scan_rings01(g, q, rmax, P.thres, k, -1);
         }
         if (!done && rmax >= 2) {
             const int hw = atomicAdd(P.hard_count, 1);
@@ -1017,47 +1066,72 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
             float* hd = P.hard_knn + 10 * (size_t)hw;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                hd[j] = k.d[j];
-                hd[5 + j] = __int_as_float(k.id[j]);
+                hd[j] = knn_d(k, j);
+                hd[5 + j] = __int_as_float(knn_id(k, j));
             }
-            queued = true;  // finished by k_associate_hard
-            break;
+            rec[1] = make_int4(0, 0, REC_QUEUED, 0);  // finished by k_associate_hard / k_associate_fit
+            continue;
         }
-        const bool ok = (double)k.d[4] < P.thres_d;  // :201,285 / :631,705
-        stored = fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, k, stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]);
+        rec[0] = make_int4(knn_id(k, 0), knn_id(k, 1), knn_id(k, 2), knn_id(k, 3));
+        rec[1] = make_int4(knn_id(k, 4), __float_as_int(knn_d(k, 4)), REC_READY | (stage << 2), cube);
     }
-    if (!stored && !queued) store_none(P, kind, b, i);
+}
+
+// Model fit of every feature pass 1 finished itself, one lane each.  A feature whose cube neighbourhood (stage 0) yields
+// no model is appended to the far-query list with the "search again in the local map" mark (:283 / :702).
+constexpr int HARD_REDO = 1 << 30;
+__global__ __launch_bounds__(128) void k_associate_fit_all(AssocParams P) {
+    const int nitems = 2 * P.count;
+    const int total = P.work_off[nitems];
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int item = assoc_item(P, w);
+        const int kind = item / P.count, slot = item % P.count;
+        const int b = slot + P.first;
+        const int i = (w - P.work_off[item]) * 128 + threadIdx.x;
+        const int nf = P.ft_n[kind * P.B + b];
+        if (i >= nf) continue;
+        const int4* rec = assoc_rec(P, kind, b, i);
+        const int4 r0 = rec[0], r1 = rec[1];
+        const int state = r1.z & 3, stage = r1.z >> 2, cube = r1.w;
+        if (state == REC_QUEUED) continue;
+        if (state == REC_NONE) {
+            store_none(P, kind, b, i);
+            continue;
+        }
+        const double* T = P.Twl + 16 * slot;
+        const float4 f = P.ft[kind][(size_t)b * P.MF + i];
+        double wx, wy, wz;
+        tf_point(T, f.x, f.y, f.z, wx, wy, wz);
+        const float sx = wx, sy = wy, sz = wz;
+        Knn5 k;
+        knn_init(k);
+        const float d5 = __int_as_float(r1.y);  // (the fit reads the five indices and this gate only)
+        k.key[0] = knn_key(d5, r0.x);
+        k.key[1] = knn_key(d5, r0.y);
+        k.key[2] = knn_key(d5, r0.z);
+        k.key[3] = knn_key(d5, r0.w);
+        k.key[4] = knn_key(d5, r1.x);
+        bool ok = (double)d5 < P.thres_d;  // :201,285 / :631,705
+#ifdef MML_EXP_NOFIT
+        ok = false;
+#endif
+        const bool stored = fit_and_store(P, kind, b, i, f, T, sx, sy, sz, ok, k, stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]);
+        if (!stored) {
+            if (stage == 0 && P.map_m[kind] > 20) {
+                const int hw = atomicAdd(P.hard_count, 1);
+                P.hard_list[hw] = make_int4(slot, kind, i, (cube << 1) | HARD_REDO);
+            } else {
+                store_none(P, kind, b, i);
+            }
+        }
     }
 }
 
 // pass 2: queued features, one 16-lane group each (4 per wavefront).  The group continues from the top-5 list pass 1
 // left after ring 1: its lanes split the rows of every further shell and merge their private lists with shuffles
 // (xor 8,4,2,1 stays inside the group).  Lane 0 of the group then runs the model fit.
-__device__ __forceinline__ void group_merge5(const Knn5& local, Knn5& out) {
-    int head = 0;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        float d;
-        int id;
-        knn_head(local, head, d, id);
-        float md = d;
-        int mid = id;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float od = __shfl_xor(md, o);
-            const int oid = __shfl_xor(mid, o);
-            const bool take = (od < md) || (od == md && oid < mid);
-            md = take ? od : md;
-            mid = take ? oid : mid;
-        }
-        out.d[r] = md;
-        out.id[r] = mid;
-        if (d == md && id == mid && md < INFINITY) head++;
-    }
-}
-
-// Queue entry word: bit 0 stage (0 cube cloud, 1 local map), bits 1..14 cube, bit 30 "search again in the local map".
-constexpr int HARD_REDO = 1 << 30;
+// Queue entry word: bit 0 stage (0 cube cloud, 1 local map), bits 1..14 cube, bit 30 HARD_REDO "search again in the
+// local map".
 
 // Far queries, search only: one 16-lane group per queued feature, the lanes split the rows of every shell and merge
 // their private top-5 lists with shuffles.  The result goes back to hard_knn; the model fit runs in k_associate_fit with
@@ -1079,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
         knn_init(best);
         if (live) {
             const int4 e = P.hard_list[w];
-            if (round == 1 && !(e.w & HARD_REDO)) live = false;
+            if ((round == 1) != ((e.w & HARD_REDO) != 0)) live = false;  // round 0: not the entries k_associate_fit_all appended
             slot = e.x;
             kind = e.y;
             i = e.z;
@@ -1098,37 +1172,59 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
                 const float* hd = P.hard_knn + 10 * (size_t)w;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    loc.d[j] = hd[j];
-                    loc.id[j] = __float_as_int(hd[5 + j]);
+                    loc.key[j] = knn_key(hd[j], __float_as_int(hd[5 + j]));
                 }
             }
         }
         const int r0 = round == 0 ? 2 : 0;
-        const MmlGrid& g = stage == 0 ? P.gg[kind] : P.g[kind];
+        const float start_d5 = __shfl(knn_d(loc, 4), (threadIdx.x & 63) & ~15);  // the group's lane 0 (INFINITY unless round 0)
+        // the entry's grid descriptor, selected field by field into registers once (a reference to one of four kernel
+        // argument structs picked per lane is re-read from memory at every use)
+        MmlGrid g = P.g[0];
+        {
+            const bool k1 = kind == 1, s0 = stage == 0;
+            const MmlGrid &a = P.g[1], &c = P.gg[0], &d = P.gg[1];
+#define MML_PICK(field) g.field = s0 ? (k1 ? d.field : c.field) : (k1 ? a.field : g.field)
+            MML_PICK(pts);
+            MML_PICK(cell_start);
+            MML_PICK(tags);
+            MML_PICK(origin[0]);
+            MML_PICK(origin[1]);
+            MML_PICK(origin[2]);
+            MML_PICK(cell);
+            MML_PICK(inv_cell);
+            MML_PICK(dim[0]);
+            MML_PICK(dim[1]);
+            MML_PICK(dim[2]);
+#undef MML_PICK
+        }
         const int mytag = stage == 0 ? cube : -1;
         const KnnQuery q = knn_query(g, sx, sy, sz);
         const int rmax = live ? (int)ceilf(sqrtf(P.thres) * g.inv_cell) + 1 : 0;
         bool sdone = !live;
         if (!sdone && r0 > rmax) {
             sdone = true;
-            group_merge5(loc, best);
+            lanes_merge5<16>(loc, best);
         }
         for (int r = r0;; ++r) {
             if (!sdone && r > rmax) sdone = true;
             if (__all(sdone)) break;
             if (!sdone) {
                 const int ww = 2 * r + 1;
-                for (int t = gl; t < ww * ww; t += 16) scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc, mytag);
+                // (best: merged list of the shells before this one; loc: this lane's own list; lane 0's starting list
+                //  of round 0 holds five real points, so its d[4] bounds the result as well)
+                for (int t = gl; t < ww * ww; t += 16)
+                    scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc, mytag, fminf(fminf(knn_d(best, 4), knn_d(loc, 4)), start_d5));
             }
-            group_merge5(loc, best);
-            if (!sdone && knn_done(g, q.inset, r, best.d[4], P.thres)) sdone = true;
+            lanes_merge5<16>(loc, best);
+            if (!sdone && knn_done(g, q.inset, r, knn_d(best, 4), P.thres)) sdone = true;
         }
         if (live && gl == 0) {
             float* hd = P.hard_knn + 10 * (size_t)w;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                hd[j] = best.d[j];
-                hd[5 + j] = __int_as_float(best.id[j]);
+                hd[j] = knn_d(best, j);
+                hd[5 + j] = __int_as_float(knn_id(best, j));
             }
         }
     }
@@ -1139,7 +1235,7 @@ __global__ __launch_bounds__(128) void k_associate_fit(AssocParams P, int round)
     const int total = *P.hard_count;
     for (int w = blockIdx.x * 128 + threadIdx.x; w < total; w += gridDim.x * 128) {
         const int4 e = P.hard_list[w];
-        if (round == 1 && !(e.w & HARD_REDO)) continue;
+        if ((round == 1) != ((e.w & HARD_REDO) != 0)) continue;
         const int slot = e.x, kind = e.y, i = e.z, b = slot + P.first;
         const int stage = round == 1 ? 1 : (e.w & 1);
         const float4 f = P.ft[kind][(size_t)b * P.MF + i];
@@ -1150,10 +1246,9 @@ __global__ __launch_bounds__(128) void k_associate_fit(AssocParams P, int round)
         const float* hd = P.hard_knn + 10 * (size_t)w;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            best.d[j] = hd[j];
-            best.id[j] = __float_as_int(hd[5 + j]);
+            best.key[j] = knn_key(hd[j], __float_as_int(hd[5 + j]));
         }
-        const bool ok = (double)best.d[4] < P.thres_d;
+        const bool ok = (double)knn_d(best, 4) < P.thres_d;
         const bool stored = fit_and_store(P, kind, b, i, f, P.Twl + 16 * slot, sx, sy, sz, ok, best,
                                           stage == 0 ? P.gmap_orig[kind] : P.map_orig[kind]);
         if (!stored) {
@@ -1431,6 +1526,11 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
         MmlStageScope t(ctx, "associate");
         hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, MML_STREAM(ctx), first, count, ctx->B, ctx->ft_n, work_off);
         hipLaunchKernelGGL(k_associate, dim3(4096), dim3(128), 0, MML_STREAM(ctx), P);
+    }
+    {
+        // (before the far-query fit: that one overwrites the parked records of its features with their factors)
+        MmlStageScope t(ctx, "associate_fit");
+        hipLaunchKernelGGL(k_associate_fit_all, dim3(4096), dim3(128), 0, MML_STREAM(ctx), P);
     }
     {
         MmlStageScope t(ctx, "associate_far");

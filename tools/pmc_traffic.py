@@ -12,7 +12,7 @@ STAGE = {"k_assign_init": "assign_count", "k_assign_a": "assign_count", "k_assig
          "k_stencil": "stencil", "k_stencil_break": "stencil", "k_select": "select", "k_crop_a": "crop_compact", "k_crop_b": "crop_compact",
          "k_crop_c": "crop_compact", "k_crop": "crop_compact", "k_undistort_prep": "undistort", "k_undistort": "undistort",
          "k_voxel": "voxel_downsample", "k_assoc_prefix": "associate", "k_associate": "associate",
-         "k_associate_hard": "associate_far", "k_associate_fit": "associate_far", "k_assoc_stats": "assoc_stats", "k_solve": "solve"}
+         "k_associate_hard": "associate_far", "k_associate_fit": "associate_far", "k_associate_fit_all": "associate_fit", "k_assoc_stats": "assoc_stats", "k_solve": "solve"}
 
 
 def per_kernel(path, counter):
