@@ -369,6 +369,28 @@ def test_knn_exact(ctx, O, scene):
     gi, gd = ctx.knn5(0, qq)
     oi, od = O.bruteforce_knn5(dense, qq)
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    # lattice map aligned with the grid cells (spacing = half a cell edge), queries on lattice points, cell faces,
+    # edges and corners: exact distance ties everywhere, decided by the lower index, and every cell-skipping bound of
+    # the search sits exactly on a slab face
+    ax = np.arange(-4, 4.01, 0.5, dtype=np.float32)
+    lat = np.stack(np.meshgrid(ax, ax, ax[:9], indexing="ij"), -1).reshape(-1, 3)
+    lat = lat[rng.permutation(len(lat))]
+    ctx.map_set_local(0, lat)
+    qa = np.arange(-4.5, 4.51, 0.25, dtype=np.float32)
+    qq = np.stack([rng.choice(qa, 1500), rng.choice(qa, 1500), rng.choice(qa[:24], 1500)], -1).astype(np.float32)
+    gi, gd = ctx.knn5(0, qq)
+    oi, od = O.bruteforce_knn5(lat, qq)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    # a sparse map: most queries need rings >= 2 (the far-query path and its bound)
+    sparse = rng.uniform(-20, 20, (400, 3)).astype(np.float32)
+    ctx.map_set_local(0, sparse)
+    qq = rng.uniform(-22, 22, (800, 3)).astype(np.float32)
+    gi, gd = ctx.knn5(0, qq, max_d2=100.0)
+    oi, od = O.bruteforce_knn5(sparse, qq)
+    inside = od[:, 4] < 100.0
+    assert inside.sum() > 100
+    assert np.array_equal(gi[inside], oi[inside]) and np.array_equal(gd[inside], od[inside])
+    assert np.all(gi[~inside] == -1)
     # tiny maps (fewer than 5 points): nothing can be associated, no crash
     ctx.map_set_local(0, dense[:3])
     gi, gd = ctx.knn5(0, qq[:10], max_d2=25.0)
