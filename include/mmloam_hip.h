@@ -89,6 +89,13 @@ int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo,
  * (off_intensity < 0: no such field, 0 is used).  The records are decoded on the device. */
 int mml_scan_upload_pointcloud2(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x,
                                 int off_y, int off_z, int off_intensity, const mml_livox_point* livox, int n_livox);
+/* Same again, with the Livox part in wire form as well: `livox_wire` is the serialised `points` array of a
+ * livox_ros_driver/CustomMsg (the bytes after its 4-byte length prefix), 19 bytes per CustomPoint, little endian:
+ * uint32 offset_time, float32 x, y, z, uint8 reflectivity, tag, line -- the fields getHoriFeatureExtract reads at
+ * unionFeatureExtract.cpp:985-997.  For callers that hold the raw message (a bag reader, a non-roscpp transport); a
+ * roscpp callback already holds the 20-byte structs mml_scan_upload takes.  Decoded on the device. */
+int mml_scan_upload_wire(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x, int off_y,
+                         int off_z, int off_intensity, const uint8_t* livox_wire, int n_livox);
 /* The fused labelled cloud of a slot as the payload pcl::toROSMsg(pcl::PointCloud<PointXYZINormal>) produces for
  * velo_combine / livox_combine (unionFeatureExtract.cpp:918, :1287-1293): 48-byte records, float32 fields x 0, y 4,
  * z 8, normal_x 16 (in-sweep time), normal_y 20 (ring / line), normal_z 24 (label 0/1/2), intensity 32,

@@ -189,6 +189,17 @@ class Context:
                                                    _p(lv) if nl else None, C.c_int(nl)))
         self.synchronize()
 
+    def scan_upload_wire(self, slot, data, n_points, point_step, off_x, off_y, off_z, off_intensity, livox_wire, n_livox):
+        """Both parts in wire form: PointCloud2 payload + the serialised CustomPoint array (19 bytes per point)."""
+        raw = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        lw = np.frombuffer(livox_wire, dtype=np.uint8) if not isinstance(livox_wire, np.ndarray) else np.ascontiguousarray(livox_wire, dtype=np.uint8)
+        if len(lw) < 19 * n_livox:
+            raise ValueError("livox_wire shorter than 19 * n_livox bytes")
+        self._ck(lib().mml_scan_upload_wire(self._h, C.c_int(slot), _p(raw), C.c_int(n_points), C.c_int(point_step),
+                                            C.c_int(off_x), C.c_int(off_y), C.c_int(off_z), C.c_int(off_intensity),
+                                            _p(lw) if n_livox else None, C.c_int(n_livox)))
+        self.synchronize()
+
     def scan_download_pointxyzinormal(self, slot):
         """The fused labelled cloud as 48-byte PointXYZINormal records (the velo_combine / livox_combine payload)."""
         n = C.c_int(0)

@@ -275,6 +275,22 @@ __global__ void k_decode_pointcloud2(const uint8_t* raw, int n, int step, int ox
     v.w = oi >= 0 ? load_f32_unaligned(p + oi) : 0.f;
     out[i] = v;
 }
+// serialised livox_ros_driver/CustomPoint records (19 bytes, unaligned) -> the 20-byte structs of livox_in
+__global__ void k_decode_custompoints(const uint8_t* raw, int n, mml_livox_point* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = raw + (size_t)i * 19;
+    mml_livox_point q;
+    q.offset_time = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    q.x = load_f32_unaligned(p + 4);
+    q.y = load_f32_unaligned(p + 8);
+    q.z = load_f32_unaligned(p + 12);
+    q.reflectivity = p[16];
+    q.tag = p[17];
+    q.line = p[18];
+    q._pad = 0;
+    out[i] = q;
+}
 // pcl::toROSMsg<PointXYZINormal> payload: 48-byte records, x y z 1 | normal_x normal_y normal_z 0 | intensity curvature 0 0
 __global__ void k_encode_xyzinormal(const float4* xyzi, const float* rel, const uint8_t* line, const uint8_t* label, int n,
                                     float* out) {
@@ -305,32 +321,60 @@ int ensure_wire_stage(mml_ctx* ctx, size_t bytes) {
 }
 }  // namespace
 
+namespace {
+int upload_wire_impl(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x, int off_y,
+                     int off_z, int off_intensity, const mml_livox_point* livox, const uint8_t* livox_wire, int n_livox);
+}
 int mml_scan_upload_pointcloud2(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x,
                                 int off_y, int off_z, int off_intensity, const mml_livox_point* livox, int n_livox) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(n_livox <= 0 || livox, MML_ERR_INVALID, "null point buffer");
+    return upload_wire_impl(ctx, slot, data, n_points, point_step, off_x, off_y, off_z, off_intensity, livox, nullptr, n_livox);
+}
+int mml_scan_upload_wire(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x, int off_y,
+                         int off_z, int off_intensity, const uint8_t* livox_wire, int n_livox) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(n_livox <= 0 || livox_wire, MML_ERR_INVALID, "null point buffer");
+    return upload_wire_impl(ctx, slot, data, n_points, point_step, off_x, off_y, off_z, off_intensity, nullptr, livox_wire, n_livox);
+}
+namespace {
+int upload_wire_impl(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, int point_step, int off_x, int off_y,
+                     int off_z, int off_intensity, const mml_livox_point* livox, const uint8_t* livox_wire, int n_livox) {
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE(n_points >= 0 && n_livox >= 0, MML_ERR_INVALID, "negative point count");
     MML_REQUIRE(n_points <= ctx->cfg.max_velo_points && n_livox <= ctx->cfg.max_livox_points, MML_ERR_CAPACITY,
                 "scan exceeds max_velo_points / max_livox_points");
-    MML_REQUIRE((n_points == 0 || data) && (n_livox == 0 || livox), MML_ERR_INVALID, "null point buffer");
+    MML_REQUIRE(n_points == 0 || data, MML_ERR_INVALID, "null point buffer");
     MML_REQUIRE(point_step >= 12 && point_step <= 256, MML_ERR_INVALID, "point_step out of range");
     const int offs[4] = {off_x, off_y, off_z, off_intensity};
     for (int k = 0; k < 4; ++k)
         MML_REQUIRE((k == 3 && offs[k] < 0) || (offs[k] >= 0 && offs[k] + 4 <= point_step), MML_ERR_INVALID,
                     "field offset outside the point record");
-    if (n_points) {
-        const size_t bytes = (size_t)n_points * point_step;
-        int rc = ensure_wire_stage(ctx, bytes);
+    const size_t bytes = (size_t)n_points * point_step;
+    const size_t lbytes = livox_wire ? (size_t)n_livox * 19 : 0;
+    const size_t loff = (bytes + 15) & ~size_t(15);  // the Livox records follow the Velodyne payload in the staging buffer
+    if (n_points || lbytes) {
+        int rc = ensure_wire_stage(ctx, loff + lbytes);
         if (rc != MML_OK) return rc;
+    }
+    if (n_points) {
         MML_HIP(hipMemcpyAsync(ctx->wire_stage, data, bytes, hipMemcpyHostToDevice, MML_STREAM(ctx)));
         hipLaunchKernelGGL(k_decode_pointcloud2, dim3((n_points + 255) / 256), dim3(256), 0, MML_STREAM(ctx),
                            reinterpret_cast<const uint8_t*>(ctx->wire_stage), n_points, point_step, off_x, off_y, off_z,
                            off_intensity, ctx->velo_in + (size_t)slot * ctx->NV);
         MML_HIP(hipGetLastError());
     }
-    // the Livox part and the two counts travel as in mml_scan_upload
-    if (n_livox)
+    // the Livox part: decoded from its wire form, or as in mml_scan_upload; the two counts travel as there
+    if (n_livox && livox_wire) {
+        uint8_t* dst = reinterpret_cast<uint8_t*>(ctx->wire_stage) + loff;
+        MML_HIP(hipMemcpyAsync(dst, livox_wire, lbytes, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+        hipLaunchKernelGGL(k_decode_custompoints, dim3((n_livox + 255) / 256), dim3(256), 0, MML_STREAM(ctx), dst, n_livox,
+                           ctx->livox_in + (size_t)slot * ctx->NL);
+        MML_HIP(hipGetLastError());
+    } else if (n_livox) {
         MML_HIP(hipMemcpyAsync(ctx->livox_in + (size_t)slot * ctx->NL, livox, sizeof(mml_livox_point) * (size_t)n_livox,
                                hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    }
     ctx->h_n_in[2 * slot] = n_points;
     ctx->h_n_in[2 * slot + 1] = n_livox;
     double* st = stage_alloc(ctx, 1);
@@ -340,6 +384,7 @@ int mml_scan_upload_pointcloud2(mml_ctx* ctx, int slot, const uint8_t* data, int
     MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * slot, sti, sizeof(int) * 2, hipMemcpyHostToDevice, MML_STREAM(ctx)));
     return MML_OK;
 }
+}  // namespace
 
 int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int capacity_points, int* n_points) {
     CHECK_SLOTS(slot, 1);

@@ -270,6 +270,16 @@ def test_wire_formats_pointcloud2_in_pointxyzinormal_out(M, O, synth):
         assert np.array_equal(rec[:, 4], b["reltime"]) and np.array_equal(rec[:, 5], b["ring"].astype(np.float32))
         assert np.array_equal(rec[:, 6], b["label"].astype(np.float32)) and np.array_equal(rec[:, 8], b["xyzi"][:, 3])
         assert not rec[:, [7, 9, 10, 11]].any()
+        # the Livox part in wire form too: the serialised CustomPoint array, 19 unaligned bytes per point
+        lw = np.ascontiguousarray(np.ascontiguousarray(l).view(np.uint8).reshape(len(l), 20)[:, :19]).reshape(-1)
+        c.scan_upload_wire(1, raw.reshape(-1), len(v), step, 0, 4, 8, 12, lw, len(l))
+        c.extract(1, 1)
+        b2 = c.scan_download(1)
+        for key in ("xyzi", "reltime", "ring", "label"):
+            assert np.array_equal(a[key], b2[key]), key
+        c.scan_upload_wire(1, raw.reshape(-1), 0, step, 0, 4, 8, 12, lw, len(l))          # Livox only
+        c.extract(1, 1)
+        assert c.scan_info(1).n_velo == 0 and c.scan_info(1).n_points == a["info"].n_points - a["info"].n_velo
         # a payload without an intensity field
         c.scan_upload_pointcloud2(1, np.ascontiguousarray(raw[:, :12]).reshape(-1), len(v), 12, 0, 4, 8, -1, l)
         c.extract(1, 1)
