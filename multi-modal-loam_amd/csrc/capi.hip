@@ -65,7 +65,7 @@ void mml_destroy(mml_ctx* ctx) {
         if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
-                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt,
+                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue,
                     ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
@@ -156,7 +156,8 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     }
     ALLOC(ctx->assign_aux, B * 8);
     ALLOC(ctx->brk_queue, B * NT);
-    ALLOC(ctx->brk_cnt, B);
+    ALLOC(ctx->brk_cnt, 2 * B);
+    ALLOC(ctx->redo_queue, B * NT);
     ALLOC(ctx->crop_cnt, B * ((NT + 255) / 256) * 8);
     ALLOC(ctx->cb_n, B * 2);
     ALLOC(ctx->fu_xyzi, B * NT);

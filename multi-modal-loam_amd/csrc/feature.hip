@@ -74,6 +74,8 @@ struct FeatParams {
     const float* extr;  // 16 floats or nullptr
     unsigned* brk_queue;  // [B][NT] line-bucketed positions whose break-point test needs the double-precision part
     int* brk_cnt;         // [B]
+    unsigned* redo_queue;  // [B][NT] positions whose float pre-decisions were not certain (k_stencil_redo)
+    int* redo_cnt;         // [B]
 };
 
 struct D3 {
@@ -555,6 +557,269 @@ __device__ __forceinline__ bool abs_cos_gt(double dot, double n1, double n2, dou
     return diff > 0.0;
 }
 
+// The stencil of one inner point; q = its 11-point window.
+// FAST: every angle predicate is decided by its float pre-decision; when one of them falls inside its guard band the
+// function returns false and writes nothing -- the point is then recomputed by k_stencil_redo, which runs the full
+// decision chain (float, sqrt/div-free double, reference expression).  Keeping the double-precision tails out of the
+// main kernel halves its register count: they are taken by ~1 point in 100 but every wavefront paid for them in
+// occupancy.
+// squared length of the segment between consecutive points a and b, in the reference's operation order (:567-569)
+__device__ __forceinline__ float seg_sq(const float4 a, const float4 b) {
+    const float dX = b.x - a.x, dY = b.y - a.y, dZ = b.z - a.z;
+    return dX * dX + dY * dY + dZ * dZ;
+}
+// the window of the fast kernel: points and segment lengths in the workgroup's LDS tile (a segment is shared by the six
+// windows that test it, so it is computed once)
+struct WinTile {
+    const float4* p;  // p[0..10] = points -5..5
+    const float* s;   // s[k] = |p[k+1] - p[k]|^2
+    __device__ __forceinline__ float4 operator[](int k) const { return p[k]; }
+    __device__ __forceinline__ float seg(int o) const { return s[5 + o]; }  // segment between points o and o + 1
+};
+// ... and of the redo kernel: registers
+struct WinRegs {
+    const float4* p;
+    __device__ __forceinline__ float4 operator[](int k) const { return p[k]; }
+    __device__ __forceinline__ float seg(int o) const { return seg_sq(p[5 + o], p[5 + o + 1]); }
+};
+// W: the window, indexable -5..5 around its centre (an LDS pointer in the fast kernel, registers in the redo kernel).
+// SECTION(): in the fast kernel the window is re-read from LDS section by section, so that no more than one section's
+// points are live in registers at a time.
+template <bool FAST, typename WIN>
+__device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float& curv, float& refl, bool& brk) {
+#define PT(o) q[5 + (o)]
+#define SECTION()                               \
+    do {                                        \
+        if constexpr (FAST) asm volatile("" ::: "memory"); \
+    } while (0)
+    const float thDistanceFaraway = 50.0;
+    const float thFlatThreshold = 0.02;
+    const float thLidarNearestDis = 1.0;
+    const float thBreakCornerDis = 1;
+    // ---- :407-451 ----
+    float diffX = 0, diffY = 0, diffZ = 0;
+    const float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
+    const float dis = sqrtf(dis2);  // == (float)sqrt((double)dis2): IEEE float sqrt
+    // :421-422 fabs(cos) > 0.966 for both neighbours.  Float pre-decision (error ~1e-6 of the cosine, accepted only
+    // when the squared form is more than 1e-3 away from the threshold), then the double squared form, then the
+    // reference expression.
+    bool gl, gn;
+    {
+        const float lx = PT(-1).x - PT(0).x, ly = PT(-1).y - PT(0).y, lz = PT(-1).z - PT(0).z;
+        const float nx = PT(1).x - PT(0).x, ny = PT(1).y - PT(0).y, nz = PT(1).z - PT(0).z;
+        // (fused multiply-adds are fine here: this is the banded pre-decision, not the reference arithmetic)
+        const float dotl = fmaf(lz, PT(0).z, fmaf(ly, PT(0).y, lx * PT(0).x));
+        const float dotn = fmaf(nz, PT(0).z, fmaf(ny, PT(0).y, nx * PT(0).x));
+        const float rl = (0.966f * 0.966f) * (q.seg(-1) * dis2);
+        const float rn = (0.966f * 0.966f) * (q.seg(0) * dis2);
+        const float el = fmaf(dotl, dotl, -rl), en = fmaf(dotn, dotn, -rn);
+        gl = el > 0.f;
+        gn = en > 0.f;
+        const bool sure = (fabsf(el) > 1e-3f * rl) & (fabsf(en) > 1e-3f * rn) & (rl < 1e30f) & (rn < 1e30f) &
+                          (rl > 1e-30f) & (rn > 1e-30f);
+        if (!sure) {
+            if constexpr (FAST) return false;
+            const D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
+            const D3 dl = d3((double)PT(-1).x - pt_cur.x, (double)PT(-1).y - pt_cur.y, (double)PT(-1).z - pt_cur.z);
+            const D3 dn = d3((double)PT(1).x - pt_cur.x, (double)PT(1).y - pt_cur.y, (double)PT(1).z - pt_cur.z);
+            const double n0 = ddot(pt_cur, pt_cur);
+            bool c1, c2;
+            gl = abs_cos_gt(ddot(dl, pt_cur), ddot(dl, dl), n0, 0.966 * 0.966, c1);
+            gn = abs_cos_gt(ddot(dn, pt_cur), ddot(dn, dn), n0, 0.966 * 0.966, c2);
+            if (!(c1 && c2)) {  // reference expression (:421-422)
+                const double ncur = dnorm(pt_cur);
+                const double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
+                const double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
+                gl = fabs(angle_last) > 0.966;
+                gn = fabs(angle_next) > 0.966;
+            }
+        }
+    }
+    const bool grazing = gl && gn;
+    int thNumCurvSize;
+    if (dis > thDistanceFaraway || grazing) {
+        thNumCurvSize = 2;
+        attr |= A_W2;
+    } else {
+        thNumCurvSize = 3;
+    }
+    if (grazing) attr |= A_ANGLE;
+    float diffR = -2 * thNumCurvSize * PT(0).w;
+    // the loop at :435-440, unrolled (j = 1, 2 always; j = 3 when the window is 3)
+    diffX += PT(-1).x + PT(1).x;
+    diffY += PT(-1).y + PT(1).y;
+    diffZ += PT(-1).z + PT(1).z;
+    diffR += PT(-1).w + PT(1).w;
+    diffX += PT(-2).x + PT(2).x;
+    diffY += PT(-2).y + PT(2).y;
+    diffZ += PT(-2).z + PT(2).z;
+    diffR += PT(-2).w + PT(2).w;
+    if (thNumCurvSize == 3) {
+        diffX += PT(-3).x + PT(3).x;
+        diffY += PT(-3).y + PT(3).y;
+        diffZ += PT(-3).z + PT(3).z;
+        diffR += PT(-3).w + PT(3).w;
+    }
+    diffX -= 2 * thNumCurvSize * PT(0).x;
+    diffY -= 2 * thNumCurvSize * PT(0).y;
+    diffZ -= 2 * thNumCurvSize * PT(0).z;
+    curv = diffX * diffX + diffY * diffY + diffZ * diffZ;
+    refl = diffR;
+    // ---- predicates of :488, :499/:512, :524, :534-535 ----
+    SECTION();
+    if (curv < thFlatThreshold * dis * thFlatThreshold * dis) attr |= A_CAND3;
+    const bool far = dis > thDistanceFaraway;
+    if (far) attr |= A_FAR;
+    if (curv < 0.7 * thFlatThreshold * dis * thFlatThreshold * dis && refl > 20.0) attr |= A_REFL;
+    {
+        // the reference compares the float sum with the double 0.02 (:569, :584).  0.02f is the float just below
+        // 0.02, so for a float x: x > 0.02 <=> x > 0.02f.
+        constexpr float kTh002 = 0.02f;
+        static_assert((double)kTh002 < 0.02, "0.02f must round down");
+        int a3 = 0;
+#pragma unroll
+        for (int l = 1; l <= 3; l++) {
+            if (q.seg(l - 1) > kTh002 || far) break;  // |PT(l) - PT(l - 1)|^2
+            a3 = l;
+        }
+        int b3 = 0;
+#pragma unroll
+        for (int l = -1; l >= -3; l--) {
+            if (q.seg(l) > kTh002 || far) break;  // |PT(l) - PT(l + 1)|^2: the same squares as |PT(l + 1) - PT(l)|^2
+            b3 = -l;
+        }
+        attr |= (unsigned)a3 << A_A3_SHIFT;
+        attr |= (unsigned)b3 << A_B3_SHIFT;
+    }
+    // ---- :543-650 (per visited point; which points are visited is decided in k_select) ----
+    SECTION();
+    {
+        const float depth = dis;
+        float ldiffX = PT(-4).x + PT(-3).x - 4 * PT(-2).x + PT(-1).x + PT(0).x;
+        float ldiffY = PT(-4).y + PT(-3).y - 4 * PT(-2).y + PT(-1).y + PT(0).y;
+        float ldiffZ = PT(-4).z + PT(-3).z - 4 * PT(-2).z + PT(-1).z + PT(0).z;
+        float left_curvature = ldiffX * ldiffX + ldiffY * ldiffY + ldiffZ * ldiffZ;
+        const bool lflat = left_curvature < thFlatThreshold * depth;
+        float rdiffX = PT(4).x + PT(3).x - 4 * PT(2).x + PT(1).x + PT(0).x;
+        float rdiffY = PT(4).y + PT(3).y - 4 * PT(2).y + PT(1).y + PT(0).y;
+        float rdiffZ = PT(4).z + PT(3).z - 4 * PT(2).z + PT(1).z + PT(0).z;
+        float right_curvature = rdiffX * rdiffX + rdiffY * rdiffY + rdiffZ * rdiffZ;
+        const bool rflat = right_curvature < thFlatThreshold * depth;
+        if (lflat) attr |= A_LFLAT;
+        if (rflat) attr |= A_RFLAT;
+        SECTION();
+        if (lflat && rflat) {
+            // :615-644: cc = |cos| between the weighted sums of the unit vectors to the four neighbours on either
+            // side; flag 150 needs cc < 0.5 and both outermost neighbours farther than 5 cm.
+            // (1) float pre-decision of cc >= 0.5 (the common case on a plane: cc ~ 1), accepted only when the
+            //     squared form is 1e-3 away from the threshold and neither sum nearly cancels;
+            // (2) the same squared form in double (v_rsq_f64 + Newton) with a 1e-10 band;
+            // (3) the reference expression.
+            bool c150 = false, decided = false;
+            {
+                float lx = 0.f, ly = 0.f, lz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, za4 = 0.f, zb4 = 0.f;
+#pragma unroll
+                for (int k = 1; k < 5; k++) {
+                    const float ax = PT(-k).x - PT(0).x, ay = PT(-k).y - PT(0).y, az = PT(-k).z - PT(0).z;
+                    const float bx = PT(k).x - PT(0).x, by = PT(k).y - PT(0).y, bz = PT(k).z - PT(0).z;
+                    const float za = fmaf(az, az, fmaf(ay, ay, ax * ax)), zb = fmaf(bz, bz, fmaf(by, by, bx * bx));
+                    const float wa = (k / 10.0f) * (za > 0.f ? __builtin_amdgcn_rsqf(za) : 1.f);
+                    const float wb = (k / 10.0f) * (zb > 0.f ? __builtin_amdgcn_rsqf(zb) : 1.f);
+                    lx = fmaf(wa, ax, lx);
+                    ly = fmaf(wa, ay, ly);
+                    lz = fmaf(wa, az, lz);
+                    rx = fmaf(wb, bx, rx);
+                    ry = fmaf(wb, by, ry);
+                    rz = fmaf(wb, bz, rz);
+                    if (k == 4) {
+                        za4 = za;
+                        zb4 = zb;
+                    }
+                }
+                const float dt = fmaf(lz, rz, fmaf(ly, ry, lx * rx));
+                const float n1 = fmaf(lz, lz, fmaf(ly, ly, lx * lx)), n2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+                const float rhs = 0.25f * (n1 * n2), df = fmaf(dt, dt, -rhs);
+                const bool inr = (n1 > 0.25f) & (n2 > 0.25f) & (n1 < 4.f) & (n2 < 4.f);
+                // cc >= 0.5 for sure: not a 150 point.  cc < 0.5 for sure: the 5 cm test on the outermost
+                // neighbours decides, in float when neither squared distance is within 1e-5 of 0.0025.
+                const bool ge = (df > 1e-3f * rhs) & inr, lt = (df < -1e-3f * rhs) & inr;
+                const bool k4 = (fabsf(za4 - 0.0025f) > 2.5e-8f) & (fabsf(zb4 - 0.0025f) > 2.5e-8f);
+                decided = ge | (lt & k4);
+                c150 = lt & (za4 > 0.0025f) & (zb4 > 0.0025f);
+            }
+            if (!decided) {
+            if constexpr (FAST) return false;
+            D3 nl = d3(0, 0, 0), nr = d3(0, 0, 0);
+            double last2 = 0, cur2 = 0;
+#pragma unroll
+            for (int k = 1; k < 5; k++) {
+                const D3 tl = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+                const D3 tr = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+                const double zl = ddot(tl, tl), zr = ddot(tr, tr);
+                const double il = zl > 0.0 ? rsqrt_nr(zl) : 1.0, ir = zr > 0.0 ? rsqrt_nr(zr) : 1.0;
+                const double wl = (k / 10.0) * il, wr = (k / 10.0) * ir;
+                nl.x += wl * tl.x;
+                nl.y += wl * tl.y;
+                nl.z += wl * tl.z;
+                nr.x += wr * tr.x;
+                nr.y += wr * tr.y;
+                nr.z += wr * tr.z;
+                if (k == 4) {
+                    last2 = zl;
+                    cur2 = zr;
+                }
+            }
+            bool ca;
+            const bool cc_ge = abs_cos_gt(ddot(nl, nr), ddot(nl, nl), ddot(nr, nr), 0.25, ca);  // cc > 0.5
+            const bool cl = fabs(last2 - 0.0025) > 1e-12, cr = fabs(cur2 - 0.0025) > 1e-12;
+            c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
+            if (!(ca && cl && cr)) {  // reference expression (:615-644)
+                D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
+#pragma unroll
+                for (int k = 1; k < 5; k++) {
+                    D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+                    dnormalize(tmp);
+                    norm_left.x += (k / 10.0) * tmp.x;
+                    norm_left.y += (k / 10.0) * tmp.y;
+                    norm_left.z += (k / 10.0) * tmp.z;
+                }
+#pragma unroll
+                for (int k = 1; k < 5; k++) {
+                    D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+                    dnormalize(tmp);
+                    norm_right.x += (k / 10.0) * tmp.x;
+                    norm_right.y += (k / 10.0) * tmp.y;
+                    norm_right.z += (k / 10.0) * tmp.z;
+                }
+                double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
+                D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
+                D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
+                double last_dis = dnorm(last_tmp);
+                double current_dis = dnorm(current_tmp);
+                c150 = cc < 0.5 && last_dis > 0.05 && current_dis > 0.05;
+            }
+            }
+            if (c150) attr |= A_C150;
+        }
+    }
+    // ---- :651-806 break points ----
+    SECTION();
+    // Only a range discontinuity of more than 1 m can make a break point; what follows that test (two more square
+    // roots, a double-precision angle, six double normalisations) concerns a few dozen points per scan, but a
+    // wavefront pays for it as soon as ONE of its 64 lanes qualifies.  Those points are therefore queued and
+    // finished by k_stencil_break with every lane busy.
+    {
+        const float sq_right = q.seg(0), sq_left = q.seg(-1);
+        // two distances below 1 m cannot differ by more than thBreakCornerDis = 1 (sqrtf is monotone and
+        // sqrtf(x) <= 1 for x < 1)
+        brk = !(sq_right < 1.f && sq_left < 1.f);
+    }
+    if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
+#undef PT
+#undef SECTION
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     const int b = blockIdx.y + P.first;
     // the STENCIL_PTS + 10 points this workgroup's windows cover, read once (lines are contiguous in ln_pts, so the
@@ -568,6 +833,9 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     LineTab tab;
     load_line_tab(P, b, tab);
     __syncthreads();
+    __shared__ float s_sq[STENCIL_PTS + 10];
+    for (int k = threadIdx.x; k < STENCIL_PTS + 9; k += 256) s_sq[k] = seg_sq(s_pt[k], s_pt[k + 1]);
+    __syncthreads();
     for (int rep = 0; rep < STENCIL_PTS / 256; ++rep) {
     const int tp = rep * 256 + threadIdx.x, p = p_first + tp;
     if (__builtin_amdgcn_readfirstlane(p) >= P.NT) break;
@@ -577,240 +845,12 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
     const size_t base = (size_t)b * P.NT + start;
     unsigned attr = 0;
     float curv = 0.f, refl = 0.f;
-    bool brk = false;
+    bool brk = false, redo = false;
     if (live && i >= 5 && i < n - 5) {
-        const float thDistanceFaraway = 50.0;
-        const float thFlatThreshold = 0.02;
-        const float thLidarNearestDis = 1.0;
-        const float thBreakCornerDis = 1;
-        float4 q[11];
-#pragma unroll
-        for (int k = 0; k < 11; ++k) q[k] = s_pt[tp + k];
-#define PT(o) q[5 + (o)]
-        // ---- :407-451 ----
-        float diffX = 0, diffY = 0, diffZ = 0;
-        const float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
-        const float dis = sqrtf(dis2);  // == (float)sqrt((double)dis2): IEEE float sqrt
-        // :421-422 fabs(cos) > 0.966 for both neighbours.  Float pre-decision (error ~1e-6 of the cosine, accepted only
-        // when the squared form is more than 1e-3 away from the threshold), then the double squared form, then the
-        // reference expression.
-        bool gl, gn;
-        {
-            const float lx = PT(-1).x - PT(0).x, ly = PT(-1).y - PT(0).y, lz = PT(-1).z - PT(0).z;
-            const float nx = PT(1).x - PT(0).x, ny = PT(1).y - PT(0).y, nz = PT(1).z - PT(0).z;
-            // (fused multiply-adds are fine here: this is the banded pre-decision, not the reference arithmetic)
-            const float dotl = fmaf(lz, PT(0).z, fmaf(ly, PT(0).y, lx * PT(0).x));
-            const float dotn = fmaf(nz, PT(0).z, fmaf(ny, PT(0).y, nx * PT(0).x));
-            const float rl = (0.966f * 0.966f) * (fmaf(lz, lz, fmaf(ly, ly, lx * lx)) * dis2);
-            const float rn = (0.966f * 0.966f) * (fmaf(nz, nz, fmaf(ny, ny, nx * nx)) * dis2);
-            const float el = fmaf(dotl, dotl, -rl), en = fmaf(dotn, dotn, -rn);
-            gl = el > 0.f;
-            gn = en > 0.f;
-            const bool sure = (fabsf(el) > 1e-3f * rl) & (fabsf(en) > 1e-3f * rn) & (rl < 1e30f) & (rn < 1e30f) &
-                              (rl > 1e-30f) & (rn > 1e-30f);
-            if (!sure) {
-                const D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
-                const D3 dl = d3((double)PT(-1).x - pt_cur.x, (double)PT(-1).y - pt_cur.y, (double)PT(-1).z - pt_cur.z);
-                const D3 dn = d3((double)PT(1).x - pt_cur.x, (double)PT(1).y - pt_cur.y, (double)PT(1).z - pt_cur.z);
-                const double n0 = ddot(pt_cur, pt_cur);
-                bool c1, c2;
-                gl = abs_cos_gt(ddot(dl, pt_cur), ddot(dl, dl), n0, 0.966 * 0.966, c1);
-                gn = abs_cos_gt(ddot(dn, pt_cur), ddot(dn, dn), n0, 0.966 * 0.966, c2);
-                if (!(c1 && c2)) {  // reference expression (:421-422)
-                    const double ncur = dnorm(pt_cur);
-                    const double angle_last = ddot(dl, pt_cur) / (dnorm(dl) * ncur);
-                    const double angle_next = ddot(dn, pt_cur) / (dnorm(dn) * ncur);
-                    gl = fabs(angle_last) > 0.966;
-                    gn = fabs(angle_next) > 0.966;
-                }
-            }
-        }
-        const bool grazing = gl && gn;
-        int thNumCurvSize;
-        if (dis > thDistanceFaraway || grazing) {
-            thNumCurvSize = 2;
-            attr |= A_W2;
-        } else {
-            thNumCurvSize = 3;
-        }
-        if (grazing) attr |= A_ANGLE;
-        float diffR = -2 * thNumCurvSize * PT(0).w;
-        // the loop at :435-440, unrolled (j = 1, 2 always; j = 3 when the window is 3)
-        diffX += PT(-1).x + PT(1).x;
-        diffY += PT(-1).y + PT(1).y;
-        diffZ += PT(-1).z + PT(1).z;
-        diffR += PT(-1).w + PT(1).w;
-        diffX += PT(-2).x + PT(2).x;
-        diffY += PT(-2).y + PT(2).y;
-        diffZ += PT(-2).z + PT(2).z;
-        diffR += PT(-2).w + PT(2).w;
-        if (thNumCurvSize == 3) {
-            diffX += PT(-3).x + PT(3).x;
-            diffY += PT(-3).y + PT(3).y;
-            diffZ += PT(-3).z + PT(3).z;
-            diffR += PT(-3).w + PT(3).w;
-        }
-        diffX -= 2 * thNumCurvSize * PT(0).x;
-        diffY -= 2 * thNumCurvSize * PT(0).y;
-        diffZ -= 2 * thNumCurvSize * PT(0).z;
-        curv = diffX * diffX + diffY * diffY + diffZ * diffZ;
-        refl = diffR;
-        // ---- predicates of :488, :499/:512, :524, :534-535 ----
-        if (curv < thFlatThreshold * dis * thFlatThreshold * dis) attr |= A_CAND3;
-        const bool far = dis > thDistanceFaraway;
-        if (far) attr |= A_FAR;
-        if (curv < 0.7 * thFlatThreshold * dis * thFlatThreshold * dis && refl > 20.0) attr |= A_REFL;
-        {
-            // the reference compares the float sum with the double 0.02 (:569, :584).  0.02f is the float just below
-            // 0.02, so for a float x: x > 0.02 <=> x > 0.02f.
-            constexpr float kTh002 = 0.02f;
-            static_assert((double)kTh002 < 0.02, "0.02f must round down");
-            int a3 = 0;
-#pragma unroll
-            for (int l = 1; l <= 3; l++) {
-                float dX = PT(l).x - PT(l - 1).x;
-                float dY = PT(l).y - PT(l - 1).y;
-                float dZ = PT(l).z - PT(l - 1).z;
-                if (dX * dX + dY * dY + dZ * dZ > kTh002 || far) break;
-                a3 = l;
-            }
-            int b3 = 0;
-#pragma unroll
-            for (int l = -1; l >= -3; l--) {
-                float dX = PT(l).x - PT(l + 1).x;
-                float dY = PT(l).y - PT(l + 1).y;
-                float dZ = PT(l).z - PT(l + 1).z;
-                if (dX * dX + dY * dY + dZ * dZ > kTh002 || far) break;
-                b3 = -l;
-            }
-            attr |= (unsigned)a3 << A_A3_SHIFT;
-            attr |= (unsigned)b3 << A_B3_SHIFT;
-        }
-        // ---- :543-650 (per visited point; which points are visited is decided in k_select) ----
-        {
-            const float depth = dis;
-            float ldiffX = PT(-4).x + PT(-3).x - 4 * PT(-2).x + PT(-1).x + PT(0).x;
-            float ldiffY = PT(-4).y + PT(-3).y - 4 * PT(-2).y + PT(-1).y + PT(0).y;
-            float ldiffZ = PT(-4).z + PT(-3).z - 4 * PT(-2).z + PT(-1).z + PT(0).z;
-            float left_curvature = ldiffX * ldiffX + ldiffY * ldiffY + ldiffZ * ldiffZ;
-            const bool lflat = left_curvature < thFlatThreshold * depth;
-            float rdiffX = PT(4).x + PT(3).x - 4 * PT(2).x + PT(1).x + PT(0).x;
-            float rdiffY = PT(4).y + PT(3).y - 4 * PT(2).y + PT(1).y + PT(0).y;
-            float rdiffZ = PT(4).z + PT(3).z - 4 * PT(2).z + PT(1).z + PT(0).z;
-            float right_curvature = rdiffX * rdiffX + rdiffY * rdiffY + rdiffZ * rdiffZ;
-            const bool rflat = right_curvature < thFlatThreshold * depth;
-            if (lflat) attr |= A_LFLAT;
-            if (rflat) attr |= A_RFLAT;
-            if (lflat && rflat) {
-                // :615-644: cc = |cos| between the weighted sums of the unit vectors to the four neighbours on either
-                // side; flag 150 needs cc < 0.5 and both outermost neighbours farther than 5 cm.
-                // (1) float pre-decision of cc >= 0.5 (the common case on a plane: cc ~ 1), accepted only when the
-                //     squared form is 1e-3 away from the threshold and neither sum nearly cancels;
-                // (2) the same squared form in double (v_rsq_f64 + Newton) with a 1e-10 band;
-                // (3) the reference expression.
-                bool c150 = false, decided = false;
-                {
-                    float lx = 0.f, ly = 0.f, lz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, za4 = 0.f, zb4 = 0.f;
-#pragma unroll
-                    for (int k = 1; k < 5; k++) {
-                        const float ax = PT(-k).x - PT(0).x, ay = PT(-k).y - PT(0).y, az = PT(-k).z - PT(0).z;
-                        const float bx = PT(k).x - PT(0).x, by = PT(k).y - PT(0).y, bz = PT(k).z - PT(0).z;
-                        const float za = fmaf(az, az, fmaf(ay, ay, ax * ax)), zb = fmaf(bz, bz, fmaf(by, by, bx * bx));
-                        const float wa = (k / 10.0f) * (za > 0.f ? __builtin_amdgcn_rsqf(za) : 1.f);
-                        const float wb = (k / 10.0f) * (zb > 0.f ? __builtin_amdgcn_rsqf(zb) : 1.f);
-                        lx = fmaf(wa, ax, lx);
-                        ly = fmaf(wa, ay, ly);
-                        lz = fmaf(wa, az, lz);
-                        rx = fmaf(wb, bx, rx);
-                        ry = fmaf(wb, by, ry);
-                        rz = fmaf(wb, bz, rz);
-                        if (k == 4) {
-                            za4 = za;
-                            zb4 = zb;
-                        }
-                    }
-                    const float dt = fmaf(lz, rz, fmaf(ly, ry, lx * rx));
-                    const float n1 = fmaf(lz, lz, fmaf(ly, ly, lx * lx)), n2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
-                    const float rhs = 0.25f * (n1 * n2), df = fmaf(dt, dt, -rhs);
-                    const bool inr = (n1 > 0.25f) & (n2 > 0.25f) & (n1 < 4.f) & (n2 < 4.f);
-                    // cc >= 0.5 for sure: not a 150 point.  cc < 0.5 for sure: the 5 cm test on the outermost
-                    // neighbours decides, in float when neither squared distance is within 1e-5 of 0.0025.
-                    const bool ge = (df > 1e-3f * rhs) & inr, lt = (df < -1e-3f * rhs) & inr;
-                    const bool k4 = (fabsf(za4 - 0.0025f) > 2.5e-8f) & (fabsf(zb4 - 0.0025f) > 2.5e-8f);
-                    decided = ge | (lt & k4);
-                    c150 = lt & (za4 > 0.0025f) & (zb4 > 0.0025f);
-                }
-                if (!decided) {
-                D3 nl = d3(0, 0, 0), nr = d3(0, 0, 0);
-                double last2 = 0, cur2 = 0;
-#pragma unroll
-                for (int k = 1; k < 5; k++) {
-                    const D3 tl = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
-                    const D3 tr = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
-                    const double zl = ddot(tl, tl), zr = ddot(tr, tr);
-                    const double il = zl > 0.0 ? rsqrt_nr(zl) : 1.0, ir = zr > 0.0 ? rsqrt_nr(zr) : 1.0;
-                    const double wl = (k / 10.0) * il, wr = (k / 10.0) * ir;
-                    nl.x += wl * tl.x;
-                    nl.y += wl * tl.y;
-                    nl.z += wl * tl.z;
-                    nr.x += wr * tr.x;
-                    nr.y += wr * tr.y;
-                    nr.z += wr * tr.z;
-                    if (k == 4) {
-                        last2 = zl;
-                        cur2 = zr;
-                    }
-                }
-                bool ca;
-                const bool cc_ge = abs_cos_gt(ddot(nl, nr), ddot(nl, nl), ddot(nr, nr), 0.25, ca);  // cc > 0.5
-                const bool cl = fabs(last2 - 0.0025) > 1e-12, cr = fabs(cur2 - 0.0025) > 1e-12;
-                c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
-                if (!(ca && cl && cr)) {  // reference expression (:615-644)
-                    D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
-#pragma unroll
-                    for (int k = 1; k < 5; k++) {
-                        D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
-                        dnormalize(tmp);
-                        norm_left.x += (k / 10.0) * tmp.x;
-                        norm_left.y += (k / 10.0) * tmp.y;
-                        norm_left.z += (k / 10.0) * tmp.z;
-                    }
-#pragma unroll
-                    for (int k = 1; k < 5; k++) {
-                        D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
-                        dnormalize(tmp);
-                        norm_right.x += (k / 10.0) * tmp.x;
-                        norm_right.y += (k / 10.0) * tmp.y;
-                        norm_right.z += (k / 10.0) * tmp.z;
-                    }
-                    double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
-                    D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
-                    D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
-                    double last_dis = dnorm(last_tmp);
-                    double current_dis = dnorm(current_tmp);
-                    c150 = cc < 0.5 && last_dis > 0.05 && current_dis > 0.05;
-                }
-                }
-                if (c150) attr |= A_C150;
-            }
-        }
-        // ---- :651-806 break points ----
-        // Only a range discontinuity of more than 1 m can make a break point; what follows that test (two more square
-        // roots, a double-precision angle, six double normalisations) concerns a few dozen points per scan, but a
-        // wavefront pays for it as soon as ONE of its 64 lanes qualifies.  Those points are therefore queued and
-        // finished by k_stencil_break with every lane busy.
-        {
-            float dX1 = PT(1).x - PT(0).x, dY1 = PT(1).y - PT(0).y, dZ1 = PT(1).z - PT(0).z;
-            float dX2 = PT(-1).x - PT(0).x, dY2 = PT(-1).y - PT(0).y, dZ2 = PT(-1).z - PT(0).z;
-            const float sq_right = dX1 * dX1 + dY1 * dY1 + dZ1 * dZ1, sq_left = dX2 * dX2 + dY2 * dY2 + dZ2 * dZ2;
-            // two distances below 1 m cannot differ by more than thBreakCornerDis = 1 (sqrtf is monotone and
-            // sqrtf(x) <= 1 for x < 1)
-            brk = !(sq_right < 1.f && sq_left < 1.f);
-        }
-        if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
-#undef PT
+        redo = !stencil_point<true>(WinTile{s_pt + tp, s_sq + tp}, attr, curv, refl, brk);
+        brk = brk && !redo;
     }
-    if (live) {
+    if (live && !redo) {
         P.ln_curv[base + i] = curv;
         P.ln_refl[base + i] = refl;
         P.ln_attr[base + i] = (uint16_t)attr;
@@ -824,8 +864,39 @@ __global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
         first = __shfl(first, (int)__ffsll((long long)bm) - 1);
         if (brk) P.brk_queue[(size_t)b * P.NT + first + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(start + i);
     }
+    // ... and to its redo queue
+    const unsigned long long rm = __ballot(redo);
+    if (rm) {
+        const int lane = threadIdx.x & 63;
+        int first = 0;
+        if (lane == (int)__ffsll((long long)rm) - 1) first = atomicAdd(&P.redo_cnt[b], __popcll(rm));
+        first = __shfl(first, (int)__ffsll((long long)rm) - 1);
+        if (redo) P.redo_queue[(size_t)b * P.NT + first + __popcll(rm & ((1ull << lane) - 1ull))] = (unsigned)(start + i);
+    }
     }
 }
+
+// the points whose float pre-decisions were not certain, one per lane, with the full decision chain
+__global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {
+    const int b = blockIdx.y + P.first;
+    const int cnt = P.redo_cnt[b];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
+        const unsigned pos_in_slot = P.redo_queue[(size_t)b * P.NT + e];
+        const size_t pos = (size_t)b * P.NT + pos_in_slot;
+        float4 q[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) q[k] = P.ln_pts[pos + k - 5];
+        unsigned attr = 0;
+        float curv = 0.f, refl = 0.f;
+        bool brk = false;
+        stencil_point<false>(WinRegs{q}, attr, curv, refl, brk);
+        P.ln_curv[pos] = curv;
+        P.ln_refl[pos] = refl;
+        P.ln_attr[pos] = (uint16_t)attr;
+        if (brk) P.brk_queue[(size_t)b * P.NT + atomicAdd(&P.brk_cnt[b], 1)] = pos_in_slot;
+    }
+}
+
 
 // the queued break-point candidates (:651-806), one per lane
 __global__ __launch_bounds__(256) void k_stencil_break(FeatParams P) {
@@ -1761,6 +1832,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.extr = nullptr;
     P.brk_queue = ctx->brk_queue;
     P.brk_cnt = ctx->brk_cnt;
+    P.redo_queue = ctx->redo_queue;
+    P.redo_cnt = ctx->brk_cnt + ctx->B;
     return P;
 }
 
@@ -1787,7 +1860,9 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     {
         MmlStageScope t(ctx, "stencil");
         MML_HIP(hipMemsetAsync(ctx->brk_cnt + first, 0, sizeof(int) * count, s));
+        MML_HIP(hipMemsetAsync(ctx->brk_cnt + ctx->B + first, 0, sizeof(int) * count, s));
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, count), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
     }
     {
@@ -1822,8 +1897,10 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
     const int pblocks = (n + STENCIL_PTS - 1) / STENCIL_PTS;
     MML_HIP(hipMemsetAsync(ctx->brk_cnt, 0, sizeof(int), s));
+    MML_HIP(hipMemsetAsync(ctx->brk_cnt + ctx->B, 0, sizeof(int), s));
     if (pblocks > 0) {
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_stencil_redo, dim3(4, 1), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, 1), dim3(256), 0, s, P);
     }
     hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);

@@ -88,7 +88,8 @@ struct mml_ctx {
     int sel_cap = 0;
     int sel_cap_velo = 0;
     unsigned* brk_queue = nullptr;  // B * NT: queued break-point candidates of k_stencil
-    int* brk_cnt = nullptr;         // B
+    int* brk_cnt = nullptr;         // 2 B: break-point queue sizes, then redo queue sizes
+    unsigned* redo_queue = nullptr; // B * NT: points k_stencil left to k_stencil_redo
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
     int* cb_n = nullptr;  // B * 2

@@ -9,7 +9,7 @@ import sys
 import pandas as pd
 
 STAGE = {"k_assign_init": "assign_count", "k_assign_a": "assign_count", "k_assign_b": "assign_scan", "k_assign_c": "assign_scatter",
-         "k_stencil": "stencil", "k_stencil_break": "stencil", "k_select": "select", "k_crop_a": "crop_compact", "k_crop_b": "crop_compact",
+         "k_stencil": "stencil", "k_stencil_break": "stencil", "k_stencil_redo": "stencil", "k_select": "select", "k_crop_a": "crop_compact", "k_crop_b": "crop_compact",
          "k_crop_c": "crop_compact", "k_crop": "crop_compact", "k_undistort_prep": "undistort", "k_undistort": "undistort",
          "k_voxel": "voxel_downsample", "k_assoc_prefix": "associate", "k_associate": "associate",
          "k_associate_hard": "associate_far", "k_associate_fit": "associate_far", "k_associate_fit_all": "associate_fit", "k_assoc_stats": "assoc_stats", "k_solve": "solve"}
