@@ -226,21 +226,38 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
     }
 }
 
-// block reduction of acc[28] into out[28] (LDS or global); result valid for thread 0 after the trailing barrier
+// block reduction of acc[28] into out[28] (LDS or global); result valid for thread 0 after the trailing barrier.
+// Inside a wavefront the 28 sums are reduced as a butterfly that halves the number of values a lane carries at every
+// step (at offset o the lanes with bit o set keep the upper half of their values and hand over the lower half): 16 + 8 +
+// 4 + 2 + 1 + 1 = 32 exchanged doubles instead of 28 x 6.  Every value still meets its partners in the order xor 32, 16,
+// 8, 4, 2, 1, i.e. it is the same summation tree as one xor-butterfly per value, bit for bit.
+__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
+    const unsigned lo = __shfl_xor((unsigned)__double2loint(v), o), hi = __shfl_xor((unsigned)__double2hiint(v), o);
+    return __hiloint2double((int)hi, (int)lo);
+}
 __device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, double* out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v[32];
 #pragma unroll
-    for (int k = 0; k < 28; ++k) {
-        double v = acc[k];
+    for (int k = 0; k < 32; ++k) v[k] = k < 28 ? acc[k] : 0.0;
+    int idx = 0;  // which of the 32 sums this lane ends up holding
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) s_part[wave * 28 + k] = v;
+    for (int c = 16, o = 32; c >= 1; c >>= 1, o >>= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int j = 0; j < c; ++j) {
+            const double keep = up ? v[j + c] : v[j], send = up ? v[j] : v[j + c];
+            v[j] = keep + shfl_xor_f64(send, o);
+        }
+        idx += up ? c : 0;
     }
+    const double tot = v[0] + shfl_xor_f64(v[0], 1);
+    if (!(lane & 1) && idx < 28) s_part[wave * 28 + idx] = tot;
     __syncthreads();
     if (threadIdx.x < 28) {
-        double v = s_part[threadIdx.x];
-        for (int w = 1; w < SOLVE_WAVES; ++w) v += s_part[w * 28 + threadIdx.x];
-        out[threadIdx.x] = v;
+        double r = s_part[threadIdx.x];
+        for (int w = 1; w < SOLVE_WAVES; ++w) r += s_part[w * 28 + threadIdx.x];
+        out[threadIdx.x] = r;
     }
     __syncthreads();
 }
