@@ -434,6 +434,193 @@ __host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
     S.evaluate = 1;
 }
 
+// tr_propose for the one-frame problem of the live mode (W = 1), run by the 64 lanes of the first wavefront.  The
+// generic form is a single lane walking ~50 double-precision square roots and divisions and two 36-term quadratic forms
+// one after the other while the rest of the workgroup waits; here everything that is independent runs on its own lane
+// (the 36 matrix entries, the 6 diagonal / gradient entries, the rows of a Cholesky column) and only the sums whose
+// order of addition defines the result stay serial.  Every value is computed by the same expression, and every sum
+// accumulated in the same order, as in tr_propose: the iterates are identical.
+// w: 92 doubles of LDS.  Lanes exchange through LDS; inside one wavefront LDS operations execute in program order, so a
+// compiler barrier is all the synchronisation needed.
+#define WSYNC()                          \
+    do {                                 \
+        __builtin_amdgcn_wave_barrier(); \
+        asm volatile("" ::: "memory");   \
+    } while (0)
+__device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
+    const int lane = threadIdx.x;  // 0..63
+    double* T = w;         // 36 terms of a quadratic form
+    double* A = w + 36;    // 36: the damped matrix, then its Cholesky factor (lower triangle)
+    double* bv = w + 72;   // 6
+    double* sg = w + 78;   // 6
+    double* st = w + 84;   // 6: the step
+    double* fl = w + 90;   // 2 flags
+    const int iter = S.iter, num_invalid = S.num_invalid, reuse = S.reuse;
+    const double radius = S.radius;
+    WSYNC();
+    if (lane == 0) S.evaluate = 0;
+    if (iter >= max_iters || radius < 1e-32 || num_invalid > 5) {
+        if (lane == 0) S.go = 0;
+        return;
+    }
+    if (lane == 0) S.iter = iter + 1;
+    const int a = lane / 6, b = lane - 6 * a;
+    const bool in36 = lane < 36, in6 = lane < 6;
+    // entry (a, b) of S H S as quad_form and the matrix build compute it
+    const double mab = in36 ? Hget(S.rec, a, b) * S.scale[a] * S.scale[b] : 0.0;
+    bool solve_ok = true;
+    if (!reuse) {
+        if (lane == 0) S.reuse = 1;
+        if (in6) {
+            double d = Hget(S.rec, lane, lane) * S.scale[lane] * S.scale[lane];
+            d = fmin(fmax(d, 1e-6), 1e32);
+            const double dg = sqrt(d);
+            S.diag[lane] = dg;
+            const double gr = S.rec[21 + lane] * S.scale[lane] / dg;
+            S.grad[lane] = gr;
+            sg[lane] = gr / dg;
+        }
+        WSYNC();
+        if (in36) T[lane] = sg[a] * mab * sg[b];
+        WSYNC();
+        if (lane == 0) {
+            double gg = 0, q = 0;
+            for (int k = 0; k < 6; ++k) gg += S.grad[k] * S.grad[k];
+            for (int k = 0; k < 36; ++k) q += T[k];
+            S.alpha = gg / q;
+        }
+        double mu = S.mu;
+        solve_ok = false;
+        while (mu < 1.0) {
+            if (in36) A[lane] = (a == b) ? mab + mu * S.diag[a] * S.diag[a] : mab;
+            if (in6) bv[lane] = S.rec[21 + lane] * S.scale[lane];
+            WSYNC();
+            bool ok = true;
+            for (int j = 0; j < 6; ++j) {
+                if (lane == 0) {
+                    double d = A[7 * j];
+                    for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+                    const bool pos = d > 0.0;
+                    fl[0] = pos ? 1.0 : 0.0;
+                    if (pos) A[7 * j] = sqrt(d);
+                }
+                WSYNC();
+                if (fl[0] == 0.0) {
+                    ok = false;
+                    break;
+                }
+                if (lane > j && lane < 6) {
+                    double t = A[lane * 6 + j];
+                    for (int k = 0; k < j; ++k) t -= A[lane * 6 + k] * A[j * 6 + k];
+                    A[lane * 6 + j] = t / A[7 * j];
+                }
+                WSYNC();
+            }
+            if (ok) {
+                if (lane == 0) {
+                    for (int i = 0; i < 6; ++i) {
+                        double t = bv[i];
+                        for (int k = 0; k < i; ++k) t -= A[i * 6 + k] * bv[k];
+                        bv[i] = t / A[i * 6 + i];
+                    }
+                    bool fin = true;
+                    for (int i = 5; i >= 0; --i) {
+                        double t = bv[i];
+                        for (int k = i + 1; k < 6; ++k) t -= A[k * 6 + i] * bv[k];
+                        bv[i] = t / A[i * 6 + i];
+                    }
+                    for (int i = 0; i < 6; ++i) fin = fin && isfinite(bv[i]);
+                    fl[1] = fin ? 1.0 : 0.0;
+                }
+                WSYNC();
+                ok = fl[1] != 0.0;
+            }
+            WSYNC();
+            if (!ok) {
+                mu *= 10.0;
+                continue;
+            }
+            solve_ok = true;
+            break;
+        }
+        if (lane == 0) S.mu = mu;
+        if (solve_ok && in6) S.gn[lane] = bv[lane] * -S.diag[lane];
+        WSYNC();
+    }
+    bool step_valid = solve_ok;
+    if (solve_ok) {
+        if (lane == 0) {
+            const double alpha = S.alpha;
+            double gradient_norm = 0, gn_norm = 0;
+            for (int i = 0; i < 6; ++i) {
+                gradient_norm += S.grad[i] * S.grad[i];
+                gn_norm += S.gn[i] * S.gn[i];
+            }
+            gradient_norm = sqrt(gradient_norm);
+            gn_norm = sqrt(gn_norm);
+            if (gn_norm <= radius) {
+                for (int i = 0; i < 6; ++i) st[i] = S.gn[i];
+                S.dogleg_norm = gn_norm;
+            } else if (gradient_norm * alpha >= radius) {
+                for (int i = 0; i < 6; ++i) st[i] = -(radius / gradient_norm) * S.grad[i];
+                S.dogleg_norm = radius;
+            } else {
+                double gdot = 0;
+                for (int i = 0; i < 6; ++i) gdot += S.grad[i] * S.gn[i];
+                double b_dot_a = -alpha * gdot;
+                double a_sq = (alpha * gradient_norm) * (alpha * gradient_norm);
+                double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+                double c = b_dot_a - a_sq;
+                double d = sqrt(c * c + bma_sq * (radius * radius - a_sq));
+                double beta = (c <= 0) ? (d - c) / bma_sq : (radius * radius - a_sq) / (d + c);
+                double sn = 0;
+                for (int i = 0; i < 6; ++i) {
+                    st[i] = (-alpha * (1.0 - beta)) * S.grad[i] + beta * S.gn[i];
+                    sn += st[i] * st[i];
+                }
+                S.dogleg_norm = sqrt(sn);
+            }
+            for (int i = 0; i < 6; ++i) {
+                st[i] /= S.diag[i];
+                S.step[i] = st[i];
+            }
+        }
+        WSYNC();
+        if (in36) T[lane] = st[a] * mab * st[b];
+        WSYNC();
+        if (lane == 0) {
+            double sgd = 0, q = 0;
+            for (int i = 0; i < 6; ++i) sgd += st[i] * S.rec[21 + i] * S.scale[i];
+            for (int k = 0; k < 36; ++k) q += T[k];
+            const double mc = -(sgd + 0.5 * q);
+            S.model_change = mc;
+            fl[0] = (mc > 0.0) ? 1.0 : 0.0;
+        }
+        WSYNC();
+        step_valid = fl[0] != 0.0;
+    }
+    if (!step_valid) {
+        if (lane == 0) {
+            S.num_invalid++;
+            S.mu *= 10.0;
+            S.reuse = 0;
+        }
+        return;  // go stays 1, evaluate 0: next round proposes again
+    }
+    if (lane == 0) {
+        S.num_invalid = 0;
+        double sn = 0;
+        for (int i = 0; i < 6; ++i) {
+            double delta = st[i] * S.scale[i];
+            S.xc[i] = S.x[i] + delta;
+            sn += delta * delta;
+        }
+        S.step_norm = sqrt(sn);
+        S.evaluate = 1;
+    }
+}
+#undef WSYNC
+
 __host__ __device__ void tr_decide(TRState& S, int W, int fixed) {
     const int n = 6 * W;
     double cand = 0;
@@ -484,6 +671,7 @@ __host__ __device__ void tr_decide(TRState& S, int W, int fixed) {
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     __shared__ TRState S;
     __shared__ double s_part[SOLVE_WAVES * 28];
+    __shared__ double s_work[92];
     const int prob = blockIdx.x;
     const int W = P.window;
     const int b0 = P.first + prob * W;
@@ -539,7 +727,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     __syncthreads();
     while (go) {
         // lane 0 owns the trust-region state between the barriers; every other lane only reads it after one
-        if (tid == 0) tr_propose(S, W, P.max_iters);
+        // lane 0 (first wavefront for W = 1) owns the trust-region state between the barriers
+        if (W == 1) {
+            if (tid < 64) tr_propose_w1_wave(S, s_work, P.max_iters);
+        } else if (tid == 0) {
+            tr_propose(S, W, P.max_iters);
+        }
         __syncthreads();
         go = S.go;
         const int ev = S.evaluate;
