@@ -162,8 +162,13 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
         accum(acc, J, r, rho1);
     }
     const double kb = w_tan / kLidarM;
+    // (the next record is requested before the current one is worked on: one exposed memory round trip per pass
+    //  instead of one per factor)
+    MmlPlaneFactor nxt;
+    if ((int)threadIdx.x < npf) nxt = pf[threadIdx.x];
     for (int i = threadIdx.x; i < npf; i += SOLVE_THREADS) {
-        const MmlPlaneFactor f = pf[i];
+        const MmlPlaneFactor f = nxt;
+        if (i + SOLVE_THREADS < npf) nxt = pf[i + SOLVE_THREADS];
         if (f.src < 0 || !(fabs(f.error) > 1e-5)) continue;  // Estimator.cpp:1396
         const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
         double Pw[3];
