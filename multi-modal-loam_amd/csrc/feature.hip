@@ -343,16 +343,27 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
         const uint8_t* rline = P.raw_line + (size_t)b * P.NT;
         const float* rori = P.raw_ori + (size_t)b * P.NV;
         int best = 0x7fffffff;
-        for (int i = tid; i < n; i += 1024) {
-            if (rline[i] >= 254) continue;
-            float ori = rori[i];
-            if (ori < startOri - M_PI / 2)
-                ori += 2 * M_PI;
-            else if (ori > startOri + M_PI * 3 / 2)
-                ori -= 2 * M_PI;
-            if (ori - startOri > M_PI) {
-                best = i;
-                break;  // indices grow along this thread's stride
+        // eight points of this thread's stride per round, their loads in flight together (the first hit sits half-way
+        // through the sweep: one point per round is a dozen dependent memory round trips)
+        for (int i0 = tid; i0 < n && best == 0x7fffffff; i0 += 8 * 1024) {
+            uint8_t rl8[8];
+            float ro8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * 1024, n - 1);
+                rl8[u] = rline[i];
+                ro8[u] = rori[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 1024;
+                if (i >= n || rl8[u] >= 254 || best != 0x7fffffff) continue;
+                float ori = ro8[u];
+                if (ori < startOri - M_PI / 2)
+                    ori += 2 * M_PI;
+                else if (ori > startOri + M_PI * 3 / 2)
+                    ori -= 2 * M_PI;
+                if (ori - startOri > M_PI) best = i;  // indices grow along this thread's stride
             }
         }
         for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
