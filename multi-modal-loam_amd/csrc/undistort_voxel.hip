@@ -64,21 +64,6 @@ constexpr int VX_THREADS = 1024;
 constexpr int VX_WAVES = VX_THREADS / 64;
 constexpr int VX_TAIL = 64;
 
-__device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float* s_red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) {
-        float other = __shfl_xor(v, o);
-        v = is_min ? fminf(v, other) : fmaxf(v, other);
-    }
-    __syncthreads();
-    if (lane == 0) s_red[wave] = v;
-    __syncthreads();
-    float r = s_red[0];
-    for (int w = 1; w < VX_WAVES; ++w) r = is_min ? fminf(r, s_red[w]) : fmaxf(r, s_red[w]);
-    __syncthreads();
-    return r;
-}
-
 // Bitonic sort of npad = KPT * VX_THREADS keys, ascending, element e = tid + VX_THREADS * k held by thread tid in
 // key[k].  The partner of element e at distance j is e ^ j: for j >= VX_THREADS that is another register of the same
 // thread, for j < 64 another lane of the same wavefront (two 32-bit shuffles), and only the four distances in between
@@ -160,7 +145,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     __shared__ int s_wtot[VX_WAVES];
     __shared__ float s_stage[3][VX_THREADS + VX_TAIL];
     __shared__ int s_base;
-    __shared__ float s_red[VX_WAVES];
+    __shared__ float s_red6[6][VX_WAVES];
     __shared__ int s_nout;
 
     const int b = blockIdx.x + first;
@@ -191,10 +176,31 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
         mx[1] = fmaxf(mx[1], p.y);
         mx[2] = fmaxf(mx[2], p.z);
     }
+    // the six extrema reduced together: one shuffle tree each, one exchange through LDS
     float gmn[3], gmx[3];
-    for (int c = 0; c < 3; ++c) {
-        gmn[c] = block_reduce_minmax(mn[c], true, s_red);
-        gmx[c] = block_reduce_minmax(mx[c], false, s_red);
+    {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            for (int o = 32; o > 0; o >>= 1) {
+                mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+                mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+            }
+            if (lane == 0) {
+                s_red6[c][wave] = mn[c];
+                s_red6[3 + c][wave] = mx[c];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float r0 = s_red6[c][0], r1 = s_red6[3 + c][0];
+            for (int w = 1; w < VX_WAVES; ++w) {
+                r0 = fminf(r0, s_red6[c][w]);
+                r1 = fmaxf(r1, s_red6[3 + c][w]);
+            }
+            gmn[c] = r0;
+            gmx[c] = r1;
+        }
     }
     if (cnt == 0) {
         if (tid == 0) ft_n[kind * B + b] = 0;
