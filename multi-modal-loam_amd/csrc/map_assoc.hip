@@ -241,14 +241,18 @@ __device__ __forceinline__ void scan_shell_row(const MmlGrid& g, const KnnQuery&
                                                int mytag = -1, float bound = INFINITY) {
     const int DX = g.dim[0], DY = g.dim[1], DZ = g.dim[2];
     if (y < 0 || y >= DY || z < 0 || z >= DZ) return;
-    const float gy = y > q.hy ? (float)y - q.fy : (y < q.hy ? q.fy - (float)(y + 1) : 0.f);
-    const float gz = z > q.hz ? (float)z - q.fz : (z < q.hz ? q.fz - (float)(z + 1) : 0.f);
-    const float reach = sqrtf(bound * 1.00001f) * g.inv_cell + 4e-3f;  // cells; inf when bound is
-    const float w2 = reach * reach - (gy * gy + gz * gz);
-    if (w2 < 0.f) return;
-    const float w = sqrtf(w2);
-    // cells of this row whose slab comes within w cells of the query along x
-    const int xlo = (int)floorf(fmaxf(q.fx - w, -1.f)), xhi = (int)floorf(fminf(q.fx + w, (float)DX));
+    int xlo = -1, xhi = DX;  // no bound yet (a far query still looking for its first five points): nothing to work out
+    if (bound < INFINITY) {
+        const float gy = y > q.hy ? (float)y - q.fy : (y < q.hy ? q.fy - (float)(y + 1) : 0.f);
+        const float gz = z > q.hz ? (float)z - q.fz : (z < q.hz ? q.fz - (float)(z + 1) : 0.f);
+        const float reach = sqrtf(bound * 1.00001f) * g.inv_cell + 4e-3f;  // cells
+        const float w2 = reach * reach - (gy * gy + gz * gz);
+        if (w2 < 0.f) return;
+        const float w = sqrtf(w2);
+        // cells of this row whose slab comes within w cells of the query along x
+        xlo = (int)floorf(fmaxf(q.fx - w, -1.f));
+        xhi = (int)floorf(fminf(q.fx + w, (float)DX));
+    }
     const int x0 = q.hx - r, x1 = q.hx + r;
     const bool face = (z == q.hz - r || z == q.hz + r || y == q.hy - r || y == q.hy + r);
     const int rowbase = DX * (y + DY * z);
