@@ -60,8 +60,8 @@ typedef struct {
     float near_th, far_th;  /* near/far_points_threshold, mm_lio_full.launch:28-29 (2.0 / 50.0) */
     float leaf_corner;      /* filter_parameter_corner, launch:43 (0.4), Estimator.cpp:78 */
     float leaf_surf;        /* filter_parameter_surf,   launch:44 (0.2), Estimator.cpp:79 */
-    float cell_corner;      /* kNN grid cell edge for the corner map, metres (<=0: 2.5 * leaf) */
-    float cell_surf;        /* kNN grid cell edge for the surf map (<=0: 2.5 * leaf) */
+    float cell_corner;      /* kNN grid cell edge for the corner map, metres (<=0: 5 * leaf) */
+    float cell_surf;        /* kNN grid cell edge for the surf map (<=0: 5 * leaf) */
     int max_features;       /* per slot per kind after down-sampling (<=0: 8192) */
     int max_map_points;     /* per map (<=0: 1<<21) */
 } mml_config;

@@ -102,8 +102,8 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     mml_ctx* ctx = new mml_ctx();
     ctx->cfg = *cfg;
     ctx->device = device;
-    if (ctx->cfg.cell_corner <= 0) ctx->cfg.cell_corner = 2.5f * ctx->cfg.leaf_corner;
-    if (ctx->cfg.cell_surf <= 0) ctx->cfg.cell_surf = 2.5f * ctx->cfg.leaf_surf;
+    if (ctx->cfg.cell_corner <= 0) ctx->cfg.cell_corner = 5.0f * ctx->cfg.leaf_corner;
+    if (ctx->cfg.cell_surf <= 0) ctx->cfg.cell_surf = 5.0f * ctx->cfg.leaf_surf;
     if (ctx->cfg.max_features <= 0) ctx->cfg.max_features = 8192;
     if (ctx->cfg.max_map_points <= 0) ctx->cfg.max_map_points = 1 << 21;
     ctx->B = cfg->max_scans;
