@@ -102,6 +102,20 @@ int mml_scan_upload_wire(mml_ctx* ctx, int slot, const uint8_t* data, int n_poin
  * curvature 36; packed on the device.  out may be NULL to query *n_points only. */
 int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int capacity_points, int* n_points);
 
+/* ---- the aligner's time-offset search ---------------------------
+ * The numeric core of LidarsParamEstimator::estimate_timeoffset (unionLidarsAligner.cpp:1077-1153): the Velodyne
+ * cloud (n_velo x 3 floats) goes through pcl::transformPointCloud with tf (row-major 4x4 floats, NULL = identity;
+ * _velo_hori_tf_matrix, :1080-1082); every Livox point (n_livox x 3 floats, the merged last eight messages in arrival
+ * order, :1053-1068) gets the squared distance to its nearest transformed Velodyne point (:1084-1103, exact, on the
+ * device grid that serves the association); window cnt sums dis_errors[i] + 0.2 * sqrt(x_i^2 + y_i^2) over
+ * i in [cnt * search_resolution, cnt * search_resolution + sliced_points) while that end stays below n_livox (:1111-1131).
+ * Outputs: nn_d2 (optional, n_livox floats), window_error (optional, `capacity` doubles), *n_windows, *best_window =
+ * the window of the first strict minimum below 1e6 (-1: none) and *lowest_error (:1107,1141-1150).  n_velo must not
+ * exceed max_map_points.  The caller turns best_window into a stamp (:1143) and applies _time_esti_error_th (:1155). */
+int mml_time_offset_search(mml_ctx* ctx, const float* velo_xyz, int n_velo, const float* tf, const float* livox_xyz,
+                           int n_livox, int search_resolution, int sliced_points, float* nn_d2, double* window_error,
+                           int capacity, int* n_windows, int* best_window, double* lowest_error);
+
 /* ---- a1..a8: feature extraction -----------------------------------------------------------------
  * feature_extraction::unionCloudHandler minus the PCL GICP refresh (unionFeatureExtract.cpp:266-321):
  * getVeloFeature (:1113-1317) + getHoriFeature/getHoriFeatureExtract (:891-1035) with

@@ -200,6 +200,22 @@ class Context:
                                             _p(lw) if n_livox else None, C.c_int(n_livox)))
         self.synchronize()
 
+    def time_offset_search(self, velo_xyz, livox_xyz, search_resolution=30, sliced_points=12000, tf=None):
+        """estimate_timeoffset's numeric core (unionLidarsAligner.cpp:1077-1153): per-point 1-NN squared distances and
+        the sliding-window error; defaults are the reference's (:111-112)."""
+        v = np.ascontiguousarray(np.asarray(velo_xyz, np.float32).reshape(-1, 3))
+        l = np.ascontiguousarray(np.asarray(livox_xyz, np.float32).reshape(-1, 3))
+        t = np.ascontiguousarray(np.asarray(tf, np.float32).reshape(16)) if tf is not None else None
+        nn = np.zeros(max(len(l), 1), np.float32)
+        cap = max((len(l) - sliced_points) // max(search_resolution, 1) + 2, 1)
+        err = np.zeros(cap, np.float64)
+        nwin, best, lowest = C.c_int(0), C.c_int(-1), C.c_double(0)
+        self._ck(lib().mml_time_offset_search(self._h, _p(v) if len(v) else None, C.c_int(len(v)), _p(t) if t is not None else None,
+                                              _p(l) if len(l) else None, C.c_int(len(l)), C.c_int(search_resolution),
+                                              C.c_int(sliced_points), _p(nn), _p(err), C.c_int(cap), C.byref(nwin),
+                                              C.byref(best), C.byref(lowest)))
+        return {"nn_d2": nn[:len(l)], "window_error": err[:nwin.value], "best_window": best.value, "lowest_error": lowest.value}
+
     def scan_download_pointxyzinormal(self, slot):
         """The fused labelled cloud as 48-byte PointXYZINormal records (the velo_combine / livox_combine payload)."""
         n = C.c_int(0)

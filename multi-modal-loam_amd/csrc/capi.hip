@@ -1045,6 +1045,79 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     return MML_OK;
 }
 
+int mml_time_offset_search(mml_ctx* ctx, const float* velo_xyz, int n_velo, const float* tf, const float* livox_xyz,
+                           int n_livox, int search_resolution, int sliced_points, float* nn_d2, double* window_error,
+                           int capacity, int* n_windows, int* best_window, double* lowest_error) {
+    if (!ctx) return MML_ERR_INVALID;
+    MML_REQUIRE(n_velo >= 0 && n_livox >= 0 && (n_velo == 0 || velo_xyz) && (n_livox == 0 || livox_xyz), MML_ERR_INVALID,
+                "bad point buffers");
+    MML_REQUIRE(search_resolution >= 1 && sliced_points >= 1, MML_ERR_INVALID, "search_resolution / sliced_points must be >= 1");
+    MML_REQUIRE(n_windows && best_window && lowest_error, MML_ERR_INVALID, "null output");
+    MML_REQUIRE(n_velo <= ctx->MM, MML_ERR_CAPACITY, "Velodyne cloud exceeds max_map_points");
+    MML_REQUIRE(n_velo > 0 || n_livox == 0, MML_ERR_INVALID, "nearest-neighbour search in an empty cloud");
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    ctx->cur = 0;
+    // windows: cnt = 0, 1, ... while cnt * res + sliced < n_livox
+    int nwin = 0;
+    if (n_livox > sliced_points) nwin = (n_livox - sliced_points - 1) / search_resolution + 1;
+    *n_windows = nwin;
+    *best_window = -1;
+    *lowest_error = 1000000.0;
+    if (n_livox == 0) return MML_OK;
+    // a one-off calibration step: its buffers live for the call only
+    MmlGrid g;
+    float4* d_v4 = nullptr;
+    float *d_v = nullptr, *d_l = nullptr, *d_nn = nullptr, *d_tf = nullptr;
+    double* d_err = nullptr;
+    std::vector<void*> owned;
+    auto take = [&](void** p, size_t bytes) {
+        if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) return false;
+        owned.push_back(*p);
+        return true;
+    };
+    auto release = [&]() {
+        for (void* p : owned) hipFree(p);
+    };
+    const size_t nv = (size_t)(n_velo > 0 ? n_velo : 1), nl = (size_t)n_livox;
+    bool ok = take((void**)&g.pts, sizeof(float4) * nv) && take((void**)&g.cell_start, sizeof(int) * (4 * (size_t)ctx->MM + 4096 + 2)) &&
+              take((void**)&d_v4, sizeof(float4) * nv) && take((void**)&d_v, sizeof(float) * 3 * nv) &&
+              take((void**)&d_l, sizeof(float) * 3 * nl) && take((void**)&d_nn, sizeof(float) * nl) &&
+              take((void**)&d_err, sizeof(double) * (size_t)(nwin > 0 ? nwin : 1)) && take((void**)&d_tf, sizeof(float) * 16);
+    if (!ok) {
+        release();
+        ctx->err = "mml_time_offset_search: device allocation failed";
+        return MML_ERR_HIP;
+    }
+    hipStream_t s = MML_STREAM(ctx);
+    hipError_t e = hipSuccess;
+    if (n_velo) e = hipMemcpyAsync(d_v, velo_xyz, sizeof(float) * 3 * nv, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_l, livox_xyz, sizeof(float) * 3 * nl, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && tf) e = hipMemcpyAsync(d_tf, tf, sizeof(float) * 16, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+        rc = mml_launch_time_offset(ctx, g, d_v4, d_v, n_velo, tf ? d_tf : nullptr, d_l, n_livox, search_resolution, sliced_points,
+                                    nwin, d_nn, d_err);
+    std::vector<double> herr((size_t)(nwin > 0 ? nwin : 1));
+    if (e == hipSuccess && rc == MML_OK && nn_d2) e = hipMemcpyAsync(nn_d2, d_nn, sizeof(float) * nl, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rc == MML_OK && nwin) e = hipMemcpyAsync(herr.data(), d_err, sizeof(double) * nwin, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    release();
+    if (e != hipSuccess) {
+        ctx->err = std::string("mml_time_offset_search: ") + hipGetErrorString(e);
+        return MML_ERR_HIP;
+    }
+    if (rc != MML_OK) return rc;
+    for (int c = 0; c < nwin; ++c) {  // :1141-1150
+        if (window_error && c < capacity) window_error[c] = herr[c];
+        if (herr[c] < *lowest_error) {
+            *lowest_error = herr[c];
+            *best_window = c;
+        }
+    }
+    return MML_OK;
+}
+
 int mml_set_lanes(mml_ctx* ctx, int lanes) {
     if (!ctx) return MML_ERR_INVALID;
     MML_REQUIRE(lanes >= 1 && lanes <= mml_ctx::MAX_LANES, MML_ERR_INVALID, "lanes must be in [1, 8]");

@@ -315,7 +315,10 @@ __device__ __forceinline__ void lanes_merge5(const Knn5& local, Knn5& out) {
 __device__ void knn5_search(const MmlGrid& g, bool valid, float qx, float qy, float qz, float max_d2, Knn5& k) {
     knn_init(k);
     const KnnQuery q = knn_query(g, qx, qy, qz);
-    const int rmax = (int)ceilf(sqrtf(max_d2) * g.inv_cell) + 1;
+    // no shell beyond the grid's far side holds a cell (keeps an unbounded search, max_d2 = inf, finite)
+    const int rgrid = max(max(max(q.hx, g.dim[0] - 1 - q.hx), max(q.hy, g.dim[1] - 1 - q.hy)), max(q.hz, g.dim[2] - 1 - q.hz));
+    const float rf = ceilf(sqrtf(max_d2) * g.inv_cell) + 1.f;
+    const int rmax = rf < (float)rgrid ? (int)rf : max(rgrid, 0);
     bool pending = false;
     if (valid) {
         pending = !scan_rings01(g, q, rmax, max_d2, k, -1);
@@ -344,11 +347,18 @@ __device__ void knn5_search(const MmlGrid& g, bool valid, float qx, float qy, fl
             knn_init(loc);
         Knn5 best;
         knn_init(best);
-        for (int r = 2; r <= rmax; ++r) {
-            const int w = 2 * r + 1;
+        const int rmax_s = __shfl(rmax, src);  // (the bound of the query being served, not of the serving lane's own)
+        // a query outside the grid: the shells before the grid's near side hold no cell
+        const int rnear = max(max(max(-s.hx, s.hx - (g.dim[0] - 1)), max(-s.hy, s.hy - (g.dim[1] - 1))),
+                              max(-s.hz, s.hz - (g.dim[2] - 1)));
+        for (int r = max(2, rnear); r <= rmax_s; ++r) {
             const float bnd = fminf(knn_d(best, 4), __shfl(knn_d(k, 4), src));  // both bound the final 5th distance from above
-            for (int t = lane; t < w * w; t += 64)
-                scan_shell_row(g, s, r, s.hy - r + (t % w), s.hz - r + (t / w), loc, -1, fminf(bnd, knn_d(loc, 4)));
+            // the rows of the shell that lie inside the grid
+            const int ylo = max(s.hy - r, 0), yhi = min(s.hy + r, g.dim[1] - 1), zlo = max(s.hz - r, 0), zhi = min(s.hz + r, g.dim[2] - 1);
+            const int wy = yhi - ylo + 1, wz = zhi - zlo + 1;
+            if (wy > 0 && wz > 0)
+                for (int t = lane; t < wy * wz; t += 64)
+                    scan_shell_row(g, s, r, ylo + (t % wy), zlo + (t / wy), loc, -1, fminf(bnd, knn_d(loc, 4)));
             lanes_merge5<64>(loc, best);
             if (knn_done(g, s.inset, r, knn_d(best, 4), max_d2)) break;
         }
@@ -1214,11 +1224,14 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
             if (!sdone && r > rmax) sdone = true;
             if (__all(sdone)) break;
             if (!sdone) {
-                const int ww = 2 * r + 1;
+                // the rows of the shell that lie inside the grid
                 // (best: merged list of the shells before this one; loc: this lane's own list; lane 0's starting list
                 //  of round 0 holds five real points, so its d[4] bounds the result as well)
-                for (int t = gl; t < ww * ww; t += 16)
-                    scan_shell_row(g, q, r, q.hy - r + (t % ww), q.hz - r + (t / ww), loc, mytag, fminf(fminf(knn_d(best, 4), knn_d(loc, 4)), start_d5));
+                const int ylo = max(q.hy - r, 0), yhi = min(q.hy + r, g.dim[1] - 1), zlo = max(q.hz - r, 0), zhi = min(q.hz + r, g.dim[2] - 1);
+                const int wy = yhi - ylo + 1, wz = zhi - zlo + 1;
+                if (wy > 0 && wz > 0)
+                    for (int t = gl; t < wy * wz; t += 16)
+                        scan_shell_row(g, q, r, ylo + (t % wy), zlo + (t / wy), loc, mytag, fminf(fminf(knn_d(best, 4), knn_d(loc, 4)), start_d5));
             }
             lanes_merge5<16>(loc, best);
             if (!sdone && knn_done(g, q.inset, r, knn_d(best, 4), P.thres)) sdone = true;
@@ -1487,6 +1500,59 @@ int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_
     MmlStageScope t(ctx, "knn5");
     hipLaunchKernelGGL(k_knn5, dim3((nq + 255) / 256), dim3(256), 0, MML_STREAM(ctx), ctx->grid[kind], d_q, nq, max_d2,
                        d_idx, d_d2);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+// ---- the numeric core of estimate_timeoffset (unionLidarsAligner.cpp:1077-1153) ----------
+namespace {
+// pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float, left to right; tf == nullptr: copy
+__global__ void k_tf_cloud(const float* xyz, int n, const float* tf, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    float4 o = make_float4(x, y, z, 0.f);
+    if (tf) {
+        o.x = tf[0] * x + tf[1] * y + tf[2] * z + tf[3];
+        o.y = tf[4] * x + tf[5] * y + tf[6] * z + tf[7];
+        o.z = tf[8] * x + tf[9] * y + tf[10] * z + tf[11];
+    }
+    out[i] = o;
+}
+// :1084-1103 squared distance to the nearest neighbour (the exact 5-NN search, first entry)
+__global__ __launch_bounds__(256) void k_nn1(MmlGrid g, const float* q, int nq, float* d2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < nq;
+    Knn5 k;
+    knn5_search(g, valid, valid ? q[3 * i] : 0.f, valid ? q[3 * i + 1] : 0.f, valid ? q[3 * i + 2] : 0.f, INFINITY, k);
+    if (valid) d2[i] = knn_d(k, 0);
+}
+// :1111-1131 one lane per window, the terms added in index order as the reference's loop does
+__global__ void k_window_err(const float* q, const float* d2, int res, int sliced, int nwin, double* err) {
+    const int cnt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cnt >= nwin) return;
+    double sum_error = 0;
+    for (int i = cnt * res; i < cnt * res + sliced; ++i) {
+        const float x = q[3 * i], y = q[3 * i + 1];
+        sum_error += d2[i] + 0.2 * sqrtf(x * x + y * y);
+    }
+    err[cnt] = sum_error;
+}
+}  // namespace
+
+// d_velo_xyz / d_livox_xyz: device copies of the inputs (3 floats per point); d_tf: 16 floats or nullptr; scratch and
+// outputs are the caller's (capi.hip).  The grid is built into `g` (storage sized for n_velo points by the caller).
+int mml_launch_time_offset(mml_ctx* ctx, MmlGrid& g, float4* d_velo4, const float* d_velo_xyz, int n_velo, const float* d_tf,
+                           const float* d_livox_xyz, int n_livox, int res, int sliced, int nwin, float* d_nn, double* d_err) {
+    hipStream_t s = MML_STREAM(ctx);
+    if (n_velo > 0)
+        hipLaunchKernelGGL(k_tf_cloud, dim3((n_velo + 255) / 256), dim3(256), 0, s, d_velo_xyz, n_velo, d_tf, d_velo4);
+    // an unfiltered scan: start from a 0.5 m cell, the builder halves it where the cloud is dense
+    int rc = build_grid_into(ctx, g, d_velo4, nullptr, n_velo, 0.5f, nullptr);
+    if (rc != MML_OK) return rc;
+    if (n_livox > 0) hipLaunchKernelGGL(k_nn1, dim3((n_livox + 255) / 256), dim3(256), 0, s, g, d_livox_xyz, n_livox, d_nn);
+    if (nwin > 0)
+        hipLaunchKernelGGL(k_window_err, dim3((nwin + 63) / 64), dim3(64), 0, s, d_livox_xyz, d_nn, res, sliced, nwin, d_err);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }

@@ -217,6 +217,8 @@ struct MmlStageScope {
 // launchers implemented in the .hip files (all asynchronous on ctx->stream)
 int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic);
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params);
+int mml_launch_time_offset(mml_ctx* ctx, MmlGrid& g, float4* d_velo4, const float* d_velo_xyz, int n_velo, const float* d_tf,
+                           const float* d_livox_xyz, int n_livox, int res, int sliced, int nwin, float* d_nn, double* d_err);
 int mml_launch_downsample(mml_ctx* ctx, int first, int count);
 int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
 int mml_build_grid_device(mml_ctx* ctx, int kind, int m);

@@ -1272,6 +1272,58 @@ extern "C" int mmlo_estimate_single(const float* corner_feat, int n_corner, cons
     return it_done;
 }
 
+// ------------------------------------------------------------------------------------------------
+// unionLidarsAligner.cpp:1077-1153, the numeric core of estimate_timeoffset.
+extern "C" int mmlo_time_offset_search(const float* velo_xyz, int n_velo, const float* tf, const float* livox_xyz,
+                                       int n_livox, int res, int sliced, float* nn_d2, double* win_err, int capacity,
+                                       int* best, double* lowest) {
+    // :1080-1082 pcl::transformPointCloud(full_cloud_in, out_cloud, _velo_hori_tf_matrix): float, left to right
+    // (PCL 1.8.1 common/impl/transforms.hpp)
+    std::vector<float> tv((size_t)3 * (n_velo > 0 ? n_velo : 1));
+    for (int i = 0; i < n_velo; ++i) {
+        const float x = velo_xyz[3 * i], y = velo_xyz[3 * i + 1], z = velo_xyz[3 * i + 2];
+        if (tf) {
+            tv[3 * i] = tf[0] * x + tf[1] * y + tf[2] * z + tf[3];
+            tv[3 * i + 1] = tf[4] * x + tf[5] * y + tf[6] * z + tf[7];
+            tv[3 * i + 2] = tf[8] * x + tf[9] * y + tf[10] * z + tf[11];
+        } else {
+            tv[3 * i] = x;
+            tv[3 * i + 1] = y;
+            tv[3 * i + 2] = z;
+        }
+    }
+    // :1084-1103 nearestKSearch(searchPoint, 1, ...): squared distance to the nearest neighbour (FLANN L2_Simple)
+    mmlo_kdtree* tree = mmlo_kdtree_build(tv.data(), n_velo);
+    for (int i = 0; i < n_livox; ++i) {
+        int idx[5];
+        float d2[5];
+        mmlo_kdtree_knn5(tree, livox_xyz + 3 * i, idx, d2);
+        nn_d2[i] = d2[0];
+    }
+    mmlo_kdtree_free(tree);
+    // :1107-1150 sliding windows
+    double lowest_error = 1000000.0;
+    int cnt = 0, best_cnt = -1;
+    while (cnt * res + sliced < n_livox) {
+        double sum_error = 0;
+        for (int i = cnt * res; i < cnt * res + sliced; i++) {
+            const float x = livox_xyz[3 * i], y = livox_xyz[3 * i + 1];
+            // `sqrt(pt.x * pt.x + pt.y * pt.y)` on floats: with <math.h> in scope (tf/LinearMath/Scalar.h) the float
+            // overload is the one selected
+            sum_error += nn_d2[i] + 0.2 * std::sqrt(x * x + y * y);
+        }
+        if (cnt < capacity && win_err) win_err[cnt] = sum_error;
+        if (sum_error < lowest_error) {
+            lowest_error = sum_error;
+            best_cnt = cnt;
+        }
+        cnt++;
+    }
+    *best = best_cnt;
+    *lowest = lowest_error;
+    return cnt;
+}
+
 // ---- helpers for tests ----
 extern "C" void mmlo_so3_exp(const double* phi, double* q) {
     Quat r = so3_exp(mk(phi[0], phi[1], phi[2]));

@@ -179,6 +179,15 @@ int mmlo_estimate_single(const float* corner_feat, int n_corner, const float* su
                          int* is_degenerate, double* outer_trace);
 
 /* helpers exposed for tests */
+/* unionLidarsAligner.cpp:1077-1153 (estimate_timeoffset, the numeric core): the Velodyne cloud goes through
+ * pcl::transformPointCloud with tf (row-major 4x4, NULL = identity, :1080-1082), every Livox point gets the squared
+ * distance to its nearest transformed Velodyne point (:1084-1103), and window cnt sums
+ * dis_errors[i] + 0.2 * sqrt(x_i^2 + y_i^2) over i in [cnt*res, cnt*res + sliced) while cnt*res + sliced < n (:1111-1131).
+ * nn_d2: n_livox floats; win_err: capacity doubles.  Returns the number of windows; *best is the window of the first
+ * strict minimum below 1e6 (-1: none), *lowest its error (:1107,1141-1150). */
+int mmlo_time_offset_search(const float* velo_xyz, int n_velo, const float* tf, const float* livox_xyz, int n_livox,
+                            int res, int sliced, float* nn_d2, double* win_err, int capacity, int* best, double* lowest);
+
 void mmlo_so3_exp(const double* phi, double* q_xyzw);   /* sophus/so3.hpp:585-622 */
 void mmlo_so3_log(const double* q_xyzw, double* phi);   /* sophus/so3.hpp:247-287 */
 void mmlo_eig3_sym(const double* A /*row-major 3x3*/, double* evals /*ascending*/, double* evecs /*columns, row-major 3x3*/);

@@ -160,6 +160,21 @@ def bruteforce_knn5(xyz, q):
     return idx, d2
 
 
+def time_offset_search(velo_xyz, livox_xyz, res, sliced, tf=None):
+    """estimate_timeoffset's numeric core (unionLidarsAligner.cpp:1077-1153)."""
+    v = _f32(velo_xyz).reshape(-1, 3)
+    l = _f32(livox_xyz).reshape(-1, 3)
+    t = _f32(tf).reshape(16) if tf is not None else None
+    nn = np.zeros(max(len(l), 1), np.float32)
+    cap = max((len(l) - sliced) // max(res, 1) + 2, 1)
+    err = np.zeros(cap, np.float64)
+    best, lowest = C.c_int(-1), C.c_double(0)
+    lib().mmlo_time_offset_search.restype = C.c_int
+    n = lib().mmlo_time_offset_search(_p(v), C.c_int(len(v)), _p(t) if t is not None else None, _p(l), C.c_int(len(l)),
+                                      C.c_int(res), C.c_int(sliced), _p(nn), _p(err), C.c_int(cap), C.byref(best), C.byref(lowest))
+    return {"nn_d2": nn[:len(l)], "window_error": err[:n], "best_window": best.value, "lowest_error": lowest.value}
+
+
 def associate_lines(feat, tree, T_wl, thres):
     feat = _f32(feat).reshape(-1, 3)
     out = np.zeros(max(len(feat), 1), LINE_DT)

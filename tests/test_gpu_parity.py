@@ -1002,3 +1002,34 @@ def test_full_window_estimate_with_imu_matches_oracle_loop(M, O, synth, scene):
                 assert np.abs(xg[f][6:9] - synth.velocity_at(k)).max() < 0.25
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_time_offset_search_matches_oracle(M, O, synth):
+    """the aligner's time-offset search (unionLidarsAligner.cpp:1077-1153) -- nearest-neighbour
+    squared distances on the device grid, the sliding-window errors and the selected window, bit for bit."""
+    velo = synth.velo_scan(31)[:, :3]
+    parts = [synth.livox_scan(31 + k, motion=True) for k in range(3)]
+    livox = np.concatenate([np.stack([p["x"], p["y"], p["z"]], 1) for p in parts]).astype(np.float32)
+    th = 0.02
+    tf = np.array([[np.cos(th), -np.sin(th), 0, 0.05], [np.sin(th), np.cos(th), 0, -0.1], [0, 0, 1, 0.02], [0, 0, 0, 1]], np.float32)
+    c = M.Context(max_scans=1)
+    try:
+        for t, res, sliced in ((tf, 30, 12000), (None, 997, 5000)):
+            g = c.time_offset_search(velo, livox, res, sliced, t)
+            o = O.time_offset_search(velo, livox, res, sliced, t)
+            assert np.array_equal(g["nn_d2"], o["nn_d2"])
+            assert len(g["window_error"]) == len(o["window_error"]) > 0
+            assert np.array_equal(g["window_error"], o["window_error"])
+            assert g["best_window"] == o["best_window"] >= 0 and g["lowest_error"] == o["lowest_error"]
+        # fewer points than one window; queries far outside the cloud; a 3-point cloud (fewer than the 5 the search keeps)
+        g = c.time_offset_search(velo, livox[:1000], 30, 12000)
+        assert len(g["window_error"]) == 0 and g["best_window"] == -1 and g["lowest_error"] == 1000000.0
+        far = (livox[:4000] + np.float32(500.0)).astype(np.float32)
+        g, o = c.time_offset_search(velo[:3], far, 100, 1000), O.time_offset_search(velo[:3], far, 100, 1000)
+        assert np.array_equal(g["nn_d2"], o["nn_d2"]) and np.array_equal(g["window_error"], o["window_error"])
+        assert g["best_window"] == o["best_window"] == -1     # every window error is above the 1e6 start value
+        with pytest.raises(M.MmlError):
+            c.time_offset_search(np.zeros((0, 3), np.float32), livox[:10], 30, 5)
+    finally:
+        c.close()

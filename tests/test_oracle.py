@@ -573,3 +573,32 @@ def test_estimate_recovers_pose(O, scene):
     assert 1 <= it <= 5 and not deg
     assert np.abs(P - fr["T_gt"][:3, 3]).max() < 0.02
     assert (Rsc.from_quat(Q).inv() * Rsc.from_matrix(fr["T_gt"][:3, :3])).magnitude() < 2e-3
+
+
+def test_time_offset_search_oracle_against_plain_loops(O):
+    """estimate_timeoffset's numeric core -- the kd-tree distances equal brute force and the
+    window errors equal the reference's loop written out in numpy scalars."""
+    rng = np.random.default_rng(5)
+    velo = rng.uniform(-8, 8, (700, 3)).astype(np.float32)
+    livox = (velo[rng.integers(0, len(velo), 900)] + rng.normal(0, 0.3, (900, 3))).astype(np.float32)
+    th = 0.05
+    tf = np.array([[np.cos(th), -np.sin(th), 0, 0.1], [np.sin(th), np.cos(th), 0, -0.2], [0, 0, 1, 0.05], [0, 0, 0, 1]], np.float32)
+    r = O.time_offset_search(velo, livox, 37, 250, tf)
+    tv = np.stack([tf[k, 0] * velo[:, 0] + tf[k, 1] * velo[:, 1] + tf[k, 2] * velo[:, 2] + tf[k, 3] for k in range(3)], 1)
+    assert tv.dtype == np.float32
+    _, d2 = O.bruteforce_knn5(tv, livox)
+    assert np.array_equal(r["nn_d2"], d2[:, 0])
+    errs = []
+    cnt = 0
+    while cnt * 37 + 250 < len(livox):
+        acc = np.float64(0)
+        for i in range(cnt * 37, cnt * 37 + 250):
+            x, y = livox[i, 0], livox[i, 1]
+            acc = acc + (np.float64(d2[i, 0]) + np.float64(0.2) * np.float64(np.sqrt(x * x + y * y, dtype=np.float32)))
+        errs.append(acc)
+        cnt += 1
+    assert len(errs) == len(r["window_error"]) and np.array_equal(np.array(errs), r["window_error"])
+    assert r["best_window"] == int(np.argmin(errs)) and r["lowest_error"] == min(errs)
+    # no window fits: nothing is selected and the 1e6 start value stays (:1107)
+    r0 = O.time_offset_search(velo, livox[:200], 37, 250)
+    assert len(r0["window_error"]) == 0 and r0["best_window"] == -1 and r0["lowest_error"] == 1000000.0
