@@ -1,5 +1,6 @@
 """Developer diagnostic: run every stage on the GPU and diff against the oracle, verbosely.
-(Not a test: tests/ holds the assertions.  Usage on the GPU box: python tools/dev_gpu_check.py)"""
+(Not a collected test: the test_*.py files hold the assertions.  It lives under tests/ because it calls the oracle.
+Usage on the GPU box: python tests/dev_gpu_check.py)"""
 import importlib
 import os
 import sys
