@@ -101,6 +101,16 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "mml_oracle" not in txt and "oracle/" not in txt.replace("oracle/linalg.h", "").replace(
                     "oracle/estimate.cpp", ""), "%s references the oracle" % f
+    # the developer tools measure and summarise the product only
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            assert "mml_oracle" not in open(os.path.join(ROOT, "tools", f)).read(), "tools/%s imports the oracle" % f
+    # bench.py: the oracle is imported once, inside the cpu_baseline leg, and nothing before that leg names it
+    lines = open(os.path.join(ROOT, "bench.py")).read().split("\n")
+    hits = [k for k, ln in enumerate(lines) if "mml_oracle" in ln or '"oracle"' in ln]
+    start = next(k for k, ln in enumerate(lines) if "---- CPU baseline" in ln)
+    assert hits and min(hits) > start, "bench.py touches the oracle outside the cpu_baseline leg"
+    assert sum("import mml_oracle" in ln for ln in lines) == 1
 
 
 def _frame_problem(O, scene, k, thres=1.0):
