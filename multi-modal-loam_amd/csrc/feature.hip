@@ -1190,17 +1190,6 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     }
     if (tid == 0) *s_cnt = 0;
     if (tid < 3) s_flag[tid] = 0;
-    // transfer table of the stride walk over 8 positions: (RFLAT byte, entry offset 0..3) -> visited byte | exit << 8
-    for (int t = tid; t < 1024; t += SELP_THREADS) {
-        const unsigned m8 = (unsigned)t >> 2;
-        int pos = t & 3;
-        unsigned v = 0;
-        while (pos < 8) {
-            v |= 1u << pos;
-            pos += ((m8 >> pos) & 1u) ? 4 : 1;
-        }
-        s_walk[t] = (unsigned short)(v | ((unsigned)(pos - 8) << 8));
-    }
     __syncthreads();
 
     SEL_MARK(1);
@@ -1234,6 +1223,143 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     __syncthreads();
 
     SEL_MARK(2);
+    constexpr bool MASKED = CACHED && KK <= 8;  // (the two mask tables of the masked form fit the 2 KB of s_walk)
+    if constexpr (MASKED) {
+        // The dependency rounds on bit masks.  A wavefront owns, for each k, the 64 consecutive points i = tid + 512 k: one
+        // window.  The window's states are two 64-bit masks (picked S, undecided U) in scalar registers, rebuilt with a
+        // ballot after every step; a lane reads the states of its six neighbours as a 7-bit field of the masks (three
+        // bits of the adjacent windows appended at either end) and tests it against its static predecessor mask:
+        //   suppressed = U & any(S-field & P),   picked = U & !any(S-field & P) & !any(U-field & P)
+        // -- a dozen vector instructions per step instead of seven LDS reads and their unpacking.  A window iterates on
+        // its own until nothing changes, publishes its masks, and a workgroup round lets the edges propagate.
+        unsigned long long* s_wS = reinterpret_cast<unsigned long long*>(s_walk);
+        unsigned long long* s_wU = s_wS + 8 * KK;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        auto uni64 = [](unsigned long long v) -> unsigned long long {
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        unsigned r_mk[KK];  // 7-bit fields over my neighbours -3..-1 (bits 0..2) and +1..+3 (bits 4..6):
+                            // [0:6] predecessor of mine, [7:13] candidate whose mark range covers me, [14:20] in a later partition
+        unsigned long long Sm[KK], Um[KK];
+        // ---- phase 1: the static neighbour relations of every point; candidates nobody can suppress start as picked ----
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int i = tid + k * SELP_THREADS;
+            const bool act = i < n;
+            unsigned me = 0, mk = 0, pm = 0, cm = 0, lt = 0;
+            if (act) {
+                me = W[2 * i + 1];
+                mk = W[2 * i];
+                uint2 o[6];
+                load_nb(W, i, o);
+                const bool cand = (me & I_CAND) != 0;
+                const int mypart = (me & I_INPART) ? (int)(me & I_PART_MASK) : (i < 5 ? -1 : 64);
+                auto rel = [&](const uint2 nb, bool covers, bool nb_first, unsigned bit) {
+                    const bool c = ((nb.y & I_CAND) != 0) & covers;
+                    cm |= c ? bit : 0u;
+                    pm |= (c & cand & nb_first) ? bit : 0u;
+                    lt |= ((int)(nb.y & I_PART_MASK) > mypart) ? bit : 0u;
+                };
+                rel(o[0], nb_covers_me<-3>(o[0].y), nb_visits_before_me<-3>(o[0].y, o[0].x, me, mk), 1u << 0);
+                rel(o[1], nb_covers_me<-2>(o[1].y), nb_visits_before_me<-2>(o[1].y, o[1].x, me, mk), 1u << 1);
+                rel(o[2], nb_covers_me<-1>(o[2].y), nb_visits_before_me<-1>(o[2].y, o[2].x, me, mk), 1u << 2);
+                rel(o[3], nb_covers_me<1>(o[3].y), nb_visits_before_me<1>(o[3].y, o[3].x, me, mk), 1u << 4);
+                rel(o[4], nb_covers_me<2>(o[4].y), nb_visits_before_me<2>(o[4].y, o[4].x, me, mk), 1u << 5);
+                rel(o[5], nb_covers_me<3>(o[5].y), nb_visits_before_me<3>(o[5].y, o[5].x, me, mk), 1u << 6);
+            }
+            r_mk[k] = pm | (cm << 7) | (lt << 14);
+            const bool cand = (me & I_CAND) != 0;
+            Sm[k] = __ballot(cand && pm == 0);
+            Um[k] = __ballot(cand && pm != 0);
+            if (lane == 0) {
+                s_wS[k * 8 + wave] = Sm[k];
+                s_wU[k * 8 + wave] = Um[k];
+            }
+        }
+        __syncthreads();
+        SEL_MARK(3);
+        int rnd = 0;
+        // the 7-bit field [i - 3, i + 3] of a window mask M extended by the adjacent windows' edge bits
+        auto field = [&](unsigned long long M, unsigned long long Ml, unsigned long long Mr) -> unsigned {
+            const unsigned long long e_lo = (M << 3) | (Ml >> 61);
+            const unsigned e0 = (unsigned)e_lo, e1 = (unsigned)(e_lo >> 32), e2 = (unsigned)(M >> 61) | ((unsigned)(Mr & 7ull) << 3);
+            const unsigned lo = lane < 32 ? e0 : e1, hi = lane < 32 ? e1 : e2;
+            return __builtin_amdgcn_alignbit(hi, lo, lane & 31) & 0x7Fu;
+        };
+        for (;;) {
+            bool pending = false;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                if (Um[k] == 0) continue;  // wave-uniform
+                const int w = k * 8 + wave;
+                // A neighbour window publishes S before U; reading U before S therefore never shows a point that has
+                // left U without its S bit (it may show both set: the S bit is then the truth and it suppresses).
+                const unsigned long long Ul = w > 0 ? uni64(s_wU[w - 1]) : 0ull, Ur = w + 1 < 8 * KK ? uni64(s_wU[w + 1]) : 0ull;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long Sl = w > 0 ? uni64(s_wS[w - 1]) : 0ull, Sr = w + 1 < 8 * KK ? uni64(s_wS[w + 1]) : 0ull;
+                unsigned long long S = Sm[k], U = Um[k];
+                const unsigned pm = r_mk[k] & 0x7Fu;
+                bool ch = false;
+                for (;;) {
+                    const unsigned fS = field(S, Sl, Sr), fU = field(U, Ul, Ur);
+                    const bool isU = (fU >> 3) & 1u;
+                    const bool anyS = (fS & pm) != 0, anyU = (fU & pm) != 0;
+                    const unsigned long long toN = __ballot(isU && anyS), toS = __ballot(isU && !anyS && !anyU);
+                    if (!(toN | toS)) break;
+                    S |= toS;
+                    U &= ~(toN | toS);
+                    ch = true;
+                }
+                if (ch) {
+                    Sm[k] = S;
+                    Um[k] = U;
+                    if (lane == 0) {
+                        s_wS[w] = S;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // S lands before U (see the read side)
+                        s_wU[w] = U;
+                    }
+                }
+                pending |= U != 0;
+            }
+#ifdef MML_SEL_TIMING
+            if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[20] += 1;
+#endif
+            // No workgroup barrier between passes: a wavefront with undecided windows only waits for edge bits of its
+            // neighbours, which they publish as soon as they have them (LDS is coherent across the workgroup and the
+            // dependencies form a DAG, so some window can always advance); it simply looks again.
+            if (!pending) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        (void)rnd;
+        __syncthreads();
+        SEL_MARK(4);
+        // ---- phase 2: value held when :521-539 runs (f3a) + "a later partition marks me", from the final masks ---------
+        // (a picked neighbour whose range covers me marks me 1 at its own, later visit -- it cannot have come first, or I
+        //  would not be picked -- unless it sits in a later partition, whose marks land after :521-539 has read me)
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int i = tid + k * SELP_THREADS;
+            if ((i & ~63) >= n) break;  // wave-uniform
+            const int w = k * 8 + wave;
+            const unsigned long long Sl = w > 0 ? uni64(s_wS[w - 1]) : 0ull, Sr = w + 1 < 8 * KK ? uni64(s_wS[w + 1]) : 0ull;
+            const unsigned hit = field(Sm[k], Sl, Sr) & (r_mk[k] >> 7) & 0x7Fu;
+            const unsigned later = (r_mk[k] >> 14) & 0x7Fu;
+            const bool covLater = (hit & later) != 0, covL = (hit & ~later) != 0;
+            const bool sel = (Sm[k] >> lane) & 1ull;
+            if (i < n) {
+                const unsigned me = W[2 * i + 1];
+                const unsigned f3a = covL ? 1u : (sel ? 3u : 0u);
+                const unsigned f = f3a | (covLater ? 4u : 0u);
+                // the word is only read by its owner from here on
+                W[2 * i + 1] = me | (f << I_F_SHIFT);
+                // (a) first round of the reflect-candidate minimum
+                if ((me & I_REFL) && (me & I_INPART))
+                    atomicMin(&s_pm[me & I_PART_MASK][0], ((unsigned long long)RKEY(i) << 32) | (unsigned)i);
+            }
+        }
+        __syncthreads();
+    } else {
     // ---- phase 1: which neighbours can suppress me (static); points nobody can suppress are picked at once ------
     FOR_POINTS(
         const uint2 rec = make_uint2(W[2 * i], W[2 * i + 1]);
@@ -1349,6 +1475,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             atomicMin(&s_pm[me & I_PART_MASK][0], ((unsigned long long)RKEY(i) << 32) | (unsigned)i);
     )
     __syncthreads();
+    }
 
     SEL_MARK(5);
     // ---- phase 3: :521-539 in closed form ---------------------------------------------------------------------------
@@ -1483,6 +1610,18 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     SEL_MARK(8);
     // ---- phase 4: stride walk of :543-650, window transfer functions ------------------------------------------------
     const int nw = (n + 63) / 64;
+    // transfer table of the stride walk over 8 positions: (RFLAT byte, entry offset 0..3) -> visited byte | exit << 8
+    // (built here: until now its storage held the window state masks of the dependency rounds)
+    for (int t = tid; t < 1024; t += SELP_THREADS) {
+        const unsigned m8 = (unsigned)t >> 2;
+        int pos = t & 3;
+        unsigned v = 0;
+        while (pos < 8) {
+            v |= 1u << pos;
+            pos += ((m8 >> pos) & 1u) ? 4 : 1;
+        }
+        s_walk[t] = (unsigned short)(v | ((unsigned)(pos - 8) << 8));
+    }
     if constexpr (CACHED) {
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
@@ -1610,7 +1749,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     __shared__ int s_sp[52];
     __shared__ int s_cnt;
     __shared__ int s_flag[3];
-    __shared__ unsigned short s_walk[1024];
+    __shared__ __attribute__((aligned(8))) unsigned short s_walk[1024];
     // only the global-scratch form (lines beyond the LDS budget) uses these two; its dynamic LDS block is otherwise idle
     unsigned char* s_bfirst = smem;
     unsigned char* s_list = smem + 160;
