@@ -421,5 +421,25 @@ class Estimator {
     bool _fail_detected = false;
 };
 
+// ---- LidarsParamEstimator (unionLidarsAligner.cpp): the numeric core of estimate_timeoffset (:1077-1153) ----------------
+// velo_fov / livox: packed x, y, z floats (the FOV-cropped Velodyne cloud of :1080 and the merged Livox points of
+// :1053-1068); velo_hori_tf: _velo_hori_tf_matrix, row-major.  Returns the start index of the best window in the merged
+// Livox array (cnt * resolution, the argument of livox_msg_offset_vec at :1143), or -1 when no window beats the 1e6
+// start value; *lowest_error is what :1155 compares with _time_esti_error_th.
+struct TimeOffsetResult {
+    int n_windows = 0, best_window = -1;
+    double lowest_error = 1000000.0;
+};
+inline TimeOffsetResult EstimateTimeOffsetCore(Context& ctx, const float* velo_fov, int n_velo, const float* velo_hori_tf,
+                                               const float* livox, int n_livox, int offset_search_resolution = 30,
+                                               int offset_search_sliced_points = 12000) {
+    TimeOffsetResult r;
+    check(ctx.get(), mml_time_offset_search(ctx.get(), velo_fov, n_velo, velo_hori_tf, livox, n_livox, offset_search_resolution,
+                                            offset_search_sliced_points, nullptr, nullptr, 0, &r.n_windows, &r.best_window,
+                                            &r.lowest_error),
+          "mml_time_offset_search");
+    return r;
+}
+
 }  // namespace mml
 #endif

@@ -76,7 +76,9 @@ def test_cpp_adapter_compiles_links_and_runs_host_side(M, tmp_path):
             try {
                 mml::Context ctx(1, 0);
                 mml::Estimator est(ctx, 0.4f, 0.2f);
-                std::printf("context ok\n");
+                const float v[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0}, l[12] = {0.1f, 0, 0, 0.9f, 0, 0, 0, 0.8f, 0, 1, 1, 0};
+                mml::TimeOffsetResult r = mml::EstimateTimeOffsetCore(ctx, v, 3, nullptr, l, 4, 1, 2);
+                std::printf("context ok, %d windows, best %d\n", r.n_windows, r.best_window);
             } catch (const std::exception& e) {
                 std::printf("no device: %s\n", e.what());
             }
