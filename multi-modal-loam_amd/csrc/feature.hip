@@ -10,7 +10,8 @@
 //   k_select                       : one workgroup per scan line: the order-dependent part of the state machine
 //                                    (flags 3/1/2/300 by dependency rounds on order keys -- the partition sorts
 //                                    are never materialised -- stride walk for 150) + label scatter
-//   k_crop_compact                 : near/far crop, order-preserving compaction into the fused cloud
+//   k_crop                         : label counts, corner / surf index lists, Livox extrinsic (the crop itself is
+//                                    geometric and happens in k_assign_c)
 // Everything that is order-independent was hoisted into per-point predicates (k_stencil).
 //
 // Floating point: compiled with -ffp-contract=off; float expressions are written exactly as in the reference
@@ -1814,7 +1815,7 @@ static int select_round_cap(int want) {
 // One workgroup per slot: labels are 1 byte per fused point, so a whole scan is a few tens of KB -- counting, the scan of
 // the counts and the emission of the two index lists fit one launch (two sweeps over the label bytes).
 constexpr int CROP_THREADS = 1024;
-__global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap) {
+__global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, int lds_words) {
     __shared__ int s_w[CROP_THREADS / 64][4];
     __shared__ int s_tot[4];
     const int b = blockIdx.x + P.first;
@@ -1829,6 +1830,15 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap) {
     const int w0 = tid * per, w1 = min(words, w0 + per);
     int c[4] = {0, 0, 0, 0};  // corner, surf, velo corner, velo surf
     const uint32_t* lw = reinterpret_cast<const uint32_t*>(lab);
+    // The label bytes are staged in LDS first when they fit (lds_words > 0): coalesced, all loads of a thread in flight
+    // together -- the per-thread chunks below are `per` words apart from lane to lane, and walking them in global memory
+    // is one dependent, uncoalesced load per word, twice.
+    extern __shared__ uint32_t s_lab[];
+    if (words <= lds_words) {
+        for (int w = tid; w < words; w += CROP_THREADS) s_lab[w] = lw[w];
+        __syncthreads();
+        lw = s_lab;
+    }
     for (int w = w0; w < w1; ++w) {
         const uint32_t v = lw[w];
         if (v == 0) continue;
@@ -2032,7 +2042,10 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "crop_compact");
-        hipLaunchKernelGGL(k_crop, dim3(count), dim3(CROP_THREADS), 0, s, P, ctx->VX_CAP);
+        // label staging: the whole fused cloud of a slot when that leaves two workgroups per CU (<= 64 KB), else none
+        const int lab_words = (ctx->NT + 3) / 4;
+        const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 0;
+        hipLaunchKernelGGL(k_crop, dim3(count), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
     }
     MML_HIP(hipGetLastError());
     return MML_OK;
