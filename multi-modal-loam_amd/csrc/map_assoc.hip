@@ -980,8 +980,8 @@ __device__ __forceinline__ bool fit_and_store(const AssocParams& P, int kind, in
 // prefix over the 2 * count items.  A fixed-size grid walks the chunks, so no empty workgroups are dispatched
 // (with max_features = 8192 the dense grid spent more time retiring ~30 k empty workgroups than computing).
 __global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int B, const int* ft_n, int* work_off) {
-    __shared__ int s_sum[1024];
-    const int tid = threadIdx.x;
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nitems = 2 * count;
     int acc = 0;  // running prefix over tiles of 1024 items
     for (int t0 = 0; t0 < nitems; t0 += 1024) {
@@ -992,16 +992,24 @@ __global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int
             const int nf = ft_n[kind * B + first + slot];
             v = nf > 0 ? (nf + 127) / 128 : 0;
         }
-        s_sum[tid] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int x = tid >= o ? s_sum[tid - o] : 0;
-            __syncthreads();
-            s_sum[tid] += x;
-            __syncthreads();
+        // inclusive scan inside the wavefront (shuffles), then the 16 wavefront totals
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
         }
-        if (it < nitems) work_off[it] = acc + s_sum[tid] - v;
-        acc += s_sum[1023];
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        int base = 0, tile = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_wsum[w];
+            base += w < wave ? t : 0;
+            tile += t;
+        }
+        if (it < nitems) work_off[it] = acc + base + x - v;
+        acc += tile;
         __syncthreads();
     }
     if (tid == 0) work_off[nitems] = acc;
