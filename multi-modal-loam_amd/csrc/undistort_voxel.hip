@@ -167,14 +167,23 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
     const bool overflow = nsel > cap;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int s = tid; s < cnt; s += VX_THREADS) {
-        const float4 p = px[seq2idx[s]];
-        mn[0] = fminf(mn[0], p.x);
-        mn[1] = fminf(mn[1], p.y);
-        mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x);
-        mx[1] = fmaxf(mx[1], p.y);
-        mx[2] = fmaxf(mx[2], p.z);
+    // four points of this thread's stride per round: the index loads, then the gathers, in flight together
+    for (int s0 = tid; s0 < cnt; s0 += 4 * VX_THREADS) {
+        unsigned id4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id4[u] = seq2idx[min(s0 + u * VX_THREADS, cnt - 1)];
+        float4 p4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p4[u] = px[id4[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // (a clamped repeat of the last point changes no extremum)
+            mn[0] = fminf(mn[0], p4[u].x);
+            mn[1] = fminf(mn[1], p4[u].y);
+            mn[2] = fminf(mn[2], p4[u].z);
+            mx[0] = fmaxf(mx[0], p4[u].x);
+            mx[1] = fmaxf(mx[1], p4[u].y);
+            mx[2] = fmaxf(mx[2], p4[u].z);
+        }
     }
     // the six extrema reduced together: one shuffle tree each, one exchange through LDS
     float gmn[3], gmx[3];
