@@ -1195,15 +1195,19 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 
     SEL_MARK(1);
     // ---- phase 0: per-point record --------------------------------------------------------------------------
-    const float inv_m = range >= 1 ? 50.0f / (float)range : 0.f;
+    const float inv_r = range >= 1 ? 1.0f / (float)range : 0.f;
     FOR_POINTS(
         unsigned inf = 0, kk = 0;
         if (range >= 1 && i >= 5 && i <= n - 7) {
             const unsigned at = ATTR(i, k);
-            int j = (int)((float)(i - 5) * inv_m);
-            j = j < 0 ? 0 : (j > 49 ? 49 : j);
-            while (i >= s_sp[j + 1]) ++j;  // partitions tile [5, n-7]; empty ones have sp[j+1] == sp[j]
-            while (i < s_sp[j]) --j;
+            // partition of i: the last j with sp[j] = 5 + range * j / 50 <= i (partitions tile [5, n-7]; an empty one has
+            // sp[j+1] == sp[j]), i.e. j = (50 (i - 4) - 1) / range, capped at 49.  The quotient through a float reciprocal
+            // (the numerator is below 2^24, the estimate is off by at most one) and one exact correction.
+            const int num = 50 * (i - 4) - 1;
+            int j = (int)((float)num * inv_r);
+            const int rem = num - j * range;
+            j += rem < 0 ? -1 : (rem >= range ? 1 : 0);
+            j = j > 49 ? 49 : j;
             const unsigned a = min((int)((at >> A_A3_SHIFT) & 3u), T), bb = min((int)((at >> A_B3_SHIFT) & 3u), T);
             inf = (unsigned)j | (a << I_A_SHIFT) | (bb << I_B_SHIFT) | I_INPART;
             if (at & A_ANGLE) inf |= I_ANGLE;
