@@ -1033,3 +1033,21 @@ def test_time_offset_search_matches_oracle(M, O, synth):
             c.time_offset_search(np.zeros((0, 3), np.float32), livox[:10], 30, 5)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_livox", [30000, 66000, 120000])
+def test_extract_long_livox_lines(M, O, synth, n_livox):
+    """Livox lines of 5 000 / 11 000 / 20 000 points: the k_select variants with 12 and 24 points per thread (the
+    LDS-resident form without the mask tables) and the global-scratch form for lines beyond the LDS budget."""
+    c = M.Context(max_scans=1, max_livox_points=n_livox)
+    try:
+        v, l = synth.velo_scan(7), synth.livox_scan(7, n=n_livox)
+        c.scan_upload(0, v, l)
+        c.extract(0, 1)
+        g = c.scan_download(0)
+        ev, el = O.extract_velo(v), O.extract_livox(l)
+        assert np.array_equal(g["label"], np.concatenate([ev["label"], el["label"]]))
+        assert np.array_equal(g["xyzi"][:, :3], np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]]))
+    finally:
+        c.close()
