@@ -999,29 +999,42 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     double* h_x = stage_alloc(ctx, 7 * (size_t)count + 1);  // pinned read-back area: poses, then the two stack-size arrays
     int* h_ftn = reinterpret_cast<int*>(h_x + 6 * (size_t)count);
     int rc = MML_OK;
-    for (int l = 0; l < lanes && rc == MML_OK; ++l) {
-        const int f = first_slot + l * chunk;
-        const int c = std::min(chunk, first_slot + count - f);
-        if (c <= 0) break;
-        const int off = f - first_slot;
-        ctx->cur = l;
-        rc = mml_launch_extract(ctx, f, c, false);
-        if (rc == MML_OK) rc = mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
-        if (rc == MML_OK) rc = mml_launch_downsample(ctx, f, c);
-        if (rc != MML_OK) break;
-        for (int i = 0; i < c; ++i) {
-            double q[4];
-            so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
-            pose_to_Twl(q, x_inout + 6 * (size_t)(off + i), T_bl, &Twl[16 * (size_t)i]);
-        }
-        rc = mml_associate(ctx, f, c, Twl.data(), thres_dist, nullptr);
-        if (rc == MML_OK) rc = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
-        if (rc == MML_OK) {
-            hipError_t e = hipMemcpyAsync(h_x + 6 * (size_t)off, ctx->d_x + 6 * (size_t)f, sizeof(double) * 6 * c,
-                                          hipMemcpyDeviceToHost, MML_STREAM(ctx));
-            if (e != hipSuccess) {
-                ctx->err = std::string("mml_step read-back: ") + hipGetErrorString(e);
-                rc = MML_ERR_HIP;
+    // The stages are enqueued stage by stage across the lanes (each lane's stream keeps its own order): every lane has
+    // its first kernels in its queue within a few tens of microseconds, instead of lane 3 waiting for the host to finish
+    // enqueueing the whole chains of lanes 0..2.
+    auto lane_span = [&](int l, int& f, int& c) {
+        f = first_slot + l * chunk;
+        c = std::min(chunk, first_slot + count - f);
+        return c > 0;
+    };
+    for (int stage = 0; stage < 5 && rc == MML_OK; ++stage) {
+        for (int l = 0; l < lanes && rc == MML_OK; ++l) {
+            int f, c;
+            if (!lane_span(l, f, c)) break;
+            const int off = f - first_slot;
+            ctx->cur = l;
+            switch (stage) {
+                case 0: rc = mml_launch_extract(ctx, f, c, false); break;
+                case 1: rc = mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off); break;
+                case 2: rc = mml_launch_downsample(ctx, f, c); break;
+                case 3:
+                    for (int i = 0; i < c; ++i) {
+                        double q[4];
+                        so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
+                        pose_to_Twl(q, x_inout + 6 * (size_t)(off + i), T_bl, &Twl[16 * (size_t)i]);
+                    }
+                    rc = mml_associate(ctx, f, c, Twl.data(), thres_dist, nullptr);
+                    break;
+                default:
+                    rc = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
+                    if (rc == MML_OK) {
+                        hipError_t e = hipMemcpyAsync(h_x + 6 * (size_t)off, ctx->d_x + 6 * (size_t)f, sizeof(double) * 6 * c,
+                                                      hipMemcpyDeviceToHost, MML_STREAM(ctx));
+                        if (e != hipSuccess) {
+                            ctx->err = std::string("mml_step read-back: ") + hipGetErrorString(e);
+                            rc = MML_ERR_HIP;
+                        }
+                    }
             }
         }
     }
