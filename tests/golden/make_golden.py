@@ -106,6 +106,15 @@ def main():
                         marg_Jtr=Jm.T @ rm, local_corner_feat=cf, local_surf_feat=sf,
                         local_poses=np.stack([synth.pose_matrix(k) for k in (22, 23, 24, 25)]), local_corner_map=lm.get(0),
                         local_surf_map=lm.get(1))
+    # 6. the aligner's time-offset search (part): a decimated Velodyne scan, two Livox scans
+    tv = synth.velo_scan(26)[::6, :3].copy()
+    tl = np.concatenate([np.stack([p_["x"], p_["y"], p_["z"]], 1) for p_ in (synth.livox_scan(26, n=6000), synth.livox_scan(27, n=6000))]).astype(np.float32)
+    th = 0.03
+    ttf = np.array([[np.cos(th), -np.sin(th), 0, 0.08], [np.sin(th), np.cos(th), 0, -0.05], [0, 0, 1, 0.02], [0, 0, 0, 1]], np.float32)
+    to = O.time_offset_search(tv, tl, 25, 3000, ttf)
+    np.savez_compressed(os.path.join(OUT, "time_offset_small.npz"), velo=tv, livox=tl, tf=ttf, resolution=25, sliced=3000,
+                        nn_d2=to["nn_d2"], window_error=to["window_error"], best_window=to["best_window"],
+                        lowest_error=to["lowest_error"])
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1051,3 +1051,15 @@ def test_extract_long_livox_lines(M, O, synth, n_livox):
         assert np.array_equal(g["xyzi"][:, :3], np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]]))
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_time_offset_golden(M):
+    g = load("time_offset_small.npz")
+    c = M.Context(max_scans=1)
+    try:
+        r = c.time_offset_search(g["velo"], g["livox"], int(g["resolution"]), int(g["sliced"]), g["tf"])
+        assert np.array_equal(r["nn_d2"], g["nn_d2"]) and np.array_equal(r["window_error"], g["window_error"])
+        assert r["best_window"] == int(g["best_window"]) and r["lowest_error"] == float(g["lowest_error"])
+    finally:
+        c.close()

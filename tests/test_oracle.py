@@ -602,3 +602,10 @@ def test_time_offset_search_oracle_against_plain_loops(O):
     # no window fits: nothing is selected and the 1e6 start value stays (:1107)
     r0 = O.time_offset_search(velo, livox[:200], 37, 250)
     assert len(r0["window_error"]) == 0 and r0["best_window"] == -1 and r0["lowest_error"] == 1000000.0
+
+
+def test_time_offset_golden(O):
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "time_offset_small.npz"))
+    r = O.time_offset_search(g["velo"], g["livox"], int(g["resolution"]), int(g["sliced"]), g["tf"])
+    assert np.array_equal(r["nn_d2"], g["nn_d2"]) and np.array_equal(r["window_error"], g["window_error"])
+    assert r["best_window"] == int(g["best_window"]) and r["lowest_error"] == float(g["lowest_error"])
