@@ -19,7 +19,7 @@ hipError_t dalloc(T** p, size_t n) {
 }
 
 // pinned staging ring for small host<->device parameter blocks
-constexpr size_t kStageDoubles = 1u << 19;  // 4 MiB
+constexpr size_t kStageDoubles = 1u << 22;  // 32 MiB: a 1024-scan step stages ~45 k doubles; a wrap synchronises the device
 
 double* stage_alloc(mml_ctx* ctx, size_t doubles) {
     if (ctx->stage_cursor + doubles > ctx->h_stage_doubles) {
