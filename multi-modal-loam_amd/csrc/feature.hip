@@ -142,8 +142,10 @@ __global__ void k_assign_init(FeatParams P, int count) {
         a->last_finite = -1;
         a->trig = 0x7fffffff;
         int* info = P.fu_info + 8 * (P.first + t);
-        info[4] = 0;  // livox corner / surf: k_select adds the labelled points beyond far_th, k_crop_b the kept ones
+        info[4] = 0;  // livox corner / surf: k_select adds the labelled points beyond far_th, k_crop the kept ones
         info[5] = 0;
+        P.brk_cnt[P.first + t] = 0;   // the stencil's two queues start empty
+        P.redo_cnt[P.first + t] = 0;
     }
 }
 
@@ -2023,8 +2025,6 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "stencil");
-        MML_HIP(hipMemsetAsync(ctx->brk_cnt + first, 0, sizeof(int) * count, s));
-        MML_HIP(hipMemsetAsync(ctx->brk_cnt + ctx->B + first, 0, sizeof(int) * count, s));
         hipLaunchKernelGGL(k_stencil, dim3(pblocks, count), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);

@@ -979,9 +979,10 @@ __device__ __forceinline__ bool fit_and_store(const AssocParams& P, int kind, in
 // work decomposition: item = (kind, slot) pair, ceil(nf / 128) workgroup-sized chunks each; work_off is the exclusive
 // prefix over the 2 * count items.  A fixed-size grid walks the chunks, so no empty workgroups are dispatched
 // (with max_features = 8192 the dense grid spent more time retiring ~30 k empty workgroups than computing).
-__global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int B, const int* ft_n, int* work_off) {
+__global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int B, const int* ft_n, int* work_off, int* hard_count) {
     __shared__ int s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *hard_count = 0;  // the far-query list of this call starts empty
     const int nitems = 2 * count;
     int acc = 0;  // running prefix over tiles of 1024 items
     for (int t0 = 0; t0 < nitems; t0 += 1024) {
@@ -1596,13 +1597,12 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     P.hard_count = ctx->d_misc + 32 + ctx->cur;
     P.hard_list = ctx->hard_list + (size_t)first * ctx->MF * 2;
     P.hard_knn = ctx->hard_knn + (size_t)first * ctx->MF * 2 * 10;
-    MML_HIP(hipMemsetAsync(P.hard_count, 0, sizeof(int), MML_STREAM(ctx)));
     P.count = count;
     int* work_off = ctx->work_off + 2 * (size_t)first + ctx->cur;
     P.work_off = work_off;
     {
         MmlStageScope t(ctx, "associate");
-        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, MML_STREAM(ctx), first, count, ctx->B, ctx->ft_n, work_off);
+        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, MML_STREAM(ctx), first, count, ctx->B, ctx->ft_n, work_off, P.hard_count);
         hipLaunchKernelGGL(k_associate, dim3(4096), dim3(128), 0, MML_STREAM(ctx), P);
     }
     {
