@@ -269,7 +269,12 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
+#ifndef MML_ASB_THREADS
+#define MML_ASB_THREADS 512
+#endif
+constexpr int ASB_THREADS = MML_ASB_THREADS;  // one workgroup per (slot, sensor); 512: a 1024-thread workgroup waits long for 16
+                                             // free wave slots on one CU while other lanes' kernels fill the device
+__global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
     __shared__ int s_trig, s_first, s_last;
     __shared__ int s_tot[MAX_LINES + 2];
     const int b = blockIdx.x + P.first;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
     // exclusive scan over blocks: one wavefront per key (+ one for the valid-point count), 64 blocks per step
     {
         const int lane = tid & 63;
-        for (int kk = tid >> 6; kk <= nkeys + 1; kk += 1024 / 64) {
+        for (int kk = tid >> 6; kk <= nkeys + 1; kk += ASB_THREADS / 64) {
             const int k = kk < nkeys ? kk : MAX_LINES + (kk - nkeys);
             int acc = 0;
             for (int b0 = 0; b0 < nblk; b0 += 64) {
@@ -312,12 +317,12 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
         const uint8_t* rl = P.raw_line + (size_t)b * P.NT;
         // first / last finite point (:1136-1139): strided search, min / max reduction
         int ff = 0x7fffffff, lf = -1;
-        for (int i = tid; i < n; i += 1024)
+        for (int i = tid; i < n; i += ASB_THREADS)
             if (rl[i] != 255) {
                 ff = i;
                 break;
             }
-        for (int i = n - 1 - tid; i >= 0; i -= 1024)
+        for (int i = n - 1 - tid; i >= 0; i -= ASB_THREADS)
             if (rl[i] != 255) {
                 lf = i;
                 break;
@@ -348,18 +353,18 @@ __global__ __launch_bounds__(1024) void k_assign_b(FeatParams P) {
         int best = 0x7fffffff;
         // eight points of this thread's stride per round, their loads in flight together (the first hit sits half-way
         // through the sweep: one point per round is a dozen dependent memory round trips)
-        for (int i0 = tid; i0 < n && best == 0x7fffffff; i0 += 8 * 1024) {
+        for (int i0 = tid; i0 < n && best == 0x7fffffff; i0 += 8 * ASB_THREADS) {
             uint8_t rl8[8];
             float ro8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = min(i0 + u * 1024, n - 1);
+                const int i = min(i0 + u * ASB_THREADS, n - 1);
                 rl8[u] = rline[i];
                 ro8[u] = rori[i];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * 1024;
+                const int i = i0 + u * ASB_THREADS;
                 if (i >= n || rl8[u] >= 254 || best != 0x7fffffff) continue;
                 float ori = ro8[u];
                 if (ori < startOri - M_PI / 2)
@@ -2017,7 +2022,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "assign_scan");
-        hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(1024), 0, s, P);
+        hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(ASB_THREADS), 0, s, P);
     }
     {
         MmlStageScope t(ctx, "assign_scatter");
