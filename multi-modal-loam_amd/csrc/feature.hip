@@ -1825,7 +1825,7 @@ static int select_round_cap(int want) {
 // the Livox extrinsic, which the reference applies only once livox_corner_num is known (:302-318).
 // One workgroup per slot: labels are 1 byte per fused point, so a whole scan is a few tens of KB -- counting, the scan of
 // the counts and the emission of the two index lists fit one launch (two sweeps over the label bytes).
-constexpr int CROP_THREADS = 1024;
+constexpr int CROP_THREADS = 512;  // (1024-thread workgroups wait long for wave slots next to other lanes' kernels)
 __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, int lds_words) {
     __shared__ int s_w[CROP_THREADS / 64][4];
     __shared__ int s_tot[4];
