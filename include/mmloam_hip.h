@@ -73,6 +73,8 @@ int mml_abi_version(void);
 int mml_create(const mml_config* cfg, int device, mml_ctx** out);
 void mml_destroy(mml_ctx* ctx);
 const char* mml_last_error(const mml_ctx* ctx);
+/* The configuration the context was created with, defaults resolved (cell sizes, max_features, max_map_points). */
+int mml_config_get(const mml_ctx* ctx, mml_config* out);
 int mml_synchronize(mml_ctx* ctx);
 
 /* ---- input ------------------------------------------------------------------------------------
@@ -101,6 +103,17 @@ int mml_scan_upload_wire(mml_ctx* ctx, int slot, const uint8_t* data, int n_poin
  * z 8, normal_x 16 (in-sweep time), normal_y 20 (ring / line), normal_z 24 (label 0/1/2), intensity 32,
  * curvature 36; packed on the device.  out may be NULL to query *n_points only. */
 int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int capacity_points, int* n_points);
+
+/* The way INTO a slot for a labelled cloud that was extracted elsewhere -- the PoseEstimation process receives
+ * velo_combine / livox_combine over /union_feature_cloud (unionPoseEstimation.cpp:679-688: pcl::fromROSMsg into
+ * laserCloudFullVeloRes / laserCloudFullHoriRes, merged at :746-757) and hands the cloud to RemoveLidarDistortion(cloud,
+ * dR, dt) (:862) and, inside a LidarFrame (Estimator.h:33-56), to EstimateLidarPose (:872).  Inverse of
+ * mml_scan_download_pointxyzinormal: n_points 48-byte PointXYZINormal records (msg.data.data(), velo_combine followed
+ * by livox_combine; the first n_velo are the Velodyne part), decoded on the device: normal_x -> in-sweep time,
+ * normal_y -> ring / line, normal_z -> label by abs(normal_z - k) < 1e-5 (Estimator.cpp:995-1003; anything else 0),
+ * intensity kept.  Afterwards the slot is in the state mml_extract leaves (mml_scan_info_get, mml_undistort,
+ * mml_downsample, mml_estimate work on it); livox_*_num count the kept points only.  Synchronous. */
+int mml_cloud_upload(mml_ctx* ctx, int slot, const uint8_t* pointxyzinormal, int n_points, int n_velo);
 
 /* ---- the aligner's time-offset search ---------------------------
  * The numeric core of LidarsParamEstimator::estimate_timeoffset (unionLidarsAligner.cpp:1077-1153): the Velodyne
@@ -284,6 +297,39 @@ void mml_window_solver_destroy(mml_window_solver* s);
  * < 0 on error. */
 int mml_window_solver_step(mml_window_solver* s, const double* records /* W x 32 */, double* x_eval /* W x 6 */);
 int mml_window_solver_summary(const mml_window_solver* s, mml_solve_summary* out);
+
+/* ---- multi-GPU: RCCL inside the C-ABI ---------------------------------------------------------------
+ * One process per GPU, one ctx per process.  The caller distributes the 128-byte id of rank 0 by whatever means it
+ * has (a ROS parameter, a file, torch.distributed, MPI); mml_comm_init is collective (ncclCommInitRank on the ctx
+ * device).  Collectives run on the ctx stream over RCCL / xGMI; no host round trip inside them. */
+#define MML_COMM_ID_BYTES 128
+int mml_comm_unique_id(uint8_t* id /* MML_COMM_ID_BYTES, filled by the calling rank */);
+int mml_comm_init(mml_ctx* ctx, int n_ranks, int rank, const uint8_t* id);
+int mml_comm_destroy(mml_ctx* ctx);   /* also done by mml_destroy */
+int mml_comm_info(mml_ctx* ctx, int* n_ranks, int* rank);
+typedef struct {
+    int evaluations;     /* linearisations of the own frames that did work */
+    int rounds;          /* kernels enqueued (max_num_iterations + 2) */
+    int exchanges;       /* all-gathers enqueued */
+    double device_ms;    /* HIP events on the ctx stream around the whole solve */
+} mml_window_timing;
+/* The joint window solve of Estimator::Estimate across ranks (Estimator.cpp:1265-1299 evaluates the frames of the
+ * window one after the other, :1425-1432 solves): the window holds W = n_ranks * n_local frames (<= 8), rank r owns
+ * frames [r * n_local, (r + 1) * n_local) in its slots [first_slot, first_slot + n_local), already associated
+ * (mml_associate).  Per trust-region evaluation every rank linearises its own frames on the device, the
+ * MML_NEQ_RECORD_DOUBLES-double records travel by ncclAllGather, and every rank advances the same device-resident
+ * dogleg state machine (the iteration of mml_solve), so all ranks finish with bit-identical poses and no second
+ * broadcast.  x_local: n_local x 6 in/out (own frames); x_window (may be NULL): W x 6 out; summary / timing may be
+ * NULL.  Collective: every rank of the communicator must call it with the same n_local and opts. */
+int mml_window_solve_allgather(mml_ctx* ctx, int first_slot, int n_local, const double* T_bl, const mml_solve_opts* opts,
+                               double* x_local, double* x_window, mml_solve_summary* summary, mml_window_timing* timing);
+/* Map-update exchange: the down-sampled corner / surf stacks of `slot` on rank `root` replace those of `slot` on
+ * every rank (ncclBroadcast, stream-ordered), so that each replica can run the same mml_map_increment_local /
+ * mml_map_global_append (the key-scan update of Estimator.cpp:1083-1085, 1125-1130).  Collective. */
+int mml_comm_broadcast_features(mml_ctx* ctx, int slot, int root);
+/* Replicates rank `root`'s local maps (both kinds, as set or as grown on the device) on every rank and builds the
+ * kNN grids there.  Collective; synchronises the ctx. */
+int mml_comm_broadcast_local_map(mml_ctx* ctx, int root);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the ctx stream. */

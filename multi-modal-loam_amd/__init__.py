@@ -67,6 +67,22 @@ class EstimateInfo(C.Structure):
                 ("n_surf_feat", C.c_int)]
 
 
+class WindowTiming(C.Structure):
+    _fields_ = [("evaluations", C.c_int), ("rounds", C.c_int), ("exchanges", C.c_int), ("device_ms", C.c_double)]
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C-ABI: called by one rank, handed to mml_comm_init of every rank."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib().mml_comm_unique_id(buf)
+    if rc != MML_OK:
+        raise MmlError(rc, "mml_comm_unique_id")
+    return bytes(buf)
+
+
 class Profile(C.Structure):
     _fields_ = [("n_stages", C.c_int), ("name", C.c_char_p * MAX_STAGES), ("total_ms", C.c_double * MAX_STAGES),
                 ("launches", C.c_long * MAX_STAGES)]
@@ -184,6 +200,8 @@ class Context:
         raw = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         lv = np.ascontiguousarray(livox) if livox is not None else None
         nl = 0 if lv is None else len(lv)
+        if len(raw) < n_points * point_step:
+            raise ValueError("PointCloud2 payload shorter than n_points * point_step bytes")
         self._ck(lib().mml_scan_upload_pointcloud2(self._h, C.c_int(slot), _p(raw), C.c_int(n_points), C.c_int(point_step),
                                                    C.c_int(off_x), C.c_int(off_y), C.c_int(off_z), C.c_int(off_intensity),
                                                    _p(lv) if nl else None, C.c_int(nl)))
@@ -195,6 +213,8 @@ class Context:
         lw = np.frombuffer(livox_wire, dtype=np.uint8) if not isinstance(livox_wire, np.ndarray) else np.ascontiguousarray(livox_wire, dtype=np.uint8)
         if len(lw) < 19 * n_livox:
             raise ValueError("livox_wire shorter than 19 * n_livox bytes")
+        if len(raw) < n_points * point_step:
+            raise ValueError("PointCloud2 payload shorter than n_points * point_step bytes")
         self._ck(lib().mml_scan_upload_wire(self._h, C.c_int(slot), _p(raw), C.c_int(n_points), C.c_int(point_step),
                                             C.c_int(off_x), C.c_int(off_y), C.c_int(off_z), C.c_int(off_intensity),
                                             _p(lw) if n_livox else None, C.c_int(n_livox)))
@@ -223,6 +243,13 @@ class Context:
         out = np.zeros((max(n.value, 1), 12), np.float32)
         self._ck(lib().mml_scan_download_pointxyzinormal(self._h, C.c_int(slot), _p(out), C.c_int(n.value), C.byref(n)))
         return out[:n.value]
+
+    def cloud_upload(self, slot, records, n_velo=None):
+        """A labelled fused cloud (n x 12 float32 = 48-byte PointXYZINormal records, velo_combine then livox_combine)
+        into a slot: the PoseEstimation side of /union_feature_cloud."""
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 12)
+        nv = len(rec) if n_velo is None else int(n_velo)
+        self._ck(lib().mml_cloud_upload(self._h, C.c_int(slot), _p(rec) if len(rec) else None, C.c_int(len(rec)), C.c_int(nv)))
 
     def extract(self, first=0, count=1, livox_extrinsic=None):
         e = _f32(livox_extrinsic).reshape(16) if livox_extrinsic is not None else None
@@ -389,6 +416,38 @@ class Context:
                                 _p(_f64(dt).reshape(count, 3)), _p(_f64(exTlb).reshape(16)), C.c_double(thres_dist),
                                 C.c_int(gn_iters), _p(x)))
         return x
+
+    # ---- multi-GPU (RCCL inside the C-ABI) ----
+    def comm_init(self, n_ranks, rank, comm_id):
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("the communicator id is %d bytes" % COMM_ID_BYTES)
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self._ck(lib().mml_comm_init(self._h, C.c_int(n_ranks), C.c_int(rank), buf))
+
+    def comm_destroy(self):
+        self._ck(lib().mml_comm_destroy(self._h))
+
+    def comm_info(self):
+        n, r = C.c_int(0), C.c_int(0)
+        self._ck(lib().mml_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def window_solve_allgather(self, first, n_local, x_local, T_bl, max_iters=10, fixed=False, huber=0.0, w_tan=3e-4):
+        """Joint window solve over n_ranks * n_local frames; returns (own poses, window poses, summary, timing)."""
+        n_ranks, _ = self.comm_info()
+        x = _f64(x_local).reshape(n_local, 6).copy()
+        xw = np.zeros((n_ranks * n_local, 6))
+        opts = SolveOpts(max_iters, 1 if fixed else 0, huber, w_tan)
+        summ, tim = SolveSummary(), WindowTiming()
+        self._ck(lib().mml_window_solve_allgather(self._h, C.c_int(first), C.c_int(n_local), _p(_f64(T_bl).reshape(16)),
+                                                  C.byref(opts), _p(x), _p(xw), C.byref(summ), C.byref(tim)))
+        return x, xw, summ, tim
+
+    def comm_broadcast_features(self, slot, root):
+        self._ck(lib().mml_comm_broadcast_features(self._h, C.c_int(slot), C.c_int(root)))
+
+    def comm_broadcast_local_map(self, root):
+        self._ck(lib().mml_comm_broadcast_local_map(self._h, C.c_int(root)))
 
     # ---- measurement ----
     def set_lanes(self, lanes):

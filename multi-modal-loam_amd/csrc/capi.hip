@@ -58,9 +58,16 @@ int mml_abi_version(void) { return MML_ABI_VERSION; }
 
 const char* mml_last_error(const mml_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+int mml_config_get(const mml_ctx* ctx, mml_config* out) {
+    if (!ctx || !out) return MML_ERR_INVALID;
+    *out = ctx->cfg;
+    return MML_OK;
+}
+
 void mml_destroy(mml_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    mml_comm_destroy(ctx);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
         if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
@@ -405,6 +412,22 @@ int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int 
                        reinterpret_cast<float*>(ctx->wire_stage));
     MML_HIP(hipGetLastError());
     MML_HIP(hipMemcpyAsync(out, ctx->wire_stage, bytes, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    return MML_OK;
+}
+
+int mml_cloud_upload(mml_ctx* ctx, int slot, const uint8_t* pointxyzinormal, int n_points, int n_velo) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE(n_points >= 0 && n_velo >= 0 && n_velo <= n_points, MML_ERR_INVALID, "bad point counts");
+    MML_REQUIRE(n_points == 0 || pointxyzinormal, MML_ERR_INVALID, "null point buffer");
+    MML_REQUIRE(n_points <= ctx->NT, MML_ERR_CAPACITY, "cloud exceeds max_velo_points + max_livox_points");
+    const size_t bytes = (size_t)n_points * 48;
+    int rc = ensure_wire_stage(ctx, bytes ? bytes : 48);
+    if (rc != MML_OK) return rc;
+    if (bytes) MML_HIP(hipMemcpyAsync(ctx->wire_stage, pointxyzinormal, bytes, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    rc = mml_launch_cloud_decode(ctx, slot, reinterpret_cast<const float*>(ctx->wire_stage), n_points, n_velo);
+    if (rc != MML_OK) return rc;
+    // the staging buffer is reused by the next wire-format call and the host buffer belongs to the caller
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     return MML_OK;
 }

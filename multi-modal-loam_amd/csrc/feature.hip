@@ -2060,6 +2060,46 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     return MML_OK;
 }
 
+// ---- mml_cloud_upload back end: a labelled fused cloud that arrived over /union_feature_cloud ------------------------
+// pcl::fromROSMsg<PointXYZINormal> of velo_combine / livox_combine (unionPoseEstimation.cpp:679-688) on the device:
+// 48-byte records (x 0, y 4, z 8, normal_x 16 in-sweep time, normal_y 20 ring / line, normal_z 24 label, intensity 32)
+// into the slot's fused cloud, labels by the tests of Estimator.cpp:995-1003 (abs(normal_z - k) < 1e-5), then the
+// bookkeeping extract would have left behind (point counts for k_crop, which rebuilds the label counts and lists).
+__global__ void k_decode_xyzinormal(const float* raw, int n, int n_velo, int slot, FeatParams P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + slot;
+        a->kept_velo = n_velo;
+        a->kept_livox = n - n_velo;
+        int* info = P.fu_info + 8 * slot;
+        info[4] = 0;
+        info[5] = 0;
+    }
+    if (i >= n) return;
+    const float* r = raw + 12 * (size_t)i;
+    const size_t o = (size_t)slot * P.NT + i;
+    P.fu_xyzi[o] = make_float4(r[0], r[1], r[2], r[8]);
+    P.fu_rel[o] = r[4];
+    const float ln = r[5], nz = r[6];
+    P.fu_line[o] = (uint8_t)(ln >= 0.f && ln < 255.f ? (int)ln : 255);
+    // std::abs(normal_z - 1.0) < 1e-5 etc. are evaluated in double on the float field
+    uint8_t lab = 0;
+    if (fabs((double)nz - 1.0) < 1e-5) lab = 1;
+    else if (fabs((double)nz - 2.0) < 1e-5) lab = 2;
+    P.fu_label[o] = lab;
+}
+
+int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, int n_velo) {
+    FeatParams P = make_params(ctx, slot);
+    hipStream_t s = MML_STREAM(ctx);
+    hipLaunchKernelGGL(k_decode_xyzinormal, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, d_raw, n, n_velo, slot, P);
+    const int lab_words = (ctx->NT + 3) / 4;
+    const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 0;
+    hipLaunchKernelGGL(k_crop, dim3(1), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
 // mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in fu_label[0..n) and ln_final.
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     FeatParams P = make_params(ctx, 0);

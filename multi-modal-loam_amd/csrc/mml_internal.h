@@ -49,8 +49,11 @@ struct MmlStageTimer {
     long launches = 0;
 };
 
+struct MmlComm;  // comm.hip: RCCL communicator + window-solve buffers
+
 struct mml_ctx {
     mml_config cfg;
+    MmlComm* comm = nullptr;
     int device = 0;
     // `lanes`: independent HIP streams.  Entry points enqueue on lane `cur` (0 unless mml_step is pipelining
     // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.
@@ -216,6 +219,7 @@ struct MmlStageScope {
 
 // launchers implemented in the .hip files (all asynchronous on ctx->stream)
 int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic);
+int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, int n_velo);
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params);
 int mml_launch_time_offset(mml_ctx* ctx, MmlGrid& g, float4* d_velo4, const float* d_velo_xyz, int n_velo, const float* d_tf,
                            const float* d_livox_xyz, int n_livox, int res, int sliced, int nwin, float* d_nn, double* d_err);

@@ -789,7 +789,167 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_linearize(int b, int B, int M
     }
 }
 
+// ---- multi-GPU joint window solve: one ROUND of the device-resident state machine -----------------
+// The window of W = n_ranks * n_local frames is solved redundantly by every rank; a rank evaluates only its own
+// n_local frames (slots first .. first + n_local) and the 32-double records travel by ncclAllGather (comm.hip).
+// One kernel per exchange: ADVANCE the trust-region state with the records gathered by the previous exchange
+// (initialisation / tr_decide, then tr_propose until a candidate needs evaluating), then EVALUATE the own frames at that
+// candidate straight into this rank's section of the gather buffer.  The state lives in global memory between the
+// rounds and in LDS inside one; the host enqueues max_iterations + 1 rounds without ever reading a flag back (a
+// finished state machine turns the remaining rounds into no-ops), so all ranks issue the same collectives.
+struct WindowRoundParams {
+    int first, n_local, rank, W, B, MF, max_iters, fixed, round, do_eval;
+    double huber, w_tan;
+    const int* ft_n;
+    const MmlLineFactor* lf;
+    const MmlPlaneFactor* pf;
+    const double* Tbl;
+    const double* x_all;   // W x 6: the gathered initial poses (round 0)
+    double* rec_all;       // W x 32: gathered records in, own records out
+    TRState* state;        // global copy of the state machine
+    double* aux;           // [0] initial cost, [1] evaluations done, [2] rounds that did work
+};
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_window_round(WindowRoundParams P) {
+    __shared__ TRState S;
+    __shared__ double s_part[SOLVE_WAVES * 28];
+    __shared__ double s_out[28];
+    const int tid = threadIdx.x, W = P.W;
+    {
+        const double* src = reinterpret_cast<const double*>(P.state);
+        double* dst = reinterpret_cast<double*>(&S);
+        for (int i = tid; i < (int)(sizeof(TRState) / sizeof(double)); i += SOLVE_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (P.round == 0) {
+            for (int i = 0; i < 6 * W; ++i) S.x[i] = S.xc[i] = P.x_all[i];
+            S.go = 1;
+            S.evaluate = 1;
+            S.iter = 0;
+            S.successful = 0;
+            S.termination = 0;
+            S.cost = 0;
+        } else if (S.go) {
+            if (P.round == 1) {  // records at x0: the initialisation of k_solve / mml_window_solver_step
+                double xn = 0;
+                S.cost = 0;
+                for (int f = 0; f < W; ++f) {
+                    for (int k = 0; k < 28; ++k) S.rec[28 * f + k] = P.rec_all[32 * f + k];
+                    S.cost += S.rec[28 * f + 27];
+                    for (int i = 0; i < 6; ++i) {
+                        S.scale[6 * f + i] = 1.0 / (1.0 + sqrt(Hget(S.rec + 28 * f, i, i)));
+                        xn += S.x[6 * f + i] * S.x[6 * f + i];
+                    }
+                }
+                S.x_norm = sqrt(xn);
+                S.radius = 1e4;
+                S.mu = 1e-8;
+                S.reuse = 0;
+                S.num_invalid = 0;
+                S.alpha = 0;
+                S.dogleg_norm = 0;
+                P.aux[0] = S.cost;
+                if (!P.fixed) {
+                    double gm = 0;
+                    for (int f = 0; f < W; ++f)
+                        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(S.rec[28 * f + 21 + i]));
+                    if (gm <= 1e-10) {
+                        S.termination = 1;
+                        S.go = 0;
+                    }
+                }
+            } else {
+                for (int f = 0; f < W; ++f)
+                    for (int k = 0; k < 28; ++k) S.recc[28 * f + k] = P.rec_all[32 * f + k];
+                tr_decide(S, W, P.fixed);
+            }
+            while (S.go) {
+                tr_propose(S, W, P.max_iters);
+                if (!S.go || S.evaluate) break;
+            }
+            P.aux[2] += 1.0;
+        }
+    }
+    __syncthreads();
+    const int go = S.go;
+    if (P.do_eval && go) {
+        double acc[28];
+        for (int j = 0; j < P.n_local; ++j) {
+            const int f = P.rank * P.n_local + j, b = P.first + j;
+            Pose pose;
+            make_pose(S.xc + 6 * f, P.Tbl, pose);
+            eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan, P.huber, acc);
+            block_reduce28(acc, s_part, s_out);
+            if (tid < 32) P.rec_all[32 * f + tid] = tid < 28 ? s_out[tid] : 0.0;
+            __syncthreads();
+        }
+        if (tid == 0) P.aux[1] += 1.0;
+    }
+    __syncthreads();
+    {
+        double* dst = reinterpret_cast<double*>(P.state);
+        const double* src = reinterpret_cast<const double*>(&S);
+        for (int i = tid; i < (int)(sizeof(TRState) / sizeof(double)); i += SOLVE_THREADS) dst[i] = src[i];
+    }
+}
+static_assert(sizeof(TRState) % sizeof(double) == 0, "TRState is copied as doubles");
+
 }  // namespace
+
+size_t mml_window_state_bytes() { return sizeof(TRState); }
+
+int mml_launch_window_round(mml_ctx* ctx, int first, int n_local, int rank, int W, const double* d_Tbl, mml_solve_opts opts,
+                            int round, bool do_eval, const double* d_x_all, double* d_rec_all, void* d_state, double* d_aux) {
+    WindowRoundParams P;
+    P.first = first;
+    P.n_local = n_local;
+    P.rank = rank;
+    P.W = W;
+    P.B = ctx->B;
+    P.MF = ctx->MF;
+    P.max_iters = opts.max_num_iterations;
+    P.fixed = opts.fixed_iterations;
+    P.round = round;
+    P.do_eval = do_eval ? 1 : 0;
+    P.huber = opts.huber_delta;
+    P.w_tan = opts.plan_weight_tan;
+    P.ft_n = ctx->ft_n;
+    P.lf = ctx->lf;
+    P.pf = ctx->pf;
+    P.Tbl = d_Tbl;
+    P.x_all = d_x_all;
+    P.rec_all = d_rec_all;
+    P.state = reinterpret_cast<TRState*>(d_state);
+    P.aux = d_aux;
+    MmlStageScope t(ctx, "window_round");
+    hipLaunchKernelGGL(k_window_round, dim3(1), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+// final pose / summary of the window state machine (device TRState -> host)
+int mml_window_state_read(mml_ctx* ctx, const void* d_state, int W, double* x_window, mml_solve_summary* summ, double initial_cost) {
+    TRState* h = new TRState();
+    hipError_t e = hipMemcpyAsync(h, d_state, sizeof(TRState), hipMemcpyDeviceToHost, MML_STREAM(ctx));
+    if (e == hipSuccess) e = hipStreamSynchronize(MML_STREAM(ctx));
+    if (e != hipSuccess) {
+        delete h;
+        ctx->err = std::string("window state read-back: ") + hipGetErrorString(e);
+        return MML_ERR_HIP;
+    }
+    if (x_window)
+        for (int i = 0; i < 6 * W; ++i) x_window[i] = h->x[i];
+    if (summ) {
+        summ->iterations = h->iter;
+        summ->successful = h->successful;
+        summ->initial_cost = initial_cost;
+        summ->final_cost = h->cost;
+        summ->termination = h->termination;
+    }
+    delete h;
+    return MML_OK;
+}
 
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
                      bool want_trace) {

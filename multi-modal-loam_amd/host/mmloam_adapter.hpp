@@ -149,12 +149,46 @@ inline void RemoveLidarDistortion(Context& ctx, int slot, const Matrix3d& dRlc, 
     check(ctx.get(), mml_undistort(ctx.get(), slot, 1, dRlc.m, dtlc.v), "RemoveLidarDistortion");
 }
 
+// A labelled cloud that arrived over /union_feature_cloud (velo_combine followed by livox_combine, the merge of
+// unionPoseEstimation.cpp:746-757) -> scan slot: pcl::fromROSMsg on the device.  n_velo = velo_combine's size.
+inline void uploadCloud(Context& ctx, int slot, const PointCloud& cloud, int n_velo = -1) {
+    const int n = (int)cloud.size();
+    check(ctx.get(), mml_cloud_upload(ctx.get(), slot, reinterpret_cast<const uint8_t*>(cloud.data()), n, n_velo < 0 ? n : n_velo),
+          "mml_cloud_upload");
+}
+
+// void RemoveLidarDistortion(pcl::PointCloud<PointType>::Ptr& cloud, const Eigen::Matrix3d& dRlc, const Eigen::Vector3d& dtlc)
+// exactly as the pose node calls it (unionPoseEstimation.cpp:862): the CALLER's cloud is undistorted in place (x, y, z
+// rewritten, normal_x = 1, :416-419).  The cloud stays resident in `slot` as well, so a LidarFrame built from it can
+// name the slot instead of carrying the points back (LidarFrame::resident).
+inline void RemoveLidarDistortion(Context& ctx, PointCloud& cloud, const Matrix3d& dRlc, const Vector3d& dtlc, int slot = 0,
+                                  int n_velo = -1) {
+    const int n = (int)cloud.size();
+    if (n == 0) return;
+    uploadCloud(ctx, slot, cloud, n_velo);
+    check(ctx.get(), mml_undistort(ctx.get(), slot, 1, dRlc.m, dtlc.v), "RemoveLidarDistortion");
+    std::vector<float> xyzi(4 * (size_t)n), rel(n);
+    check(ctx.get(), mml_scan_download(ctx.get(), slot, xyzi.data(), rel.data(), nullptr, nullptr, n), "scan_download");
+    for (int i = 0; i < n; ++i) {
+        cloud[i].x = xyzi[4 * i];
+        cloud[i].y = xyzi[4 * i + 1];
+        cloud[i].z = xyzi[4 * i + 2];
+        cloud[i].normal_x = rel[i];
+    }
+}
+
 // ---- Estimator (Estimator.h:25-343), hot-path members only ------------------------------------------------------------
 class Estimator {
    public:
     static const int SLIDEWINDOWSIZE = 5;  // Estimator.h:30
 
-    struct LidarFrame {  // Estimator.h:33-56; the cloud lives in scan slot `slot` of the context
+    struct LidarFrame {  // Estimator.h:33-56
+        // laserCloud (Estimator.h:35): the caller's labelled, undistorted cloud.  When set (and not `resident`) it is
+        // uploaded into scan slot `slot` at the start of EstimateLidarPose / EstimateFullWindow; a cloud that is already
+        // in the slot (extracted there, or left there by RemoveLidarDistortion(ctx, cloud, ...)) is named by slot alone.
+        PointCloud* laserCloud = nullptr;
+        int n_velo = -1;        // velo_combine's share of laserCloud (-1: all of it)
+        bool resident = false;  // the slot already holds this cloud
         int slot = 0;
         Vector3d P{{0, 0, 0}};
         Vector3d V{{0, 0, 0}};
@@ -168,8 +202,15 @@ class Estimator {
     // Estimator(const float& filter_corner, const float& filter_surf) (Estimator.h:147): the leaf sizes are part of
     // mml_config (leaf_corner / leaf_surf) and must match the context's.
     Estimator(Context& ctx, float filter_corner, float filter_surf) : ctx_(ctx) {
-        (void)filter_corner;
-        (void)filter_surf;
+        mml_config c;
+        check(ctx.get(), mml_config_get(ctx.get(), &c), "mml_config_get");
+        if (c.leaf_corner != filter_corner || c.leaf_surf != filter_surf)
+            throw std::invalid_argument("Estimator: filter_corner / filter_surf differ from the context's leaf_corner / leaf_surf");
+    }
+
+    // pcl::fromROSMsg + the LidarFrame hand-over: bring every frame's cloud into its slot
+    void residentClouds(std::list<LidarFrame>& frames) {
+        for (auto& f : frames) stage(f);
     }
 
     // laserCloud{Corner,Surf}FromLocal (Estimator.cpp:1159-1167): replaces kdtree->setInputCloud
@@ -229,6 +270,7 @@ class Estimator {
         to_be_mapped(lidarFrameList.back(), T);  // :975-977
         int corner_cnt = 0;
         for (auto& f : lidarFrameList) {
+            stage(f);
             mml_scan_info si;
             check(ctx_.get(), mml_scan_info_get(ctx_.get(), f.slot, &si), "scan info");
             corner_cnt += si.fused_corner_num;  // :990-996
@@ -278,6 +320,12 @@ class Estimator {
                             const Vector3d& gravity) {
         const int W = (int)frames.size();
         if (W < 1 || W > 8 || (int)imu.size() < W) throw std::runtime_error("EstimateFullWindow: bad window");
+        for (auto* f : frames) {
+            if (f->laserCloud && !f->resident) {
+                stage(*f);
+                check(ctx_.get(), mml_downsample(ctx_.get(), f->slot, 1), "downsample");  // Estimator.cpp:1013-1024
+            }
+        }
         double T_bl[16];  // inverse of exTlb
         for (int r = 0; r < 3; ++r) {
             for (int c = 0; c < 3; ++c) T_bl[4 * r + c] = exTlb.m[4 * c + r];
@@ -364,6 +412,12 @@ class Estimator {
     bool failureDetected() const { return _fail_detected; }  // Estimator.h:278
 
    private:
+    void stage(LidarFrame& f) {
+        if (f.laserCloud && !f.resident) {
+            uploadCloud(ctx_, f.slot, *f.laserCloud, f.n_velo);
+            f.resident = true;
+        }
+    }
     // Sophus::SO3d(Q).log() / SO3d::exp(phi).unit_quaternion()
     static void quat_log(const Quaterniond& q, double* w) {
         const double n2 = q.x * q.x + q.y * q.y + q.z * q.z, n = std::sqrt(n2);

@@ -1,0 +1,99 @@
+"""GPU suite, SURVEY.md 8(e) on ONE device: the 8-frame joint window (BASELINE configs[2]'s window size) against the
+oracle, and the RCCL path of the C-ABI (mml_comm_* / mml_window_solve_allgather / the two broadcasts) at world size 1 --
+ncclCommInitRank, ncclAllGather and ncclBroadcast really run, the state machine is the one N ranks execute, and with one
+rank owning all W frames the result must equal mml_solve(window = W) bit for bit."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rsc
+
+from conftest import perturbed, pose_to_x
+
+pytestmark = pytest.mark.gpu
+
+W8 = 8
+
+
+def _window8(M, O, scene):
+    """8 frames: the four scene frames twice, the second time from differently perturbed poses."""
+    c = M.Context(max_scans=W8)
+    c.map_set_local(0, scene["corner_map"])
+    c.map_set_local(1, scene["surf_map"])
+    tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
+    rng = np.random.default_rng(8)
+    T, lfs, pfs = [], [], []
+    for f in range(W8):
+        fr = scene["frames"][f % 4]
+        c.features_upload(f, 0, fr["corner"])
+        c.features_upload(f, 1, fr["surf"])
+        Tf = perturbed(fr["T_gt"], dt=rng.normal(0, 0.02, 3), rotvec=rng.normal(0, 0.003, 3))
+        T.append(Tf)
+        lfs.append(O.associate_lines(fr["corner"], tc, Tf, 1.0)[0])
+        pfs.append(O.associate_planes(fr["surf"], ts, Tf, 1.0)[0])
+    T = np.stack(T)
+    c.associate(0, W8, T, 1.0)
+    T_bl = np.eye(4)
+    T_bl[:3, :3] = Rsc.from_rotvec([0.01, -0.02, 0.015]).as_matrix()
+    T_bl[:3, 3] = [0.03, 0.01, -0.02]
+    x0 = np.stack([pose_to_x(T[f]) for f in range(W8)])
+    return c, lfs, pfs, x0, T_bl
+
+
+@pytest.mark.parametrize("w_tan,huber", [(3e-4, 0.0), (0.0, 0.1 / 1.5e-3)])
+def test_window8_joint_solve_matches_oracle(M, O, scene, w_tan, huber):
+    c, lfs, pfs, x0, T_bl = _window8(M, O, scene)
+    try:
+        xg, sg, tg = c.solve(0, W8, x0, T_bl, window=W8, max_iters=10, huber=huber, w_tan=w_tan, trace=True)
+        xo, so, to = O.solve_window(lfs, pfs, x0, T_bl, 10, huber=huber, w_tan=w_tan)
+        assert (sg[0].iterations, sg[0].successful, sg[0].termination) == (so["iterations"], so["successful"], so["termination"])
+        n = so["iterations"]
+        assert n >= 2
+        assert np.abs(tg[0][:n].reshape(n, W8, 6) - np.asarray(to).reshape(-1, W8, 6)[:n]).max() < 1e-9   # bar: 1e-4 per iteration
+        assert np.abs(xg - xo).max() < 1e-9
+        assert np.isclose(sg[0].final_cost, so["final_cost"], rtol=1e-10)
+        # two 4-frame windows in one launch are independent problems
+        xh, sh, _ = c.solve(0, W8, x0, T_bl, window=4, max_iters=10, huber=huber, w_tan=w_tan)
+        for h in range(2):
+            xo4, so4, _ = O.solve_window(lfs[4 * h:4 * h + 4], pfs[4 * h:4 * h + 4], x0[4 * h:4 * h + 4], T_bl, 10, huber=huber, w_tan=w_tan)
+            assert sh[h].iterations == so4["iterations"] and np.abs(xh[4 * h:4 * h + 4] - xo4).max() < 1e-9
+    finally:
+        c.close()
+
+
+def test_window_solve_allgather_world_size_one(M, O, scene):
+    c, lfs, pfs, x0, T_bl = _window8(M, O, scene)
+    try:
+        c.comm_init(1, 0, M.comm_unique_id())
+        assert c.comm_info() == (1, 0)
+        for fixed, huber, w_tan in ((False, 0.0, 3e-4), (True, 0.1 / 1.5e-3, 0.0)):
+            xs, ss, _ = c.solve(0, W8, x0, T_bl, window=W8, max_iters=10, fixed=fixed, huber=huber, w_tan=w_tan)
+            xl, xw, sm, tim = c.window_solve_allgather(0, W8, x0, T_bl, max_iters=10, fixed=fixed, huber=huber, w_tan=w_tan)
+            assert np.array_equal(xw, xs) and np.array_equal(xl, xs)          # the same iteration, bit for bit
+            assert (sm.iterations, sm.successful, sm.termination) == (ss[0].iterations, ss[0].successful, ss[0].termination)
+            assert sm.initial_cost == ss[0].initial_cost and sm.final_cost == ss[0].final_cost
+            assert tim.rounds == 12 and 1 <= tim.evaluations <= 11 and tim.device_ms > 0
+            if fixed:
+                assert sm.iterations == 10 and tim.evaluations == 11
+        # one frame per rank is the 8-GPU layout; with one rank that is the W = 1 problem of slot 3
+        xs, ss, _ = c.solve(3, 1, x0[3:4], T_bl, window=1, max_iters=10, huber=0.0, w_tan=3e-4)
+        xl, xw, sm, tim = c.window_solve_allgather(3, 1, x0[3:4], T_bl, max_iters=10, huber=0.0, w_tan=3e-4)
+        assert np.array_equal(xl, xs) and sm.iterations == ss[0].iterations
+        xo, so, _ = O.solve_window(lfs[3:4], pfs[3:4], x0[3:4], T_bl, 10, huber=0.0, w_tan=3e-4)
+        assert np.abs(xl - xo).max() < 1e-9
+        # broadcasts with a single rank leave everything as it was (and must not hang or fault)
+        f0 = [c.features_download(2, k).copy() for k in (0, 1)]
+        c.comm_broadcast_features(2, 0)
+        c.synchronize()
+        for k in (0, 1):
+            assert np.array_equal(c.features_download(2, k), f0[k])
+        q = scene["frames"][0]["surf"][:64]
+        i0, d0 = c.knn5(1, q)
+        c.comm_broadcast_local_map(0)
+        i1, d1 = c.knn5(1, q)
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+        with pytest.raises(M.MmlError):
+            c.window_solve_allgather(0, 9, np.zeros((9, 6)), T_bl)
+        c.comm_destroy()
+        with pytest.raises(M.MmlError):
+            c.comm_info()
+    finally:
+        c.close()
