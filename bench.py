@@ -1,22 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- scans/s of the mm-loam scan-registration hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): fused VLP-16 (16 x 1800) + Livox Horizon (24 000) scans = 52 800 points,
-local map of 200 000 points, one step = feature extraction + undistortion + down-sampling + one 5-NN association
-pass + 10 trust-region (GN/dogleg) iterations for a batch of B scans whose raw points are already resident in
-HBM.  value = whole-job scans/s.  One process per GPU (torch.distributed / RCCL only for the barrier and the
-max-over-ranks clock; the path shards by scan, no data-path collective: "scaling": "weak").
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): fused VLP-16 (16 x 1800) + Livox
+Horizon (24 000) scans = 52 800 points, local map of 200 000 points; one STEP = feature extraction + undistortion +
+down-sampling + one 5-NN association pass + 10 trust-region (GN / dogleg) iterations for a batch of scans whose raw
+points are already resident in HBM.  value = whole-job scans/s.
 
-Adds to the JSON line:
-  roofline     -- dominant kernel, algorithmic bytes per launch / its mean launch time (HIP events on the library's
-                  own stream, recorded around every launch inside the timed region) against 8 TB/s HBM
-  cpu_baseline -- the CPU oracle (oracle/, a line-by-line port of the reference arithmetic; the reference binary
-                  cannot be built here) timed on this box's host cores over a bounded sample of the same scans
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
+
+  --config 1  BASELINE configs[1] (default; the driver's line)
+  --config 2  BASELINE configs[2]: replay, one scan at a time through the WHOLE odometry loop (upload, extract, undistort,
+              down-sample, Estimate 5 outer x 10 inner, key-scan rule + map upkeep on the device) plus the joint solve of
+              the 8-scan sliding window; value = sustained scans/s next to the 10 Hz bag rate, with per-scan latency
+              percentiles and the B = 1 latency of the configs[1] step
+  --config 3  BASELINE configs[3]: 128 x 2048 scans (262 144 points), 2 M-point map, 10 GN iterations
+  --config 4  BASELINE configs[4]: 240 k-point fused scans, 10 M-point map, 20 GN iterations
+
+One process per GPU.  `--gpus N` with N > 1 spawns the N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) unless
+a launcher (python -m torch.distributed.run ...) already did; torch.distributed (RCCL) carries the barrier and the
+max-over-ranks clock.  The path shards by scan with no data-path collective ("scaling": "weak"); the one real exchange of
+the path -- the joint window solve -- runs through the C-ABI's own RCCL calls (mml_window_solve_allgather) and is
+reported in "window_solve".
+
+Added to the JSON line:
+  roofline     -- dominant kernel: algorithmic bytes per launch / its mean launch time (HIP events on the library's own
+                  stream around every launch of a single-stream pass) against 8 TB/s HBM
+  cpu_baseline -- oracle/bench_cpu (the CPU restatement, pure C++, -O3 -ffp-contract=off; the reference binary cannot be
+                  built here) on this box's host cores over a bounded sample of the same scans: single thread, the
+                  reference's own threading, and one scan per core
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,24 +44,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+BAG_RATE_HZ = 10.0      # mm_lio_full.launch:21 (10 Hz Velodyne, one union message per sweep)
 
 # Algorithmic bytes per unit for every stage (DESIGN.md section "Kernels"): N fused points, F features per scan.
 # The SURVEY 8(d) figures: extraction 20 B/pt in total, undistort 28 B/pt, association 112 B/feature,
 # linearisation 72 B/factor/iteration.  The extraction chain is split over its kernels by what each must move.
 STAGE_BYTES = {
-    "assign_count":     lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l, # k_assign_a: read the raw records, ring id / crop test
-    "assign_scan":      lambda n_v, n_l, nf, it: 0,                   # k_assign_b: block records only
+    "assign_count":     lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l,  # k_assign_a: read the raw records, ring id / crop test
+    "assign_scan":      lambda n_v, n_l, nf, it: 0,                    # k_assign_b: block records only
     "assign_scatter":   lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l + 20 * (n_v + n_l),  # k_assign_c: read again, write xyzi + label slot
-    "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),    # read xyzi of every bucketed point
-    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),    # attr 2 B + 2 order keys 8 B + label 1 B
-    "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),     # write the 4 B label/line/time record
+    "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),     # read xyzi of every bucketed point
+    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),     # attr 2 B + 2 order keys 8 B + label 1 B
+    "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),      # write the 4 B label/line/time record
     "undistort":        lambda n_v, n_l, nf, it: 28 * (n_v + n_l),
-    "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),    # label scan + xyz of labelled points
+    "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),     # label scan + xyz of labelled points
     "associate":        lambda n_v, n_l, nf, it: 112 * nf,
-    "associate_far":    lambda n_v, n_l, nf, it: 0,                   # queue of the few far queries (bytes counted in associate)
-    "associate_fit":    lambda n_v, n_l, nf, it: 0,                   # model fit of the searched features (bytes counted in associate)
+    "associate_far":    lambda n_v, n_l, nf, it: 0,                    # queue of the few far queries (bytes counted in associate)
+    "associate_fit":    lambda n_v, n_l, nf, it: 0,                    # model fit of the searched features (bytes counted in associate)
     "assoc_stats":      lambda n_v, n_l, nf, it: 0,
-    "solve":            lambda n_v, n_l, nf, it: 72 * nf * (it + 1),  # it iterations + the initial linearisation
+    "solve":            lambda n_v, n_l, nf, it: 72 * nf * (it + 1),   # it iterations + the initial linearisation
+}
+
+# BASELINE.json configs[i] -> shapes.  slots = resident scan slots per GPU; scans_per_step = the batch one step processes
+# (the resident slots are passed over scans_per_step / slots times: every pass recomputes everything from the raw points).
+CONFIGS = {
+    1: dict(name="BASELINE configs[1]: fused VLP-16 16x1800 + Livox Horizon 24000 scan (52800 pts)", n_rings=16, n_az=1800,
+            pitch0=-15.0, pitch_step=2.0, livox=24000, map_points=200000, gn_iters=10, slots=2048, scans_per_step=32768,
+            max_features=0, distinct=64),
+    3: dict(name="BASELINE configs[3]: 128-ring x 2048 dense scan (262144 pts)", n_rings=128, n_az=2048, pitch0=-25.0,
+            pitch_step=40.0 / 127.0, livox=0, map_points=2000000, gn_iters=10, slots=128, scans_per_step=512,
+            max_features=1 << 16, distinct=8),
+    4: dict(name="BASELINE configs[4]: 240k-pt fused scan (128 x 1687 + Livox 24000)", n_rings=128, n_az=1687, pitch0=-25.0,
+            pitch_step=40.0 / 127.0, livox=24000, map_points=10000000, gn_iters=20, slots=64, scans_per_step=256,
+            max_features=1 << 16, distinct=8),
 }
 
 
@@ -52,79 +85,240 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2048, help="scans per step per GPU")
-    ap.add_argument("--map-points", type=int, default=200000)
-    ap.add_argument("--gn-iters", type=int, default=10)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="index into BASELINE.json configs")
+    ap.add_argument("--slots", type=int, default=0, help="resident scan slots per GPU (0: the config's default)")
+    ap.add_argument("--batch", type=int, default=0, help="scans per step per GPU (0: the config's default; rounded up to whole passes over the slots)")
+    ap.add_argument("--map-points", type=int, default=0)
+    ap.add_argument("--gn-iters", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic scans cycled through the slots")
+    ap.add_argument("--no-spread", action="store_true", help="keep every scan on the map's original tile (the round-1 layout)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the N > 1 code path)")
-    ap.add_argument("--window-demo", action="store_true", help="run the joint window solve section on one GPU as well")
+    ap.add_argument("--window-demo", action="store_true", help="run the C-ABI / RCCL joint window solve section on one GPU as well")
     ap.add_argument("--kernel-steps", type=int, default=4, help="single-stream steps after the timed region (per-kernel timing)")
-    ap.add_argument("--cpu-scans", type=int, default=-1, help="CPU baseline sample size (-1: auto, 0: skip)")
-    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the scan-parallel CPU leg (-1: all cores up to 64, 0: skip)")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scans cycled through the batch")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="time budget of each CPU-baseline variant (0: skip the CPU leg)")
     ap.add_argument("--cell-corner", type=float, default=0.0, help="kNN grid cell edge for the corner map (0: library default)")
     ap.add_argument("--cell-surf", type=float, default=0.0, help="kNN grid cell edge for the surf map (0: library default)")
+    ap.add_argument("--replay-scans", type=int, default=240, help="--config 2: scans replayed through the odometry loop")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: CPU plumbing test only)")
+    ap.add_argument("--stub-step", action="store_true", help="CPU plumbing test: no device, a step is a short sleep")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    M = importlib.import_module("multi-modal-loam_amd")
-    synth = importlib.import_module("multi-modal-loam_amd.synth")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    B = args.batch
-    ctx = M.Context(max_scans=B, device=local_rank, max_map_points=max(args.map_points, 1 << 16),
-                    cell_corner=args.cell_corner, cell_surf=args.cell_surf)
-    dev_name, cus, hbm = ctx.device_info()
+# ---- launcher ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`bench.py --gpus N` started bare: become the launcher of N ranks on this node (one process per GPU)."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):  # one rank died: do not leave the others in a collective
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+            rc = rc or (p.returncode or 0)
+    return rc
 
-    # ---- synthetic inputs (same on every rank except the seed offset) ---------------------------------------
-    base = 100 + 1000 * rank
-    nd = max(1, min(args.distinct, B))
-    scans = [(synth.velo_scan(base + k, motion=True), synth.livox_scan(base + k, motion=True)) for k in range(nd)]
-    # map: features of the 8 scans preceding the batch (the role of the 50-keyframe local map, Estimator.cpp:1585-1643),
-    # extracted with the product path itself, moved to the world frame with the generating poses, then grown to
-    # --map-points by tiled replication (synth.grow_map)
+
+def pctl(a, q):
+    return float(np.percentile(np.asarray(a, dtype=np.float64), q)) if len(a) else None
+
+
+# ---- CPU plumbing test (tests/test_host.py): the launcher, the rendezvous, the max-over-ranks clock, the JSON line ----
+def run_stub(args, rank, world, dist):
+    import torch
+    B = args.batch or 64
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))  # ranks deliberately unequal: the slowest one sets the clock
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "scans/s (stub step, CPU plumbing test)", "value": world * B * args.steps / elapsed,
+                          "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "stub"}}), flush=True)
+
+
+# ---- workload ---------------------------------------------------------------------------------------------------------
+def make_scan(synth, cfg, k, motion=True):
+    v = synth.velo_scan(k, n_rings=cfg["n_rings"], n_az=cfg["n_az"], pitch0=cfg["pitch0"], pitch_step=cfg["pitch_step"], motion=motion)
+    l = synth.livox_scan(k, n=cfg["livox"], motion=motion) if cfg["livox"] else np.zeros(0, synth.LIVOX_DTYPE)
+    return v, l
+
+
+def make_context(M, cfg, slots, device, args, map_points):
+    nv = cfg["n_rings"] * cfg["n_az"]
+    kw = dict(max_scans=slots, max_velo_points=nv, max_livox_points=max(cfg["livox"], 64), n_rings=cfg["n_rings"],
+              pitch0_deg=cfg["pitch0"], pitch_step_deg=cfg["pitch_step"], max_map_points=max(int(map_points * 1.05), 1 << 16),
+              cell_corner=args.cell_corner, cell_surf=args.cell_surf)
+    if cfg["max_features"]:
+        kw["max_features"] = cfg["max_features"]
+    return M.Context(M.default_config(**kw), device=device)
+
+
+def build_maps(ctx, synth, cfg, base, map_points):
+    """Features of the 8 scans preceding the batch (the role of the 50-keyframe local map, Estimator.cpp:1585-1643),
+    extracted with the product path itself, moved to the world frame with the generating poses, voxel-filtered as the
+    reference filters the merged local map on every update (:1630-1637), then grown to `map_points` by tiled
+    replication (synth.grow_map)."""
     cm, sm = [], []
     for k in range(base - 8, base):
-        ctx.scan_upload(0, synth.velo_scan(k), synth.livox_scan(k))
+        v, l = make_scan(synth, cfg, k, motion=False)
+        ctx.scan_upload(0, v, l)
         ctx.extract(0, 1)
         ctx.undistort(0, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
         ctx.downsample(0, 1)
         T = synth.pose_matrix(k)
         cm.append(synth.transform(T, ctx.features_download(0, 0).astype(np.float64)).astype(np.float32))
         sm.append(synth.transform(T, ctx.features_download(0, 1).astype(np.float64)).astype(np.float32))
-    # the reference voxel-filters the merged local map on every update (Estimator.cpp:1630-1637)
     cm = synth.voxel_filter(np.concatenate(cm), ctx.cfg.leaf_corner)
     sm = synth.voxel_filter(np.concatenate(sm), ctx.cfg.leaf_surf)
-    n_corner_map = max(64, args.map_points // 10)
+    n_corner_map = max(64, map_points // 10)
     corner_map = synth.grow_map(cm, n_corner_map, seed=7)
-    surf_map = synth.grow_map(sm, args.map_points - n_corner_map, seed=8)
+    surf_map = synth.grow_map(sm, map_points - n_corner_map, seed=8)
+    full_tiles = max(1, min(n_corner_map // max(len(cm), 1), (map_points - n_corner_map) // max(len(sm), 1)))
+    return corner_map, surf_map, full_tiles
+
+
+def pinned(a):
+    """Host copy in page-locked memory (the staging a real feeder would use)."""
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.size == 0:
+        return a
+    t = torch.from_numpy(a.view(np.uint8).reshape(-1)).pin_memory()
+    return t.numpy().view(a.dtype).reshape(a.shape)
+
+
+# >>> cpu_baseline leg (the only code that may name the oracle)
+def write_cpu_workload(path, ctx, cfg, scans, dR, dt, x0, corner_map, surf_map, gn_iters, thres):
+    import struct
+    c = ctx.cfg
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", 0x424c4d4d, len(scans), c.n_rings))
+        f.write(struct.pack("<ffff", c.pitch0_deg, c.pitch_step_deg, c.near_th, c.far_th))
+        f.write(struct.pack("<i", c.n_livox_lines))
+        f.write(struct.pack("<ff", c.leaf_corner, c.leaf_surf))
+        f.write(struct.pack("<i", gn_iters))
+        f.write(struct.pack("<d", thres))
+        for k, (v, l) in enumerate(scans):
+            v = np.ascontiguousarray(v, np.float32).reshape(-1, 4)
+            f.write(struct.pack("<i", len(v)))
+            f.write(v.tobytes())
+            f.write(struct.pack("<i", len(l)))
+            f.write(np.ascontiguousarray(l).tobytes())
+            f.write(np.ascontiguousarray(dR[k], np.float64).tobytes())
+            f.write(np.ascontiguousarray(dt[k], np.float64).tobytes())
+            f.write(np.ascontiguousarray(x0[k], np.float64).tobytes())
+        for m in (corner_map, surf_map):
+            m = np.ascontiguousarray(m, np.float32).reshape(-1, 3)
+            f.write(struct.pack("<i", len(m)))
+            f.write(m.tobytes())
+
+
+def cpu_baseline_cpp(ctx, cfg, scans, dR, dt, x0, corner_map, surf_map, gn_iters, thres, seconds, x_gpu):
+    """oracle/bench_cpu on this box's host cores.  The oracle is the checker / reported baseline, never the product."""
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "build", "bench_cpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    n_cpu = min(len(scans), 8)  # kd-tree queries dominate: 8 distinct scans keep the workload file small
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "workload.bin")
+        write_cpu_workload(path, ctx, cfg, scans[:n_cpu], dR, dt, x0, corner_map, surf_map, gn_iters, thres)
+        out = subprocess.run([exe, path, "--single-seconds", str(seconds), "--shaped-seconds", str(seconds), "--parallel-seconds",
+                              str(seconds * 1.5)], capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        return {"error": (out.stderr or out.stdout)[-300:]}
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    poses = np.array(r.pop("poses"))
+    sp = r["scan_parallel"]
+    return {"value": sp["scans_per_s"], "unit": "scans/s", "cores": sp["cores"], "kind": "port",
+            "sample": "%d scans (cycled over %d distinct), one worker process per pinned core for %.0f s; same map / poses / %d fixed "
+                      "iterations as the GPU step, kd-tree build excluded; oracle/bench_cpu, g++ -O3 -ffp-contract=off"
+                      % (sp["scans"], n_cpu, seconds * 1.5, gn_iters),
+            "cpu_model": r["cpu_model"], "host_cores": r["host_cores"], "cgroup_cpu_quota": r.get("cgroup_cpu_quota"),
+            "single_thread": r["single"],
+            "reference_shaped": dict(r["reference_shaped"], layout="6 threads over the Livox lines, rings serial, corner || surf "
+                                                                     "association, 6-thread solve (unionFeatureExtract.cpp:1008-1015,1228-1230; "
+                                                                     "Estimator.cpp:1271-1297,1430)"),
+            "kdtree_build_s": r["kdtree_build_s"], "pose_diff_vs_gpu": float(np.abs(poses - x_gpu[:len(poses)]).max())}
+
+
+# <<< cpu_baseline leg
+
+
+# ---- throughput (configs 1, 3, 4) ---------------------------------------------------------------------------------------
+def run_throughput(args, rank, local_rank, world, dist):
+    import torch
+    from scipy.spatial.transform import Rotation as Rsc
+    M = importlib.import_module("multi-modal-loam_amd")
+    synth = importlib.import_module("multi-modal-loam_amd.synth")
+    cfg = dict(CONFIGS[args.config])
+    B = args.slots or cfg["slots"]
+    batch = args.batch or cfg["scans_per_step"]
+    passes = max(1, (batch + B - 1) // B)
+    batch = passes * B
+    map_points = args.map_points or cfg["map_points"]
+    gn_iters = args.gn_iters or cfg["gn_iters"]
+    ctx = make_context(M, cfg, B, local_rank, args, map_points)
+    dev_name, cus, hbm = ctx.device_info()
+
+    # ---- synthetic inputs (same on every rank except the seed offset) ---------------------------------------
+    base = 100 + 1000 * rank
+    nd = max(1, min(args.distinct or cfg["distinct"], B))
+    scans = [make_scan(synth, cfg, base + k) for k in range(nd)]
+    corner_map, surf_map, full_tiles = build_maps(ctx, synth, cfg, base, map_points)
     ctx.map_set_local(0, corner_map)
     ctx.map_set_local(1, surf_map)
-
-    from scipy.spatial.transform import Rotation as Rsc
+    # The map is the scene tiled on a lattice: unless --no-spread, consecutive groups of slots sit on different tiles
+    # (their initial poses are shifted by the tile offset, the sensor-frame points are what they are), so the
+    # association of a batch touches the whole map, not the one tile around the origin.
+    tiles = synth.tile_offsets(1 if args.no_spread else full_tiles)
     dR = np.zeros((B, 9))
     dt = np.zeros((B, 3))
     x0 = np.zeros((B, 6))
+    gt = np.zeros((B, 3))
     for s in range(B):
         k = s % nd
         ctx.scan_upload(s, scans[k][0], scans[k][1])
         # true motion over the sweep (the scans are simulated with it) and a perturbed initial pose
         mR, mt = synth.sweep_motion(base + k)
         dR[s], dt[s] = mR.reshape(9), mt
+        off = tiles[(s // nd) % len(tiles)]
         Tp = synth.pose_matrix(base + k).copy()
-        Tp[:3, 3] += [0.03, -0.02, 0.01]
+        gt[s] = Tp[:3, 3] + off
+        Tp[:3, 3] += np.array([0.03, -0.02, 0.01]) + off
         Tp[:3, :3] = Tp[:3, :3] @ Rsc.from_rotvec([0.002, -0.001, 0.004]).as_matrix()
         x0[s] = np.concatenate([Tp[:3, 3], Rsc.from_matrix(Tp[:3, :3]).as_rotvec()])
     ctx.synchronize()
@@ -136,172 +330,169 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_step():
+        x = None
+        for _ in range(passes):
+            x = ctx.step(0, B, dR, dt, exTlb, 25.0, gn_iters, x0)
+        return x
+
     for _ in range(args.warmup):
-        ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x = ctx.step(0, B, dR, dt, exTlb, 25.0, args.gn_iters, x0)
+        x = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
     # Per-kernel durations for the roofline object: the timed region overlaps sub-batches on 4 streams, so kernel
     # time there is shared between concurrent kernels.  The same step is therefore repeated on ONE stream (every
     # kernel covers the whole batch and owns the device) with HIP events around each stage on that stream; these
-    # are the launches of grid size `KB scans` in the rocprofv3 summary under profiles/.
-    # The kernel pass runs over KB = min(B, 1024) scans: launches of that size are distinct, in the rocprofv3 summary,
-    # from the timed region's per-lane launches of B / 4 scans.
+    # are the launches of grid size `KB scans` in the rocprofv3 summary under profiles/ (KB = min(B, 1024): distinct,
+    # in that summary, from the timed region's per-lane launches of B / 4 scans).
     KB = min(B, 1024)
     ctx.set_lanes(1)
     ctx.profile_enable(True)
     ctx.profile_reset()
     for _ in range(args.kernel_steps):
-        ctx.step(0, KB, dR[:KB], dt[:KB], exTlb, 25.0, args.gn_iters, x0[:KB])
+        ctx.step(0, KB, dR[:KB], dt[:KB], exTlb, 25.0, gn_iters, x0[:KB])
     prof = ctx.profile_get()
     ctx.profile_enable(False)
+    ctx.set_lanes(4)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # pose sanity: the step must actually have registered the scans
-    gt_err = max(np.abs(x[s][:3] - synth.pose_matrix(base + (s % nd))[:3, 3]).max() for s in range(B))
+    gt_err = float(np.abs(x[:, :3] - gt).max())
 
     # ---- roofline for the dominant kernel ---------------------------------------------------------------------
     info = [ctx.scan_info(s) for s in range(min(B, nd))]
-    # (per kernel-pass launch of KB scans)
     n_v = float(np.mean([i.n_velo for i in info])) * KB
     n_l = float(np.mean([i.n_points - i.n_velo for i in info])) * KB
     nf = float(np.mean([len(ctx.features_download(s, 0)) + len(ctx.features_download(s, 1)) for s in range(min(B, nd))])) * KB
-    stage_ms = {k: v[0] / max(v[1], 1) for k, v in prof.items() if v[1] > 0}
+    # a stage's brackets of one step cover all its kernels over the KB scans: time per step = time per "launch of KB scans"
+    stage_ms = {k: v[0] / max(args.kernel_steps, 1) for k, v in prof.items() if v[1] > 0}
     dom = max(stage_ms, key=stage_ms.get)
-    alg_bytes = STAGE_BYTES.get(dom, lambda *a: 0)(n_v, n_l, nf, args.gn_iters)
+    alg_bytes = STAGE_BYTES.get(dom, lambda *a: 0)(n_v, n_l, nf, gn_iters)
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    tr_file = os.path.join(ROOT, "profiles", "traffic_r02.json" if args.config == 1 else "traffic_r02_config%d.json" % args.config)
     if os.path.exists(tr_file):
         try:
             tr = json.load(open(tr_file))
             traffic = tr.get(dom)
             if traffic is not None:
-                traffic = traffic * KB / float(tr.get("scans_per_launch", 256))
+                traffic = traffic * KB / float(tr.get("scans_per_launch", KB))
         except Exception:
             traffic = None
-    bytes_per_scan = 48 * (n_v + n_l) / KB + 112 * nf / KB + 72 * nf / KB * args.gn_iters
-    total_scans = world * B * args.steps
+    bytes_per_scan = 48 * (n_v + n_l) / KB + 112 * nf / KB + 72 * nf / KB * gn_iters
+    total_scans = world * batch * args.steps
     value = total_scans / elapsed
 
-    # ---- joint window solve across ranks: one frame per GPU, RCCL all-gather of the 32-double
-    # normal-equation record per iteration, every rank advancing the same host-side dogleg state machine.  Outside the
+    # ---- PCIe-inclusive rate: the boundary hands over host buffers (mml_scan_upload) --------------------------------
+    # one pass with every scan of the batch copied in from pinned host memory in front of the step (serial: upload, then
+    # compute); never `value`
+    with_upload = None
+    try:
+        ps = [(pinned(v), pinned(l)) for v, l in scans]
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for s in range(B):
+            ctx.scan_upload(s, ps[s % nd][0], ps[s % nd][1])
+        ctx.synchronize()
+        t_up = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        ctx.step(0, B, dR, dt, exTlb, 25.0, gn_iters, x0)
+        t_st = time.perf_counter() - t1
+        up_bytes = sum(scans[s % nd][0].nbytes + scans[s % nd][1].nbytes for s in range(B))
+        with_upload = {"scans_per_s": B / (t_up + t_st) * world, "upload_GBps": up_bytes / t_up / 1e9,
+                       "upload_ms_per_scan": t_up / B * 1e3, "note": "uploads (pinned host memory, one hipMemcpyAsync per "
+                       "sensor per scan) serialised in front of the step; with uploads overlapped the bound is min(upload, compute)"}
+    except Exception as e:
+        with_upload = {"error": repr(e)[:200]}
+
+    # ---- joint window solve across ranks through the C-ABI: one frame per GPU, ncclAllGather of the
+    # 32-double normal-equation record per evaluation, the dogleg state machine resident on every device.  Outside the
     # timed region; reported next to the sharded throughput because the live path never exchanges data.
     window = None
     if dist is not None or args.window_demo:
         try:
-            if dist is None:
-                import torch.distributed as dist_w
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29577")
-                dist_w.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            W = world
+            if dist is not None:
+                idt = torch.zeros(M.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt = torch.frombuffer(bytearray(M.comm_unique_id()), dtype=torch.uint8).to("cuda")
+                dist.broadcast(idt, src=0)
+                comm_id = bytes(idt.cpu().numpy().tobytes())
             else:
-                dist_w = dist
-            W = dist_w.get_world_size()
-            dev = torch.device("cuda", local_rank)
-            xw = torch.from_numpy(x0[0].copy()).to(dev)
-            xs_all = torch.zeros(W * 6, dtype=torch.float64, device=dev)
-            dist_w.all_gather_into_tensor(xs_all, xw)
-            x_eval = xs_all.cpu().numpy().reshape(W, 6)
-            ws = M.WindowSolver(W, max_iters=args.gn_iters, fixed=False, huber=0.1 / 1.5e-3, w_tan=0.0)
-            rec = torch.zeros(32, dtype=torch.float64, device=dev)
-            recs = torch.zeros(W * 32, dtype=torch.float64, device=dev)
-            torch.cuda.synchronize()
+                comm_id = M.comm_unique_id()
+            ctx.comm_init(W, rank, comm_id)
+            # replicate rank 0's map (what a fleet of pose nodes sharing one map would do), then every rank associates its
+            # own frame (slot 0 still holds the features of the last step) against it
             t1 = time.perf_counter()
-            its = 0
-            while True:
-                ctx.linearize_record(0, x_eval[rank], np.eye(4), rec.data_ptr())   # slot 0 keeps the factors of the last step
-                ctx.synchronize()
-                dist_w.all_gather_into_tensor(recs, rec)
-                done, x_eval = ws.step(recs.cpu().numpy().reshape(W, 32), x_eval)
-                its += 1
-                if done or its > 4 * args.gn_iters:
-                    break
-            torch.cuda.synchronize()
-            t_win = time.perf_counter() - t1
-            chk = torch.from_numpy(x_eval.reshape(-1).copy()).to(dev)
-            ref = chk.clone()
-            dist_w.broadcast(ref, src=0)
-            agree = torch.tensor([1.0 if torch.equal(ref, chk) else 0.0], device=dev)
-            dist_w.all_reduce(agree, op=dist_w.ReduceOp.MIN)
-            sm = ws.summary()
-            window = {"frames": W, "evaluations": its, "iterations": sm.iterations, "termination": sm.termination,
-                      "ms_per_evaluation": t_win / its * 1e3, "ranks_agree_bitwise": bool(agree.item() == 1.0),
-                      "own_frame_err_vs_gt_m": float(np.abs(x_eval[rank][:3] - synth.pose_matrix(base)[:3, 3]).max())}
-            if dist is None:
-                dist_w.destroy_process_group()
+            ctx.comm_broadcast_local_map(0)
+            t_map = time.perf_counter() - t1
+            xm = x0[0].copy()
+            xm[:3] -= tiles[0]
+            Tw = np.eye(4)
+            Tw[:3, :3] = Rsc.from_rotvec(xm[3:]).as_matrix()
+            Tw[:3, 3] = xm[:3]
+            ctx.associate(0, 1, Tw[None], 1.0)
+            res = None
+            lat = []
+            for rep in range(6):
+                res = ctx.window_solve_allgather(0, 1, xm[None], np.eye(4), max_iters=gn_iters, fixed=False, huber=0.0, w_tan=3e-4)
+                lat.append(res[3].device_ms)
+            xl, xw, sm, tim = res
+            chk = torch.from_numpy(xw.reshape(-1).copy()).to("cuda")
+            agree = True
+            if dist is not None:
+                ref = chk.clone()
+                dist.broadcast(ref, src=0)
+                ag = torch.tensor([1.0 if torch.equal(ref, chk) else 0.0], device="cuda")
+                dist.all_reduce(ag, op=dist.ReduceOp.MIN)
+                agree = bool(ag.item() == 1.0)
+            # map-update exchange: rank 0's key scan to every replica
+            t1 = time.perf_counter()
+            ctx.comm_broadcast_features(0, 0)
+            ctx.synchronize()
+            t_feat = time.perf_counter() - t1
+            window = {"frames": W, "path": "C-ABI mml_window_solve_allgather (ncclAllGather on the ctx stream, device-resident dogleg)",
+                      "iterations": sm.iterations, "termination": sm.termination, "evaluations": tim.evaluations,
+                      "rounds": tim.rounds, "device_ms": float(np.median(lat)), "ms_per_evaluation": float(np.median(lat)) / max(tim.rounds, 1),
+                      "ranks_agree_bitwise": agree, "map_broadcast_ms": t_map * 1e3, "feature_broadcast_ms": t_feat * 1e3,
+                      "own_frame_err_vs_gt_m": float(np.abs(xl[0][:3] - synth.pose_matrix(base)[:3, 3]).max())}
+            ctx.comm_destroy()
         except Exception as e:  # never lose the bench line to the demo
             window = {"error": repr(e)[:300]}
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) ----------------------------------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_scans != 0:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import mml_oracle as O
-        O.build()
-        tc, ts = O.KdTree(corner_map), O.KdTree(surf_map)  # map build excluded on both sides
-        T_bl = np.eye(4)
-
-        def cpu_scan(k):
-            v, l = scans[k % nd]
-            ev, el = O.extract_velo(v), O.extract_livox(l)
-            xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
-            rel = np.concatenate([ev["reltime"], el["reltime"]])
-            lab = np.concatenate([ev["label"], el["label"]])
-            und = O.undistort(xyz, rel, dR[k % B].reshape(3, 3), dt[k % B])
-            cf = O.voxel_downsample(und[lab == 1], 0.4)
-            sf = O.voxel_downsample(und[lab == 2], 0.2)
-            xx = x0[k % B]
-            Tw = np.eye(4)
-            Tw[:3, :3] = Rsc.from_rotvec(xx[3:]).as_matrix()
-            Tw[:3, 3] = xx[:3]
-            lf, _ = O.associate_lines(cf, tc, Tw, 25.0)
-            pf, _ = O.associate_planes(sf, ts, Tw, 25.0)
-            xs, _, _ = O.solve_window([lf], [pf], xx[None], T_bl, args.gn_iters, fixed=True)
-            return xs
-
-        t1 = time.perf_counter()
-        xs = cpu_scan(0)
-        one = time.perf_counter() - t1
-        n_cpu = args.cpu_scans if args.cpu_scans > 0 else int(max(8, min(2048, 15.0 / max(one, 1e-3))))
-        t1 = time.perf_counter()
-        for k in range(n_cpu):
-            xs = cpu_scan(k)
-        cpu_t = time.perf_counter() - t1
-        cpu = {"value": n_cpu / cpu_t, "unit": "scans/s", "cores": 1, "kind": "port",
-               "sample": "%d fused 52.8k-pt scans (cycled over %d distinct), same map / poses / 10 fixed iterations, "
-                         "single thread of %d host cores, kd-tree build excluded" % (n_cpu, nd, os.cpu_count()),
-               "pose_diff_vs_gpu": float(np.abs(xs[0] - x[(n_cpu - 1) % B]).max())}
-        # the same port with one scan per host thread (the C++ calls release the GIL): an upper bound for what the
-        # reference's 6-thread layout (unionFeatureExtract.cpp:1008-1015, Estimator.cpp:1271-1297,1430) could reach here
-        if args.cpu_threads != 0:
-            from concurrent.futures import ThreadPoolExecutor
-            nthr = args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64)
-            n_mt = int(max(2 * nthr, min(4096, 10.0 * nthr / max(one, 1e-3))))
-            t1 = time.perf_counter()
-            with ThreadPoolExecutor(nthr) as ex:
-                list(ex.map(cpu_scan, range(n_mt)))
-            mt_t = time.perf_counter() - t1
-            cpu["all_threads"] = {"value": n_mt / mt_t, "unit": "scans/s", "cores": nthr, "sample": "%d scans, one scan per thread" % n_mt}
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            xs = x0.copy()
+            xs[:, :3] -= np.array([tiles[(s // nd) % len(tiles)] for s in range(B)])
+            xg = x.copy()
+            xg[:, :3] -= np.array([tiles[(s // nd) % len(tiles)] for s in range(B)])
+            cpu = cpu_baseline_cpp(ctx, cfg, scans, dR, dt, xs, corner_map, surf_map, gn_iters, 25.0, args.cpu_seconds, xg)
+        except Exception as e:
+            cpu = {"error": repr(e)[:300]}
 
     if rank == 0:
         out = {
-            "metric": "scans/s (feature-extract+kNN+10 GN iters) on 16-ring x1800 + Livox 24k fused cloud",
+            "metric": "scans/s (feature-extract+kNN+%d GN iters) on %s" % (gn_iters, "16-ring x1800 + Livox 24k fused cloud" if args.config == 1 else cfg["name"].split(": ")[1]),
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: fused VLP-16 16x1800 + Livox Horizon 24000 scan (52800 pts), "
-                                   "local map %d pts, 1 association pass (thres_dist 25), %d GN iterations, W=1"
-                                   % (args.map_points, args.gn_iters),
-                       "scans_per_step_per_gpu": B, "distinct_scans": nd, "parallelism": "scan-sharded x%d" % world,
-                       "device": dev_name, "cus": cus, "features_per_scan": nf / KB,
-                       "algorithmic_bytes_per_scan": bytes_per_scan, "max_pose_err_vs_gt_m": float(gt_err)},
+            "config": {"workload": "%s, local map %d pts, 1 association pass (thres_dist 25), %d GN iterations, W=1"
+                                   % (cfg["name"], map_points, gn_iters),
+                       "scans_per_step_per_gpu": batch, "resident_slots": B, "passes_per_step": passes, "distinct_scans": nd,
+                       "map_tiles_touched": len(tiles), "parallelism": "scan-sharded x%d" % world,
+                       "device": dev_name, "cus": cus, "features_per_scan": nf / KB, "points_per_scan": (n_v + n_l) / KB,
+                       "algorithmic_bytes_per_scan": bytes_per_scan, "max_pose_err_vs_gt_m": gt_err,
+                       "timed_region_s": elapsed},
+            "value_with_upload": with_upload,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "avg_launch_ms": stage_ms[dom], "algorithmic_bytes_per_launch": alg_bytes,
@@ -311,10 +502,224 @@ def main():
             "cpu_baseline": cpu,
             "window_solve": window,
         }
-        line = json.dumps(out)
+        return json.dumps(out)
+    return None
+
+
+# ---- configs[2]: replay through the whole odometry loop ----------------------------------------------------------------
+def run_replay(args, rank, local_rank, world, dist):
+    import torch
+    from scipy.spatial.transform import Rotation as Rsc
+    M = importlib.import_module("multi-modal-loam_amd")
+    synth = importlib.import_module("multi-modal-loam_amd.synth")
+    odometry = importlib.import_module("multi-modal-loam_amd.odometry")
+    cfg = dict(CONFIGS[1])
+    W = 8
+    ctx = make_context(M, cfg, W, local_rank, args, 1 << 20)
+    dev_name, cus, hbm = ctx.device_info()
+    n = args.replay_scans
+    k0 = 20 + 2000 * rank
+    scans = [tuple(pinned(a) for a in make_scan(synth, cfg, k0 + i)) for i in range(n)]
+    motions = [synth.sweep_motion(k0 + i) for i in range(n)]
+    T_bl = np.eye(4)
+
+    def perturbed(T, dt_=(0.02, -0.015, 0.01), rv=(0.002, -0.001, 0.003)):
+        T2 = T.copy()
+        T2[:3, :3] = T[:3, :3] @ Rsc.from_rotvec(rv).as_matrix()
+        T2[:3, 3] = T[:3, 3] + np.asarray(dt_)
+        return T2
+
+    def replay(timed):
+        odo = odometry.LidarOdometry(ctx, lidar_mode=2)
+        poses = {}
+        lat, lat_win = [], []
+        T_prev = T_prev_gt = None
+        worst_gt = 0.0
+        t_all = time.perf_counter()
+        for i in range(n):
+            k = k0 + i
+            T_gt = synth.pose_matrix(k)
+            # prediction: previous estimate advanced by the true relative motion plus an IMU-sized error
+            Tp = T_gt.copy() if T_prev is None else perturbed(T_prev @ np.linalg.inv(T_prev_gt) @ T_gt)
+            slot = i % W
+            t1 = time.perf_counter()
+            ctx.scan_upload(slot, scans[i][0], scans[i][1])
+            ctx.extract(slot, 1)
+            ctx.undistort(slot, 1, motions[i][0].reshape(1, 9), motions[i][1].reshape(1, 3))
+            P, Q, grew = odo.estimate_lidar_pose(slot, Tp[:3, 3], Rsc.from_matrix(Tp[:3, :3]).as_quat())
+            T = np.eye(4)
+            T[:3, :3] = Rsc.from_quat(Q).as_matrix()
+            T[:3, 3] = P
+            poses[slot] = T
+            t2 = time.perf_counter()
+            if i + 1 >= W and odo.n_surf_local > 100:
+                # the 8-scan sliding window: every frame re-associated at its current pose (thres_dist 1, full-window
+                # weights, Estimator.cpp:1203-1204) and solved jointly on the device
+                Tw = np.stack([poses[s] for s in range(W)])
+                ctx.associate(0, W, Tw, 1.0)
+                xw = np.stack([np.concatenate([Tw[s][:3, 3], Rsc.from_matrix(Tw[s][:3, :3]).as_rotvec()]) for s in range(W)])
+                xs, _, _ = ctx.solve(0, W, xw, T_bl, window=W, max_iters=10, huber=0.0, w_tan=3e-4)
+                for s in range(W):
+                    poses[s][:3, :3] = Rsc.from_rotvec(xs[s][3:]).as_matrix()
+                    poses[s][:3, 3] = xs[s][:3]
+                T = poses[slot]
+            t3 = time.perf_counter()
+            lat.append((t3 - t1) * 1e3)
+            lat_win.append((t3 - t2) * 1e3)
+            if i > 0:
+                worst_gt = max(worst_gt, float(np.abs(T[:3, 3] - T_gt[:3, 3]).max()))
+            T_prev, T_prev_gt = T, T_gt
+        total = time.perf_counter() - t_all
+        return dict(total=total, lat=lat, lat_win=lat_win, worst_gt=worst_gt, key_scans=odo.key_scans,
+                    map=(odo.n_corner_local, odo.n_surf_local))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    replay(False)  # warm-up pass (allocations of the map upkeep, code objects)
+    barrier()
+    r = replay(True)
+    barrier()
+    elapsed = r["total"]
     if dist is not None:
-        dist.destroy_process_group()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    hz = world * n / elapsed
+
+    # B = 1 latency of the configs[1] step against the replay's final map, and of the W = 8 joint solve alone
+    dR1, dt1 = motions[-1][0].reshape(1, 9), motions[-1][1].reshape(1, 3)
+    x1 = np.concatenate([synth.pose_matrix(k0 + n - 1)[:3, 3] + [0.03, -0.02, 0.01],
+                         Rsc.from_matrix(synth.pose_matrix(k0 + n - 1)[:3, :3]).as_rotvec()])[None]
+    lat1 = []
+    for it in range(220):
+        t1 = time.perf_counter()
+        ctx.step((n - 1) % W, 1, dR1, dt1, np.eye(4), 25.0, 10, x1)
+        if it >= 20:
+            lat1.append((time.perf_counter() - t1) * 1e3)
+    # stage times of the same B = 1 step (HIP events)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(20):
+        ctx.step((n - 1) % W, 1, dR1, dt1, np.eye(4), 25.0, 10, x1)
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    stage_ms = {k: v[0] / 20.0 for k, v in prof.items() if v[1] > 0}
+    dom = max(stage_ms, key=stage_ms.get)
+    info = ctx.scan_info((n - 1) % W)
+    nf = len(ctx.features_download((n - 1) % W, 0)) + len(ctx.features_download((n - 1) % W, 1))
+    alg = STAGE_BYTES.get(dom, lambda *a: 0)(info.n_velo, info.n_points - info.n_velo, nf, 10)
+
+    # >>> cpu_baseline leg: the same loop through the oracle on one host core, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import mml_oracle as O
+            O.build()
+            lm = O.LocalMap(window=50, leaf_corner=ctx.cfg.leaf_corner, leaf_surf=ctx.cfg.leaf_surf)
+            last_update = np.array([-1.0, -1.0, -1.0])
+            T_prev = T_prev_gt = None
+            t1 = time.perf_counter()
+            done = 0
+            for i in range(n):
+                k = k0 + i
+                T_gt = synth.pose_matrix(k)
+                Tp = T_gt.copy() if T_prev is None else perturbed(T_prev @ np.linalg.inv(T_prev_gt) @ T_gt)
+                ev, el = O.extract_velo(scans[i][0]), O.extract_livox(scans[i][1])
+                xyz = np.concatenate([ev["xyzi"][:, :3], el["xyzi"][:, :3]])
+                rel = np.concatenate([ev["reltime"], el["reltime"]])
+                lab = np.concatenate([ev["label"], el["label"]])
+                und = O.undistort(xyz, rel, motions[i][0], motions[i][1])
+                cf, sf = O.voxel_downsample(und[lab == 1], 0.4), O.voxel_downsample(und[lab == 2], 0.2)
+                Po, Qo = Tp[:3, 3].copy(), Rsc.from_matrix(Tp[:3, :3]).as_quat()
+                cmap, smap = lm.get(0), lm.get(1)
+                deg = False
+                if len(cmap) > 0 and len(smap) > 100:
+                    Po, Qo, _, deg, _ = O.estimate_single(cf, sf, cmap, smap, np.eye(4), Po, Qo, 5, 10)
+                T = np.eye(4)
+                T[:3, :3] = Rsc.from_quat(Qo).as_matrix()
+                T[:3, 3] = Po
+                if not deg:
+                    d = last_update - T[:3, 3]
+                    if float(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) >= 0.5:
+                        lm.increment(cf, sf, T)
+                        last_update = T[:3, 3].copy()
+                T_prev, T_prev_gt = T, T_gt
+                done += 1
+                if time.perf_counter() - t1 > 3 * args.cpu_seconds:
+                    break
+            t_cpu = time.perf_counter() - t1
+            cpu = {"value": done / t_cpu, "unit": "scans/s", "cores": 1, "kind": "port",
+                   "sample": "first %d scans of the same replay through the oracle (extract, undistort, down-sample, "
+                             "Estimate 5 x 10 incl. the kd-tree rebuilds the reference does on every call, key-scan rule, "
+                             "MapIncrementLocal), one host thread of %d, Python glue between the C++ calls; no 8-scan window"
+                             % (done, os.cpu_count())}
+        except Exception as e:
+            cpu = {"error": repr(e)[:300]}
+    # <<< cpu_baseline leg
+
     if rank == 0:
+        out = {
+            "metric": "scans/s sustained (full odometry loop incl. upload + 8-scan window solve), one scan at a time",
+            "value": hz, "unit": "scans/s", "n_gpus": world, "steps": n, "warmup": n,
+            "ms_per_step": elapsed / n * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32/f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: replay of %d fused 52.8k-pt scans (synthetic room, the office bag is not "
+                                   "available offline) through EstimateLidarPose (5 outer x 10 inner) with the local map grown on the "
+                                   "device, plus the joint solve of the 8-scan sliding window after every scan" % n,
+                       "window": W, "device": dev_name, "cus": cus, "bag_rate_hz": BAG_RATE_HZ,
+                       "headroom_vs_bag_rate": hz / world / BAG_RATE_HZ, "key_scans": r["key_scans"], "local_map_points": list(r["map"]),
+                       "max_pose_err_vs_gt_m": r["worst_gt"], "timed_region_s": elapsed},
+            "latency_ms": {"per_scan_p50": pctl(r["lat"], 50), "per_scan_p99": pctl(r["lat"], 99), "per_scan_max": float(np.max(r["lat"])),
+                           "window8_part_p50": pctl(r["lat_win"][W:], 50), "window8_part_p99": pctl(r["lat_win"][W:], 99),
+                           "configs1_step_B1_p50": pctl(lat1, 50), "configs1_step_B1_p99": pctl(lat1, 99)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg / (stage_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": alg / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "avg_launch_ms": stage_ms[dom], "algorithmic_bytes_per_launch": alg, "scans_per_launch": 1,
+                         "timing": "HIP events, 20 one-scan steps", "stage_ms_per_launch": stage_ms,
+                         "note": "one scan per launch cannot fill 256 CUs: this mode is bound by launch latency and the serial "
+                                 "dependency chain, not by HBM"},
+            "cpu_baseline": cpu,
+        }
+        return json.dumps(out)
+    return None
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    line = None
+    try:
+        if args.stub_step:
+            run_stub(args, rank, world, dist)
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+            line = run_replay(args, rank, local_rank, world, dist) if args.config == 2 else run_throughput(args, rank, local_rank, world, dist)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
+    if rank == 0 and line is not None:
         sys.stdout.flush()
         print(line, flush=True)  # the one JSON line, after anything the collectives library may have printed
 

@@ -154,7 +154,8 @@ int mml_scan_download(mml_ctx* ctx, int slot, float* xyzi, float* reltime, uint8
 
 /* Unit-level twin of feature_extraction::detectFeaturePoints (unionFeatureExtract.cpp:341-343) for one
  * scan line: pts = n x (x,y,z,intensity) on the host; sharp / flat receive indices into the line
- * (capacity n each); flags (optional, n ints) receives CloudFeatureFlag[]. */
+ * (capacity n each); flags (optional, n ints) receives CloudFeatureFlag[].  Runs in the buffers of scan slot 0:
+ * whatever mml_extract / mml_cloud_upload left in slot 0 (fused cloud, labels, scan info) is invalid afterwards. */
 int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sharp, int* flat, int* n_flat,
                     int* flags);
 
@@ -162,7 +163,11 @@ int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sh
  * In place on the fused cloud of each slot.  dR: count x 9, dt: count x 3 (host). Sets reltime to 1. */
 int mml_undistort(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt);
 
-/* ---- a10: label split + pcl::VoxelGrid down-sample (Estimator.cpp:992-1026) ---------------------- */
+/* ---- a10: label split + pcl::VoxelGrid down-sample (Estimator.cpp:992-1026) ----------------------
+ * Any number of labelled points per slot (up to 8192 per kind are sorted in LDS, denser clouds take a global-sort
+ * path); the output stacks hold at most max_features voxels per kind (MML_ERR_CAPACITY at the next read-back
+ * otherwise).  Not reproduced: PCL's refusal to filter when the voxel grid of a cloud has more than 2^31 cells (it
+ * returns the input unfiltered; needs e.g. a 100 m cloud at 5 cm leaves). */
 int mml_downsample(mml_ctx* ctx, int first_slot, int count);
 /* kind: 0 corner (laserCloudCornerStack), 1 surf (laserCloudSurfStack). xyz: 3 floats per feature. */
 int mml_features_download(mml_ctx* ctx, int slot, int kind, float* xyz, int capacity, int* n);
@@ -251,12 +256,14 @@ typedef struct {
 typedef struct {
     int iterations, successful;
     double initial_cost, final_cost;
-    int termination;         /* 0 max iterations, 1 gradient, 2 parameter, 3 function tolerance */
+    int termination;         /* 0 max iterations, 1 gradient, 2 parameter, 3 function tolerance, 4 failure (5 consecutive
+                                invalid steps: the poses are handed back as they came in, as Solver::Solve does) */
 } mml_solve_summary;
 /* ceres::Solve replacement (Estimator.cpp:1425-1432): trust-region dogleg on the device, one problem per
  * window of `window` consecutive slots (window = 1: the reference's live 1-frame mode).  x: count x 6
  * in/out; summaries: count / window entries (may be NULL); trace (may be NULL): per problem
- * max_num_iterations x (6*window) doubles, x after every iteration. */
+ * max_num_iterations x (6*window) doubles, x after every iteration (rows past summaries[p].iterations repeat the
+ * final x). */
 int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double* T_bl,
               const mml_solve_opts* opts, double* x, mml_solve_summary* summaries, double* trace);
 

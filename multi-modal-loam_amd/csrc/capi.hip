@@ -83,7 +83,9 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1],
                     ctx->ring[0],  ctx->ring[1],  ctx->ring_cat, ctx->vox_flag, ctx->wire_stage, ctx->gs_pts[0], ctx->gs_pts[1], ctx->gs_tag[0],
                     ctx->gs_tag[1], ctx->gs_pts2[0], ctx->gs_pts2[1], ctx->gs_tag2[0], ctx->gs_tag2[1], ctx->gp_pts[0],
-                    ctx->gp_pts[1], ctx->gs_work, ctx->gs_keys};
+                    ctx->gp_pts[1], ctx->gs_work, ctx->gs_keys, ctx->seg_keys, ctx->seg_vals, ctx->seg_cat, ctx->seg_flag, ctx->seg_meta,
+                    ctx->seg_tmp[0], ctx->seg_tmp[1], ctx->seg_tmp[2], ctx->seg_tmp[3], ctx->seg_tmp[4], ctx->seg_tmp[5],
+                    ctx->seg_tmp[6], ctx->seg_tmp[7]};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -120,9 +122,10 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ctx->L = cfg->n_rings + cfg->n_livox_lines;
     ctx->MF = ctx->cfg.max_features;
     ctx->MM = ctx->cfg.max_map_points;
-    // label lists per (slot, kind): 8192 entries feed the LDS sort of k_voxel; scans beyond 64k points (e.g. 128 x 2048
-    // rings) list every point and take the global-sort filter (mml_downsample_big)
-    ctx->VX_CAP = ctx->NT > 65536 ? (int)ctx->NT : 8192;
+    // label lists per (slot, kind) hold every labelled point (8 B x NT per slot): up to MML_VOXEL_LDS_CAP of them feed
+    // the LDS sort of k_voxel, denser labelled clouds and scans beyond 64k points (e.g. 128 x 2048 rings) take the
+    // global-sort filter (mml_downsample_big)
+    ctx->VX_CAP = (int)ctx->NT;
     ctx->h_n_in.assign((size_t)ctx->B * 2, 0);
     auto fail = [&](hipError_t e, const char* what) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -528,7 +531,10 @@ int mml_undistort(mml_ctx* ctx, int first_slot, int count, const double* dR, con
 
 int mml_downsample(mml_ctx* ctx, int first_slot, int count) {
     CHECK_SLOTS(first_slot, count);
-    return mml_launch_downsample(ctx, first_slot, count);
+    int rc = mml_launch_downsample(ctx, first_slot, count);
+    if (rc != MML_OK) return rc;
+    // pcl::VoxelGrid takes a cloud of any size: slots whose labelled cloud is beyond the LDS sort are redone
+    return mml_downsample_redo_overflow(ctx, first_slot, count, nullptr);
 }
 
 int mml_features_download(mml_ctx* ctx, int slot, int kind, float* xyz, int capacity, int* n) {
@@ -1075,9 +1081,55 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     int rs = mml_sync_all(ctx);
     if (rc != MML_OK) return rc;
     if (rs != MML_OK) return rs;
-    for (int i = 0; i < 2 * count; ++i)
-        MML_REQUIRE(h_ftn[i] >= 0, MML_ERR_CAPACITY, "down-sample overflowed max_features / the voxel sort capacity");
-    memcpy(x_inout, h_x, sizeof(double) * 6 * (size_t)count);
+    // A negative stack size is the down-sampler's overflow mark.  Slots whose labelled cloud is merely too dense for the
+    // LDS sort are redone through the global-sort filter and re-registered one by one (rare: > 8192 corner- or
+    // surf-labelled points in one scan); a slot that exceeds max_features stays failed.  Either way every other slot of
+    // the batch gets its pose, and a failed slot keeps the pose it came with.
+    std::vector<int> bad;
+    for (int i = 0; i < count; ++i)
+        if (h_ftn[i] < 0 || h_ftn[count + i] < 0) bad.push_back(i);
+    std::vector<char> failed((size_t)count, 0);
+    for (int i : bad) {
+        std::vector<int> redone;
+        rc = mml_downsample_redo_overflow(ctx, first_slot + i, 1, &redone);
+        bool ok = rc == MML_OK && !redone.empty();
+        if (ok) {
+            int fn[2] = {-1, -1};  // (on the ctx stream: the lanes are non-blocking streams, the null stream does not order with them)
+            if (hipMemcpyAsync(&fn[0], ctx->ft_n + first_slot + i, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)) != hipSuccess ||
+                hipMemcpyAsync(&fn[1], ctx->ft_n + ctx->B + first_slot + i, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)) != hipSuccess ||
+                hipStreamSynchronize(MML_STREAM(ctx)) != hipSuccess)
+                return MML_ERR_HIP;
+            ok = fn[0] >= 0 && fn[1] >= 0;
+        }
+        if (ok) {
+            double q[4], T1[16];
+            so3_exp_h(x_inout + 6 * (size_t)i + 3, q);
+            pose_to_Twl(q, x_inout + 6 * (size_t)i, T_bl, T1);
+            rc = mml_associate(ctx, first_slot + i, 1, T1, thres_dist, nullptr);
+            if (rc != MML_OK) return rc;
+            double xs[6];
+            memcpy(xs, x_inout + 6 * (size_t)i, sizeof(xs));
+            rc = mml_solve(ctx, first_slot + i, 1, 1, T_bl, &so, xs, nullptr, nullptr);
+            if (rc != MML_OK) return rc;
+            memcpy(h_x + 6 * (size_t)i, xs, sizeof(xs));
+        } else {
+            failed[i] = 1;
+        }
+    }
+    int n_failed = 0, first_failed = -1;
+    for (int i = 0; i < count; ++i) {
+        if (failed[i]) {
+            if (first_failed < 0) first_failed = first_slot + i;
+            ++n_failed;
+            continue;
+        }
+        memcpy(x_inout + 6 * (size_t)i, h_x + 6 * (size_t)i, sizeof(double) * 6);
+    }
+    if (n_failed) {
+        ctx->err = "down-sample overflowed max_features in " + std::to_string(n_failed) + " slot(s), first: slot " +
+                   std::to_string(first_failed) + " (the other slots' poses were returned)";
+        return MML_ERR_CAPACITY;
+    }
     return MML_OK;
 }
 

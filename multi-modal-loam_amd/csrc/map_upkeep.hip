@@ -148,6 +148,18 @@ int ensure_tmp(mml_ctx* ctx, size_t need) {
     return MML_OK;
 }
 
+// rocPRIM temporary storage of the current stream lane (lanes run concurrently: no sharing)
+int ensure_tmp_lane(mml_ctx* ctx, size_t need) {
+    const int l = ctx->cur;
+    if (need > ctx->seg_tmp_bytes[l]) {
+        MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+        if (ctx->seg_tmp[l]) MML_HIP(hipFree(ctx->seg_tmp[l]));
+        MML_HIP(hipMalloc(&ctx->seg_tmp[l], need));
+        ctx->seg_tmp_bytes[l] = need;
+    }
+    return MML_OK;
+}
+
 // pcl::VoxelGrid over `m` device points; the filtered cloud goes to `out` (capacity cap), its size to *h_n
 int voxel_filter_device(mml_ctx* ctx, const float4* pts, int m, float leaf, float4* out, int cap, int* h_n) {
     hipStream_t s = MML_STREAM(ctx);
@@ -204,32 +216,239 @@ int ensure_vox_scratch(mml_ctx* ctx, size_t pts) {
 }
 }  // namespace
 
-// a10 for scans whose labelled clouds do not fit the LDS sort of k_voxel (max_velo_points + max_livox_points > 65536,
-// e.g. 128 x 2048 rings): the same filter through the global radix sort, one (slot, kind) at a time.
+// ---- a10 for labelled clouds beyond the LDS sort of k_voxel: the whole batch through ONE global sort --------------------
+// Segment = (slot, kind).  The labelled points of every segment are gathered into one array, keyed by
+// (segment << 32 | PCL voxel index in the segment's own grid), sorted by one stable rocPRIM radix sort (a voxel's points
+// stay in input order = the order the oracle sums them in), and one lane per voxel writes the centroid to its slot's
+// stack.  One 4-byte read-back (the number of labelled points in the batch) is the only host round trip.
+namespace {
+struct SegParams {
+    int first, count, B, NT, MF, list_stride;
+    float leaf_corner, leaf_surf;
+    const int* fu_info;
+    const float4* fu_xyzi;
+    const unsigned* lists;
+    int* seg_off;     // 2 * count + 1
+    int* seg_bbox;    // 2 * count x 6 order-preserving int keys
+    float4* cat;      // gathered points
+    unsigned long long* keys;
+    unsigned* vals;
+    float4* ft0;
+    float4* ft1;
+    int* ft_n;
+};
+
+__global__ void k_seg_prefix(SegParams P, int* total) {
+    __shared__ int s_run;
+    const int nseg = 2 * P.count;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    // few thousand segments at most: a serial scan by one lane is a few microseconds
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int g = 0; g < nseg; ++g) {
+            const int b = P.first + (g >> 1), kind = g & 1;
+            P.seg_off[g] = run;
+            run += P.fu_info[8 * b + 6 + kind];
+        }
+        P.seg_off[nseg] = run;
+        *total = run;
+    }
+    for (int i = threadIdx.x; i < 6 * nseg; i += blockDim.x)
+        P.seg_bbox[i] = (i % 6) < 3 ? 0x7f800000 : ((int)0xff800000 ^ 0x7fffffff);  // +inf, key(-inf)
+}
+
+// grid (blocks, segment): gather the labelled points and reduce the segment's bounding box
+__global__ void k_seg_gather_bbox(SegParams P) {
+    __shared__ float s[6][4];
+    const int g = blockIdx.y, b = P.first + (g >> 1), kind = g & 1;
+    const int n = P.fu_info[8 * b + 6 + kind], off = P.seg_off[g];
+    const unsigned* list = P.lists + ((size_t)b * 2 + kind) * P.list_stride;
+    const float4* px = P.fu_xyzi + (size_t)b * P.NT;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = px[list[i]];
+        P.cat[off + i] = p;
+        mn[0] = fminf(mn[0], p.x);
+        mn[1] = fminf(mn[1], p.y);
+        mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x);
+        mx[1] = fmaxf(mx[1], p.y);
+        mx[2] = fmaxf(mx[2], p.z);
+    }
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+        if (lane == 0) {
+            s[c][wave] = mn[c];
+            s[3 + c][wave] = mx[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float v = s[c][0];
+        for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, s[c][w]) : fmaxf(v, s[c][w]);
+        const int iv = __float_as_int(v);
+        const int key = iv >= 0 ? iv : (iv ^ 0x7fffffff);
+        if (c < 3)
+            atomicMin(P.seg_bbox + 6 * g + c, key);
+        else
+            atomicMax(P.seg_bbox + 6 * g + c, key);
+    }
+}
+
+__global__ void k_seg_keys(SegParams P) {
+    const int g = blockIdx.y, kind = g & 1;
+    const int off = P.seg_off[g], n = P.seg_off[g + 1] - off;
+    const float leaf = kind == 0 ? P.leaf_corner : P.leaf_surf;
+    const float inv = 1.0f / leaf;
+    int min_b[3], div_b[3];
+    for (int c = 0; c < 3; ++c) {
+        min_b[c] = static_cast<int>(floor(unkey(P.seg_bbox[6 * g + c]) * inv));
+        const int max_b = static_cast<int>(floor(unkey(P.seg_bbox[6 * g + 3 + c]) * inv));
+        div_b[c] = max_b - min_b[c] + 1;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = P.cat[off + i];
+        const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
+        const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
+        const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
+        const unsigned vox = (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
+        P.keys[off + i] = ((unsigned long long)g << 32) | vox;
+        P.vals[off + i] = (unsigned)(off + i);
+    }
+}
+
+__global__ void k_seg_heads(const unsigned long long* keys, int m, int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// one lane per voxel; the lane of a segment's first voxel also publishes the segment's voxel count
+__global__ void k_seg_centroid(SegParams P, const unsigned long long* keys, const unsigned* vals, const int* flag, const int* pos, int m) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m || !flag[s]) return;
+    const unsigned long long key = keys[s];
+    const int g = (int)(key >> 32), b = P.first + (g >> 1), kind = g & 1;
+    const int off = P.seg_off[g], end = P.seg_off[g + 1];
+    const int dst = pos[s] - pos[off];
+    if (s == off) {
+        const int nvox = (end < m ? pos[end] : pos[m - 1] + flag[m - 1]) - pos[off];
+        P.ft_n[kind * P.B + b] = nvox > P.MF ? -1 : nvox;
+    }
+    if (dst >= P.MF) return;
+    float sx = 0, sy = 0, sz = 0;
+    int e = s;
+    while (e < m && keys[e] == key) {
+        const float4 p = P.cat[vals[e]];
+        sx += p.x;
+        sy += p.y;
+        sz += p.z;
+        ++e;
+    }
+    const float c = static_cast<float>(e - s);
+    (kind == 0 ? P.ft0 : P.ft1)[(size_t)b * P.MF + dst] = make_float4(sx / c, sy / c, sz / c, 0.f);
+}
+
+__global__ void k_seg_empty(SegParams P) {  // segments without labelled points have an empty stack
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 2 * P.count) return;
+    if (P.seg_off[g + 1] == P.seg_off[g]) P.ft_n[(g & 1) * P.B + P.first + (g >> 1)] = 0;
+}
+}  // namespace
+
 int mml_downsample_big(mml_ctx* ctx, int first, int count) {
     hipStream_t s = MML_STREAM(ctx);
-    std::vector<int> info(8 * (size_t)count);
+    const int nseg = 2 * count;
+    // scratch for the worst case (every point of every slot labelled), allocated on first use
+    const size_t cap = (size_t)ctx->B * ctx->NT;
+    if (!ctx->seg_keys) {
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_keys), sizeof(unsigned long long) * 2 * cap));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_vals), sizeof(unsigned) * 2 * cap));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_cat), sizeof(float4) * cap));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_flag), sizeof(int) * 2 * (cap + 1)));
+        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_meta), sizeof(int) * (8 * (size_t)ctx->B * 2 + 16) * mml_ctx::MAX_LANES));
+    }
+    // lanes work on disjoint slot ranges: each gets the part of the scratch that its slots' points can fill
+    const size_t base = (size_t)first * ctx->NT;
+    SegParams P;
+    P.first = first;
+    P.count = count;
+    P.B = ctx->B;
+    P.NT = ctx->NT;
+    P.MF = ctx->MF;
+    P.list_stride = ctx->VX_CAP;
+    P.leaf_corner = ctx->cfg.leaf_corner;
+    P.leaf_surf = ctx->cfg.leaf_surf;
+    P.fu_info = ctx->fu_info;
+    P.fu_xyzi = ctx->fu_xyzi;
+    P.lists = reinterpret_cast<const unsigned*>(ctx->vx_keys);
+    int* meta = ctx->seg_meta + (size_t)ctx->cur * (8 * (size_t)ctx->B * 2 + 16);
+    P.seg_off = meta + 8;
+    P.seg_bbox = meta + 8 + (2 * (size_t)ctx->B + 8);
+    int* d_total = meta;
+    P.cat = ctx->seg_cat + base;
+    P.keys = ctx->seg_keys + base;
+    P.vals = ctx->seg_vals + base;
+    unsigned long long* keys2 = ctx->seg_keys + cap + base;
+    unsigned* vals2 = ctx->seg_vals + cap + base;
+    int* flag = ctx->seg_flag + base;
+    int* pos = ctx->seg_flag + (cap + 1) + base;
+    P.ft0 = ctx->ft_xyz[0];
+    P.ft1 = ctx->ft_xyz[1];
+    P.ft_n = ctx->ft_n;
+    hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(256), 0, s, P, d_total);
+    int total = 0;
+    MML_HIP(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
+    // (the gather does not depend on the read-back: it runs while the host waits for `total`)
+    const int gblocks = (ctx->NT / 4 + 255) / 256 > 0 ? (ctx->NT / 4 + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_seg_gather_bbox, dim3(gblocks, nseg), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_seg_keys, dim3(gblocks, nseg), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_seg_empty, dim3((nseg + 255) / 256), dim3(256), 0, s, P);
+    MML_HIP(hipStreamSynchronize(s));
+    MML_REQUIRE(total >= 0 && (size_t)total <= (size_t)count * ctx->NT, MML_ERR_STATE, "labelled-point counts of the slots are inconsistent");
+    if (total == 0) return MML_OK;
+    int seg_bits = 1;
+    while ((1 << seg_bits) < nseg) ++seg_bits;
+    size_t need = 0;
+    MML_HIP(rocprim::radix_sort_pairs(nullptr, need, P.keys, keys2, P.vals, vals2, (size_t)total, 0, 32 + seg_bits, s));
+    int rc = ensure_tmp_lane(ctx, need);
+    if (rc != MML_OK) return rc;
+    MML_HIP(rocprim::radix_sort_pairs(ctx->seg_tmp[ctx->cur], need, P.keys, keys2, P.vals, vals2, (size_t)total, 0, 32 + seg_bits, s));
+    const int blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_seg_heads, dim3(blocks), dim3(256), 0, s, keys2, total, flag);
+    need = 0;
+    MML_HIP(rocprim::exclusive_scan(nullptr, need, flag, pos, 0, (size_t)total, rocprim::plus<int>(), s));
+    rc = ensure_tmp_lane(ctx, need);
+    if (rc != MML_OK) return rc;
+    MML_HIP(rocprim::exclusive_scan(ctx->seg_tmp[ctx->cur], need, flag, pos, 0, (size_t)total, rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_seg_centroid, dim3(blocks), dim3(256), 0, s, P, keys2, vals2, flag, pos, total);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
+// Slots of [first, first + count) that k_voxel marked with ft_n = -1 because a labelled cloud exceeds its LDS sort:
+// redone one by one through the global-sort filter.  Synchronises the stream (the marks are read back).  A slot whose
+// overflow is a real capacity limit (more voxels than max_features) keeps its mark.
+int mml_downsample_redo_overflow(mml_ctx* ctx, int first, int count, std::vector<int>* redone) {
+    if (ctx->NT > 65536) return MML_OK;  // those contexts took the global-sort path to begin with
+    hipStream_t s = MML_STREAM(ctx);
+    std::vector<int> n0(count), n1(count), info(8 * (size_t)count);
+    MML_HIP(hipMemcpyAsync(n0.data(), ctx->ft_n + first, sizeof(int) * count, hipMemcpyDeviceToHost, s));
+    MML_HIP(hipMemcpyAsync(n1.data(), ctx->ft_n + ctx->B + first, sizeof(int) * count, hipMemcpyDeviceToHost, s));
     MML_HIP(hipMemcpyAsync(info.data(), ctx->fu_info + 8 * (size_t)first, sizeof(int) * info.size(), hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));
-    int rc = ensure_vox_scratch(ctx, (size_t)ctx->NT);
-    if (rc != MML_OK) return rc;
-    const unsigned* lists = reinterpret_cast<const unsigned*>(ctx->vx_keys);
     for (int c = 0; c < count; ++c) {
-        const int b = first + c;
-        for (int kind = 0; kind < 2; ++kind) {
-            const int n = info[8 * c + 6 + kind];
-            MML_REQUIRE(n <= ctx->VX_CAP && n <= ctx->MM, MML_ERR_CAPACITY, "labelled cloud larger than the voxel scratch");
-            int m = 0;
-            if (n) {
-                hipLaunchKernelGGL(k_gather_list, dim3((n + 255) / 256), dim3(256), 0, s, ctx->fu_xyzi + (size_t)b * ctx->NT,
-                                   lists + ((size_t)b * 2 + kind) * ctx->VX_CAP, n, ctx->ring_cat);
-                rc = voxel_filter_device(ctx, ctx->ring_cat, n, kind == 0 ? ctx->cfg.leaf_corner : ctx->cfg.leaf_surf,
-                                         ctx->ft_xyz[kind] + (size_t)b * ctx->MF, ctx->MF, &m);
-                if (rc != MML_OK) return rc;
-            }
-            MML_HIP(hipMemcpyAsync(ctx->ft_n + kind * ctx->B + b, &m, sizeof(int), hipMemcpyHostToDevice, s));
-            MML_HIP(hipStreamSynchronize(s));
-        }
+        if (n0[c] >= 0 && n1[c] >= 0) continue;
+        if (info[8 * c + 6] <= MML_VOXEL_LDS_CAP && info[8 * c + 7] <= MML_VOXEL_LDS_CAP) continue;  // not a sort overflow
+        int rc = mml_downsample_big(ctx, first + c, 1);
+        if (rc != MML_OK) return rc;
+        if (redone) redone->push_back(first + c);
     }
     return MML_OK;
 }
@@ -251,9 +470,10 @@ int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_
     Tf12 T;
     memcpy(T.m, T_wl, sizeof(double) * 12);
     const int Id = (int)(ctx->local_map_id % W);  // :1597
+    for (int kind = 0; kind < 2; ++kind)  // both stacks are checked before any ring state changes
+        MML_REQUIRE(n_feat[kind] >= 0 && n_feat[kind] <= ctx->MF, MML_ERR_STATE, "slot holds no down-sampled feature stack");
     for (int kind = 0; kind < 2; ++kind) {
         const int n = n_feat[kind];
-        MML_REQUIRE(n >= 0 && n <= ctx->MF, MML_ERR_STATE, "slot holds no down-sampled feature stack");
         if (n)
             hipLaunchKernelGGL(k_to_world, dim3((n + 255) / 256), dim3(256), 0, s, ctx->ft_xyz[kind] + (size_t)slot * ctx->MF,
                                n, T, ctx->ring[kind] + (size_t)Id * ctx->MF);

@@ -13,6 +13,7 @@
 #include "mmloam_hip.h"
 
 #define MML_WAVE 64
+#define MML_VOXEL_LDS_CAP 8192  // labelled points per (slot, kind) that k_voxel sorts in LDS; more go the global-sort way
 
 // ---- factor records kept on the device (SoA would save little: every field is read once per GN pass) ----
 struct MmlLineFactor {   // Estimator.h:59-84 FeatureLine (values are floats in the reference, :256-271)
@@ -108,7 +109,15 @@ struct mml_ctx {
     float4* ft_xyz[2] = {nullptr, nullptr};  // B * MF
     int* ft_n = nullptr;                     // 2 * B
     unsigned long long* vx_keys = nullptr;   // voxel sort scratch: B * 2 * VX_CAP
-    int VX_CAP = 0;
+    // batched global-sort down-sampler (map_upkeep.hip mml_downsample_big), allocated on first use
+    unsigned long long* seg_keys = nullptr;
+    unsigned* seg_vals = nullptr;
+    float4* seg_cat = nullptr;
+    int* seg_flag = nullptr;
+    int* seg_meta = nullptr;
+    void* seg_tmp[8] = {};
+    size_t seg_tmp_bytes[8] = {};
+    int VX_CAP = 0;                          // label-list stride per (slot, kind) = NT: every labelled point is listed
 
     // factors
     MmlLineFactor* lf = nullptr;   // B * MF
@@ -227,6 +236,7 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count);
 int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
 int mml_build_grid_device(mml_ctx* ctx, int kind, int m);
 int mml_downsample_big(mml_ctx* ctx, int first, int count);
+int mml_downsample_redo_overflow(mml_ctx* ctx, int first, int count, std::vector<int>* redone);
 int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_out);
 int mml_build_global_grid(mml_ctx* ctx, int kind, const float* h_xyz, const int* h_cube, int m, const int* cen);
 int mml_build_global_grid_device(mml_ctx* ctx, int kind, const float4* d_pts, const uint16_t* d_tags, const int* d_cnt, int m,

@@ -314,7 +314,7 @@ struct SolveParams {
 // Trust-region state kept in LDS, manipulated by lane 0 (restates ceres 2.1.0 trust_region_minimizer.cc +
 // dogleg_strategy.cc; constants are Ceres defaults, see oracle/estimate.cpp for the line-by-line commentary).
 struct TRState {
-    double x[6 * MAXW], xc[6 * MAXW];
+    double x[6 * MAXW], xc[6 * MAXW], x_init[6 * MAXW];
     double rec[28 * MAXW], recc[28 * MAXW];  // per frame: H upper (21), g (6), cost
     double scale[6 * MAXW], diag[6 * MAXW], grad[6 * MAXW], gn[6 * MAXW], step[6 * MAXW];
     double cost, radius, mu, alpha, dogleg_norm, x_norm, model_change, step_norm;
@@ -333,7 +333,7 @@ __host__ __device__ double quad_form(const TRState& S, int W, const double* v) {
 __host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
     const int n = 6 * W;
     S.evaluate = 0;
-    if (S.iter >= max_iters || S.radius < 1e-32 || S.num_invalid > 5) {
+    if (S.iter >= max_iters || S.radius < 1e-32) {
         S.go = 0;
         return;
     }
@@ -423,7 +423,15 @@ __host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
         if (!(S.model_change > 0.0)) step_valid = false;
     }
     if (!step_valid) {
-        S.num_invalid++;
+        // TrustRegionMinimizer::HandleInvalidStep: the max_num_consecutive_invalid_steps-th (5th) invalid step in a row
+        // ends the solve with FAILURE before the strategy is told; Solver::Solve then hands the parameters back as they
+        // were on entry (Summary::IsSolutionUsable() is false)
+        if (++S.num_invalid >= 5) {
+            for (int i = 0; i < n; ++i) S.x[i] = S.x_init[i];
+            S.termination = 4;
+            S.go = 0;
+            return;
+        }
         S.mu *= 10.0;
         S.reuse = 0;
         return;  // go stays 1, evaluate 0: next round proposes again
@@ -464,7 +472,7 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
     const double radius = S.radius;
     WSYNC();
     if (lane == 0) S.evaluate = 0;
-    if (iter >= max_iters || radius < 1e-32 || num_invalid > 5) {
+    if (iter >= max_iters || radius < 1e-32) {
         if (lane == 0) S.go = 0;
         return;
     }
@@ -606,11 +614,17 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
     }
     if (!step_valid) {
         if (lane == 0) {
-            S.num_invalid++;
-            S.mu *= 10.0;
-            S.reuse = 0;
+            if (num_invalid + 1 >= 5) {  // HandleInvalidStep: FAILURE, parameters as on entry (see tr_propose)
+                for (int i = 0; i < 6; ++i) S.x[i] = S.x_init[i];
+                S.termination = 4;
+                S.go = 0;
+            } else {
+                S.mu *= 10.0;
+                S.reuse = 0;
+            }
+            S.num_invalid = num_invalid + 1;
         }
-        return;  // go stays 1, evaluate 0: next round proposes again
+        return;  // go stays 1 unless failed, evaluate 0: next round proposes again
     }
     if (lane == 0) {
         S.num_invalid = 0;
@@ -681,7 +695,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     const int W = P.window;
     const int b0 = P.first + prob * W;
     const int tid = threadIdx.x;
-    if (tid < 6 * W) S.x[tid] = P.x[(size_t)b0 * 6 + tid];
+    if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x[(size_t)b0 * 6 + tid];
     __syncthreads();
 
     double acc[28];
@@ -759,6 +773,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         __syncthreads();
     }
     if (tid < 6 * W) P.x[(size_t)b0 * 6 + tid] = S.x[tid];
+    // rows of the trace beyond the last iteration that ran repeat the final point
+    if (P.trace && tid < 6 * W)
+        for (int it = S.iter; it < P.max_iters; ++it) P.trace[((size_t)prob * P.max_iters + it) * 6 * W + tid] = S.x[tid];
     if (tid == 0) {
         double* o = P.summ + 8 * prob;
         o[0] = S.iter;
@@ -823,7 +840,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_window_round(WindowRoundParam
     __syncthreads();
     if (tid == 0) {
         if (P.round == 0) {
-            for (int i = 0; i < 6 * W; ++i) S.x[i] = S.xc[i] = P.x_all[i];
+            for (int i = 0; i < 6 * W; ++i) S.x[i] = S.xc[i] = S.x_init[i] = P.x_all[i];
             S.go = 1;
             S.evaluate = 1;
             S.iter = 0;
@@ -1021,7 +1038,7 @@ extern "C" int mml_window_solver_step(mml_window_solver* s, const double* record
             for (int k = 0; k < 28; ++k) S.rec[28 * f + k] = records[MML_NEQ_RECORD_DOUBLES * f + k];
             S.cost += S.rec[28 * f + 27];
             for (int i = 0; i < 6; ++i) {
-                S.x[6 * f + i] = x_eval[6 * f + i];
+                S.x[6 * f + i] = S.x_init[6 * f + i] = x_eval[6 * f + i];
                 S.scale[6 * f + i] = 1.0 / (1.0 + sqrt(Hget(S.rec + 28 * f, i, i)));
                 xn += S.x[6 * f + i] * S.x[6 * f + i];
             }

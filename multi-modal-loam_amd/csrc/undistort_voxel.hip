@@ -136,7 +136,7 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 }
 
 // One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
-__global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int MF, int B, int cap, const int* fu_info,
+__global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
                                                      const float4* fu_xyzi, const uint8_t* fu_label,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     const float leaf = kind == 0 ? leaf_corner : leaf_surf;
     float4* out = (kind == 0 ? ft0 : ft1) + (size_t)b * MF;
     // sequence -> fused index map lives in global scratch (cap entries per (slot, kind))
-    unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * cap;
+    unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * list_stride;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     // 1. the labelled points were listed by the crop pass (feature.hip k_crop_c) in fused-cloud order; min / max of
@@ -335,13 +335,15 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
 
 int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     MmlStageScope t(ctx, "voxel_downsample");
-    if (ctx->VX_CAP > 8192) return mml_downsample_big(ctx, first, count);  // labelled clouds beyond the LDS sort
-    const int cap = ctx->VX_CAP;
+    if (ctx->NT > 65536) return mml_downsample_big(ctx, first, count);  // labelled clouds beyond the LDS sort
+    // `cap` labelled points per (slot, kind) fit the LDS sort; a slot with more gets ft_n = -1 here and is redone through
+    // the global-sort path by mml_downsample_redo_overflow (the label lists hold every labelled point: stride VX_CAP)
+    const int cap = MML_VOXEL_LDS_CAP;
     int npad = 1;
     while (npad < cap) npad <<= 1;
     size_t lds = (size_t)npad * sizeof(unsigned long long);
     hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, MML_STREAM(ctx), first, ctx->NT, ctx->MF, ctx->B,
-                       cap, ctx->fu_info, ctx->fu_xyzi, ctx->fu_label, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
+                       cap, ctx->VX_CAP, ctx->fu_info, ctx->fu_xyzi, ctx->fu_label, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
                        ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     MML_HIP(hipGetLastError());
     return MML_OK;

@@ -476,7 +476,7 @@ struct mml_fullwindow {
     double gravity[3] = {0, 0, 0};
     Prior prior;
     // trust-region state (Ceres 2.1 TRADITIONAL_DOGLEG, same constants as mml_solve / tr_propose / tr_decide)
-    std::vector<double> x, xc, scale, diag, grad, gn, step;
+    std::vector<double> x, xc, x_init, scale, diag, grad, gn, step;
     Eval cur, cand;
     double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0, x_norm = 0, model_change = 0, step_norm = 0;
     int reuse = 0, num_invalid = 0, iter = 0, successful = 0, termination = 0, started = 0, done = 0;
@@ -560,7 +560,7 @@ double quad(const mml_fullwindow* s, const std::vector<double>& v) {  // v^T (S 
 // -1 when the minimiser has stopped
 int propose(mml_fullwindow* s) {
     const int n = s->n;
-    if (s->iter >= s->opts.max_num_iterations || s->radius < 1e-32 || s->num_invalid > 5) return -1;
+    if (s->iter >= s->opts.max_num_iterations || s->radius < 1e-32) return -1;
     s->iter++;
     bool solve_ok = true;
     if (!s->reuse) {
@@ -639,7 +639,11 @@ int propose(mml_fullwindow* s) {
         if (!(s->model_change > 0.0)) step_valid = false;
     }
     if (!step_valid) {
-        s->num_invalid++;
+        if (++s->num_invalid >= 5) {  // HandleInvalidStep: FAILURE, Solver::Solve restores the parameters it was given
+            s->x = s->x_init;
+            s->termination = 4;
+            return -1;
+        }
         s->mu *= 10.0;
         s->reuse = 0;
         return 0;
@@ -758,6 +762,7 @@ int mml_fullwindow_step(mml_fullwindow* s, const double* records, double* x_eval
     if (!s->started) {
         s->started = 1;
         memcpy(s->x.data(), x_eval, sizeof(double) * n);
+        s->x_init = s->x;
         int rc = assemble(s, records, s->x.data(), s->cur);
         if (rc != MML_OK) return rc;
         s->initial_cost = s->cur.cost;

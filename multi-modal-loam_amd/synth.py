@@ -173,6 +173,18 @@ def voxel_filter(xyz, leaf):
     return (sums / cnt[:, None]).astype(np.float32)
 
 
+def tile_offsets(count, tile=(40.0, 30.0)):
+    """Offsets of the first `count` lattice tiles grow_map lays copies on (tile 0 = the original, at the origin)."""
+    side = int(np.ceil(np.sqrt(max(count, 1))))
+    cells = [(i, j) for i in range(-side, side + 1) for j in range(-side, side + 1) if (i, j) != (0, 0)]
+    cells.sort(key=lambda c: (max(abs(c[0]), abs(c[1])), c))
+    out = [np.zeros(3)]
+    for r in range(count - 1):
+        i, j = cells[r]
+        out.append(np.array([i * tile[0], j * tile[1], 0.0]))
+    return out
+
+
 def grow_map(xyz, target, seed=7, jitter=0.02, tile=(40.0, 30.0)):
     """Grow a (m,3) float32 feature cloud to `target` points ("replicated / jittered").
 

@@ -8,6 +8,12 @@
 
 #include "linalg.h"
 #include "mml_oracle.h"
+#include "threads.h"
+
+extern "C" void mmlo_set_threading(int livox_line_threads, int solve_threads) {
+    mmlo::threading().livox_line_threads = livox_line_threads < 1 ? 1 : livox_line_threads;
+    mmlo::threading().solve_threads = solve_threads < 1 ? 1 : solve_threads;
+}
 
 using namespace mmlo;
 
@@ -877,9 +883,43 @@ static inline void huber(double s, double a, double* rho0, double* rho1) {
     }
 }
 
+static void linearize_pe_serial(const mmlo_line_factor* lf, int n_line, const mmlo_plane_factor* pf, int n_plane,
+                                const PoseEval& pe, double plan_weight_tan, double huber_delta, double* H, double* g,
+                                double* cost, bool want_jac);
+// num_threads > 1 (Estimator.cpp:1430): the residual blocks split into contiguous chunks, partial sums added in chunk order
 static void linearize_pe(const mmlo_line_factor* lf, int n_line, const mmlo_plane_factor* pf, int n_plane,
                          const PoseEval& pe, double plan_weight_tan, double huber_delta, double* H, double* g,
                          double* cost, bool want_jac) {
+    const int T = mmlo::threading().solve_threads;
+    if (T <= 1 || n_line + n_plane < 4 * T) {
+        linearize_pe_serial(lf, n_line, pf, n_plane, pe, plan_weight_tan, huber_delta, H, g, cost, want_jac);
+        return;
+    }
+    std::vector<double> part((size_t)T * 43, 0.0);
+    mmlo::pool(T).run(T, [&](int t) {
+        const int l0 = (int)((long long)n_line * t / T), l1 = (int)((long long)n_line * (t + 1) / T);
+        const int p0 = (int)((long long)n_plane * t / T), p1 = (int)((long long)n_plane * (t + 1) / T);
+        double* o = part.data() + (size_t)t * 43;
+        linearize_pe_serial(lf + l0, l1 - l0, pf + p0, p1 - p0, pe, plan_weight_tan, huber_delta, o, o + 36, o + 42, want_jac);
+    });
+    if (want_jac) {
+        for (int i = 0; i < 36; ++i) H[i] = 0;
+        for (int i = 0; i < 6; ++i) g[i] = 0;
+    }
+    double c = 0;
+    for (int t = 0; t < T; ++t) {
+        const double* o = part.data() + (size_t)t * 43;
+        if (want_jac) {
+            for (int i = 0; i < 36; ++i) H[i] += o[i];
+            for (int i = 0; i < 6; ++i) g[i] += o[36 + i];
+        }
+        c += o[42];
+    }
+    *cost = c;
+}
+static void linearize_pe_serial(const mmlo_line_factor* lf, int n_line, const mmlo_plane_factor* pf, int n_plane,
+                                const PoseEval& pe, double plan_weight_tan, double huber_delta, double* H, double* g,
+                                double* cost, bool want_jac) {
     if (want_jac) {
         for (int i = 0; i < 36; ++i) H[i] = 0;
         for (int i = 0; i < 6; ++i) g[i] = 0;
@@ -993,6 +1033,7 @@ extern "C" void mmlo_solve_window(const mmlo_line_factor* lf, const int* n_line,
     double alpha = 0;
     double dogleg_step_norm = 0;
     int num_invalid = 0;
+    const std::vector<double> x_entry(x, x + n);
 
     double cost = prob.eval(x, H.data(), g.data());
     summary->initial_cost = cost;
@@ -1030,7 +1071,6 @@ extern "C" void mmlo_solve_window(const mmlo_line_factor* lf, const int* n_line,
     while (true) {
         if (iter >= opts->max_num_iterations) break;  // NO_CONVERGENCE
         if (radius < 1e-32) break;
-        if (num_invalid > 5) break;
         ++iter;
         summary->iterations = iter;
 
@@ -1122,8 +1162,14 @@ extern "C" void mmlo_solve_window(const mmlo_line_factor* lf, const int* n_line,
             if (!(model_cost_change > 0.0)) step_valid = false;
         }
         if (!step_valid) {
-            // HandleInvalidStep -> StepIsInvalid
-            ++num_invalid;
+            // HandleInvalidStep (trust_region_minimizer.cc): the 5th consecutive invalid step
+            // (max_num_consecutive_invalid_steps) ends the solve with FAILURE before StepIsInvalid(); Solver::Solve then
+            // restores the parameters it was given (Summary::IsSolutionUsable() is false for FAILURE)
+            if (++num_invalid >= 5) {
+                std::memcpy(x, x_entry.data(), sizeof(double) * n);
+                summary->termination = 4;
+                break;
+            }
             mu *= mu_increase;
             reuse = false;
             if (trace) std::memcpy(trace + (size_t)(iter - 1) * n, x, sizeof(double) * n);

@@ -9,6 +9,7 @@
 //     PacketSize 2), normalize() divides each coefficient by the norm and leaves a zero vector alone.
 // Build with -ffp-contract=off.
 #include "mml_oracle.h"
+#include "threads.h"
 
 #include <cmath>
 #include <cstring>
@@ -368,7 +369,7 @@ struct CombPt {
 
 // Shared tail of getHoriFeatureExtract (:1001-1032) / getVeloFeature (:1209-1252): bucket by line,
 // detect per line, scatter labels back through normal_z.
-void detect_lines_and_label(std::vector<CombPt>& cloud, int n_lines) {
+void detect_lines_and_label(std::vector<CombPt>& cloud, int n_lines, int threads) {
     std::vector<std::vector<P4>> vlines(n_lines);
     std::vector<std::vector<int>> vgidx(n_lines);
     for (size_t i = 0; i < cloud.size(); ++i) {
@@ -378,14 +379,19 @@ void detect_lines_and_label(std::vector<CombPt>& cloud, int n_lines) {
             vgidx[line_idx].push_back((int)i);
         }
     }
-    for (int l = 0; l < n_lines; ++l) {
+    // lines write disjoint points of `cloud`: one thread per line (:1008-1015) gives the serial result bit for bit
+    auto one_line = [&](int l) {
         int n = (int)vlines[l].size();
         std::vector<int> corner(n > 0 ? n : 1), surf(n > 0 ? n : 1);
         int nc = 0, nsf = 0;
         mmlo_detect_feature_points(n ? &vlines[l][0].x : nullptr, n, corner.data(), &nc, surf.data(), &nsf, nullptr);
         for (int j = 0; j < nc; ++j) cloud[vgidx[l][corner[j]]].normal_z = 1.0;
         for (int j = 0; j < nsf; ++j) cloud[vgidx[l][surf[j]]].normal_z = 2.0;
-    }
+    };
+    if (threads > 1)
+        mmlo::pool(threads).run(n_lines, one_line);
+    else
+        for (int l = 0; l < n_lines; ++l) one_line(l);
 }
 
 }  // namespace
@@ -455,7 +461,7 @@ extern "C" int mmlo_extract_velo(const float* in_xyzi, int n_in, int n_rings, fl
         laserCloud.push_back(point);
     }
 
-    detect_lines_and_label(laserCloud, n_rings);
+    detect_lines_and_label(laserCloud, n_rings, 1);  // rings serially, :1228-1230
 
     // :1244-1256, :1278-1300
     int nc = 0, nsf = 0, nout = 0;
@@ -512,7 +518,7 @@ extern "C" int mmlo_extract_livox(const mmlo_livox_point* in, int n, int n_lines
         laserCloud.push_back(point);
     }
 
-    detect_lines_and_label(laserCloud, n_lines);
+    detect_lines_and_label(laserCloud, n_lines, mmlo::threading().livox_line_threads);
 
     // :916 combined: removeNearFarPoints; :925/:933 surf/corner: removeNearPointCloud
     int nc = 0, nsf = 0, nout = 0;

@@ -146,7 +146,7 @@ def dense_trust_region(evaluate, x0, max_iters=10, fixed=False):
     gn = grad = diag = None
     alpha = 0.0
     while True:
-        if it >= max_iters or radius < 1e-32 or invalid > 5:
+        if it >= max_iters or radius < 1e-32:
             break
         it += 1
         ok = True
@@ -191,6 +191,9 @@ def dense_trust_region(evaluate, x0, max_iters=10, fixed=False):
             valid = model_change > 0
         if not valid:
             invalid += 1
+            if invalid >= 5:       # HandleInvalidStep: FAILURE; Solver::Solve hands back the parameters it was given
+                x, term = np.array(x0, dtype=np.float64).reshape(-1), 4
+                break
             mu *= 10.0
             reuse = False
             continue

@@ -178,6 +178,11 @@ int mmlo_estimate_single(const float* corner_feat, int n_corner, const float* su
                          const double* exTlb, double* P, double* Q, int max_outer, int inner_iters,
                          int* is_degenerate, double* outer_trace);
 
+/* Threading of the calling host thread (defaults 1, 1 = the bit-reference configuration of every parity test):
+ * livox_line_threads: detectFeaturePoints of the Livox lines in parallel (unionFeatureExtract.cpp:1008-1015, 6 there);
+ * solve_threads: residual blocks of mmlo_linearize / mmlo_solve_window in parallel (ceres num_threads, Estimator.cpp:1430). */
+void mmlo_set_threading(int livox_line_threads, int solve_threads);
+
 /* helpers exposed for tests */
 /* unionLidarsAligner.cpp:1077-1153 (estimate_timeoffset, the numeric core): the Velodyne cloud goes through
  * pcl::transformPointCloud with tf (row-major 4x4, NULL = identity, :1080-1082), every Livox point gets the squared

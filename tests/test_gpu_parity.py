@@ -1063,3 +1063,54 @@ def test_time_offset_golden(M):
         assert r["best_window"] == int(g["best_window"]) and r["lowest_error"] == float(g["lowest_error"])
     finally:
         c.close()
+
+
+def test_dense_labelled_cloud_takes_the_global_sort_path(M, O, synth):
+    """pcl::VoxelGrid accepts any cloud: a scan whose surf-labelled points (here ~19 k, every point beyond 50 m is promoted,
+    unionFeatureExtract.cpp:524) exceed the 8192-key LDS sort of k_voxel is down-sampled through the global-sort filter --
+    by mml_downsample directly and inside mml_step, where the other slots of the batch are not disturbed."""
+    kw = dict(n_rings=32, pitch0=-15.5, pitch_step=1.0)
+    cfg = M.default_config(3, n_rings=32, pitch0_deg=-15.5, pitch_step_deg=1.0, far_th=1000.0, max_velo_points=57600,
+                           max_livox_points=64, max_features=32768)
+    c = M.Context(cfg)
+    try:
+        dense = synth.velo_scan(3, n_az=1800, noise=0.002, **kw).copy()
+        dense[:, :3] *= 6.0
+        normal = synth.velo_scan(4, n_az=1800, **kw)
+        scans = [dense, normal, dense]
+        ev = [O.extract_velo(v, far=1000.0, **kw) for v in scans]
+        assert (ev[0]["label"] == 2).sum() > 2 * 8192 and (ev[1]["label"] == 2).sum() < 8192
+        for s, v in enumerate(scans):
+            c.scan_upload(s, v, None)
+        c.extract(0, 3)
+        c.undistort(0, 3, np.tile(np.eye(3).reshape(1, 9), (3, 1)), np.zeros((3, 3)))
+        c.downsample(0, 3)
+        feats = []
+        for s in range(3):
+            xyz, lab = ev[s]["xyzi"][:, :3], ev[s]["label"]
+            assert np.array_equal(c.scan_download(s)["label"], lab)
+            cf, sf = c.features_download(s, 0), c.features_download(s, 1)
+            assert np.array_equal(cf, O.voxel_downsample(xyz[lab == 1], 0.4))
+            assert np.array_equal(sf, O.voxel_downsample(xyz[lab == 2], 0.2))
+            feats.append((cf, sf))
+        assert len(feats[0][1]) > 8192
+        # registration of the batch: map = the dense scan's own features, slot 1 (a different, small scene) just rides along
+        c.map_set_local(0, feats[0][0])
+        c.map_set_local(1, feats[0][1])
+        x0 = np.tile(np.array([0.03, -0.02, 0.01, 0.002, -0.001, 0.004]), (3, 1))
+        dR, dt = np.tile(np.eye(3).reshape(1, 9), (3, 1)), np.zeros((3, 3))
+        x = c.step(0, 3, dR, dt, np.eye(4), 25.0, 10, x0)
+        assert np.array_equal(x[0], x[2]) and np.abs(x[0][:3]).max() < 5e-3           # registered back onto itself
+        # the same through the staged calls
+        c.extract(0, 3)
+        c.undistort(0, 3, dR, dt)
+        c.downsample(0, 3)
+        T = np.stack([np.eye(4)] * 3)
+        for s in range(3):
+            T[s][:3, :3] = Rsc.from_rotvec(x0[s][3:]).as_matrix()
+            T[s][:3, 3] = x0[s][:3]
+        c.associate(0, 3, T, 25.0)
+        xs, _, _ = c.solve(0, 3, x0, np.eye(4), window=1, max_iters=10, fixed=True, huber=0.1 / 1.5e-3, w_tan=0.0)
+        assert np.array_equal(xs, x)
+    finally:
+        c.close()

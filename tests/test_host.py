@@ -107,12 +107,58 @@ def test_product_does_not_import_oracle():
     for f in os.listdir(os.path.join(ROOT, "tools")):
         if f.endswith(".py"):
             assert "mml_oracle" not in open(os.path.join(ROOT, "tools", f)).read(), "tools/%s imports the oracle" % f
-    # bench.py: the oracle is imported once, inside the cpu_baseline leg, and nothing before that leg names it
-    lines = open(os.path.join(ROOT, "bench.py")).read().split("\n")
-    hits = [k for k, ln in enumerate(lines) if "mml_oracle" in ln or '"oracle"' in ln]
-    start = next(k for k, ln in enumerate(lines) if "---- CPU baseline" in ln)
-    assert hits and min(hits) > start, "bench.py touches the oracle outside the cpu_baseline leg"
-    assert sum("import mml_oracle" in ln for ln in lines) == 1
+    # bench.py: code that names the oracle (a string with the directory / library name, the module name) lives only inside
+    # the regions marked as the cpu_baseline leg; doc strings and comments may talk about it
+    import ast
+    import io
+    import tokenize
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    lines = src.split("\n")
+    regions, start = [], None
+    for k, ln in enumerate(lines, 1):
+        if ln.strip().startswith("# >>> cpu_baseline leg"):
+            start = k
+        elif ln.strip().startswith("# <<< cpu_baseline leg"):
+            regions.append((start, k))
+            start = None
+    assert regions and start is None
+    doc_lines = set()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, (ast.Module, ast.FunctionDef, ast.ClassDef)) and ast.get_docstring(node, clean=False) is not None:
+            d = node.body[0]
+            doc_lines.update(range(d.lineno, d.end_lineno + 1))
+    hits = 0
+    for tok in tokenize.generate_tokens(io.StringIO(src).readline):
+        named = (tok.type == tokenize.NAME and tok.string == "mml_oracle") or \
+                (tok.type == tokenize.STRING and ("oracle" in tok.string) and tok.start[0] not in doc_lines)
+        if named:
+            hits += 1
+            assert any(a <= tok.start[0] <= b for a, b in regions), "bench.py line %d names the oracle outside the cpu_baseline leg" % tok.start[0]
+    assert hits >= 2
+
+
+def test_bench_spawns_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` started bare launches two ranks (RANK / WORLD_SIZE / MASTER_*), they rendezvous (gloo
+    here, no device: --stub-step), the slowest rank sets the clock and rank 0 prints ONE line with n_gpus = 2."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                          "--backend", "gloo", "--stub-step"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    js = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(js) == 1, out.stdout
+    r = json.loads(js[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["scaling"] == "weak"
+    assert r["ms_per_step"] >= 4.0          # rank 1 sleeps 4 ms per step: max over ranks, not rank 0's own 2 ms
+    # the same entry point under an external launcher (the driver's way) must not spawn again
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--backend", "gloo", "--stub-step"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    js = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(js) == 1 and json.loads(js[0])["n_gpus"] == 2
 
 
 def _frame_problem(O, scene, k, thres=1.0):

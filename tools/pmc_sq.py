@@ -1,4 +1,7 @@
-"""Developer aid: per-kernel SQ counter summary from a rocprofv3 --pmc SQ_* counter_collection.csv."""
+"""Per-kernel SQ counter summary (waves, VALU / SALU instructions per wave, wait / active shares of the wave cycles) from the
+counter_collection.csv of a rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU pass (split over as many passes as the counter slots need; concatenate the CSVs).
+Usage: python tools/pmc_sq.py counter_collection.csv > profiles/rNN_sq_counters.md"""
 import collections
 import csv
 import re
