@@ -247,6 +247,13 @@ int mml_factors_download(mml_ctx* ctx, int slot, int kind, double* out, int* src
 int mml_linearize(mml_ctx* ctx, int slot, const double* x, const double* T_bl, double plan_weight_tan,
                   double huber_delta, double* H, double* g, double* cost);
 
+/* The same for the `frames` (<= 8) consecutive slots of a window in ONE launch and one read-back: frame f is linearised
+ * at x + f * x_stride (6 doubles [t, phi]; x_stride = 15 walks the [PR | VBias] states of the full-window solver) and
+ * its record (MML_NEQ_RECORD_DOUBLES doubles, layout below) is written to records + 32 f.  This is what one trust-region
+ * evaluation of Estimator::Estimate costs on the device side (Estimator.cpp:1265-1299 loops over the frames). */
+int mml_linearize_window(mml_ctx* ctx, int first_slot, int frames, int x_stride, const double* x, const double* T_bl,
+                         double plan_weight_tan, double huber_delta, double* records);
+
 typedef struct {
     int max_num_iterations;  /* Estimator.cpp:1428 (10) */
     int fixed_iterations;    /* != 0: run exactly max_num_iterations, no convergence tests */

@@ -387,6 +387,14 @@ class Context:
                                      C.c_double(huber), _p(H), _p(g), C.byref(c)))
         return H, g, c.value
 
+    def linearize_window(self, first, frames, x, T_bl, w_tan=0.0, huber=0.1 / 1.5e-3):
+        """Records (frames, 32) of the consecutive slots first .. first + frames - 1 at x (frames, >= 6): one launch."""
+        x = _f64(x).reshape(frames, -1)
+        rec = np.zeros((frames, NEQ_RECORD_DOUBLES))
+        self._ck(lib().mml_linearize_window(self._h, C.c_int(first), C.c_int(frames), C.c_int(x.shape[1]), _p(x),
+                                            _p(_f64(T_bl).reshape(16)), C.c_double(w_tan), C.c_double(huber), _p(rec)))
+        return rec
+
     def linearize_record(self, slot, x, T_bl, d_record_ptr, w_tan=0.0, huber=0.1 / 1.5e-3):
         self._ck(lib().mml_linearize_record(self._h, C.c_int(slot), _p(_f64(x)), _p(_f64(T_bl).reshape(16)),
                                             C.c_double(w_tan), C.c_double(huber), C.c_void_p(d_record_ptr)))

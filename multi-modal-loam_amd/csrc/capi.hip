@@ -811,6 +811,25 @@ int mml_linearize_record(mml_ctx* ctx, int slot, const double* x, const double* 
     return mml_launch_linearize(ctx, slot, d_par, d_par + 6, plan_weight_tan, huber_delta, d_record);
 }
 
+int mml_linearize_window(mml_ctx* ctx, int first_slot, int frames, int x_stride, const double* x, const double* T_bl,
+                         double plan_weight_tan, double huber_delta, double* records) {
+    CHECK_SLOTS(first_slot, frames);
+    MML_REQUIRE(x && T_bl && records && x_stride >= 6 && frames <= 8, MML_ERR_INVALID, "bad arguments");
+    double h[6 * 8 + 16];
+    for (int f = 0; f < frames; ++f) memcpy(h + 6 * f, x + (size_t)x_stride * f, sizeof(double) * 6);
+    memcpy(h + 6 * frames, T_bl, sizeof(double) * 16);
+    // 64 doubles of parameter space per slot: poses of the window, then T_bl, in the first slot's block
+    double* d_par = ctx->d_pose_in + 64 * (size_t)first_slot;
+    int rc = upload_doubles(ctx, d_par, h, 6 * (size_t)frames + 16);
+    if (rc != MML_OK) return rc;
+    double* d_rec = ctx->d_rec + 32 * (size_t)first_slot;
+    rc = mml_launch_linearize(ctx, first_slot, d_par, d_par + 6 * frames, plan_weight_tan, huber_delta, d_rec, frames);
+    if (rc != MML_OK) return rc;
+    MML_HIP(hipMemcpyAsync(records, d_rec, sizeof(double) * 32 * frames, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    return MML_OK;
+}
+
 int mml_linearize(mml_ctx* ctx, int slot, const double* x, const double* T_bl, double plan_weight_tan,
                   double huber_delta, double* H, double* g, double* cost) {
     CHECK_SLOTS(slot, 1);

@@ -252,6 +252,6 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
 int mml_feature_init(mml_ctx* ctx);
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan,
-                         double huber, double* d_record);
+                         double huber, double* d_record, int frames = 1);
 
 #endif

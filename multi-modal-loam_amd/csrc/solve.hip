@@ -317,6 +317,7 @@ struct TRState {
     double x[6 * MAXW], xc[6 * MAXW], x_init[6 * MAXW];
     double rec[28 * MAXW], recc[28 * MAXW];  // per frame: H upper (21), g (6), cost
     double scale[6 * MAXW], diag[6 * MAXW], grad[6 * MAXW], gn[6 * MAXW], step[6 * MAXW];
+    double work[42];  // the 6 x 6 system of one frame while tr_propose factors it (kept out of private memory)
     double cost, radius, mu, alpha, dogleg_norm, x_norm, model_change, step_norm;
     int reuse, num_invalid, iter, successful, termination, go, evaluate;
 };
@@ -348,7 +349,7 @@ __host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
                 S.diag[6 * f + i] = sqrt(d);
             }
         double gg = 0;
-        double sg[6 * MAXW];
+        double* sg = S.step;  // scratch: the step itself is only formed further down
         for (int f = 0; f < W; ++f)
             for (int i = 0; i < 6; ++i) {
                 int k = 6 * f + i;
@@ -361,7 +362,8 @@ __host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
         while (S.mu < 1.0) {
             bool ok = true;
             for (int f = 0; f < W && ok; ++f) {
-                double A[36], bvec[6];
+                double* A = S.work;
+                double* bvec = S.work + 36;
                 for (int a = 0; a < 6; ++a) {
                     for (int b = 0; b < 6; ++b)
                         A[6 * a + b] = Hget(S.rec + 28 * f, a, b) * S.scale[6 * f + a] * S.scale[6 * f + b];
@@ -785,13 +787,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     }
 }
 
-// single-frame linearisation to a 32-double record (SURVEY 8(e) all-gather payload)
-__global__ __launch_bounds__(SOLVE_THREADS) void k_linearize(int b, int B, int MF, const int* ft_n,
+// linearisation of frame blockIdx.x of a window to its 32-double record (SURVEY 8(e) all-gather payload): slot b0 + f at
+// x + 6 f -> record + 32 f
+__global__ __launch_bounds__(SOLVE_THREADS) void k_linearize(int b0, int B, int MF, const int* ft_n,
                                                             const MmlLineFactor* lf, const MmlPlaneFactor* pf,
                                                             const double* x, const double* Tbl, double w_tan,
                                                             double huber_delta, const double* stats, double* record) {
     __shared__ double s_part[SOLVE_WAVES * 28];
     __shared__ double s_out[28];
+    const int b = b0 + blockIdx.x;
+    x += 6 * blockIdx.x;
+    record += 32 * blockIdx.x;
     Pose pose;
     make_pose(x, Tbl, pose);
     double acc[28];
@@ -995,9 +1001,9 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
 }
 
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan, double huber,
-                         double* d_record) {
+                         double* d_record, int frames) {
     MmlStageScope t(ctx, "linearize");
-    hipLaunchKernelGGL(k_linearize, dim3(1), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), slot, ctx->B, ctx->MF, ctx->ft_n,
+    hipLaunchKernelGGL(k_linearize, dim3(frames), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), slot, ctx->B, ctx->MF, ctx->ft_n,
                        ctx->lf, ctx->pf, d_x, d_Tbl, w_tan, huber, ctx->assoc_stats, d_record);
     MML_HIP(hipGetLastError());
     return MML_OK;

@@ -360,7 +360,14 @@ class Estimator {
             if (!fw) throw std::runtime_error("mml_fullwindow_create");
             for (int f = 1; f < W; ++f) mml_fullwindow_set_imu(fw, f, &imu[f], gravity.v);
             if (have_prior_) mml_fullwindow_set_prior(fw, &prior_);
+            bool consecutive = true;
+            for (int f = 1; f < W; ++f) consecutive = consecutive && frames[f]->slot == frames[0]->slot + f;
             auto lidar_records = [&]() {
+                if (consecutive) {  // one launch + one read-back for the whole window
+                    check(ctx_.get(), mml_linearize_window(ctx_.get(), frames[0]->slot, W, 15, x.data(), T_bl, w_tan, 0.0, rec.data()),
+                          "linearize_window");
+                    return;
+                }
                 for (int f = 0; f < W; ++f) {
                     double H[36], g[6], c;
                     check(ctx_.get(), mml_linearize(ctx_.get(), frames[f]->slot, &x[15 * (size_t)f], T_bl, w_tan, 0.0, H, g, &c),

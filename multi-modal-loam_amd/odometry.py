@@ -122,6 +122,9 @@ class WindowEstimator:
         return T
 
     def _records(self, slots, x):
+        # one launch + one read-back per trust-region evaluation when the window sits in consecutive slots
+        if all(s == slots[0] + f for f, s in enumerate(slots)):
+            return self.ctx.linearize_window(slots[0], len(slots), x, self.T_bl, self.plan_weight_tan, 0.0)
         M = self.M
         return np.stack([M.pack_record(*self.ctx.linearize(s, x[f][:6], self.T_bl, self.plan_weight_tan, 0.0))
                          for f, s in enumerate(slots)])
