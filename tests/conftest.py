@@ -109,3 +109,38 @@ def perturbed(T, dt=(0.03, -0.02, 0.01), rotvec=(0.002, -0.001, 0.004)):
 def pose_to_x(T):
     from scipy.spatial.transform import Rotation as Rsc
     return np.concatenate([T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_rotvec()])
+
+
+def fuzz_line(rng):
+    """One randomised scan line: piecewise walls with range jumps (break points, 100 / 101), corners (150), occluding
+    pillars, grazing incidence, dropouts, repeated points, constant and saturating reflectivity."""
+    n = int(rng.choice([37, 200, 777, 1800, 2500, 4000, 4096, 4097, 6000]))
+    az = np.cumsum(rng.uniform(0.0005, 0.003, n)) * rng.choice([1.0, 0.3])
+    r = np.empty(n)
+    i = 0
+    while i < n:
+        seg = int(rng.integers(5, 400))
+        kind = rng.integers(0, 5)
+        a = az[i:i + seg]
+        base = rng.uniform(1.5, 60.0)
+        if kind == 0:      # wall at an angle (range varies like 1 / cos)
+            r[i:i + seg] = base / np.maximum(np.cos((a - a[0]) * rng.uniform(0.2, 3.0) + rng.uniform(-1.2, 1.2)), 0.05)
+        elif kind == 1:    # constant range
+            r[i:i + seg] = base
+        elif kind == 2:    # corner: two planes meeting inside the segment
+            h = max(1, len(a) // 2)
+            r[i:i + h] = base / np.maximum(np.cos(a[:h] - a[h - 1] + 0.6), 0.05)
+            r[i + h:i + seg] = base / np.maximum(np.cos(a[h:] - a[h - 1] - 0.6), 0.05) * (np.cos(0.6) / np.cos(-0.6))
+        elif kind == 3:    # noisy vegetation
+            r[i:i + seg] = base + rng.normal(0, 0.3, len(a))
+        else:              # slow ramp
+            r[i:i + seg] = base + np.linspace(0, rng.uniform(-1, 1), len(a))
+        i += seg
+    r = np.clip(r + rng.normal(0, rng.choice([0.0, 0.005, 0.02]), n), 0.3, 120.0)
+    z = rng.uniform(-1, 1) + 0.02 * np.sin(7 * az)
+    pts = np.stack([r * np.cos(az), r * np.sin(az), z * np.ones(n) if np.isscalar(z) else z,
+                    rng.choice([np.zeros(n), rng.uniform(0, 255, n), np.round(rng.uniform(0, 3, n)) * 80.0])], 1).astype(np.float32)
+    for _ in range(int(rng.integers(0, 4))):          # repeated points (zero-length neighbour vectors)
+        j = int(rng.integers(0, max(1, n - 6)))
+        pts[j:j + int(rng.integers(2, 6))] = pts[j]
+    return pts

@@ -609,3 +609,89 @@ def test_time_offset_golden(O):
     r = O.time_offset_search(g["velo"], g["livox"], int(g["resolution"]), int(g["sliced"]), g["tf"])
     assert np.array_equal(r["nn_d2"], g["nn_d2"]) and np.array_equal(r["window_error"], g["window_error"])
     assert r["best_window"] == int(g["best_window"]) and r["lowest_error"] == float(g["lowest_error"])
+
+
+# ---- second opinions (tests/second_opinion.py): the two riskiest restatements re-derived in a different form ----------
+def test_detect_feature_points_against_numpy_restatement(O, synth):
+    """detectFeaturePoints written a second time, straight from unionFeatureExtract.cpp:341-844, as numpy float32 array
+    passes + explicit state-machine loops: flags and both index lists equal the C++ oracle's on randomised lines
+    (every flag value exercised), on rings / Livox lines of the synthetic scans and on the degenerate lines."""
+    from conftest import fuzz_line
+    from second_opinion import detect_feature_points_py
+    rng = np.random.default_rng(2024)
+    seen = {}
+    lines = [fuzz_line(rng) for _ in range(40)]
+    lines = [l for l in lines if len(l) <= 2500][:14]                  # (pure-Python loops: keep the CPU suite short)
+    v = synth.velo_scan(31).reshape(1800, 16, 4)
+    lines += [v[:, ring, :].copy() for ring in (0, 7, 15)]
+    lv = synth.livox_scan(5)
+    for ln in (0, 3):
+        m = lv["line"] == ln
+        lines.append(np.stack([lv["x"][m], lv["y"][m], lv["z"][m], lv["reflectivity"][m].astype(np.float32)], 1))
+    # far (> 50 m), near (< 1 m), duplicated points (NaN angles), quantised coordinates (sort ties)
+    n = 900
+    az = np.linspace(0, 1.5, n)
+    base = np.stack([np.cos(az), np.sin(az), 0.05 * np.ones(n)], 1)
+    for scale, quant in ((80.0, 0), (0.5, 0), (7.0, 32), (7.0, 4)):
+        pts = np.concatenate([base * scale * (1 + 0.3 * (az[:, None] > 0.7)), rng.uniform(0, 255, (n, 1))], 1).astype(np.float32)
+        if quant:
+            pts[:, :3] = np.round(pts[:, :3] * quant) / quant
+        pts[100:104] = pts[100]
+        lines.append(pts)
+    for n in (11, 12, 13, 25, 61, 129):
+        az = np.linspace(0, 1.0 + 0.001 * n, n)
+        r = 5.0 + 0.5 * np.sin(9 * az) + (az > 0.5) * 2.0 + rng.normal(0, 0.01, n)
+        lines.append(np.stack([r * np.cos(az), r * np.sin(az), 0.3 * np.ones(n), rng.uniform(0, 100, n)], 1).astype(np.float32))
+    for k, pts in enumerate(lines):
+        so, fo, flo = O.detect_feature_points(pts)
+        sp, fp, flp = detect_feature_points_py(pts)
+        assert np.array_equal(flp, flo), (k, len(pts), np.flatnonzero(flp != flo)[:8], flp[flp != flo][:8], flo[flp != flo][:8])
+        assert np.array_equal(sp, so) and np.array_equal(fp, fo), (k, len(pts))
+        for val in np.unique(flo):
+            seen[int(val)] = seen.get(int(val), 0) + int((flo == val).sum())
+    for val, least in ((1, 100), (2, 100), (3, 100), (100, 5), (101, 2), (150, 5), (300, 20)):
+        assert seen.get(val, 0) >= least, (val, seen)
+
+
+@pytest.mark.parametrize("W,w_tan,huber,fixed", [(1, 0.0, 0.1 / 1.5e-3, False), (1, 0.0, 0.1 / 1.5e-3, True), (2, 3e-4, 0.0, False),
+                                                 (4, 3e-4, 0.0, False)])
+def test_trust_region_against_ceres_transcription(O, scene, W, w_tan, huber, fixed):
+    """The oracle's (H, g, cost)-based restatement of Ceres' trust-region loop replayed by a transcription that works in
+    Ceres' own terms (stacked residuals, dense Jacobian, Corrector on the rows, J-based Cauchy point / model decrease):
+    same iterates, iteration count and termination."""
+    from second_opinion import ceres_trust_region_py
+    probs = []
+    tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
+    for k in range(W):
+        fr = scene["frames"][k]
+        T = perturbed(fr["T_gt"], dt=(0.04, -0.03, 0.02), rotvec=(0.004, -0.002, 0.006))
+        lf, _ = O.associate_lines(fr["corner"], tc, T, 1.0)
+        pf, _ = O.associate_planes(fr["surf"], ts, T, 1.0)
+        probs.append((lf[np.abs(lf["error"]) > 1e-5], pf[np.abs(pf["error"]) > 1e-5], pose_to_x(T)))
+    T_bl = np.eye(4)
+    T_bl[:3, 3] = [0.02, -0.01, 0.03]
+    x0 = np.stack([p[2] for p in probs])
+
+    def blocks_at(x):
+        out = []
+        for f, (lf, pf, _) in enumerate(probs):
+            xf = x[6 * f:6 * f + 6]
+            for fac in lf:
+                r, J = O.line_residual(fac, xf, T_bl)
+                Jf = np.zeros((1, 6 * W))
+                Jf[0, 6 * f:6 * f + 6] = J
+                out.append((np.array([r]), Jf))
+            for fac in pf:
+                r, J = O.plane_residual(fac, xf, T_bl, w_tan)
+                rows = 3 if w_tan != 0.0 else 1       # with w_tan = 0 the two tangent rows are identically zero
+                Jf = np.zeros((rows, 6 * W))
+                Jf[:, 6 * f:6 * f + 6] = J[:rows]
+                out.append((r[:rows], Jf))
+        return out
+
+    xo, so, to = O.solve_window([p[0] for p in probs], [p[1] for p in probs], x0, T_bl, 10, fixed=fixed, huber=huber, w_tan=w_tan)
+    xp, trace, iters, term = ceres_trust_region_py(blocks_at, x0.reshape(-1), 10, huber, fixed)
+    assert iters == so["iterations"] and iters >= 3
+    assert term == so["termination"] or (iters == 10 and not fixed)       # at the cap Ceres reports NO_CONVERGENCE first
+    assert np.abs(np.array(trace).reshape(iters, W, 6) - np.asarray(to).reshape(iters, W, 6)).max() < 1e-7
+    assert np.abs(xp.reshape(W, 6) - xo).max() < 1e-7
