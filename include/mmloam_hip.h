@@ -129,6 +129,30 @@ int mml_time_offset_search(mml_ctx* ctx, const float* velo_xyz, int n_velo, cons
                            int n_livox, int search_resolution, int sliced_points, float* nn_d2, double* window_error,
                            int capacity, int* n_windows, int* best_window, double* lowest_error);
 
+/* ---- SURVEY section 8(f) rank 4 (the other part): the per-frame GICP extrinsic refresh ---------------------------------
+ * icp_ext_matching (unionFeatureExtract.cpp:74-123): pcl::GeneralizedIterativeClosestPoint with setMaximumIterations(10),
+ * setTransformationEpsilon(1e-6), PCL defaults otherwise, identity guess -- the published PCL 1.8.1 algorithm (20-NN
+ * covariances regularised to (1, 1, 1e-3), 1-NN correspondences, BFGS over (t, roll, pitch, yaw) with the float
+ * transformation of applyState), all on the device.  src / tgt: n x 3 floats.  T_inout (row-major 4 x 4 float) is
+ * overwritten with getFinalTransformation() only when *converged = 1 (hasConverged(), :91-96); clouds with fewer than 20
+ * points or fewer than 4 correspondences do not converge ("ICP Failed", :119-122). */
+typedef struct {
+    int outer_iterations;        /* nr_iterations_ */
+    int objective_evaluations;   /* BFGS function / gradient evaluations over all outer iterations */
+    double objective;            /* f at the end of the last inner minimisation */
+    int n_source, n_target;
+} mml_gicp_info;
+int mml_gicp_align(mml_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt, float* T_inout, int* converged,
+                   mml_gicp_info* info /* may be NULL */);
+/* The call site, unionCloudHandler (:302-318), on a slot that mml_extract filled WITHOUT an extrinsic: when
+ * livox_corner_num > 100 the slot's Livox surf cloud (source) is aligned to its Velodyne surf cloud (target) -- every
+ * frame, _extrin_cnt never advances (:199,307) -- extrinsic_inout = extri_mtx is updated if the alignment converged
+ * (*refreshed), and with apply != 0 the Livox part of the fused cloud is transformed with the (updated or kept) matrix
+ * (pcl::transformPointCloud, :312).  With livox_corner_num <= 100 nothing happens, as in the reference.  Deviation: the
+ * surf clouds are taken from the fused cloud, so Livox surf points beyond far_th (kept by the reference's
+ * removeNearPointCloud, :925) are not part of the source.  Synchronous. */
+int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, int apply, int* refreshed, mml_gicp_info* info);
+
 /* ---- a1..a8: feature extraction -----------------------------------------------------------------
  * feature_extraction::unionCloudHandler minus the PCL GICP refresh (unionFeatureExtract.cpp:266-321):
  * getVeloFeature (:1113-1317) + getHoriFeature/getHoriFeatureExtract (:891-1035) with

@@ -83,6 +83,11 @@ def comm_unique_id():
     return bytes(buf)
 
 
+class GicpInfo(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int), ("objective_evaluations", C.c_int), ("objective", C.c_double),
+                ("n_source", C.c_int), ("n_target", C.c_int)]
+
+
 class Profile(C.Structure):
     _fields_ = [("n_stages", C.c_int), ("name", C.c_char_p * MAX_STAGES), ("total_ms", C.c_double * MAX_STAGES),
                 ("launches", C.c_long * MAX_STAGES)]
@@ -250,6 +255,23 @@ class Context:
         rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 12)
         nv = len(rec) if n_velo is None else int(n_velo)
         self._ck(lib().mml_cloud_upload(self._h, C.c_int(slot), _p(rec) if len(rec) else None, C.c_int(len(rec)), C.c_int(nv)))
+
+    def gicp_align(self, src, tgt, T0=None):
+        """icp_ext_matching on plain clouds: returns (converged, T 4x4 float32, GicpInfo)."""
+        src = _f32(src).reshape(-1, 3)
+        tgt = _f32(tgt).reshape(-1, 3)
+        T = np.ascontiguousarray(np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32).reshape(4, 4).copy())
+        conv, info = C.c_int(0), GicpInfo()
+        self._ck(lib().mml_gicp_align(self._h, _p(src) if len(src) else None, C.c_int(len(src)), _p(tgt) if len(tgt) else None,
+                                      C.c_int(len(tgt)), _p(T), C.byref(conv), C.byref(info)))
+        return bool(conv.value), T, info
+
+    def gicp_refresh(self, slot, extrinsic, apply=True):
+        """unionCloudHandler's extrinsic refresh (:302-318) on a slot extracted without an extrinsic."""
+        T = np.ascontiguousarray(np.asarray(extrinsic, np.float32).reshape(4, 4).copy())
+        ref, info = C.c_int(0), GicpInfo()
+        self._ck(lib().mml_gicp_refresh(self._h, C.c_int(slot), _p(T), C.c_int(1 if apply else 0), C.byref(ref), C.byref(info)))
+        return bool(ref.value), T, info
 
     def extract(self, first=0, count=1, livox_extrinsic=None):
         e = _f32(livox_extrinsic).reshape(16) if livox_extrinsic is not None else None

@@ -114,6 +114,21 @@ class feature_extraction {
         download(slot, info.n_points, fused);
     }
 
+    // unionCloudHandler including its GICP refresh (:302-318): features without an extrinsic, then -- when
+    // livox_corner_num > 100 -- extri_mtx re-estimated from the Livox surf cloud against the Velodyne surf cloud (every frame,
+    // as the reference does) and applied to the Livox part; extri_mtx (row-major) persists across frames in the caller.
+    bool unionCloudRefresh(const float* velo_xyzi, int n_velo, const mml_livox_point* livox, int n_livox, float extri_mtx[16],
+                           PointCloud& fused, mml_scan_info& info, int slot = 0) {
+        mml_ctx* c = ctx_.get();
+        check(c, mml_scan_upload(c, slot, velo_xyzi, n_velo, livox, n_livox), "scan_upload");
+        check(c, mml_extract(c, slot, 1, nullptr), "extract");
+        int refreshed = 0;
+        check(c, mml_gicp_refresh(c, slot, extri_mtx, 1, &refreshed, nullptr), "gicp_refresh");
+        check(c, mml_scan_info_get(c, slot, &info), "scan_info");
+        download(slot, info.n_points, fused);
+        return refreshed != 0;
+    }
+
     // getVeloFeature (:1113-1117) and getHoriFeatureExtract (:952-956) on their own
     void getVeloFeature(const float* velo_xyzi, int n, PointCloud& points_normal, mml_scan_info& info, int slot = 0) {
         unionCloud(velo_xyzi, n, nullptr, 0, nullptr, points_normal, info, slot);
@@ -143,6 +158,38 @@ class feature_extraction {
    private:
     Context& ctx_;
 };
+
+// ---- icp_ext_matching (unionFeatureExtract.cpp:74-123): the GICP behind the per-frame extrinsic refresh --------------------
+// bool icp_ext_matching(cloud_src, cloud_tgt, cloud_aligned, icp_mtx, en_viewer): icp_mtx (row-major here) is assigned and
+// cloud_aligned filled only when the alignment converged.
+inline bool icp_ext_matching(Context& ctx, const PointCloud& cloud_src, const PointCloud& cloud_tgt, PointCloud& cloud_aligned,
+                             float icp_mtx[16]) {
+    std::vector<float> s(3 * cloud_src.size() + 3), t(3 * cloud_tgt.size() + 3);
+    for (size_t i = 0; i < cloud_src.size(); ++i) {
+        s[3 * i] = cloud_src[i].x;
+        s[3 * i + 1] = cloud_src[i].y;
+        s[3 * i + 2] = cloud_src[i].z;
+    }
+    for (size_t i = 0; i < cloud_tgt.size(); ++i) {
+        t[3 * i] = cloud_tgt[i].x;
+        t[3 * i + 1] = cloud_tgt[i].y;
+        t[3 * i + 2] = cloud_tgt[i].z;
+    }
+    int converged = 0;
+    check(ctx.get(), mml_gicp_align(ctx.get(), s.data(), (int)cloud_src.size(), t.data(), (int)cloud_tgt.size(), icp_mtx, &converged, nullptr),
+          "icp_ext_matching");
+    if (!converged) return false;
+    cloud_aligned = cloud_src;  // icp.align(*cloud_aligned): the source under the final transformation
+    for (auto& p : cloud_aligned) {
+        const float x = icp_mtx[0] * p.x + icp_mtx[1] * p.y + icp_mtx[2] * p.z + icp_mtx[3];
+        const float y = icp_mtx[4] * p.x + icp_mtx[5] * p.y + icp_mtx[6] * p.z + icp_mtx[7];
+        const float z = icp_mtx[8] * p.x + icp_mtx[9] * p.y + icp_mtx[10] * p.z + icp_mtx[11];
+        p.x = x;
+        p.y = y;
+        p.z = z;
+    }
+    return true;
+}
 
 // ---- RemoveLidarDistortion (unionPoseEstimation.cpp:402-403): in place on the slot's device-resident fused cloud ----
 inline void RemoveLidarDistortion(Context& ctx, int slot, const Matrix3d& dRlc, const Vector3d& dtlc) {

@@ -178,6 +178,19 @@ int mmlo_estimate_single(const float* corner_feat, int n_corner, const float* su
                          const double* exTlb, double* P, double* Q, int max_outer, int inner_iters,
                          int* is_degenerate, double* outer_trace);
 
+/* ---- the per-frame GICP extrinsic refresh, icp_ext_matching (unionFeatureExtract.cpp:74-123) -------
+ * pcl::GeneralizedIterativeClosestPoint as configured there (10 iterations, transformation epsilon 1e-6, PCL defaults
+ * otherwise), restated from the published PCL 1.8.1 algorithm (gicp.hpp + bfgs.h); PARITY UNPINNED (PCL is not in the
+ * reference tree).  src / tgt: n x 3 floats (livox surf cloud -> velodyne surf cloud).  T_inout: row-major 4 x 4 float,
+ * overwritten with getFinalTransformation() only when the alignment converged (return 1); 0 = "ICP Failed". */
+int mmlo_gicp_align(const float* src, int n_src, const float* tgt, int n_tgt, float* T_inout, int* outer_iterations,
+                    int* bfgs_evaluations, double* last_objective);
+/* pieces of it for the independent checks: objective (1/m) sum res^T M res and its gradient at x = (t, roll, pitch, yaw)
+ * for given correspondences (maha9: n_src x 9, indexed by source point), and the regularised covariances of a cloud */
+double mmlo_gicp_objective(const float* src, const float* tgt, const int* idx_src, const int* idx_tgt, int m, const double* maha9,
+                           int n_src, const double* x, double* grad);
+void mmlo_gicp_covariances(const float* pts, int n, double* out9);
+
 /* Threading of the calling host thread (defaults 1, 1 = the bit-reference configuration of every parity test):
  * livox_line_threads: detectFeaturePoints of the Livox lines in parallel (unionFeatureExtract.cpp:1008-1015, 6 there);
  * solve_threads: residual blocks of mmlo_linearize / mmlo_solve_window in parallel (ceres num_threads, Estimator.cpp:1430). */

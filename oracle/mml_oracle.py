@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "build", "libmml_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("feature.cpp", "estimate.cpp", "linalg.h", "mml_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("feature.cpp", "estimate.cpp", "gicp.cpp", "threads.h", "linalg.h", "mml_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
         return _LIB_PATH
@@ -379,3 +379,34 @@ def plane_fit5(A):
     x = np.zeros(3)
     lib().mmlo_plane_fit5(_p(_f64(A).reshape(15)), _p(x))
     return x
+
+
+def gicp_align(src, tgt, T0=None):
+    """icp_ext_matching: returns (converged, T 4x4 float32, outer iterations, objective evaluations, last objective)."""
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    T = np.ascontiguousarray(np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32).reshape(4, 4).copy())
+    it, ev, fo = C.c_int(0), C.c_int(0), C.c_double(0)
+    lib().mmlo_gicp_align.restype = C.c_int
+    ok = lib().mmlo_gicp_align(_p(src), C.c_int(len(src)), _p(tgt), C.c_int(len(tgt)), _p(T), C.byref(it), C.byref(ev), C.byref(fo))
+    return bool(ok), T, it.value, ev.value, fo.value
+
+
+def gicp_objective(src, tgt, idx_src, idx_tgt, maha, x, grad=True):
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    i_s = np.ascontiguousarray(idx_src, dtype=np.int32)
+    i_t = np.ascontiguousarray(idx_tgt, dtype=np.int32)
+    m9 = _f64(maha).reshape(len(src), 9)
+    g = np.zeros(6)
+    lib().mmlo_gicp_objective.restype = C.c_double
+    f = lib().mmlo_gicp_objective(_p(src), _p(tgt), _p(i_s), _p(i_t), C.c_int(len(i_s)), _p(m9), C.c_int(len(src)), _p(_f64(x)),
+                                  _p(g) if grad else None)
+    return f, g
+
+
+def gicp_covariances(pts):
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros((len(pts), 9))
+    lib().mmlo_gicp_covariances(_p(pts), C.c_int(len(pts)), _p(out))
+    return out.reshape(-1, 3, 3)

@@ -1087,3 +1087,81 @@ def test_dense_labelled_cloud_takes_the_global_sort_path(M, O, synth):
         assert np.array_equal(xs, x)
     finally:
         c.close()
+
+
+
+# ---- the GICP extrinsic refresh ------------------------------------------------------------------
+def test_gicp_align_matches_oracle(M, O, synth):
+    c = M.Context(max_scans=1)
+    try:
+        ev, el = O.extract_velo(synth.velo_scan(12)), O.extract_livox(synth.livox_scan(12))
+        vs, ls = ev["xyzi"][ev["label"] == 2][:, :3].copy(), el["xyzi"][el["label"] == 2][:, :3].copy()
+        Tt = np.eye(4)
+        Tt[:3, :3] = Rsc.from_euler("xyz", [0.01, -0.015, 0.02]).as_matrix()
+        Tt[:3, 3] = [0.05, -0.03, 0.02]
+        rng = np.random.default_rng(0)
+        sub = vs[rng.random(len(vs)) < 0.8]
+        src = ((sub.astype(np.float64) - Tt[:3, 3]) @ Tt[:3, :3]).astype(np.float32)
+        big = np.concatenate([vs + np.float32(0.0), vs[::-1] + np.array([40.0, 0, 0], np.float32), ls + np.array([0, 30.0, 0], np.float32)])  # > 1 LDS tile
+        # well-conditioned problems (a cloud against a displaced copy of itself): same iterates
+        for s_, t_ in ((src, vs), (sub, vs)):
+            okg, Tg, info = c.gicp_align(s_, t_)
+            oko, To, ito, evo, fo = O.gicp_align(s_, t_)
+            assert okg and oko
+            # same algorithm, same float transformation; the objective sums differ in their order of addition only
+            assert np.abs(Tg - To).max() < 2e-5, np.abs(Tg - To).max()
+            assert info.outer_iterations == ito and abs(info.objective - fo) <= 1e-6 * max(fo, 1e-9) + 1e-12
+            assert (info.n_source, info.n_target) == (len(s_), len(t_))
+        # two different samplings of the room (Livox surf vs Velodyne surf) and clouds beyond one LDS tile: the minimum is
+        # flat, the objective is evaluated with a float transformation (as in PCL), and 10 outer iterations stop short of
+        # it -- a rounding-level difference in one sum changes a line-search decision, so the two runs agree only as well
+        # as the problem is conditioned: same basin, same objective to a percent, matrices to a few 1e-3
+        for s_, t_ in ((ls, vs), (big[::2], big)):
+            okg, Tg, info = c.gicp_align(s_, t_)
+            oko, To, ito, evo, fo = O.gicp_align(s_, t_)
+            assert okg and oko and 1 <= info.outer_iterations <= 10
+            assert np.abs(Tg - To).max() < 5e-3, np.abs(Tg - To).max()
+            assert abs(info.objective - fo) <= 0.02 * fo
+        okg, Tg, _ = c.gicp_align(src, vs)
+        assert np.abs(Tg - Tt).max() < 1e-4                              # and it actually recovers the displacement
+        T0 = np.eye(4, dtype=np.float32)
+        T0[1, 3] = -0.5
+        for s_, t_ in ((ls[:12], vs), (ls, vs[:19]), (np.zeros((0, 3), np.float32), vs)):
+            okg, Tg, _ = c.gicp_align(s_, t_, T0)
+            assert not okg and np.array_equal(Tg, T0)                    # "ICP Failed": the matrix is left alone
+    finally:
+        c.close()
+
+
+def test_gicp_refresh_on_a_slot(M, O, synth):
+    """unionCloudHandler's refresh (unionFeatureExtract.cpp:302-318) on the extracted cloud of a slot: Livox surf -> Velodyne
+    surf, extri_mtx updated, Livox part of the fused cloud transformed; skipped when livox_corner_num <= 100."""
+    c = M.Context(max_scans=2)
+    try:
+        v, l = synth.velo_scan(14), synth.livox_scan(14)
+        c.scan_upload(0, v, l)
+        c.scan_upload(1, v, l[:3000])                                   # too few Livox corners for the refresh
+        c.extract(0, 2)
+        before = [c.scan_download(s) for s in range(2)]
+        assert before[0]["info"].livox_corner_num > 100 and before[1]["info"].livox_corner_num <= 100
+        nv = before[0]["info"].n_velo
+        lab, xyz = before[0]["label"], before[0]["xyzi"][:, :3]
+        vs, ls = xyz[:nv][lab[:nv] == 2], xyz[nv:][lab[nv:] == 2]
+        ok, T, info = c.gicp_refresh(0, np.eye(4), apply=True)
+        oko, To, ito, _, _ = O.gicp_align(ls, vs)
+        assert ok and oko and np.abs(T - To).max() < 5e-3            # (cross-sensor case: see test_gicp_align_matches_oracle)
+        assert (info.n_source, info.n_target) == (len(ls), len(vs))
+        after = c.scan_download(0)
+        assert np.array_equal(after["xyzi"][:nv], before[0]["xyzi"][:nv]) and np.array_equal(after["label"], lab)
+        p = before[0]["xyzi"][nv:, :3]
+        exp = np.stack([T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1] + T[r, 2] * p[:, 2] + T[r, 3] for r in range(3)], 1)   # float, PCL's order
+        assert np.array_equal(after["xyzi"][nv:, :3], exp.astype(np.float32))
+        assert np.array_equal(after["xyzi"][nv:, 3], before[0]["xyzi"][nv:, 3])
+        T1 = np.eye(4, dtype=np.float32)
+        T1[2, 3] = 0.125
+        ok, T, _ = c.gicp_refresh(1, T1, apply=True)
+        assert not ok and np.array_equal(T, T1)
+        a1 = c.scan_download(1)
+        assert np.array_equal(a1["xyzi"], before[1]["xyzi"])             # nothing applied either (:302)
+    finally:
+        c.close()

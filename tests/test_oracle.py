@@ -695,3 +695,64 @@ def test_trust_region_against_ceres_transcription(O, scene, W, w_tan, huber, fix
     assert term == so["termination"] or (iters == 10 and not fixed)       # at the cap Ceres reports NO_CONVERGENCE first
     assert np.abs(np.array(trace).reshape(iters, W, 6) - np.asarray(to).reshape(iters, W, 6)).max() < 1e-7
     assert np.abs(xp.reshape(W, 6) - xo).max() < 1e-7
+
+
+# ---- GICP extrinsic refresh (oracle/gicp.cpp), checked piecewise against numpy -------------------------
+def _surf_clouds(O, synth, k):
+    ev, el = O.extract_velo(synth.velo_scan(k)), O.extract_livox(synth.livox_scan(k))
+    return ev["xyzi"][ev["label"] == 2][:, :3].copy(), el["xyzi"][el["label"] == 2][:, :3].copy()
+
+
+def test_gicp_pieces_against_numpy(O, synth):
+    vs, ls = _surf_clouds(O, synth, 12)
+    assert len(vs) > 300 and len(ls) > 300
+    # regularised covariances: 20 nearest neighbours (ties by index), eigenvalues replaced by (1, 1, 1e-3)
+    C = O.gicp_covariances(vs)
+    for i in (0, 5, 77, len(vs) - 1):
+        d = ((vs - vs[i]) ** 2).sum(1)
+        nn = np.argsort(d, kind="stable")[:20]
+        w, v = np.linalg.eigh(np.cov(vs[nn].astype(np.float64).T, bias=True))
+        if w[1] - w[0] > 1e-9 * max(w[2], 1e-12):      # the smallest direction is well defined
+            assert np.abs(np.eye(3) - (1 - 1e-3) * np.outer(v[:, 0], v[:, 0]) - C[i]).max() < 1e-5
+        assert np.allclose(np.linalg.eigvalsh(C[i]), [1e-3, 1.0, 1.0], atol=1e-9)
+    # objective and gradient for fixed correspondences
+    rng = np.random.default_rng(1)
+    src = ls[:400]
+    j = cKDTree(vs).query(src)[1]
+    M = np.linalg.inv(O.gicp_covariances(src) + C[j])
+    x = np.array([0.01, -0.02, 0.015, 0.004, -0.006, 0.01])
+
+    def fobj(x):
+        Rm = Rsc.from_euler("ZYX", [x[5], x[4], x[3]]).as_matrix()
+        res = src.astype(np.float64) @ Rm.T + x[:3] - vs[j]
+        return np.einsum("ni,nij,nj->", res, M, res) / len(src)
+    f, g = O.gicp_objective(src, vs, np.arange(len(src)), j, M, x)
+    assert np.isclose(f, fobj(x), rtol=1e-5)           # (the product's transformation is float, as PCL's)
+    gn = np.array([(fobj(x + h) - fobj(x - h)) / 2e-6 for h in np.eye(6) * 1e-6])
+    assert np.allclose(g, gn, rtol=1e-3, atol=1e-4 * np.abs(gn).max())
+
+
+def test_gicp_alignment_properties(O, synth):
+    vs, ls = _surf_clouds(O, synth, 12)
+    Tt = np.eye(4)
+    Tt[:3, :3] = Rsc.from_euler("xyz", [0.01, -0.015, 0.02]).as_matrix()
+    Tt[:3, 3] = [0.05, -0.03, 0.02]
+    rng = np.random.default_rng(0)
+    sub = vs[rng.random(len(vs)) < 0.8]
+    src = ((sub.astype(np.float64) - Tt[:3, 3]) @ Tt[:3, :3]).astype(np.float32)      # Tt maps src back onto the target
+    ok, T, it, evals, fo = O.gicp_align(src, vs)
+    assert ok and 1 <= it <= 10 and evals > 10
+    assert np.abs(T - Tt).max() < 1e-4 and fo < 1e-6
+    # already aligned: converges at once to (nearly) the identity
+    ok, T, it, _, _ = O.gicp_align(sub, vs)
+    assert ok and np.abs(T - np.eye(4)).max() < 1e-5
+    # Livox surf -> Velodyne surf of one fused scan (different sampling of the same room): a small correction
+    ok, T, it, _, _ = O.gicp_align(ls, vs)
+    assert ok and np.abs(T[:3, 3]).max() < 0.1 and np.abs(T[:3, :3] - np.eye(3)).max() < 0.02
+    # fewer points than the covariance needs: "ICP Failed", the matrix is left alone
+    T0 = np.eye(4, dtype=np.float32)
+    T0[0, 3] = 0.25
+    ok, T, it, _, _ = O.gicp_align(ls[:12], vs, T0)
+    assert not ok and np.array_equal(T, T0)
+    ok, T, _, _, _ = O.gicp_align(ls, vs[:19], T0)
+    assert not ok and np.array_equal(T, T0)
