@@ -409,6 +409,24 @@ def run_throughput(args, rank, local_rank, world, dist):
         with_upload = {"scans_per_s": B / (t_up + t_st) * world, "upload_GBps": up_bytes / t_up / 1e9,
                        "upload_ms_per_scan": t_up / B * 1e3, "note": "uploads (pinned host memory, one hipMemcpyAsync per "
                        "sensor per scan) serialised in front of the step; with uploads overlapped the bound is min(upload, compute)"}
+        # the same batch staged in two slot-strided pinned arrays and copied with mml_scan_upload_batch (two copies in all)
+        c = ctx.cfg
+        if c.max_velo_points % 64 == 0 and c.max_livox_points % 64 == 0:
+            vb = torch.zeros((B, c.max_velo_points, 4), dtype=torch.float32).pin_memory().numpy()
+            lb = torch.zeros((B, c.max_livox_points * 20), dtype=torch.uint8).pin_memory().numpy().view(synth.LIVOX_DTYPE).reshape(B, c.max_livox_points)
+            nvs, nls = np.zeros(B, np.int32), np.zeros(B, np.int32)
+            for s in range(B):
+                v, l = scans[s % nd]
+                nvs[s], nls[s] = len(v), len(l)
+                vb[s, :len(v)] = v
+                lb[s, :len(l)] = l
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            ctx.scan_upload_batch(0, vb, nvs, lb, nls)
+            ctx.synchronize()
+            t_upb = time.perf_counter() - t1
+            with_upload["batched"] = {"scans_per_s": B / (t_upb + t_st) * world, "upload_GBps": (vb.nbytes + lb.nbytes) / t_upb / 1e9,
+                                      "note": "mml_scan_upload_batch: the whole batch in two host-to-device copies, then the step"}
     except Exception as e:
         with_upload = {"error": repr(e)[:200]}
 

@@ -200,6 +200,21 @@ class Context:
             self.synchronize()
             self._keep = self._keep[-self.cfg.max_scans:]
 
+    def scan_upload_batch(self, first, velo_base, n_velo, livox_base, n_livox):
+        """count scans in two copies: velo_base (count, max_velo_points, 4) float32, livox_base (count, max_livox_points)
+        LIVOX_DTYPE, laid out with the slot stride; n_velo / n_livox: valid points per scan.  The host arrays must stay
+        valid until the next synchronising call."""
+        nv = np.ascontiguousarray(n_velo, dtype=np.int32)
+        nl = np.ascontiguousarray(n_livox, dtype=np.int32)
+        count = len(nv)
+        v = np.ascontiguousarray(velo_base, dtype=np.float32)
+        l = np.ascontiguousarray(livox_base)
+        if v.size != count * self.cfg.max_velo_points * 4 or l.size * l.dtype.itemsize != count * self.cfg.max_livox_points * 20:
+            raise ValueError("staging arrays must hold count x max points per sensor")
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append((v, l, nv, nl))
+        self._ck(lib().mml_scan_upload_batch(self._h, C.c_int(first), C.c_int(count), _p(v), _p(nv), _p(l), _p(nl)))
+
     def scan_upload_pointcloud2(self, slot, data, n_points, point_step, off_x, off_y, off_z, off_intensity, livox):
         """Velodyne part as a sensor_msgs/PointCloud2 payload (bytes / uint8 array), decoded on the device."""
         raw = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)

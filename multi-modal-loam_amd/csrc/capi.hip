@@ -73,7 +73,7 @@ void mml_destroy(mml_ctx* ctx) {
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue,
-                    ctx->cb_n,     ctx->fu_xyzi,  ctx->fu_rel,   ctx->fu_line,  ctx->fu_label,
+                    ctx->cb_n,     ctx->ln_rel,   ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
@@ -170,10 +170,9 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->redo_queue, B * NT);
     ALLOC(ctx->crop_cnt, B * ((NT + 255) / 256) * 8);
     ALLOC(ctx->cb_n, B * 2);
-    ALLOC(ctx->fu_xyzi, B * NT);
-    ALLOC(ctx->fu_rel, B * NT);
-    ALLOC(ctx->fu_line, B * NT);
-    ALLOC(ctx->fu_label, B * NT);
+    ALLOC(ctx->ln_rel, B * NT);
+    ALLOC(ctx->ln_line, B * NT);
+    ALLOC(ctx->ln_label, B * NT);
     ALLOC(ctx->fu_info, B * 8);
     ALLOC(ctx->ft_xyz[0], B * MF);
     ALLOC(ctx->ft_xyz[1], B * MF);
@@ -268,6 +267,37 @@ int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo, 
     return MML_OK;
 }
 
+int mml_scan_upload_batch(mml_ctx* ctx, int first_slot, int count, const float* velo_base, const int* n_velo,
+                          const mml_livox_point* livox_base, const int* n_livox) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(n_velo && n_livox, MML_ERR_INVALID, "null count arrays");
+    MML_REQUIRE(ctx->NV == ctx->cfg.max_velo_points && ctx->NL == ctx->cfg.max_livox_points, MML_ERR_INVALID,
+                "mml_scan_upload_batch needs max_velo_points / max_livox_points that are multiples of 64 (the slot stride)");
+    bool any_v = false, any_l = false;
+    for (int i = 0; i < count; ++i) {
+        MML_REQUIRE(n_velo[i] >= 0 && n_livox[i] >= 0, MML_ERR_INVALID, "negative point count");
+        MML_REQUIRE(n_velo[i] <= ctx->cfg.max_velo_points && n_livox[i] <= ctx->cfg.max_livox_points, MML_ERR_CAPACITY,
+                    "scan exceeds max_velo_points / max_livox_points");
+        any_v = any_v || n_velo[i] > 0;
+        any_l = any_l || n_livox[i] > 0;
+    }
+    MML_REQUIRE((!any_v || velo_base) && (!any_l || livox_base), MML_ERR_INVALID, "null point buffer");
+    if (any_v)
+        MML_HIP(hipMemcpyAsync(ctx->velo_in + (size_t)first_slot * ctx->NV, velo_base, sizeof(float4) * (size_t)count * ctx->NV,
+                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    if (any_l)
+        MML_HIP(hipMemcpyAsync(ctx->livox_in + (size_t)first_slot * ctx->NL, livox_base, sizeof(mml_livox_point) * (size_t)count * ctx->NL,
+                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    double* st = stage_alloc(ctx, (size_t)count);
+    int* sti = reinterpret_cast<int*>(st);
+    for (int i = 0; i < count; ++i) {
+        ctx->h_n_in[2 * (first_slot + i)] = sti[2 * i] = n_velo[i];
+        ctx->h_n_in[2 * (first_slot + i) + 1] = sti[2 * i + 1] = n_livox[i];
+    }
+    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * (size_t)first_slot, sti, sizeof(int) * 2 * (size_t)count, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    return MML_OK;
+}
+
 // ---- wire formats ---------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ float load_f32_unaligned(const uint8_t* p) {
@@ -302,25 +332,57 @@ __global__ void k_decode_custompoints(const uint8_t* raw, int n, mml_livox_point
     q._pad = 0;
     out[i] = q;
 }
+// The fused cloud [velo_combine ; livox_combine] in its own order, gathered from the line-bucketed storage: position pos
+// (Velodyne region [0, cv), Livox region [NV, NV + cl)) holds fused point ln_gidx[pos] when that is >= 0.  The Velodyne
+// part of an extracted cloud carries intensity 0 (unionFeatureExtract.cpp:1254-1256); an uploaded cloud keeps its own.
+struct FusedView {
+    const float4* pts;
+    const int* gidx;
+    const float* rel;
+    const uint8_t* line;
+    const uint8_t* label;
+    const int* cb_n;  // this slot's two valid counts
+    int NV, NT, keep_intensity;
+};
+__device__ __forceinline__ bool fused_at(const FusedView& V, int pos, int& g, float4& p) {
+    if (pos >= V.NT) return false;
+    if (pos < V.NV ? pos >= V.cb_n[0] : pos - V.NV >= V.cb_n[1]) return false;
+    g = V.gidx[pos];
+    if (g < 0) return false;
+    p = V.pts[pos];
+    if (pos < V.NV && !V.keep_intensity) p.w = 0.f;
+    return true;
+}
 // pcl::toROSMsg<PointXYZINormal> payload: 48-byte records, x y z 1 | normal_x normal_y normal_z 0 | intensity curvature 0 0
-__global__ void k_encode_xyzinormal(const float4* xyzi, const float* rel, const uint8_t* line, const uint8_t* label, int n,
-                                    float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = xyzi[i];
-    float* o = out + 12 * (size_t)i;
+__global__ void k_encode_xyzinormal(FusedView V, float* out) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    int g;
+    float4 p;
+    if (!fused_at(V, pos, g, p)) return;
+    float* o = out + 12 * (size_t)g;
     o[0] = p.x;
     o[1] = p.y;
     o[2] = p.z;
     o[3] = 1.0f;
-    o[4] = rel[i];             // normal_x: in-sweep time (unionFeatureExtract.cpp:1186)
-    o[5] = (float)line[i];     // normal_y: ring / Livox line
-    o[6] = (float)label[i];    // normal_z: 0 none, 1 corner, 2 surf (:1018-1021)
+    o[4] = V.rel[pos];             // normal_x: in-sweep time (unionFeatureExtract.cpp:1186)
+    o[5] = (float)V.line[pos];     // normal_y: ring / Livox line
+    o[6] = (float)V.label[pos];    // normal_z: 0 none, 1 corner, 2 surf (:1018-1021)
     o[7] = 0.f;
-    o[8] = p.w;                // intensity
-    o[9] = 0.f;                // curvature
+    o[8] = p.w;                    // intensity
+    o[9] = 0.f;                    // curvature
     o[10] = 0.f;
     o[11] = 0.f;
+}
+// the same cloud as four arrays (mml_scan_download): xyzi | reltime | line | label, back to back in one staging buffer
+__global__ void k_fused_arrays(FusedView V, int n, float4* xyzi, float* rel, uint8_t* line, uint8_t* label) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    int g;
+    float4 p;
+    if (!fused_at(V, pos, g, p)) return;
+    xyzi[g] = p;
+    rel[g] = V.rel[pos];
+    line[g] = V.line[pos];
+    label[g] = V.label[pos];
 }
 int ensure_wire_stage(mml_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->wire_stage_bytes) return MML_OK;
@@ -397,6 +459,26 @@ int upload_wire_impl(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, 
 }
 }  // namespace
 
+namespace {
+// the `uploaded` flag of the slot's AssignAux record (8 ints per slot, last one): see feature.hip
+int fused_view(mml_ctx* ctx, int slot, FusedView& V) {
+    int up = 0;
+    MML_HIP(hipMemcpyAsync(&up, ctx->assign_aux + 8 * (size_t)slot + 7, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    const size_t off = (size_t)slot * ctx->NT;
+    V.pts = ctx->ln_pts + off;
+    V.gidx = ctx->ln_gidx + off;
+    V.rel = ctx->ln_rel + off;
+    V.line = ctx->ln_line + off;
+    V.label = ctx->ln_label + off;
+    V.cb_n = ctx->cb_n + 2 * (size_t)slot;
+    V.NV = ctx->NV;
+    V.NT = ctx->NT;
+    V.keep_intensity = up;
+    return MML_OK;
+}
+}  // namespace
+
 int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int capacity_points, int* n_points) {
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE(n_points != nullptr, MML_ERR_INVALID, "null n_points");
@@ -409,9 +491,10 @@ int mml_scan_download_pointxyzinormal(mml_ctx* ctx, int slot, uint8_t* out, int 
     const size_t bytes = (size_t)info.n_points * 48;
     rc = ensure_wire_stage(ctx, bytes);
     if (rc != MML_OK) return rc;
-    const size_t off = (size_t)slot * ctx->NT;
-    hipLaunchKernelGGL(k_encode_xyzinormal, dim3((info.n_points + 255) / 256), dim3(256), 0, MML_STREAM(ctx), ctx->fu_xyzi + off,
-                       ctx->fu_rel + off, ctx->fu_line + off, ctx->fu_label + off, info.n_points,
+    FusedView V;
+    rc = fused_view(ctx, slot, V);
+    if (rc != MML_OK) return rc;
+    hipLaunchKernelGGL(k_encode_xyzinormal, dim3((ctx->NT + 255) / 256), dim3(256), 0, MML_STREAM(ctx), V,
                        reinterpret_cast<float*>(ctx->wire_stage));
     MML_HIP(hipGetLastError());
     MML_HIP(hipMemcpyAsync(out, ctx->wire_stage, bytes, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
@@ -423,7 +506,8 @@ int mml_cloud_upload(mml_ctx* ctx, int slot, const uint8_t* pointxyzinormal, int
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE(n_points >= 0 && n_velo >= 0 && n_velo <= n_points, MML_ERR_INVALID, "bad point counts");
     MML_REQUIRE(n_points == 0 || pointxyzinormal, MML_ERR_INVALID, "null point buffer");
-    MML_REQUIRE(n_points <= ctx->NT, MML_ERR_CAPACITY, "cloud exceeds max_velo_points + max_livox_points");
+    MML_REQUIRE(n_velo <= ctx->NV && n_points - n_velo <= ctx->NL, MML_ERR_CAPACITY,
+                "cloud exceeds max_velo_points / max_livox_points (the Velodyne and Livox parts have their own regions)");
     const size_t bytes = (size_t)n_points * 48;
     int rc = ensure_wire_stage(ctx, bytes ? bytes : 48);
     if (rc != MML_OK) return rc;
@@ -474,12 +558,26 @@ int mml_scan_download(mml_ctx* ctx, int slot, float* xyzi, float* reltime, uint8
     int rc = mml_scan_info_get(ctx, slot, &info);
     if (rc != MML_OK) return rc;
     MML_REQUIRE(capacity >= info.n_points, MML_ERR_CAPACITY, "download capacity too small");
-    const size_t n = info.n_points, off = (size_t)slot * ctx->NT;
+    const size_t n = info.n_points;
     if (n == 0) return MML_OK;
-    if (xyzi) MML_HIP(hipMemcpyAsync(xyzi, ctx->fu_xyzi + off, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
-    if (reltime) MML_HIP(hipMemcpyAsync(reltime, ctx->fu_rel + off, sizeof(float) * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
-    if (line) MML_HIP(hipMemcpyAsync(line, ctx->fu_line + off, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
-    if (label) MML_HIP(hipMemcpyAsync(label, ctx->fu_label + off, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    // the fused order exists only here: gathered into a staging buffer (16 + 4 + 1 + 1 bytes per point), then copied out
+    const size_t n16 = (n + 15) & ~size_t(15);
+    rc = ensure_wire_stage(ctx, n16 * 22);
+    if (rc != MML_OK) return rc;
+    uint8_t* st = reinterpret_cast<uint8_t*>(ctx->wire_stage);
+    float4* s_xyzi = reinterpret_cast<float4*>(st);
+    float* s_rel = reinterpret_cast<float*>(st + n16 * 16);
+    uint8_t* s_line = st + n16 * 20;
+    uint8_t* s_label = st + n16 * 21;
+    FusedView V;
+    rc = fused_view(ctx, slot, V);
+    if (rc != MML_OK) return rc;
+    hipLaunchKernelGGL(k_fused_arrays, dim3((ctx->NT + 255) / 256), dim3(256), 0, MML_STREAM(ctx), V, (int)n, s_xyzi, s_rel, s_line, s_label);
+    MML_HIP(hipGetLastError());
+    if (xyzi) MML_HIP(hipMemcpyAsync(xyzi, s_xyzi, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    if (reltime) MML_HIP(hipMemcpyAsync(reltime, s_rel, sizeof(float) * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    if (line) MML_HIP(hipMemcpyAsync(line, s_line, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    if (label) MML_HIP(hipMemcpyAsync(label, s_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     return MML_OK;
 }
@@ -502,7 +600,7 @@ int mml_detect_line(mml_ctx* ctx, const float* pts, int n, int* sharp, int* n_sh
     if (rc != MML_OK) return rc;
     std::vector<uint8_t> lab(n);
     std::vector<uint16_t> fin(n);
-    MML_HIP(hipMemcpyAsync(lab.data(), ctx->fu_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(lab.data(), ctx->ln_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipMemcpyAsync(fin.data(), d_final, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     int ns = 0, nf = 0;

@@ -67,10 +67,9 @@ struct FeatParams {
     int B;
     uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
     int* cb_n;
-    float4* fu_xyzi;
-    float* fu_rel;
-    uint8_t* fu_line;
-    uint8_t* fu_label;
+    float* ln_rel;       // in-sweep time of the bucketed point
+    uint8_t* ln_line;    // its ring / Livox line
+    uint8_t* ln_label;   // its label (kept points only)
     int* fu_info;
     const float* extr;  // 16 floats or nullptr
     unsigned* brk_queue;  // [B][NT] line-bucketed positions whose break-point test needs the double-precision part
@@ -124,7 +123,7 @@ __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int
 struct AssignAux {  // per slot, written by passes A / B
     int first_finite, last_finite, trig, kept_velo;
     float startOri, endOri;
-    int kept_livox, pad;
+    int kept_livox, uploaded;  // uploaded: the slot was filled by mml_cloud_upload (intensities are the caller's)
 };
 // lidars_extrinsic_cali.h:424-477: removeNearFarPoints keeps near <= |p|^2 <= far, removeNearPointCloud only tests near
 __device__ __forceinline__ void crop_test(const FeatParams& P, float x, float y, float z, bool& keep, bool& near_ok) {
@@ -141,6 +140,7 @@ __global__ void k_assign_init(FeatParams P, int count) {
         a->first_finite = 0x7fffffff;
         a->last_finite = -1;
         a->trig = 0x7fffffff;
+        a->uploaded = 0;
         int* info = P.fu_info + 8 * (P.first + t);
         info[4] = 0;  // livox corner / surf: k_select adds the labelled points beyond far_th, k_crop the kept ones
         info[5] = 0;
@@ -459,12 +459,14 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     }
     const int line = (sensor == 0 ? 0 : P.n_rings) + key;
     const int dst = P.line_start[(size_t)b * P.L + line] + pos;
-    P.ln_pts[(size_t)b * P.NT + dst] = praw;
-    // where the label of this point goes: its fused index, or -2 for a Livox point that only fails the far test (its
-    // label still counts towards livox_corner_num / livox_surf_num, :925-940), or -1
-    P.ln_gidx[(size_t)b * P.NT + dst] = keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1);
-    if (!keep) return;
-    float rel;
+    const size_t g = (size_t)b * P.NT + dst;
+    P.ln_pts[g] = praw;
+    // the point's index in the fused cloud, or -2 for a Livox point that only fails the far test (its label still counts
+    // towards livox_corner_num / livox_surf_num, :925-940), or -1
+    P.ln_gidx[g] = keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1);
+    P.ln_line[g] = (uint8_t)key;
+    P.ln_label[g] = 0;
+    float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
     if (sensor == 0) {
         const float startOri = a->startOri, endOri = a->endOri;
         float ori = P.raw_ori[(size_t)b * P.NV + i];
@@ -486,11 +488,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
         const double timeSpan = livox_to_sec(in[n - 1].offset_time);  // :985
         rel = livox_to_sec(off_time) / timeSpan;                       // :995
     }
-    const size_t g = (size_t)b * P.NT + fdst;
-    P.fu_xyzi[g] = out;
-    P.fu_rel[g] = rel;
-    P.fu_line[g] = (uint8_t)key;
-    P.fu_label[g] = 0;
+    P.ln_rel[g] = rel;
 }
 
 // locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
@@ -1703,7 +1701,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 
     SEL_MARK(10);
     // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
-    uint8_t* fulab = P.fu_label + (size_t)b * P.NT;
+    uint8_t* lnlab = P.ln_label + base;
     FOR_POINTS(
         const unsigned me = W[2 * i + 1];
         const unsigned at = ATTR(i, k);
@@ -1738,7 +1736,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             if (lab) {
                 const int gi = CACHED ? r_gidx[k] : gidx[i];
                 if (gi >= 0)
-                    fulab[gi] = (uint8_t)lab;
+                    lnlab[i] = (uint8_t)lab;
                 else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940
                     atomicAdd(&P.fu_info[8 * b + 3 + lab], 1);
             }
@@ -1823,8 +1821,12 @@ static int select_round_cap(int want) {
 // k_select has written the labels there.  What is left: the label counts of union_cloud.msg, the index lists of the
 // corner- and surf-labelled points (the label split of Estimator.cpp:992-1011, consumed by the voxel down-sampler) and
 // the Livox extrinsic, which the reference applies only once livox_corner_num is known (:302-318).
-// One workgroup per slot: labels are 1 byte per fused point, so a whole scan is a few tens of KB -- counting, the scan of
-// the counts and the emission of the two index lists fit one launch (two sweeps over the label bytes).
+// One workgroup per slot: labels are 1 byte per bucketed point, so a whole scan is a few tens of KB -- counting, the scan
+// of the counts and the emission of the two index lists fit one launch (two sweeps over the label bytes).  The labels
+// sit at the points' line-bucketed positions: Velodyne lines in [0, cb_n[0]), Livox lines in [NV, NV + cb_n[1]) (NV is a
+// multiple of 64, so both regions start on a word); the sweeps walk the concatenation of the two regions word by word.
+// The lists hold bucketed positions (ascending: the Velodyne part is a prefix); the fused order the reference sums a
+// voxel's points in is restored by the voxel sort, which carries the fused index in its key.
 constexpr int CROP_THREADS = 512;  // (1024-thread workgroups wait long for wave slots next to other lanes' kernels)
 __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, int lds_words) {
     __shared__ int s_w[CROP_THREADS / 64][4];
@@ -1833,33 +1835,44 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
     const int nv = a->kept_velo, n = nv + a->kept_livox;
+    const int cv = P.cb_n[2 * b], cl = P.cb_n[2 * b + 1];   // valid points per sensor (kept or not)
     const size_t o = (size_t)b * P.NT;
-    const uint8_t* lab = P.fu_label + o;
+    const uint32_t* lwv = reinterpret_cast<const uint32_t*>(P.ln_label + o);
+    const uint32_t* lwl = reinterpret_cast<const uint32_t*>(P.ln_label + o + P.NV);
+    const int wv = (cv + 3) / 4, wl = (cl + 3) / 4, words = wv + wl;
     // consecutive chunk of whole 4-byte words per thread
-    const int words = (n + 3) / 4;
     const int per = (words + CROP_THREADS - 1) / CROP_THREADS;
     const int w0 = tid * per, w1 = min(words, w0 + per);
     int c[4] = {0, 0, 0, 0};  // corner, surf, velo corner, velo surf
-    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lab);
-    // The label bytes are staged in LDS first when they fit (lds_words > 0): coalesced, all loads of a thread in flight
+    // The label words are staged in LDS first when they fit (lds_words > 0): coalesced, all loads of a thread in flight
     // together -- the per-thread chunks below are `per` words apart from lane to lane, and walking them in global memory
     // is one dependent, uncoalesced load per word, twice.
     extern __shared__ uint32_t s_lab[];
-    if (words <= lds_words) {
-        for (int w = tid; w < words; w += CROP_THREADS) s_lab[w] = lw[w];
+    const bool staged = words <= lds_words;
+    if (staged) {
+        for (int w = tid; w < words; w += CROP_THREADS) s_lab[w] = w < wv ? lwv[w] : lwl[w - wv];
         __syncthreads();
-        lw = s_lab;
     }
+    auto word = [&](int w) -> uint32_t { return staged ? s_lab[w] : (w < wv ? lwv[w] : lwl[w - wv]); };
+    // word w, byte q -> bucketed position (or -1 for the padding bytes behind a region)
+    auto position = [&](int w, int q) -> int {
+        if (w < wv) {
+            const int p = 4 * w + q;
+            return p < cv ? p : -1;
+        }
+        const int p = 4 * (w - wv) + q;
+        return p < cl ? P.NV + p : -1;
+    };
     for (int w = w0; w < w1; ++w) {
-        const uint32_t v = lw[w];
+        const uint32_t v = word(w);
         if (v == 0) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int p = 4 * w + q;
+            const int p = position(w, q);
             const int l = (v >> (8 * q)) & 255u;
-            if (p < n && l) {
+            if (p >= 0 && l) {
                 c[l == 1 ? 0 : 1] += 1;
-                if (p < nv) c[l == 1 ? 2 : 3] += 1;
+                if (p < P.NV) c[l == 1 ? 2 : 3] += 1;
             }
         }
     }
@@ -1890,16 +1903,16 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
     int d1 = base[0] + inc[0] - c[0], d2 = base[1] + inc[1] - c[1];
     if (c[0] | c[1]) {
         for (int w = w0; w < w1; ++w) {
-            const uint32_t v = lw[w];
+            const uint32_t v = word(w);
             if (v == 0) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int p = 4 * w + q;
+                const int p = position(w, q);
                 const int l = (v >> (8 * q)) & 255u;
-                if (p < n && l == 1) {
+                if (p >= 0 && l == 1) {
                     if (d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)p;
                     ++d1;
-                } else if (p < n && l == 2) {
+                } else if (p >= 0 && l == 2) {
                     if (d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)p;
                     ++d2;
                 }
@@ -1920,17 +1933,18 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
         info[7] = s_tot[1];
     }
     if (P.extr != nullptr && livox_corner > 100) {  // :302-318
-        // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float
+        // pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp), float; the Livox region (points the crop
+        // dropped are transformed along, nobody reads them)
         const float* e = P.extr;
-        for (int p = nv + tid; p < n; p += CROP_THREADS) {
-            float4 pt = P.fu_xyzi[o + p];
+        for (int p = tid; p < cl; p += CROP_THREADS) {
+            float4 pt = P.ln_pts[o + P.NV + p];
             const float x = e[0] * pt.x + e[1] * pt.y + e[2] * pt.z + e[3];
             const float y = e[4] * pt.x + e[5] * pt.y + e[6] * pt.z + e[7];
             const float z = e[8] * pt.x + e[9] * pt.y + e[10] * pt.z + e[11];
             pt.x = x;
             pt.y = y;
             pt.z = z;
-            P.fu_xyzi[o + p] = pt;
+            P.ln_pts[o + P.NV + p] = pt;
         }
     }
 }
@@ -1944,7 +1958,7 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
     }
     if (t < n) {
         P.ln_gidx[t] = t;
-        P.fu_label[t] = 0;
+        P.ln_label[t] = 0;
     }
     if (t == 0) {
         P.cb_n[0] = n;
@@ -1995,10 +2009,9 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.B = ctx->B;
     P.ln_final = nullptr;
     P.cb_n = ctx->cb_n;
-    P.fu_xyzi = ctx->fu_xyzi;
-    P.fu_rel = ctx->fu_rel;
-    P.fu_line = ctx->fu_line;
-    P.fu_label = ctx->fu_label;
+    P.ln_rel = ctx->ln_rel;
+    P.ln_line = ctx->ln_line;
+    P.ln_label = ctx->ln_label;
     P.fu_info = ctx->fu_info;
     P.extr = nullptr;
     P.brk_queue = ctx->brk_queue;
@@ -2071,22 +2084,27 @@ __global__ void k_decode_xyzinormal(const float* raw, int n, int n_velo, int slo
         AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + slot;
         a->kept_velo = n_velo;
         a->kept_livox = n - n_velo;
+        a->uploaded = 1;
+        P.cb_n[2 * slot] = n_velo;        // every uploaded point is a valid, kept point of its sensor's region
+        P.cb_n[2 * slot + 1] = n - n_velo;
         int* info = P.fu_info + 8 * slot;
         info[4] = 0;
         info[5] = 0;
     }
     if (i >= n) return;
     const float* r = raw + 12 * (size_t)i;
-    const size_t o = (size_t)slot * P.NT + i;
-    P.fu_xyzi[o] = make_float4(r[0], r[1], r[2], r[8]);
-    P.fu_rel[o] = r[4];
+    // fused index i -> storage position: the Velodyne part from 0, the Livox part from NV
+    const size_t o = (size_t)slot * P.NT + (i < n_velo ? i : P.NV + (i - n_velo));
+    P.ln_pts[o] = make_float4(r[0], r[1], r[2], r[8]);
+    P.ln_gidx[o] = i;
+    P.ln_rel[o] = r[4];
     const float ln = r[5], nz = r[6];
-    P.fu_line[o] = (uint8_t)(ln >= 0.f && ln < 255.f ? (int)ln : 255);
+    P.ln_line[o] = (uint8_t)(ln >= 0.f && ln < 255.f ? (int)ln : 255);
     // std::abs(normal_z - 1.0) < 1e-5 etc. are evaluated in double on the float field
     uint8_t lab = 0;
     if (fabs((double)nz - 1.0) < 1e-5) lab = 1;
     else if (fabs((double)nz - 2.0) < 1e-5) lab = 2;
-    P.fu_label[o] = lab;
+    P.ln_label[o] = lab;
 }
 
 int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, int n_velo) {
@@ -2100,7 +2118,7 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
     return MML_OK;
 }
 
-// mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in fu_label[0..n) and ln_final.
+// mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in ln_label[0..n) and ln_final.
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     FeatParams P = make_params(ctx, 0);
     P.ln_final = d_final;

@@ -641,38 +641,28 @@ __global__ void k_gicp_init(GicpState* st) {
     }
 }
 
-// the slot's surf clouds: label list of kind 1 (fused order), split at n_velo
-__global__ void k_gicp_gather(const float4* fu_xyzi, const unsigned* list, int nsel, int n_velo, float4* velo, float4* livox, int* counts) {
-    // the list is ascending in the fused index: the Velodyne part is a prefix
+// the slot's surf clouds: label list of kind 1 = ascending bucketed positions, Velodyne lines below NV, Livox lines from NV
+__global__ void k_gicp_gather(const float4* ln_pts, const unsigned* list, int nsel, int NV, float4* velo, float4* livox, int* counts) {
     __shared__ int s_split;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (threadIdx.x == 0) {  // every block finds the split for itself (log2(nsel) loads)
         int lo = 0, hi = nsel;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if ((int)list[mid] < n_velo)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        counts[0] = lo;
-        counts[1] = nsel - lo;
-    }
-    // every block recomputes the split for itself (log2(nsel) loads)
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = nsel;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((int)list[mid] < n_velo)
+            if ((int)list[mid] < NV)
                 lo = mid + 1;
             else
                 hi = mid;
         }
         s_split = lo;
+        if (blockIdx.x == 0) {
+            counts[0] = lo;
+            counts[1] = nsel - lo;
+        }
     }
     __syncthreads();
     const int split = s_split;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nsel; i += gridDim.x * blockDim.x) {
-        const float4 p = fu_xyzi[list[i]];
+        const float4 p = ln_pts[list[i]];
         if (i < split)
             velo[i] = p;
         else
@@ -785,7 +775,10 @@ extern "C" int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, 
     MML_HIP(hipMemcpyAsync(fi, ctx->fu_info + 8 * (size_t)slot, sizeof(fi), hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));
     if (!(fi[4] > 100)) return MML_OK;  // union_msg.livox_corner_num > 100 (unionFeatureExtract.cpp:302)
-    const int nsel = fi[7], n_velo = fi[1], n = fi[0];
+    const int nsel = fi[7];
+    int cb[2];  // valid points per sensor region of the slot's storage
+    MML_HIP(hipMemcpyAsync(cb, ctx->cb_n + 2 * (size_t)slot, sizeof(cb), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipStreamSynchronize(s));
     Scratch S;
     bool ok = S.take((void**)&S.src, sizeof(float4) * (size_t)(nsel + 1)) && S.take((void**)&S.tgt, sizeof(float4) * (size_t)(nsel + 1)) &&
               S.take((void**)&S.counts, sizeof(int) * 2) && S.take((void**)&S.dT, sizeof(float) * 16);
@@ -793,7 +786,7 @@ extern "C" int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, 
     int cnt[2] = {0, 0};
     if (nsel > 0) {
         const unsigned* list = reinterpret_cast<const unsigned*>(ctx->vx_keys) + ((size_t)slot * 2 + 1) * ctx->VX_CAP;
-        hipLaunchKernelGGL(k_gicp_gather, dim3((nsel + 255) / 256), dim3(256), 0, s, ctx->fu_xyzi + (size_t)slot * ctx->NT, list, nsel, n_velo,
+        hipLaunchKernelGGL(k_gicp_gather, dim3((nsel + 255) / 256), dim3(256), 0, s, ctx->ln_pts + (size_t)slot * ctx->NT, list, nsel, ctx->NV,
                            S.tgt, S.src, S.counts);
         MML_HIP(hipMemcpyAsync(cnt, S.counts, sizeof(cnt), hipMemcpyDeviceToHost, s));
         MML_HIP(hipStreamSynchronize(s));
@@ -802,10 +795,10 @@ extern "C" int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, 
     rc = gicp_run(ctx, S, cnt[1], cnt[0], extrinsic_inout, &conv, info);  // source: Livox surf, target: Velodyne surf (:307)
     if (rc != MML_OK) return rc;
     if (refreshed) *refreshed = conv;
-    if (apply && n > n_velo) {  // pcl::transformPointCloud(*livoCombinePtr, *livoCombinePtr, extri_mtx) (:312)
+    if (apply && cb[1] > 0) {  // pcl::transformPointCloud(*livoCombinePtr, *livoCombinePtr, extri_mtx) (:312): the Livox region
         MML_HIP(hipMemcpyAsync(S.dT, extrinsic_inout, sizeof(float) * 16, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_gicp_apply, dim3((n - n_velo + 255) / 256), dim3(256), 0, s, ctx->fu_xyzi + (size_t)slot * ctx->NT + n_velo,
-                           n - n_velo, S.dT);
+        hipLaunchKernelGGL(k_gicp_apply, dim3((cb[1] + 255) / 256), dim3(256), 0, s, ctx->ln_pts + (size_t)slot * ctx->NT + ctx->NV,
+                           cb[1], S.dT);
         MML_HIP(hipGetLastError());
         MML_HIP(hipStreamSynchronize(s));
     }

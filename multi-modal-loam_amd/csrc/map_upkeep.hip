@@ -226,7 +226,8 @@ struct SegParams {
     int first, count, B, NT, MF, list_stride;
     float leaf_corner, leaf_surf;
     const int* fu_info;
-    const float4* fu_xyzi;
+    const float4* ln_pts;
+    const int* ln_gidx;
     const unsigned* lists;
     int* seg_off;     // 2 * count + 1
     int* seg_bbox;    // 2 * count x 6 order-preserving int keys
@@ -264,10 +265,12 @@ __global__ void k_seg_gather_bbox(SegParams P) {
     const int g = blockIdx.y, b = P.first + (g >> 1), kind = g & 1;
     const int n = P.fu_info[8 * b + 6 + kind], off = P.seg_off[g];
     const unsigned* list = P.lists + ((size_t)b * 2 + kind) * P.list_stride;
-    const float4* px = P.fu_xyzi + (size_t)b * P.NT;
+    const float4* px = P.ln_pts + (size_t)b * P.NT;
+    const int* gx = P.ln_gidx + (size_t)b * P.NT;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = px[list[i]];
+        float4 p = px[list[i]];
+        p.w = __int_as_float(gx[list[i]]);  // the fused index rides along: it orders the points of a voxel
         P.cat[off + i] = p;
         mn[0] = fminf(mn[0], p.x);
         mn[1] = fminf(mn[1], p.y);
@@ -319,21 +322,22 @@ __global__ void k_seg_keys(SegParams P) {
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
         const unsigned vox = (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
-        P.keys[off + i] = ((unsigned long long)g << 32) | vox;
+        // (segment 12 bits | voxel 32 bits | fused index 20 bits): one sort gives segment, voxel, reference order
+        P.keys[off + i] = ((unsigned long long)g << 52) | ((unsigned long long)vox << 20) | (unsigned)__float_as_int(p.w);
         P.vals[off + i] = (unsigned)(off + i);
     }
 }
 
 __global__ void k_seg_heads(const unsigned long long* keys, int m, int* flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    if (i < m) flag[i] = (i == 0 || (keys[i] >> 20) != (keys[i - 1] >> 20)) ? 1 : 0;  // new (segment, voxel)
 }
 
 // one lane per voxel; the lane of a segment's first voxel also publishes the segment's voxel count
 __global__ void k_seg_centroid(SegParams P, const unsigned long long* keys, const unsigned* vals, const int* flag, const int* pos, int m) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= m || !flag[s]) return;
-    const unsigned long long key = keys[s];
+    const unsigned long long key = keys[s] >> 20;  // (segment, voxel)
     const int g = (int)(key >> 32), b = P.first + (g >> 1), kind = g & 1;
     const int off = P.seg_off[g], end = P.seg_off[g + 1];
     const int dst = pos[s] - pos[off];
@@ -344,7 +348,7 @@ __global__ void k_seg_centroid(SegParams P, const unsigned long long* keys, cons
     if (dst >= P.MF) return;
     float sx = 0, sy = 0, sz = 0;
     int e = s;
-    while (e < m && keys[e] == key) {
+    while (e < m && (keys[e] >> 20) == key) {
         const float4 p = P.cat[vals[e]];
         sx += p.x;
         sy += p.y;
@@ -386,7 +390,8 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
     P.leaf_corner = ctx->cfg.leaf_corner;
     P.leaf_surf = ctx->cfg.leaf_surf;
     P.fu_info = ctx->fu_info;
-    P.fu_xyzi = ctx->fu_xyzi;
+    P.ln_pts = ctx->ln_pts;
+    P.ln_gidx = ctx->ln_gidx;
     P.lists = reinterpret_cast<const unsigned*>(ctx->vx_keys);
     int* meta = ctx->seg_meta + (size_t)ctx->cur * (8 * (size_t)ctx->B * 2 + 16);
     P.seg_off = meta + 8;
@@ -416,10 +421,11 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
     int seg_bits = 1;
     while ((1 << seg_bits) < nseg) ++seg_bits;
     size_t need = 0;
-    MML_HIP(rocprim::radix_sort_pairs(nullptr, need, P.keys, keys2, P.vals, vals2, (size_t)total, 0, 32 + seg_bits, s));
+    MML_REQUIRE(ctx->NT <= (1 << 20) && nseg <= 4096, MML_ERR_CAPACITY, "global-sort down-sampler: scans up to 2^20 points, 2048 slots per call");
+    MML_HIP(rocprim::radix_sort_pairs(nullptr, need, P.keys, keys2, P.vals, vals2, (size_t)total, 0, 52 + seg_bits, s));
     int rc = ensure_tmp_lane(ctx, need);
     if (rc != MML_OK) return rc;
-    MML_HIP(rocprim::radix_sort_pairs(ctx->seg_tmp[ctx->cur], need, P.keys, keys2, P.vals, vals2, (size_t)total, 0, 32 + seg_bits, s));
+    MML_HIP(rocprim::radix_sort_pairs(ctx->seg_tmp[ctx->cur], need, P.keys, keys2, P.vals, vals2, (size_t)total, 0, 52 + seg_bits, s));
     const int blocks = (total + 255) / 256;
     hipLaunchKernelGGL(k_seg_heads, dim3(blocks), dim3(256), 0, s, keys2, total, flag);
     need = 0;

@@ -98,12 +98,13 @@ struct mml_ctx {
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
     int* cb_n = nullptr;  // B * 2
 
-    // fused cropped cloud
-    float4* fu_xyzi = nullptr;
-    float* fu_rel = nullptr;
-    uint8_t* fu_line = nullptr;
-    uint8_t* fu_label = nullptr;
-    int* fu_info = nullptr;  // B * 8: n_points, n_velo, vc, vs, lc, ls, -, -
+    // The fused cropped cloud [velo_combine ; livox_combine] has no storage of its own: a kept point lives at its
+    // line-bucketed position (ln_pts, undistorted in place) and ln_gidx says where it sits in the fused order; that order
+    // is materialised only at the API boundary (downloads) and as the tie-break of the voxel sort.
+    float* ln_rel = nullptr;      // B * NT  in-sweep time (normal_x)
+    uint8_t* ln_line = nullptr;   // B * NT  ring / Livox line (normal_y)
+    uint8_t* ln_label = nullptr;  // B * NT  0 none / 1 corner / 2 surf (normal_z), non-zero only for kept points
+    int* fu_info = nullptr;  // B * 8: n_points, n_velo, vc, vs, lc, ls, fused corner, fused surf
 
     // down-sampled feature stacks: kind 0 corner, 1 surf
     float4* ft_xyz[2] = {nullptr, nullptr};  // B * MF

@@ -45,18 +45,19 @@ __global__ void k_undistort_prep(int count, const double* params, double* derive
 // quaternion normalisation uses v_rsq_f64 + Newton; its result differs from the reference expression by ~1e-15
 // relative, so the FLOAT it rounds to is the same unless the double lies within 1e-13 of a float rounding
 // boundary -- in that case (a few points per million) the reference expression is evaluated.
-__global__ __launch_bounds__(256) void k_undistort(int first, int NT, const int* fu_info, float4* fu_xyzi,
-                                                  float* fu_rel, const double* params, const double* derived) {
+// (in place on the line-bucketed storage: Velodyne points in [0, cb_n[0]), Livox points in [NV, NV + cb_n[1]))
+__global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, const int* cb_n, float4* ln_pts,
+                                                  float* ln_rel, const double* params, const double* derived) {
     const int b = blockIdx.y + first;
-    const int n = fu_info[8 * b];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= NT) return;
+    if (i < NV ? i >= cb_n[2 * b] : i - NV >= cb_n[2 * b + 1]) return;
     const double* dR = params + 12 * blockIdx.y;
-    float4 p = fu_xyzi[(size_t)b * NT + i];
-    const float s = fu_rel[(size_t)b * NT + i];
+    float4 p = ln_pts[(size_t)b * NT + i];
+    const float s = ln_rel[(size_t)b * NT + i];
     mml_und::undistort_point(dR, dR + 9, derived + 8 * blockIdx.y, s, p);
-    fu_xyzi[(size_t)b * NT + i] = p;
-    fu_rel[(size_t)b * NT + i] = 1.0f;  // :419
+    ln_pts[(size_t)b * NT + i] = p;
+    ln_rel[(size_t)b * NT + i] = 1.0f;  // :419
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -137,7 +138,7 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 
 // One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
 __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
-                                                     const float4* fu_xyzi, const uint8_t* fu_label,
+                                                     const float4* ln_pts, const int* ln_gidx,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,13 +152,11 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     const int b = blockIdx.x + first;
     const int kind = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = fu_info[8 * b];
-    const float4* px = fu_xyzi + (size_t)b * NT;
-    const uint8_t* lab = fu_label + (size_t)b * NT;
-    const int want = kind + 1;  // normal_z == 1 corner (:996), == 2 surf (:1003)
+    const float4* px = ln_pts + (size_t)b * NT;
+    const int* gx = ln_gidx + (size_t)b * NT;
     const float leaf = kind == 0 ? leaf_corner : leaf_surf;
     float4* out = (kind == 0 ? ft0 : ft1) + (size_t)b * MF;
-    // sequence -> fused index map lives in global scratch (cap entries per (slot, kind))
+    // the labelled points of this (slot, kind): their bucketed positions, listed by the crop pass
     unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * list_stride;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -224,15 +223,18 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
         div_b[c] = max_b - min_b[c] + 1;
     }
     const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
-    // keys (voxel idx, sequence) of my elements e = tid + VX_THREADS * k; padding sorts to the end
+    // keys (voxel idx, fused index, position) of my elements e = tid + VX_THREADS * k; padding sorts to the end.  The
+    // fused index (the point's place in [velo_combine ; livox_combine]) orders the points of a voxel as the reference
+    // sums them; position and fused index both fit 16 bits on this path (NT <= 65536).
     auto make_key = [&](int sidx) -> unsigned long long {
         if (sidx >= cnt) return ~0ull;
-        const float4 p = px[seq2idx[sidx]];
+        const unsigned pos = seq2idx[sidx];
+        const float4 p = px[pos];
         const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
         const int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
-        return ((unsigned long long)(unsigned)idx << 32) | (unsigned)sidx;
+        return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos] << 16) | pos;
     };
     // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
     if (cnt <= VX_THREADS) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
         for (int t = tid; t < VX_THREADS + VX_TAIL; t += VX_THREADS) {
             const int e = c0 + t;
             if (e < cnt) {
-                const float4 p = px[seq2idx[(unsigned)(keys[e] & 0xffffffffu)]];
+                const float4 p = px[(unsigned)(keys[e] & 0xffffu)];
                 s_stage[0][t] = p.x;
                 s_stage[1][t] = p.y;
                 s_stage[2][t] = p.z;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
                     sy += s_stage[1][t];
                     sz += s_stage[2][t];
                 } else {  // a voxel with more than VX_TAIL points across the chunk edge
-                    const float4 p = px[seq2idx[(unsigned)(keys[e] & 0xffffffffu)]];
+                    const float4 p = px[(unsigned)(keys[e] & 0xffffu)];
                     sx += p.x;
                     sy += p.y;
                     sz += p.z;
@@ -327,8 +329,8 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
     MmlStageScope t(ctx, "undistort");
     dim3 grid((ctx->NT + 255) / 256, count);
     hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, MML_STREAM(ctx), count, d_params, ctx->d_und + 8 * (size_t)first);
-    hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, MML_STREAM(ctx), first, ctx->NT, ctx->fu_info, ctx->fu_xyzi,
-                       ctx->fu_rel, d_params, ctx->d_und + 8 * (size_t)first);
+    hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, MML_STREAM(ctx), first, ctx->NT, ctx->NV, ctx->cb_n, ctx->ln_pts,
+                       ctx->ln_rel, d_params, ctx->d_und + 8 * (size_t)first);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
@@ -343,7 +345,7 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     while (npad < cap) npad <<= 1;
     size_t lds = (size_t)npad * sizeof(unsigned long long);
     hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, MML_STREAM(ctx), first, ctx->NT, ctx->MF, ctx->B,
-                       cap, ctx->VX_CAP, ctx->fu_info, ctx->fu_xyzi, ctx->fu_label, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
+                       cap, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
                        ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     MML_HIP(hipGetLastError());
     return MML_OK;

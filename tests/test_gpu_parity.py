@@ -1165,3 +1165,27 @@ def test_gicp_refresh_on_a_slot(M, O, synth):
         assert np.array_equal(a1["xyzi"], before[1]["xyzi"])             # nothing applied either (:302)
     finally:
         c.close()
+
+
+def test_scan_upload_batch_equals_per_scan_upload(M, synth):
+    a, b = M.Context(max_scans=3), M.Context(max_scans=3)
+    try:
+        scans = [(synth.velo_scan(k, n_az=1800 if k != 8 else 900), synth.livox_scan(k, n=24000 if k != 9 else 0)) for k in (7, 8, 9)]
+        vb = np.zeros((3, a.cfg.max_velo_points, 4), np.float32)
+        lb = np.zeros((3, a.cfg.max_livox_points), synth.LIVOX_DTYPE)
+        for s, (v, l) in enumerate(scans):
+            a.scan_upload(s, v, l)
+            vb[s, :len(v)] = v
+            lb[s, :len(l)] = l
+        b.scan_upload_batch(0, vb, [len(v) for v, _ in scans], lb, [len(l) for _, l in scans])
+        a.extract(0, 3)
+        b.extract(0, 3)
+        for s in range(3):
+            da, db = a.scan_download(s), b.scan_download(s)
+            for k in ("xyzi", "reltime", "ring", "label"):
+                assert np.array_equal(da[k], db[k]), (s, k)
+        with pytest.raises(M.MmlError):
+            b.scan_upload_batch(0, vb, [a.cfg.max_velo_points + 1, 0, 0], lb, [0, 0, 0])
+    finally:
+        a.close()
+        b.close()
