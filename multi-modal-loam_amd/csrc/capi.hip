@@ -71,9 +71,9 @@ void mml_destroy(mml_ctx* ctx) {
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
         if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
-                    ctx->ln_gidx,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
+                    ctx->ln_meta,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue,
-                    ctx->cb_n,     ctx->ln_rel,   ctx->ln_line,  ctx->ln_label,
+                    ctx->cb_n,     ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
@@ -153,7 +153,8 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->raw_line, B * NT);
     ALLOC(ctx->raw_ori, B * NV);
     ALLOC(ctx->ln_pts, B * NT);
-    ALLOC(ctx->ln_gidx, B * NT);
+    ALLOC(ctx->ln_meta, B * NT);
+    ALLOC(ctx->slot_flags, B * 2);
     ALLOC(ctx->line_start, B * L);
     ALLOC(ctx->line_len, B * L);
     ALLOC(ctx->ln_curv, B * NT);
@@ -170,7 +171,6 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->redo_queue, B * NT);
     ALLOC(ctx->crop_cnt, B * ((NT + 255) / 256) * 8);
     ALLOC(ctx->cb_n, B * 2);
-    ALLOC(ctx->ln_rel, B * NT);
     ALLOC(ctx->ln_line, B * NT);
     ALLOC(ctx->ln_label, B * NT);
     ALLOC(ctx->fu_info, B * 8);
@@ -337,35 +337,53 @@ __global__ void k_decode_custompoints(const uint8_t* raw, int n, mml_livox_point
 // part of an extracted cloud carries intensity 0 (unionFeatureExtract.cpp:1254-1256); an uploaded cloud keeps its own.
 struct FusedView {
     const float4* pts;
-    const int* gidx;
-    const float* rel;
-    const uint8_t* line;
+    const int2* meta;
+    const uint8_t* line;      // uploaded clouds
     const uint8_t* label;
-    const int* cb_n;  // this slot's two valid counts
-    int NV, NT, keep_intensity;
+    const int* cb_n;          // this slot's two valid counts
+    const int* line_start;    // extracted clouds: the slot's line table (L entries; rings, then Livox lines)
+    int NV, NT, L, n_rings, flags;
 };
-__device__ __forceinline__ bool fused_at(const FusedView& V, int pos, int& g, float4& p) {
+__device__ __forceinline__ bool fused_at(const FusedView& V, int pos, int& g, float4& p, float& rel, int& line) {
     if (pos >= V.NT) return false;
     if (pos < V.NV ? pos >= V.cb_n[0] : pos - V.NV >= V.cb_n[1]) return false;
-    g = V.gidx[pos];
+    const int2 m = V.meta[pos];
+    g = m.x;
     if (g < 0) return false;
     p = V.pts[pos];
-    if (pos < V.NV && !V.keep_intensity) p.w = 0.f;
+    rel = (V.flags & 2) ? 1.0f : __int_as_float(m.y);  // RemoveLidarDistortion leaves normal_x = 1 (unionPoseEstimation.cpp:419)
+    if (V.flags & 1) {
+        line = V.line[pos];
+    } else {
+        if (pos < V.NV) p.w = 0.f;  // intensity of the Velodyne part is zeroed (unionFeatureExtract.cpp:1254-1256)
+        // last line of the region whose start is <= pos (starts are non-decreasing inside a region)
+        const int r0 = pos < V.NV ? 0 : V.n_rings, r1 = pos < V.NV ? V.n_rings : V.L;
+        int lo = r0, hi = r1 - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (V.line_start[mid] <= pos)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        line = lo - r0;
+    }
     return true;
 }
 // pcl::toROSMsg<PointXYZINormal> payload: 48-byte records, x y z 1 | normal_x normal_y normal_z 0 | intensity curvature 0 0
 __global__ void k_encode_xyzinormal(FusedView V, float* out) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    int g;
+    int g, line;
     float4 p;
-    if (!fused_at(V, pos, g, p)) return;
+    float rel;
+    if (!fused_at(V, pos, g, p, rel, line)) return;
     float* o = out + 12 * (size_t)g;
     o[0] = p.x;
     o[1] = p.y;
     o[2] = p.z;
     o[3] = 1.0f;
-    o[4] = V.rel[pos];             // normal_x: in-sweep time (unionFeatureExtract.cpp:1186)
-    o[5] = (float)V.line[pos];     // normal_y: ring / Livox line
+    o[4] = rel;                    // normal_x: in-sweep time (unionFeatureExtract.cpp:1186)
+    o[5] = (float)line;            // normal_y: ring / Livox line
     o[6] = (float)V.label[pos];    // normal_z: 0 none, 1 corner, 2 surf (:1018-1021)
     o[7] = 0.f;
     o[8] = p.w;                    // intensity
@@ -376,12 +394,13 @@ __global__ void k_encode_xyzinormal(FusedView V, float* out) {
 // the same cloud as four arrays (mml_scan_download): xyzi | reltime | line | label, back to back in one staging buffer
 __global__ void k_fused_arrays(FusedView V, int n, float4* xyzi, float* rel, uint8_t* line, uint8_t* label) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    int g;
+    int g, ln;
     float4 p;
-    if (!fused_at(V, pos, g, p)) return;
+    float r;
+    if (!fused_at(V, pos, g, p, r, ln)) return;
     xyzi[g] = p;
-    rel[g] = V.rel[pos];
-    line[g] = V.line[pos];
+    rel[g] = r;
+    line[g] = (uint8_t)ln;
     label[g] = V.label[pos];
 }
 int ensure_wire_stage(mml_ctx* ctx, size_t bytes) {
@@ -460,21 +479,22 @@ int upload_wire_impl(mml_ctx* ctx, int slot, const uint8_t* data, int n_points, 
 }  // namespace
 
 namespace {
-// the `uploaded` flag of the slot's AssignAux record (8 ints per slot, last one): see feature.hip
 int fused_view(mml_ctx* ctx, int slot, FusedView& V) {
-    int up = 0;
-    MML_HIP(hipMemcpyAsync(&up, ctx->assign_aux + 8 * (size_t)slot + 7, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    int fl = 0;
+    MML_HIP(hipMemcpyAsync(&fl, ctx->slot_flags + 2 * (size_t)slot, sizeof(int), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     const size_t off = (size_t)slot * ctx->NT;
     V.pts = ctx->ln_pts + off;
-    V.gidx = ctx->ln_gidx + off;
-    V.rel = ctx->ln_rel + off;
+    V.meta = ctx->ln_meta + off;
     V.line = ctx->ln_line + off;
     V.label = ctx->ln_label + off;
     V.cb_n = ctx->cb_n + 2 * (size_t)slot;
+    V.line_start = ctx->line_start + (size_t)slot * ctx->L;
     V.NV = ctx->NV;
     V.NT = ctx->NT;
-    V.keep_intensity = up;
+    V.L = ctx->L;
+    V.n_rings = ctx->cfg.n_rings;
+    V.flags = fl;
     return MML_OK;
 }
 }  // namespace

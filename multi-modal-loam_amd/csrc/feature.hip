@@ -49,7 +49,7 @@ struct FeatParams {
     uint8_t* raw_line;
     float* raw_ori;
     float4* ln_pts;
-    int* ln_gidx;
+    int2* ln_meta;       // (fused index, bits of the in-sweep time) of the bucketed point
     int* line_start;
     int* line_len;
     float* ln_curv;
@@ -67,9 +67,9 @@ struct FeatParams {
     int B;
     uint16_t* ln_final;  // optional (detect_line): final CloudFeatureFlag per line point
     int* cb_n;
-    float* ln_rel;       // in-sweep time of the bucketed point
-    uint8_t* ln_line;    // its ring / Livox line
-    uint8_t* ln_label;   // its label (kept points only)
+    uint8_t* ln_line;    // ring / Livox line of the points of an uploaded cloud
+    uint8_t* ln_label;   // label of the bucketed point (kept points only)
+    int* slot_flags;     // [2 b]: bit 0 uploaded, bit 1 undistorted
     int* fu_info;
     const float* extr;  // 16 floats or nullptr
     unsigned* brk_queue;  // [B][NT] line-bucketed positions whose break-point test needs the double-precision part
@@ -123,7 +123,7 @@ __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int
 struct AssignAux {  // per slot, written by passes A / B
     int first_finite, last_finite, trig, kept_velo;
     float startOri, endOri;
-    int kept_livox, uploaded;  // uploaded: the slot was filled by mml_cloud_upload (intensities are the caller's)
+    int kept_livox, pad;
 };
 // lidars_extrinsic_cali.h:424-477: removeNearFarPoints keeps near <= |p|^2 <= far, removeNearPointCloud only tests near
 __device__ __forceinline__ void crop_test(const FeatParams& P, float x, float y, float z, bool& keep, bool& near_ok) {
@@ -140,7 +140,7 @@ __global__ void k_assign_init(FeatParams P, int count) {
         a->first_finite = 0x7fffffff;
         a->last_finite = -1;
         a->trig = 0x7fffffff;
-        a->uploaded = 0;
+        P.slot_flags[2 * (P.first + t)] = 0;  // an extracted cloud, not undistorted yet
         int* info = P.fu_info + 8 * (P.first + t);
         info[4] = 0;  // livox corner / surf: k_select adds the labelled points beyond far_th, k_crop the kept ones
         info[5] = 0;
@@ -461,11 +461,6 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     const int dst = P.line_start[(size_t)b * P.L + line] + pos;
     const size_t g = (size_t)b * P.NT + dst;
     P.ln_pts[g] = praw;
-    // the point's index in the fused cloud, or -2 for a Livox point that only fails the far test (its label still counts
-    // towards livox_corner_num / livox_surf_num, :925-940), or -1
-    P.ln_gidx[g] = keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1);
-    P.ln_line[g] = (uint8_t)key;
-    P.ln_label[g] = 0;
     float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
     if (sensor == 0) {
         const float startOri = a->startOri, endOri = a->endOri;
@@ -488,7 +483,11 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
         const double timeSpan = livox_to_sec(in[n - 1].offset_time);  // :985
         rel = livox_to_sec(off_time) / timeSpan;                       // :995
     }
-    P.ln_rel[g] = rel;
+    // one 8-byte record per point: its index in the fused cloud (or -2 for a Livox point that only fails the far test --
+    // its label still counts towards livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The
+    // label byte is written by k_select for every point of a line, the line id follows from the line table: two
+    // scattered stores per point in all (the pass is bound by their number, not by their bytes).
+    P.ln_meta[g] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
 }
 
 // locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
@@ -1142,7 +1141,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     const uint16_t* attr = P.ln_attr + base;
     const float* curv = P.ln_curv + base;
     const float* refl = P.ln_refl + base;
-    const int* gidx = P.ln_gidx + base;
+    const int2* gidx = P.ln_meta + base;
     unsigned r_attr[KK];
     int r_gidx[KK];
     (void)r_attr;
@@ -1179,7 +1178,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             r_attr[k] = attr[i];
             r_curv[k] = curv[i];
             r_refl[k] = refl[i];
-            r_gidx[k] = gidx[i];
+            r_gidx[k] = gidx[i].x;
         }
     }
     if (n >= 11) T = (at_last & A_W2) ? 2 : 3;
@@ -1731,16 +1730,18 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             if (f5 == 2) f = 101;
         }
         if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
+        int labv = 0;
         if (inner && !(at & A_NEAR)) {
             const int lab = (f == 2) ? 2 : ((f == 100 || f == 150) ? 1 : 0);
             if (lab) {
-                const int gi = CACHED ? r_gidx[k] : gidx[i];
+                const int gi = CACHED ? r_gidx[k] : gidx[i].x;
                 if (gi >= 0)
-                    lnlab[i] = (uint8_t)lab;
+                    labv = lab;
                 else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940
                     atomicAdd(&P.fu_info[8 * b + 3 + lab], 1);
             }
         }
+        lnlab[i] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
     )
     SEL_MARK(11);
 #undef FOR_POINTS
@@ -1957,8 +1958,7 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
         P.line_len[t] = (t == 0) ? n : 0;
     }
     if (t < n) {
-        P.ln_gidx[t] = t;
-        P.ln_label[t] = 0;
+        P.ln_meta[t] = make_int2(t, 0);
     }
     if (t == 0) {
         P.cb_n[0] = n;
@@ -1985,7 +1985,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.raw_line = ctx->raw_line;
     P.raw_ori = ctx->raw_ori;
     P.ln_pts = ctx->ln_pts;
-    P.ln_gidx = ctx->ln_gidx;
+    P.ln_meta = ctx->ln_meta;
     P.line_start = ctx->line_start;
     P.line_len = ctx->line_len;
     P.ln_curv = ctx->ln_curv;
@@ -2009,8 +2009,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.B = ctx->B;
     P.ln_final = nullptr;
     P.cb_n = ctx->cb_n;
-    P.ln_rel = ctx->ln_rel;
     P.ln_line = ctx->ln_line;
+    P.slot_flags = ctx->slot_flags;
     P.ln_label = ctx->ln_label;
     P.fu_info = ctx->fu_info;
     P.extr = nullptr;
@@ -2084,7 +2084,7 @@ __global__ void k_decode_xyzinormal(const float* raw, int n, int n_velo, int slo
         AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + slot;
         a->kept_velo = n_velo;
         a->kept_livox = n - n_velo;
-        a->uploaded = 1;
+        P.slot_flags[2 * slot] = 1;       // uploaded: intensities and line ids are the caller's; normal_x as given
         P.cb_n[2 * slot] = n_velo;        // every uploaded point is a valid, kept point of its sensor's region
         P.cb_n[2 * slot + 1] = n - n_velo;
         int* info = P.fu_info + 8 * slot;
@@ -2096,8 +2096,7 @@ __global__ void k_decode_xyzinormal(const float* raw, int n, int n_velo, int slo
     // fused index i -> storage position: the Velodyne part from 0, the Livox part from NV
     const size_t o = (size_t)slot * P.NT + (i < n_velo ? i : P.NV + (i - n_velo));
     P.ln_pts[o] = make_float4(r[0], r[1], r[2], r[8]);
-    P.ln_gidx[o] = i;
-    P.ln_rel[o] = r[4];
+    P.ln_meta[o] = make_int2(i, __float_as_int(r[4]));
     const float ln = r[5], nz = r[6];
     P.ln_line[o] = (uint8_t)(ln >= 0.f && ln < 255.f ? (int)ln : 255);
     // std::abs(normal_z - 1.0) < 1e-5 etc. are evaluated in double on the float field

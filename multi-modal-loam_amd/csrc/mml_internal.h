@@ -79,7 +79,8 @@ struct mml_ctx {
 
     // line-bucketed points
     float4* ln_pts = nullptr;   // B * NT
-    int* ln_gidx = nullptr;     // B * NT
+    int2* ln_meta = nullptr;    // B * NT  (.x fused index of the point: >= 0 kept, -1 dropped, -2 Livox beyond far_th;
+                                //           .y bits of its in-sweep time, normal_x) -- one 8-byte record, one scattered store
     int* line_start = nullptr;  // B * L
     int* line_len = nullptr;    // B * L
     float* ln_curv = nullptr;
@@ -101,8 +102,9 @@ struct mml_ctx {
     // The fused cropped cloud [velo_combine ; livox_combine] has no storage of its own: a kept point lives at its
     // line-bucketed position (ln_pts, undistorted in place) and ln_gidx says where it sits in the fused order; that order
     // is materialised only at the API boundary (downloads) and as the tie-break of the voxel sort.
-    float* ln_rel = nullptr;      // B * NT  in-sweep time (normal_x)
-    uint8_t* ln_line = nullptr;   // B * NT  ring / Livox line (normal_y)
+    uint8_t* ln_line = nullptr;   // B * NT  ring / Livox line (normal_y) of an UPLOADED cloud (an extracted one has its line table)
+    int* slot_flags = nullptr;    // B * 2   [0] bit 0: filled by mml_cloud_upload, bit 1: undistorted (in-sweep time reads 1);
+                                  //         [1] bit 1 as it was when the current mml_undistort started
     uint8_t* ln_label = nullptr;  // B * NT  0 none / 1 corner / 2 surf (normal_z), non-zero only for kept points
     int* fu_info = nullptr;  // B * 8: n_points, n_velo, vc, vs, lc, ls, fused corner, fused surf
 

@@ -15,9 +15,11 @@ using namespace mml_und;
 
 // params: per slot 12 doubles (dR row-major 9, dt 3); derived: per slot 8 doubles written by k_undistort_prep
 // (qlc x,y,z,w | theta | sinTheta | 1/sinTheta | linear-branch flag)
-__global__ void k_undistort_prep(int count, const double* params, double* derived) {
+__global__ void k_undistort_prep(int count, const double* params, double* derived, int* flags /* 2 per slot of this call */) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= count) return;
+    flags[2 * s + 1] = flags[2 * s];  // what k_undistort reads: was the slot undistorted before this call?
+    flags[2 * s] |= 2;                // from now on its in-sweep time reads 1 (:419)
     const double* dR = params + 12 * s;
     // Eigen::Quaterniond(dRlc).normalized()  (:410) -- identical for every point of the scan
     const Q4 qlc = qnormalized(quat_from_matrix(dR));
@@ -46,18 +48,20 @@ __global__ void k_undistort_prep(int count, const double* params, double* derive
 // relative, so the FLOAT it rounds to is the same unless the double lies within 1e-13 of a float rounding
 // boundary -- in that case (a few points per million) the reference expression is evaluated.
 // (in place on the line-bucketed storage: Velodyne points in [0, cb_n[0]), Livox points in [NV, NV + cb_n[1]))
+// "point.normal_x = 1" (:419) is a per-slot flag, not a store per point: k_undistort_prep raises bit 1 of slot_flags[2 b]
+// after saving its previous value in slot_flags[2 b + 1]; a slot that is undistorted again reads its time as 1.
 __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, const int* cb_n, float4* ln_pts,
-                                                  float* ln_rel, const double* params, const double* derived) {
+                                                  const int2* ln_meta, const int* slot_flags, const double* params,
+                                                  const double* derived) {
     const int b = blockIdx.y + first;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NT) return;
     if (i < NV ? i >= cb_n[2 * b] : i - NV >= cb_n[2 * b + 1]) return;
     const double* dR = params + 12 * blockIdx.y;
     float4 p = ln_pts[(size_t)b * NT + i];
-    const float s = ln_rel[(size_t)b * NT + i];
+    const float s = (slot_flags[2 * b + 1] & 2) ? 1.0f : __int_as_float(ln_meta[(size_t)b * NT + i].y);
     mml_und::undistort_point(dR, dR + 9, derived + 8 * blockIdx.y, s, p);
     ln_pts[(size_t)b * NT + i] = p;
-    ln_rel[(size_t)b * NT + i] = 1.0f;  // :419
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -138,7 +142,7 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 
 // One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
 __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
-                                                     const float4* ln_pts, const int* ln_gidx,
+                                                     const float4* ln_pts, const int2* ln_meta,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     const int kind = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* px = ln_pts + (size_t)b * NT;
-    const int* gx = ln_gidx + (size_t)b * NT;
+    const int2* gx = ln_meta + (size_t)b * NT;
     const float leaf = kind == 0 ? leaf_corner : leaf_surf;
     float4* out = (kind == 0 ? ft0 : ft1) + (size_t)b * MF;
     // the labelled points of this (slot, kind): their bucketed positions, listed by the crop pass
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
         const int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
-        return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos] << 16) | pos;
+        return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos].x << 16) | pos;
     };
     // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
     if (cnt <= VX_THREADS) {
@@ -328,9 +332,10 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
 int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_params) {
     MmlStageScope t(ctx, "undistort");
     dim3 grid((ctx->NT + 255) / 256, count);
-    hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, MML_STREAM(ctx), count, d_params, ctx->d_und + 8 * (size_t)first);
+    hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, MML_STREAM(ctx), count, d_params, ctx->d_und + 8 * (size_t)first,
+                       ctx->slot_flags + 2 * (size_t)first);
     hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, MML_STREAM(ctx), first, ctx->NT, ctx->NV, ctx->cb_n, ctx->ln_pts,
-                       ctx->ln_rel, d_params, ctx->d_und + 8 * (size_t)first);
+                       ctx->ln_meta, ctx->slot_flags, d_params, ctx->d_und + 8 * (size_t)first);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
@@ -345,7 +350,7 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     while (npad < cap) npad <<= 1;
     size_t lds = (size_t)npad * sizeof(unsigned long long);
     hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, MML_STREAM(ctx), first, ctx->NT, ctx->MF, ctx->B,
-                       cap, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
+                       cap, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
                        ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     MML_HIP(hipGetLastError());
     return MML_OK;
