@@ -773,8 +773,15 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
     if rank == 0 and line is not None:
+        # the one JSON line goes LAST: RCCL prints a version banner through C stdio, which sits in that buffer until the
+        # process exits when stdout is a file or a pipe -- push it out first
         sys.stdout.flush()
-        print(line, flush=True)  # the one JSON line, after anything the collectives library may have printed
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -1189,3 +1189,38 @@ def test_scan_upload_batch_equals_per_scan_upload(M, synth):
     finally:
         a.close()
         b.close()
+
+
+def test_undistort_twice_reads_normal_x_as_one(M, O, synth):
+    """RemoveLidarDistortion leaves normal_x = 1 behind (unionPoseEstimation.cpp:419); here that is a per-slot flag, not a
+    store per point: a second call must see s = 1 for every point, downloads must report 1, and a re-extraction or an
+    upload into the slot must clear it."""
+    c = M.Context(max_scans=1)
+    try:
+        v, l = synth.velo_scan(21, motion=True), synth.livox_scan(21, motion=True)
+        c.scan_upload(0, v, l)
+        c.extract(0, 1)
+        d0 = c.scan_download(0)
+        assert d0["reltime"].min() >= 0.0 and d0["reltime"].max() <= 1.0 and np.unique(d0["reltime"]).size > 1000
+        dR, dt = synth.sweep_motion(21)
+        c.undistort(0, 1, dR.reshape(1, 9), dt.reshape(1, 3))
+        d1 = c.scan_download(0)
+        o1 = O.undistort(d0["xyzi"][:, :3], d0["reltime"], dR, dt)
+        assert np.array_equal(d1["reltime"], np.ones_like(d1["reltime"]))
+        assert (d1["xyzi"][:, :3] != o1).mean() < 1e-4 and np.abs(d1["xyzi"][:, :3] - o1).max() < 1e-5   # <= 1 ulp, > 99.99 % exact
+        dR2 = Rsc.from_rotvec([0.003, -0.001, 0.02]).as_matrix()
+        dt2 = np.array([0.04, 0.01, -0.005])
+        c.undistort(0, 1, dR2.reshape(1, 9), dt2.reshape(1, 3))
+        d2 = c.scan_download(0)
+        o2 = O.undistort(d1["xyzi"][:, :3], np.ones(len(o1), np.float32), dR2, dt2)
+        assert (d2["xyzi"][:, :3] != o2).mean() < 1e-4 and np.abs(d2["xyzi"][:, :3] - o2).max() < 1e-5
+        # the 48-byte records carry the same normal_x, and an upload of them brings its own times back
+        rec = c.scan_download_pointxyzinormal(0)
+        assert np.array_equal(rec[:, 4], np.ones(len(rec), np.float32))
+        rec[:, 4] = np.linspace(0, 1, len(rec), dtype=np.float32)
+        c.cloud_upload(0, rec, d0["info"].n_velo)
+        assert np.array_equal(c.scan_download(0)["reltime"], rec[:, 4])
+        c.extract(0, 1)
+        assert np.array_equal(c.scan_download(0)["reltime"], d0["reltime"])
+    finally:
+        c.close()
