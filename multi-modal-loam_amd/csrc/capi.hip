@@ -1104,12 +1104,22 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
             x[6 * i + 2] = P[3 * i + 2];
             pose_to_Twl(Q + 4 * i, P + 3 * i, T_bl, &Twl[16 * i]);
         }
-        int rc = mml_associate(ctx, first_slot, count, Twl.data(), thres, st.data());
+        // association and solve are enqueued back to back and read back together: one host synchronisation per outer
+        // iteration (the statistics of the association only feed the degeneracy flag, nothing the solve waits for)
+        int rc = mml_associate(ctx, first_slot, count, Twl.data(), thres, nullptr);
         if (rc != MML_OK) return rc;
         thres = (it == 0) ? 10.0 : 1.0;  // :1377-1381
         std::vector<double> xs = x;
-        rc = mml_solve(ctx, first_slot, count, 1, T_bl, &so, xs.data(), nullptr, nullptr);
+        rc = solve_enqueue(ctx, first_slot, count, 1, T_bl, &so, xs.data(), false);
         if (rc != MML_OK) return rc;
+        double* h_back = stage_alloc(ctx, 22 * (size_t)count);  // pinned: stats (16 per slot), then poses (6 per slot)
+        MML_HIP(hipMemcpyAsync(h_back, ctx->assoc_stats + 16 * (size_t)first_slot, sizeof(double) * 16 * count, hipMemcpyDeviceToHost,
+                               MML_STREAM(ctx)));
+        MML_HIP(hipMemcpyAsync(h_back + 16 * (size_t)count, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count,
+                               hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+        MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+        for (int i = 0; i < count; ++i) finish_stats(h_back + 16 * (size_t)i, &st[i]);
+        memcpy(xs.data(), h_back + 16 * (size_t)count, sizeof(double) * 6 * count);
         for (int i = 0; i < count; ++i) {
             if (done[i]) continue;
             if (st[i].is_degenerate) degen[i] = 1;
