@@ -246,6 +246,79 @@ class Estimator {
         int lidarType = 0;
     };
 
+    // FeatureLine / FeaturePlanVec (Estimator.h:59-84, 105-122) as the association leaves them.  sqrt_info of the plane
+    // factor is carried as the plane normal omega: sqrt_info^T sqrt_info = a^2 w w^T + b^2 (I - w w^T) does not depend on the
+    // basis the reference's SVD happens to pick (a = 1 / lidar_m, b = plan_weight_tan / lidar_m, Estimator.cpp:675-682).
+    struct FeatureLine {
+        Vector3d pointOri, lineP1, lineP2;
+        double error = 0;
+        bool valid = false;
+    };
+    struct FeaturePlanVec {
+        Vector3d pointOri, pointProj, omega;
+        double error = 0;
+        bool valid = false;
+    };
+    double thres_dist = 25.0;  // Estimator.h:332, set by Estimate() (25 -> 10 -> 1, Estimator.cpp:1207,1377-1381)
+
+    // processPointToLine / processPointToPlanVec (Estimator.h:159-186, Estimator.cpp:148-365, 573-777) for the down-sampled
+    // stacks of `slot` at lidar pose m4d = transformTobeMapped: kNN + model fit on the device (both kinds in one launch),
+    // the surviving features appended to the vector with their ComputeError() value; `valid` = |error| > 1e-5, i.e.
+    // the factor enters the problem (:1313,1325).  The cost functions themselves stay on the device (mml_solve).
+    void processPointToLine(std::vector<FeatureLine>& vLineFeatures, int slot, const Matrix4d& m4d) {
+        associate(slot, m4d);
+        std::vector<double> f;
+        const int n = factors(slot, 0, f);
+        for (int i = 0; i < n; ++i) {
+            FeatureLine l;
+            for (int c = 0; c < 3; ++c) {
+                l.pointOri.v[c] = f[10 * i + c];
+                l.lineP1.v[c] = f[10 * i + 3 + c];
+                l.lineP2.v[c] = f[10 * i + 6 + c];
+            }
+            l.error = f[10 * i + 9];
+            l.valid = std::fabs(l.error) > 1e-5;
+            vLineFeatures.push_back(l);
+        }
+    }
+    void processPointToPlanVec(std::vector<FeaturePlanVec>& vPlanFeatures, int slot, const Matrix4d& m4d, bool& is_degenerate) {
+        mml_assoc_stats st = associate(slot, m4d);
+        if (st.is_degenerate) is_degenerate = true;  // only ever set, never cleared (:771-775)
+        std::vector<double> f;
+        const int n = factors(slot, 1, f);
+        for (int i = 0; i < n; ++i) {
+            FeaturePlanVec pl;
+            for (int c = 0; c < 3; ++c) {
+                pl.pointOri.v[c] = f[10 * i + c];
+                pl.pointProj.v[c] = f[10 * i + 3 + c];
+                pl.omega.v[c] = f[10 * i + 6 + c];
+            }
+            pl.error = f[10 * i + 9];
+            pl.valid = std::fabs(pl.error) > 1e-5;
+            vPlanFeatures.push_back(pl);
+        }
+    }
+
+    // Estimate(lidarFrameList, exTlb, gravity, is_degenerate) (Estimator.h:216-219) in the live 1-frame mode (windowSize !=
+    // SLIDEWINDOWSIZE, Estimator.cpp:1143-1581): every frame registered against the maps, poses updated in place.
+    void Estimate(std::list<LidarFrame>& lidarFrameList, const Matrix4d& exTlb, const Vector3d& gravity, bool& is_degenerate) {
+        (void)gravity;
+        for (auto& f : lidarFrameList) {
+            double Q[4] = {f.Q.x, f.Q.y, f.Q.z, f.Q.w};
+            mml_estimate_info info;
+            check(ctx_.get(), mml_estimate(ctx_.get(), f.slot, 1, exTlb.m, f.P.v, Q, 5, 10, &info), "Estimate");
+            f.Q.x = Q[0];
+            f.Q.y = Q[1];
+            f.Q.z = Q[2];
+            f.Q.w = Q[3];
+            if (info.is_degenerate) is_degenerate = true;
+        }
+    }
+
+    // get_corner_map() / get_surf_map() (Estimator.h:221-226): the MAP_MANAGER cube store, concatenated
+    PointCloud get_corner_map() { return global_map(0); }
+    PointCloud get_surf_map() { return global_map(1); }
+
     // Estimator(const float& filter_corner, const float& filter_surf) (Estimator.h:147): the leaf sizes are part of
     // mml_config (leaf_corner / leaf_surf) and must match the context's.
     Estimator(Context& ctx, float filter_corner, float filter_surf) : ctx_(ctx) {
@@ -324,18 +397,7 @@ class Estimator {
             check(ctx_.get(), mml_downsample(ctx_.get(), f.slot, 1), "downsample");  // :1013-1024
         }
         bool is_degenerate = false;
-        if (n_corner_map_ > 0 && n_surf_map_ > 100) {  // :1032-1035
-            for (auto& f : lidarFrameList) {
-                double Q[4] = {f.Q.x, f.Q.y, f.Q.z, f.Q.w};
-                mml_estimate_info info;
-                check(ctx_.get(), mml_estimate(ctx_.get(), f.slot, 1, exTlb.m, f.P.v, Q, 5, 10, &info), "Estimate");
-                f.Q.x = Q[0];
-                f.Q.y = Q[1];
-                f.Q.z = Q[2];
-                f.Q.w = Q[3];
-                if (info.is_degenerate) is_degenerate = true;
-            }
-        }
+        if (n_corner_map_ > 0 && n_surf_map_ > 100) Estimate(lidarFrameList, exTlb, gravity, is_degenerate);  // :1032-1035
         LidarFrame& front = lidarFrameList.front();
         if ((lidarMode == 1 && !is_degenerate && corner_cnt > 100) || (lidarMode == 2 && corner_cnt > 50)) {
             to_be_mapped(front, T);  // :1041-1049
@@ -466,6 +528,32 @@ class Estimator {
     bool failureDetected() const { return _fail_detected; }  // Estimator.h:278
 
    private:
+    mml_assoc_stats associate(int slot, const Matrix4d& m4d) {
+        mml_assoc_stats st;
+        check(ctx_.get(), mml_associate(ctx_.get(), slot, 1, m4d.m, thres_dist, &st), "mml_associate");
+        return st;
+    }
+    int factors(int slot, int kind, std::vector<double>& f) {
+        int n = 0;
+        check(ctx_.get(), mml_factors_download(ctx_.get(), slot, kind, nullptr, nullptr, 0, &n), "mml_factors_download");
+        f.assign(10 * (size_t)(n > 0 ? n : 1), 0.0);
+        check(ctx_.get(), mml_factors_download(ctx_.get(), slot, kind, f.data(), nullptr, n > 0 ? n : 1, &n), "mml_factors_download");
+        return n;
+    }
+    PointCloud global_map(int kind) {
+        int n = 0, cen[3];
+        check(ctx_.get(), mml_map_global_download(ctx_.get(), kind, nullptr, nullptr, 0, &n, cen), "mml_map_global_download");
+        std::vector<float> xyz(3 * (size_t)(n > 0 ? n : 1));
+        check(ctx_.get(), mml_map_global_download(ctx_.get(), kind, xyz.data(), nullptr, n, &n, cen), "mml_map_global_download");
+        PointCloud out(n, PointXYZINormal{});
+        for (int i = 0; i < n; ++i) {
+            out[i].x = xyz[3 * i];
+            out[i].y = xyz[3 * i + 1];
+            out[i].z = xyz[3 * i + 2];
+            out[i].data_pad = 1.f;
+        }
+        return out;
+    }
     void stage(LidarFrame& f) {
         if (f.laserCloud && !f.resident) {
             uploadCloud(ctx_, f.slot, *f.laserCloud, f.n_velo);

@@ -109,6 +109,33 @@ int main(int argc, char** argv) {
                             info.n_points, info.n_velo, h, est.failureDetected() ? 1 : 0, o.P.v[0], o.P.v[1], o.P.v[2], o.Q.x, o.Q.y,
                             o.Q.z, o.Q.w, fused.empty() ? 0.f : fused[fused.size() / 2].x, fused.empty() ? 0.f : fused[fused.size() / 2].y,
                             fused.empty() ? 0.f : fused[fused.size() / 2].z, fused.empty() ? 0.f : fused[0].normal_x);
+                if (k == n_scans - 1) {
+                    // processPointToLine / processPointToPlanVec on the last scan at its estimated pose, and the cube store
+                    // (threadMapIncrement: featureAssociateToMap + MapIncrement) behind get_corner_map / get_surf_map
+                    mml::Matrix4d T{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+                    const double x = o.Q.x, y = o.Q.y, z = o.Q.z, w = o.Q.w;
+                    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                                         2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+                    for (int r = 0; r < 3; ++r) {
+                        for (int c = 0; c < 3; ++c) T.m[4 * r + c] = R[3 * r + c];
+                        T.m[4 * r + 3] = o.P.v[r];
+                    }
+                    std::vector<mml::Estimator::FeatureLine> vl;
+                    std::vector<mml::Estimator::FeaturePlanVec> vp;
+                    bool deg = false;
+                    est.thres_dist = 1.0;
+                    est.processPointToLine(vl, 0, T);
+                    est.processPointToPlanVec(vp, 0, T, deg);
+                    int nlv = 0, npv = 0;
+                    double el = 0, ep = 0;
+                    for (auto& l : vl) { nlv += l.valid; el += l.error; }
+                    for (auto& pl : vp) { npv += pl.valid; ep += pl.error; }
+                    est.appendToGlobalMap(o, T);
+                    est.incrementGlobalMap(T);
+                    est.incrementGlobalMap(T);  // the map Estimate() sees lags one update behind the live store
+                    std::printf("assoc lines %zu valid %d err %.12g planes %zu valid %d err %.12g deg %d gmap %zu %zu\n", vl.size(), nlv, el, vp.size(),
+                                npv, ep, deg ? 1 : 0, est.get_corner_map().size(), est.get_surf_map().size());
+                }
             }
         } else {
             int n_windows = 0, W = 0;

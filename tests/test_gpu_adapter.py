@@ -75,7 +75,8 @@ def test_cpp_adapter_odometry_with_callers_cloud_matches_oracle(M, O, synth, tmp
         scans.append(dict(velo=v, livox=l, dR=dR, dt=dt, P=Tp[:3, 3], Q=Rsc.from_matrix(Tp[:3, :3]).as_quat(), V=np.zeros(3)))
     scene_file = str(tmp_path / "scene0.bin")
     _write_scene(scene_file, 0, scans, np.zeros((0, 3)), np.zeros((0, 3)))
-    rows = [r for r in _run(exe, scene_file) if r and r[0] == "scan"]
+    out_rows = _run(exe, scene_file)
+    rows = [r for r in out_rows if r and r[0] == "scan"]
     assert len(rows) == len(ks)
     # oracle loop: extract -> undistort -> down-sample -> Estimate (5 x 10) -> key-scan rule -> MapIncrementLocal
     lm = O.LocalMap(window=50, leaf_corner=0.4, leaf_surf=0.2)
@@ -114,6 +115,20 @@ def test_cpp_adapter_odometry_with_callers_cloud_matches_oracle(M, O, synth, tmp
         assert not np.allclose(und[mid], xyz[mid], atol=1e-4) or np.abs(xyz[mid]).max() < 0.5
         assert float(r[24]) == 1.0
     assert n_est >= 5
+    # the last scan's features through the adapter's processPointToLine / processPointToPlanVec: same counts and error sums as
+    # the oracle's association at the printed pose against the oracle's local map; the cube store holds that scan's features
+    ar = [r for r in out_rows if r and r[0] == "assoc"][0]
+    T = np.eye(4)
+    T[:3, :3] = Rsc.from_quat(Qg).as_matrix()
+    T[:3, 3] = Pg
+    lf, _ = O.associate_lines(cf, O.KdTree(lm.get(0)), T, 1.0)
+    pf, _ = O.associate_planes(sf, O.KdTree(lm.get(1)), T, 1.0)
+    assert int(ar[2]) == len(lf) and int(ar[8]) == len(pf)
+    assert int(ar[4]) == int((np.abs(lf["error"]) > 1e-5).sum()) and int(ar[10]) == int((np.abs(pf["error"]) > 1e-5).sum())
+    assert abs(float(ar[6]) - lf["error"].sum()) < 1e-6 * max(1.0, abs(lf["error"].sum()))
+    assert abs(float(ar[12]) - pf["error"].sum()) < 1e-6 * max(1.0, abs(pf["error"].sum()))
+    # (cubes beyond 300 points are voxel-filtered at 0.4 m, Map_Manager.cpp:225-233: the surf cube shrinks)
+    assert int(ar[16]) == len(cf) <= 300 and 0 < int(ar[17]) <= len(sf)
 
 
 def test_cpp_adapter_full_window_with_callers_clouds(M, O, synth, scene, tmp_path):
