@@ -36,9 +36,9 @@ def test_struct_layouts_match_header(M):
         #include <stdio.h>
         #include "mmloam_hip.h"
         int main(void) {
-          printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mml_config), sizeof(mml_scan_info), sizeof(mml_assoc_stats),
+          printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mml_config), sizeof(mml_scan_info), sizeof(mml_assoc_stats),
                  sizeof(mml_solve_opts), sizeof(mml_solve_summary), sizeof(mml_estimate_info), sizeof(mml_profile),
-                 sizeof(mml_livox_point));
+                 sizeof(mml_livox_point), sizeof(mml_window_timing), sizeof(mml_gicp_info), sizeof(mml_imu_preint), sizeof(mml_prior));
           return 0; }""")
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -46,7 +46,8 @@ def test_struct_layouts_match_header(M):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
     mine = [C.sizeof(M.Config), C.sizeof(M.ScanInfo), C.sizeof(M.AssocStats), C.sizeof(M.SolveOpts),
-            C.sizeof(M.SolveSummary), C.sizeof(M.EstimateInfo), C.sizeof(M.Profile), M.LIVOX_DTYPE.itemsize]
+            C.sizeof(M.SolveSummary), C.sizeof(M.EstimateInfo), C.sizeof(M.Profile), M.LIVOX_DTYPE.itemsize,
+            C.sizeof(M.WindowTiming), C.sizeof(M.GicpInfo), C.sizeof(M.ImuPreint), C.sizeof(M.Prior)]
     assert sizes == mine
 
 
