@@ -434,8 +434,9 @@ def run_throughput(args, rank, local_rank, world, dist):
     # 32-double normal-equation record per evaluation, the dogleg state machine resident on every device.  Outside the
     # timed region; reported next to the sharded throughput because the live path never exchanges data.
     window = None
+    window_timed_out = False
     if dist is not None or args.window_demo:
-        try:
+        def window_section():
             W = world
             if dist is not None:
                 idt = torch.zeros(M.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
@@ -476,14 +477,32 @@ def run_throughput(args, rank, local_rank, world, dist):
             ctx.comm_broadcast_features(0, 0)
             ctx.synchronize()
             t_feat = time.perf_counter() - t1
-            window = {"frames": W, "path": "C-ABI mml_window_solve_allgather (ncclAllGather on the ctx stream, device-resident dogleg)",
+            result = {"frames": W, "path": "C-ABI mml_window_solve_allgather (ncclAllGather on the ctx stream, device-resident dogleg)",
                       "iterations": sm.iterations, "termination": sm.termination, "evaluations": tim.evaluations,
                       "rounds": tim.rounds, "device_ms": float(np.median(lat)), "ms_per_evaluation": float(np.median(lat)) / max(tim.rounds, 1),
                       "ranks_agree_bitwise": agree, "map_broadcast_ms": t_map * 1e3, "feature_broadcast_ms": t_feat * 1e3,
                       "own_frame_err_vs_gt_m": float(np.abs(xl[0][:3] - synth.pose_matrix(base)[:3, 3]).max())}
             ctx.comm_destroy()
-        except Exception as e:  # never lose the bench line to the demo
-            window = {"error": repr(e)[:300]}
+            return result
+
+        # The section talks to the other ranks through collectives that nothing in this container could exercise at N > 1
+        # (one GPU here): it runs under a watchdog so that a fault in it can cost the window report, never the bench line.
+        import threading
+        box = {}
+
+        def guarded():
+            try:
+                torch.cuda.set_device(local_rank)  # the current device is per thread
+                box["window"] = window_section()
+            except Exception as e:
+                box["window"] = {"error": repr(e)[:300]}
+        th = threading.Thread(target=guarded, daemon=True)
+        th.start()
+        th.join(180.0)
+        if th.is_alive():
+            window, window_timed_out = {"error": "window section timed out after 180 s"}, True
+        else:
+            window = box.get("window")
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) ----------------------------------
     cpu = None
@@ -520,8 +539,8 @@ def run_throughput(args, rank, local_rank, world, dist):
             "cpu_baseline": cpu,
             "window_solve": window,
         }
-        return json.dumps(out)
-    return None
+        return json.dumps(out), window_timed_out
+    return None, window_timed_out
 
 
 # ---- configs[2]: replay through the whole odometry loop ----------------------------------------------------------------
@@ -761,16 +780,19 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    line = None
+    line, stuck = None, False
     try:
         if args.stub_step:
             run_stub(args, rank, world, dist)
         else:
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-            line = run_replay(args, rank, local_rank, world, dist) if args.config == 2 else run_throughput(args, rank, local_rank, world, dist)
+            if args.config == 2:
+                line = run_replay(args, rank, local_rank, world, dist)
+            else:
+                line, stuck = run_throughput(args, rank, local_rank, world, dist)
     finally:
-        if dist is not None:
+        if dist is not None and not stuck:   # (a rank stuck in a collective cannot be torn down cleanly: just leave)
             dist.destroy_process_group()
     if rank == 0 and line is not None:
         # the one JSON line goes LAST: RCCL prints a version banner through C stdio, which sits in that buffer until the
@@ -782,6 +804,8 @@ def main():
         except Exception:
             pass
         print(line, flush=True)
+    if stuck:
+        os._exit(0)
 
 
 if __name__ == "__main__":
