@@ -1224,3 +1224,40 @@ def test_undistort_twice_reads_normal_x_as_one(M, O, synth):
         assert np.array_equal(c.scan_download(0)["reltime"], d0["reltime"])
     finally:
         c.close()
+
+
+def test_config0_single_vlp16_scan_five_iterations(M, O, synth):
+    """BASELINE configs[0] shape -- one VLP-16 scan (16 x 1800, no Livox part), 5 inner iterations, one frame in the window:
+    the CPU reference case, run through the device path and held to the oracle."""
+    c = M.Context(max_scans=1)
+    try:
+        cm, sm = [], []
+        for k in (0, 2, 4, 6):
+            ev = O.extract_velo(synth.velo_scan(k))
+            xyz, lab = ev["xyzi"][:, :3], ev["label"]
+            T = synth.pose_matrix(k)
+            cm.append(synth.transform(T, O.voxel_downsample(xyz[lab == 1], 0.4).astype(np.float64)).astype(np.float32))
+            sm.append(synth.transform(T, O.voxel_downsample(xyz[lab == 2], 0.2).astype(np.float64)).astype(np.float32))
+        cm, sm = O.voxel_downsample(np.concatenate(cm), 0.4), O.voxel_downsample(np.concatenate(sm), 0.2)
+        c.map_set_local(0, cm)
+        c.map_set_local(1, sm)
+        v = synth.velo_scan(9)
+        c.scan_upload(0, v, None)
+        c.extract(0, 1)
+        ev = O.extract_velo(v)
+        d = c.scan_download(0)
+        assert d["info"].n_points == d["info"].n_velo == len(ev["label"]) and np.array_equal(d["label"], ev["label"])
+        c.undistort(0, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+        c.downsample(0, 1)
+        xyz, lab = ev["xyzi"][:, :3], ev["label"]
+        cf, sf = O.voxel_downsample(xyz[lab == 1], 0.4), O.voxel_downsample(xyz[lab == 2], 0.2)
+        assert np.array_equal(c.features_download(0, 0), cf) and np.array_equal(c.features_download(0, 1), sf)
+        Tp = perturbed(synth.pose_matrix(9))
+        P0, Q0 = Tp[:3, 3], Rsc.from_matrix(Tp[:3, :3]).as_quat()
+        Pg, Qg, info = c.estimate(0, 1, np.eye(4), P0[None], Q0[None], max_outer=5, inner_iters=5)
+        Po, Qo, it, deg, _ = O.estimate_single(cf, sf, cm, sm, np.eye(4), P0, Q0, 5, 5)
+        assert info[0].outer_iterations == it and info[0].is_degenerate == int(deg)
+        assert np.abs(Pg[0] - Po).max() < 1e-9 and np.abs(Qg[0] - Qo).max() < 1e-9
+        assert np.abs(Pg[0] - synth.pose_matrix(9)[:3, 3]).max() < 0.03
+    finally:
+        c.close()
