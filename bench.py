@@ -637,39 +637,54 @@ def run_replay(args, rank, local_rank, world, dist):
         ctx.step((n - 1) % W, 1, dR1, dt1, np.eye(4), 25.0, 10, x1)
         if it >= 20:
             lat1.append((time.perf_counter() - t1) * 1e3)
-    # IMU_Mode = 2: the full 15 W-parameter window (5 frames, IMU factors, prior carried from a first call): the lidar frames are
-    # linearised on the device in one launch per trust-region evaluation, the dense 75 x 75 iteration runs on the host
-    fullwin = None
-    try:
-        Wf = 5
-        west = odometry.WindowEstimator(ctx, gravity=synth.GRAVITY)
-        rng = np.random.default_rng(3)
-        t_calls = []
-        evals = 0
-        for call in range(3):
-            frames, pres = [], [None]
-            for f in range(Wf):
-                k = k0 + 40 + call + f
-                v, l = make_scan(synth, cfg, k, motion=False)
-                ctx.scan_upload(f, v, l)
-                ctx.extract(f, 1)
-                ctx.downsample(f, 1)
-                Tk = perturbed(synth.pose_matrix(k), dt_=rng.normal(0, 0.02, 3), rv=rng.normal(0, 0.003, 3))
-                q = Rsc.from_matrix(Tk[:3, :3]).as_quat()
-                frames.append(dict(P=Tk[:3, 3].copy(), Q=q if q[3] >= 0 else -q, V=synth.velocity_at(k) + rng.normal(0, 0.02, 3),
-                                   bg=np.zeros(3), ba=np.zeros(3)))
-                if f > 0:
-                    pres.append(M.imu_preintegrate(synth.imu_samples(k - 1, k), np.zeros(3), np.zeros(3)))
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            info_w = west.estimate(list(range(Wf)), frames, pres)
-            t_calls.append((time.perf_counter() - t1) * 1e3)
-            evals = sum(sm.iterations + 1 for sm in info_w["summaries"])
-        fullwin = {"frames": Wf, "estimate_ms": float(np.median(t_calls[1:])), "outer_iterations": info_w["outer"],
-                   "evaluations": evals, "ms_per_evaluation": float(np.median(t_calls[1:])) / max(evals, 1),
-                   "max_pose_err_vs_gt_m": float(max(np.abs(frames[f]["P"] - synth.pose_matrix(k0 + 42 + f)[:3, 3]).max() for f in range(Wf)))}
-    except Exception as e:
-        fullwin = {"error": repr(e)[:200]}
+    # IMU_Mode = 2: the full 15 W-parameter window (IMU factors, prior carried from a first call).  "host": the lidar frames
+    # are linearised on the device in one launch per trust-region evaluation and the dense iteration runs on the host
+    # (mml_fullwindow_step); "device": the whole iteration is one kernel launch per ceres::Solve (mml_fullwindow_solve)
+    fullwin = {}
+    for solver, Wf in (("host", 5), ("device", 5), ("host", 8), ("device", 8)):
+        try:
+            west = odometry.WindowEstimator(ctx, gravity=synth.GRAVITY, solver=solver)
+            rng = np.random.default_rng(3)
+            t_calls, k_ms = [], []
+            for call in range(4):
+                frames, pres = [], [None]
+                for f in range(Wf):
+                    k = k0 + 40 + call + f
+                    v, l = make_scan(synth, cfg, k, motion=False)
+                    ctx.scan_upload(f, v, l)
+                    ctx.extract(f, 1)
+                    ctx.downsample(f, 1)
+                    Tk = perturbed(synth.pose_matrix(k), dt_=rng.normal(0, 0.02, 3), rv=rng.normal(0, 0.003, 3))
+                    q = Rsc.from_matrix(Tk[:3, :3]).as_quat()
+                    frames.append(dict(P=Tk[:3, 3].copy(), Q=q if q[3] >= 0 else -q, V=synth.velocity_at(k) + rng.normal(0, 0.02, 3),
+                                       bg=np.zeros(3), ba=np.zeros(3)))
+                    if f > 0:
+                        pres.append(M.imu_preintegrate(synth.imu_samples(k - 1, k), np.zeros(3), np.zeros(3)))
+                ctx.synchronize()
+                timed_kernel = solver == "device" and call == 3      # last call: HIP events around the solve kernel
+                if timed_kernel:
+                    ctx.profile_enable(True)
+                    ctx.profile_reset()
+                t1 = time.perf_counter()
+                info_w = west.estimate(list(range(Wf)), frames, pres)
+                if timed_kernel:
+                    ctx.synchronize()
+                    fwp = ctx.profile_get().get("fullwindow", (0.0, 0))
+                    ctx.profile_enable(False)
+                    k_ms = [fwp[0], fwp[1]]
+                else:
+                    t_calls.append((time.perf_counter() - t1) * 1e3)
+            evals = info_w["evaluations"]
+            est = float(np.median(t_calls[1:]))
+            fullwin["%s_w%d" % (solver, Wf)] = {
+                "frames": Wf, "estimate_ms": est, "outer_iterations": info_w["outer"], "evaluations": evals,
+                "ms_per_evaluation": est / max(evals, 1),
+                "max_pose_err_vs_gt_m": float(max(np.abs(frames[f]["P"] - synth.pose_matrix(k0 + 43 + f)[:3, 3]).max() for f in range(Wf)))}
+            if k_ms:
+                fullwin["%s_w%d" % (solver, Wf)].update(solve_launches=int(k_ms[1]), solve_device_ms_total=float(k_ms[0]),
+                                                        solve_device_ms_per_evaluation=float(k_ms[0]) / max(evals, 1))
+        except Exception as e:
+            fullwin["%s_w%d" % (solver, Wf)] = {"error": repr(e)[:200]}
 
     # stage times of the same B = 1 step (HIP events)
     ctx.profile_enable(True)

@@ -432,6 +432,14 @@ int mml_fullwindow_normal_equations(const mml_fullwindow*, const double* records
 /* MarginalizationInfo::marginalize for the factor set of Estimator.cpp:1453-1546 (previous prior, IMU factor 0-1,
  * lidar factors of frame 0 as their loss-free normal equations).  x: W x 15.  out: the prior for the slid window. */
 int mml_fullwindow_marginalize(const mml_fullwindow*, const double* lidar_record0, const double* x, mml_prior* out);
+/* The minimisation of the mml_fullwindow_step loop with the whole trust-region iteration resident on the device: the
+ * lidar factors of the W frames in slots first_slot .. first_slot + W - 1 (associated beforehand, evaluated with the
+ * handle's plan_weight_tan / huber_delta), the IMU factors and the prior set on `fw` are evaluated, assembled into the
+ * block-tridiagonal band of the 15 W normal equations, factored and stepped by ONE kernel launch -- no host round
+ * trip per evaluation.  x: W x 15 in/out; summary / evaluations may be NULL.  Afterwards mml_fullwindow_summary
+ * reports this solve and mml_fullwindow_marginalize can be called with the returned x. */
+int mml_fullwindow_solve(mml_ctx* ctx, mml_fullwindow* fw, int first_slot, const double* T_bl, double* x,
+                         mml_solve_summary* summary, int* evaluations);
 
 /* Number of HIP streams mml_step pipelines its sub-batches over (1..4, default 4 or $MML_LANES).  With 1 every
  * kernel covers the whole batch and runs alone on the device, which is what per-kernel timing wants. */

@@ -582,6 +582,16 @@ class FullWindowSolver:
         rc = self._ck(lib().mml_fullwindow_step(self._h, _p(rec), _p(x)), "mml_fullwindow_step")
         return rc == 1, x
 
+    def solve_device(self, ctx, first_slot, T_bl, x):
+        """mml_fullwindow_solve: the whole trust-region loop on the device (frames in consecutive, associated slots).
+        Returns (x, summary, evaluations)."""
+        x = _f64(x).reshape(self.W, 15).copy()
+        T = _f64(T_bl).reshape(16)
+        s = SolveSummary()
+        ev = C.c_int(0)
+        ctx._ck(lib().mml_fullwindow_solve(ctx._h, self._h, C.c_int(first_slot), _p(T), _p(x), C.byref(s), C.byref(ev)))
+        return x, s, ev.value
+
     def summary(self):
         s = SolveSummary()
         lib().mml_fullwindow_summary(self._h, C.byref(s))

@@ -68,6 +68,7 @@ void mml_destroy(mml_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     mml_comm_destroy(ctx);
+    mml_fullwindow_dev_release(ctx);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
         if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,

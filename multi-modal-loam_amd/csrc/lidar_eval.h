@@ -1,0 +1,272 @@
+// lidar_eval.h -- the per-frame lidar evaluation shared by the device solvers (solve.hip: k_solve, k_linearize,
+// k_window_round; fullwindow_dev.hip: the 15 W window with IMU factors): pose construction, the two residual types
+// with their analytic Jacobians and Huber correction, and the 28-value workgroup reduction.
+//   a17/a18 Cost_NavState_IMU_Line / Cost_NavState_IMU_Plan_Vec (mm-loam/include/utils/ceresfunc.h:397-458, 517-570)
+//   a19     analytic Jacobians replacing ceres::AutoDiffCostFunction<...,6> through Sophus::SO3<Jet>::exp
+//           (include/sophus/so3.hpp:585-622): dP/dt = I, dP/dphi = -[R p_b]x J_l(phi)
+//   a20     J^T J / J^T r with Ceres' Huber correction (corrector.cc: rho'' <= 0 => scale by sqrt(rho'))
+#pragma once
+#include <math.h>
+
+#include "mml_internal.h"
+
+namespace {
+
+constexpr int SOLVE_THREADS = 256;
+constexpr int SOLVE_WAVES = SOLVE_THREADS / 64;
+constexpr int MAXW = 8;  // frames per window problem
+constexpr double kLidarM = 1.5e-3;  // IMUIntegrator.h:83
+
+struct Pose {
+    double R[9];   // R_wl
+    double t[3];   // t_wl
+    double tb[3];  // t_wb (= x[0:3])
+    double Jl[9];  // left Jacobian of SO(3) at phi
+};
+
+__device__ void quat_to_R(double qx, double qy, double qz, double qw, double* R) {
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz);
+    R[1] = txy - twz;
+    R[2] = txz + twy;
+    R[3] = txy + twz;
+    R[4] = 1 - (txx + tzz);
+    R[5] = tyz - twx;
+    R[6] = txz - twy;
+    R[7] = tyz + twx;
+    R[8] = 1 - (txx + tyy);
+}
+
+// x = [t, phi]; T_bl row-major 4x4.  sophus/so3.hpp:585-622 exp with the theta^2 < 1e-20 Taylor branch.
+__device__ void make_pose(const double* x, const double* T_bl, Pose& P) {
+    const double px = x[3], py = x[4], pz = x[5];
+    const double th2 = (px * px + py * py) + pz * pz;
+    double imag, real, a, b;
+    if (th2 < 1e-10 * 1e-10) {
+        double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+        a = 0.5;
+        b = 1.0 / 6.0;
+    } else {
+        double th = sqrt(th2);
+        double half = 0.5 * th;
+        imag = sin(half) / th;
+        real = cos(half);
+        a = (1.0 - cos(th)) / th2;
+        b = (th - sin(th)) / (th2 * th);
+    }
+    double Rwb[9];
+    quat_to_R(imag * px, imag * py, imag * pz, real, Rwb);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            P.R[3 * r + c] = (Rwb[3 * r] * T_bl[c] + Rwb[3 * r + 1] * T_bl[4 + c]) + Rwb[3 * r + 2] * T_bl[8 + c];
+        P.t[r] = ((Rwb[3 * r] * T_bl[3] + Rwb[3 * r + 1] * T_bl[7]) + Rwb[3 * r + 2] * T_bl[11]) + x[r];
+        P.tb[r] = x[r];
+    }
+    const double K[9] = {0, -pz, py, pz, 0, -px, -py, px, 0};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double k2 = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+            P.Jl[3 * r + c] = a * K[3 * r + c] + b * k2 + (r == c ? 1.0 : 0.0);
+        }
+}
+
+// ceres/loss_function.cc HuberLoss::Evaluate
+__device__ __forceinline__ void huber(double s, double a, double& rho0, double& rho1) {
+    rho0 = s;
+    rho1 = 1.0;
+    if (a > 0) {
+        double bb = a * a;
+        if (s > bb) {
+            double r = sqrt(s);
+            rho0 = 2.0 * a * r - bb;
+            rho1 = fmax(2.2250738585072014e-308, a / r);
+        }
+    }
+}
+
+// accumulate rho1 * J J^T (upper triangle, 21) and rho1 * J r (6) for one scalar residual row with dr/dP = gr
+__device__ __forceinline__ void row_jacobian(const Pose& P, const double* Pw, const double* gr, double* J) {
+    // dP/dx = [I, -[Rpb]x Jl],  Rpb = P - t_wb
+    const double rx = Pw[0] - P.tb[0], ry = Pw[1] - P.tb[1], rz = Pw[2] - P.tb[2];
+    // gr^T * (-[Rpb]x) = (Rpb x gr)^T ... (-[a]x)^T g = a x g  => row = (gr x Rpb)?  use explicit form:
+    // (-[r]x) = [[0, rz, -ry], [-rz, 0, rx], [ry, -rx, 0]] ; v^T = gr^T (-[r]x)
+    const double v0 = -gr[1] * rz + gr[2] * ry;
+    const double v1 = gr[0] * rz - gr[2] * rx;
+    const double v2 = -gr[0] * ry + gr[1] * rx;
+    J[0] = gr[0];
+    J[1] = gr[1];
+    J[2] = gr[2];
+    J[3] = (v0 * P.Jl[0] + v1 * P.Jl[3]) + v2 * P.Jl[6];
+    J[4] = (v0 * P.Jl[1] + v1 * P.Jl[4]) + v2 * P.Jl[7];
+    J[5] = (v0 * P.Jl[2] + v1 * P.Jl[5]) + v2 * P.Jl[8];
+}
+
+__device__ __forceinline__ void accum(double* acc, const double* J, double r, double w) {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += w * J[a] * J[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += w * J[a] * r;
+}
+
+// Evaluate one frame at pose P: thread-strided over the factors; acc[28] per thread.
+__device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
+                           double w_tan, double huber_delta, double* acc) {
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    const double ka = 1.0 / kLidarM;
+    for (int i = threadIdx.x; i < nlf; i += SOLVE_THREADS) {
+        const MmlLineFactor f = lf[i];
+        if (f.src < 0 || !(fabs(f.error) > 1e-5)) continue;  // Estimator.cpp:1385
+        const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
+        const double ax = f.p1[0], ay = f.p1[1], az = f.p1[2], bx = f.p2[0], by = f.p2[1], bz = f.p2[2];
+        double Pw[3];
+        Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
+        Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
+        Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
+        const double l12 = sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz));
+        const double c0 = (Pw[0] - ax) * (Pw[1] - by) - (Pw[0] - bx) * (Pw[1] - ay);
+        const double c1 = (Pw[0] - ax) * (Pw[2] - bz) - (Pw[0] - bx) * (Pw[2] - az);
+        const double c2 = (Pw[1] - ay) * (Pw[2] - bz) - (Pw[1] - by) * (Pw[2] - az);
+        const double a012 = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+        const double ld2 = a012 / l12;
+        const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+        const double rs = sqrt(sqrt(s));
+        const double weight = 1.0 - 0.9 * fabs(ld2) / rs;
+        const double r = ka * weight * ld2;
+        // gradient of ld wrt P: ((a-b) x u_hat) / l12, u = (c2, -c1, c0)
+        const double ux = c2 / a012, uy = -c1 / a012, uz = c0 / a012;
+        const double dx = ax - bx, dy = ay - by, dz = az - bz;
+        double gl[3] = {(dy * uz - dz * uy) / l12, (dz * ux - dx * uz) / l12, (dx * uy - dy * ux) / l12};
+        const double sm14 = 1.0 / rs, sm54 = sm14 / s;
+        double gr[3];
+        for (int c = 0; c < 3; ++c) {
+            double gw = (-0.9) * (sm14 * gl[c] + (fabs(ld2) * (-0.5) * sm54) * Pw[c]);
+            gr[c] = ka * (weight * gl[c] + ld2 * gw);
+        }
+        double J[6];
+        row_jacobian(P, Pw, gr, J);
+        double rho0, rho1;
+        huber(r * r, huber_delta, rho0, rho1);
+        acc[27] += 0.5 * rho0;
+        accum(acc, J, r, rho1);
+    }
+    const double kb = w_tan / kLidarM;
+    // (the next record is requested before the current one is worked on: one exposed memory round trip per pass
+    //  instead of one per factor)
+    MmlPlaneFactor nxt;
+    if ((int)threadIdx.x < npf) nxt = pf[threadIdx.x];
+    for (int i = threadIdx.x; i < npf; i += SOLVE_THREADS) {
+        const MmlPlaneFactor f = nxt;
+        if (i + SOLVE_THREADS < npf) nxt = pf[i + SOLVE_THREADS];
+        if (f.src < 0 || !(fabs(f.error) > 1e-5)) continue;  // Estimator.cpp:1396
+        const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
+        double Pw[3];
+        Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
+        Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
+        Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
+        const double d[3] = {Pw[0] - f.proj[0], Pw[1] - f.proj[1], Pw[2] - f.proj[2]};
+        const double nd = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+        const double rs = sqrt(sqrt(s));
+        const double weight = 1.0 - 0.9 * nd / rs;
+        const double sm14 = 1.0 / rs, sm54 = sm14 / s;
+        double gw[3];
+        for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * ((sm14 / nd) * d[c] + (nd * (-0.5) * sm54) * Pw[c]);
+        // e = weight * d ;  de/dP = weight I + d gw^T ;  row^T de/dP = weight row + (row . d) gw
+        const double w[3] = {f.omega[0], f.omega[1], f.omega[2]};
+        double rows[3][3];
+        int nrows = 1;
+        rows[0][0] = ka * w[0];
+        rows[0][1] = ka * w[1];
+        rows[0][2] = ka * w[2];
+        if (kb != 0.0) {
+            // deterministic tangent basis (any orthonormal completion gives the same H, g, cost)
+            double h[3] = {0, 0, 0};
+            if (fabs(w[0]) <= fabs(w[1]) && fabs(w[0]) <= fabs(w[2]))
+                h[0] = 1;
+            else if (fabs(w[1]) <= fabs(w[2]))
+                h[1] = 1;
+            else
+                h[2] = 1;
+            double t0 = w[1] * h[2] - w[2] * h[1], t1 = w[2] * h[0] - w[0] * h[2], t2 = w[0] * h[1] - w[1] * h[0];
+            double n = sqrt((t0 * t0 + t1 * t1) + t2 * t2);
+            t0 /= n;
+            t1 /= n;
+            t2 /= n;
+            rows[1][0] = kb * t0;
+            rows[1][1] = kb * t1;
+            rows[1][2] = kb * t2;
+            rows[2][0] = kb * (w[1] * t2 - w[2] * t1);
+            rows[2][1] = kb * (w[2] * t0 - w[0] * t2);
+            rows[2][2] = kb * (w[0] * t1 - w[1] * t0);
+            nrows = 3;
+        }
+        double rr[3], sq = 0;
+        for (int q = 0; q < nrows; ++q) {
+            rr[q] = weight * ((rows[q][0] * d[0] + rows[q][1] * d[1]) + rows[q][2] * d[2]);
+            sq += rr[q] * rr[q];
+        }
+        double rho0, rho1;
+        huber(sq, huber_delta, rho0, rho1);
+        acc[27] += 0.5 * rho0;
+        for (int q = 0; q < nrows; ++q) {
+            const double rd = (rows[q][0] * d[0] + rows[q][1] * d[1]) + rows[q][2] * d[2];
+            double gr[3] = {weight * rows[q][0] + rd * gw[0], weight * rows[q][1] + rd * gw[1],
+                            weight * rows[q][2] + rd * gw[2]};
+            double J[6];
+            row_jacobian(P, Pw, gr, J);
+            accum(acc, J, rr[q], rho1);
+        }
+    }
+}
+
+// block reduction of acc[28] into out[28] (LDS or global); result valid for thread 0 after the trailing barrier.
+// Inside a wavefront the 28 sums are reduced as a butterfly that halves the number of values a lane carries at every
+// step (at offset o the lanes with bit o set keep the upper half of their values and hand over the lower half): 16 + 8 +
+// 4 + 2 + 1 + 1 = 32 exchanged doubles instead of 28 x 6.  Every value still meets its partners in the order xor 32, 16,
+// 8, 4, 2, 1, i.e. it is the same summation tree as one xor-butterfly per value, bit for bit.
+__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
+    const unsigned lo = __shfl_xor((unsigned)__double2loint(v), o), hi = __shfl_xor((unsigned)__double2hiint(v), o);
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, double* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = k < 28 ? acc[k] : 0.0;
+    int idx = 0;  // which of the 32 sums this lane ends up holding
+#pragma unroll
+    for (int c = 16, o = 32; c >= 1; c >>= 1, o >>= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int j = 0; j < c; ++j) {
+            const double keep = up ? v[j + c] : v[j], send = up ? v[j] : v[j + c];
+            v[j] = keep + shfl_xor_f64(send, o);
+        }
+        idx += up ? c : 0;
+    }
+    const double tot = v[0] + shfl_xor_f64(v[0], 1);
+    if (!(lane & 1) && idx < 28) s_part[wave * 28 + idx] = tot;
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double r = s_part[threadIdx.x];
+        for (int w = 1; w < SOLVE_WAVES; ++w) r += s_part[w * 28 + threadIdx.x];
+        out[threadIdx.x] = r;
+    }
+    __syncthreads();
+}
+
+__host__ __device__ __forceinline__ int tri(int a, int b) {  // index into 21-entry upper triangle, a <= b
+    return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
+__host__ __device__ __forceinline__ double Hget(const double* rec, int a, int b) { return a <= b ? rec[tri(a, b)] : rec[tri(b, a)]; }
+
+}  // namespace

@@ -50,11 +50,13 @@ struct MmlStageTimer {
     long launches = 0;
 };
 
-struct MmlComm;  // comm.hip: RCCL communicator + window-solve buffers
+struct MmlComm;   // comm.hip: RCCL communicator + window-solve buffers
+struct MmlFwDev;  // fullwindow_dev.hip: parameter / scratch buffers of the device-resident full-window solve
 
 struct mml_ctx {
     mml_config cfg;
     MmlComm* comm = nullptr;
+    MmlFwDev* fwdev = nullptr;
     int device = 0;
     // `lanes`: independent HIP streams.  Entry points enqueue on lane `cur` (0 unless mml_step is pipelining
     // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.
@@ -253,6 +255,7 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
                      bool want_trace);
 int mml_feature_init(mml_ctx* ctx);
+void mml_fullwindow_dev_release(mml_ctx* ctx);
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan,
                          double huber, double* d_record, int frames = 1);

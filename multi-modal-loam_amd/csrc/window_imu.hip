@@ -1,6 +1,7 @@
-// window_imu.hip -- SURVEY.md section 8(f) rank 1: the IMU side of the joint window solve.  Pure host code (W <= 8
-// frames, 15 parameters each: O(W) tiny dense work next to the per-frame lidar normal equations that come from the
-// device), compiled into the same library so that it sits behind the same C-ABI.
+// window_imu.hip -- SURVEY.md section 8(f) rank 1: the IMU side of the joint window solve.  Host code (W <= 8 frames,
+// 15 parameters each: O(W) tiny dense work next to the per-frame lidar normal equations that come from the device),
+// compiled into the same library so that it sits behind the same C-ABI; the same trust-region loop resident on the
+// device is fullwindow_dev.hip, the shared arithmetic imu_math.h.
 //   * IMUIntegrator::PreIntegration            mm-loam/src/lio/IMUIntegrator.cpp:108-166  -> mml_imu_preintegrate
 //   * Cost_NavState_PRV_Bias (15 residuals)    mm-loam/include/utils/ceresfunc.h:321-393   -> mml_imu_factor
 //     Jacobians: the reference lets Ceres autodiff the functor; here they are analytic (checked against central
@@ -16,143 +17,10 @@
 
 #include <vector>
 
-#include "../../include/mmloam_hip.h"
+#include "fullwindow_internal.h"
+#include "imu_math.h"
 
 namespace {
-
-// ---- small dense helpers (row-major) -------------------------------------------------------------------------------
-struct M3 {
-    double a[9];
-};
-inline M3 m3_identity() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
-inline M3 m3_mul(const M3& A, const M3& B) {
-    M3 C;
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) C.a[3 * r + c] = (A.a[3 * r] * B.a[c] + A.a[3 * r + 1] * B.a[3 + c]) + A.a[3 * r + 2] * B.a[6 + c];
-    return C;
-}
-inline M3 m3_t(const M3& A) { return M3{{A.a[0], A.a[3], A.a[6], A.a[1], A.a[4], A.a[7], A.a[2], A.a[5], A.a[8]}}; }
-inline void m3_vec(const M3& A, const double* v, double* o) {
-    for (int r = 0; r < 3; ++r) o[r] = (A.a[3 * r] * v[0] + A.a[3 * r + 1] * v[1]) + A.a[3 * r + 2] * v[2];
-}
-inline M3 hat(const double* v) { return M3{{0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}}; }
-inline M3 m3_scale(const M3& A, double s) {
-    M3 C;
-    for (int i = 0; i < 9; ++i) C.a[i] = A.a[i] * s;
-    return C;
-}
-inline M3 m3_add(const M3& A, const M3& B) {
-    M3 C;
-    for (int i = 0; i < 9; ++i) C.a[i] = A.a[i] + B.a[i];
-    return C;
-}
-
-// Sophus::SO3d::exp (so3.hpp:585-622, epsilon 1e-10 on theta^2): rotation vector -> unit quaternion (x, y, z, w)
-inline void so3_exp_q(const double* w, double* q) {
-    const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
-    double imag, real;
-    if (th2 < 1e-10 * 1e-10) {
-        const double th4 = th2 * th2;
-        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
-        real = 1.0 - 0.125 * th2 + (1.0 / 384.0) * th4;
-    } else {
-        const double th = sqrt(th2), h = 0.5 * th;
-        imag = sin(h) / th;
-        real = cos(h);
-    }
-    q[0] = imag * w[0];
-    q[1] = imag * w[1];
-    q[2] = imag * w[2];
-    q[3] = real;
-}
-inline M3 quat_to_m3(const double* q) {  // Eigen::Quaterniond::toRotationMatrix
-    const double x = q[0], y = q[1], z = q[2], w = q[3];
-    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
-                 tzz = tz * z;
-    return M3{{1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)}};
-}
-inline M3 so3_exp(const double* w) {
-    double q[4];
-    so3_exp_q(w, q);
-    return quat_to_m3(q);
-}
-// Eigen quaternionbase_assign_impl<Matrix3d>
-inline void m3_to_quat(const M3& M, double* q) {
-    const double* m = M.a;
-    double t = m[0] + m[4] + m[8];
-    if (t > 0.0) {
-        t = sqrt(t + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[7] - m[5]) * t;
-        q[1] = (m[2] - m[6]) * t;
-        q[2] = (m[3] - m[1]) * t;
-    } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-        q[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
-        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-    }
-}
-// Sophus::SO3d::log of a unit quaternion (so3.hpp logAndTheta)
-inline void so3_log_q(const double* q, double* w) {
-    const double n2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-    const double qw = q[3];
-    double two_atan;
-    if (n2 < 1e-10 * 1e-10) {
-        two_atan = 2.0 / qw - (2.0 / 3.0) * n2 / (qw * qw * qw);
-    } else {
-        const double n = sqrt(n2);
-        if (fabs(qw) < 1e-10)
-            two_atan = (qw > 0 ? M_PI : -M_PI) / n;
-        else
-            two_atan = 2.0 * atan(n / qw) / n;
-    }
-    w[0] = two_atan * q[0];
-    w[1] = two_atan * q[1];
-    w[2] = two_atan * q[2];
-}
-inline void so3_log(const M3& R, double* w) {
-    double q[4];
-    m3_to_quat(R, q);
-    const double n = sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
-    for (int i = 0; i < 4; ++i) q[i] /= n;
-    so3_log_q(q, w);
-}
-// right Jacobian of SO(3) and its inverse
-inline M3 so3_Jr(const double* w) {
-    const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
-    const M3 K = hat(w), K2 = m3_mul(K, K);
-    double a, b;
-    if (th2 < 1e-8) {
-        a = 0.5 - th2 / 24.0;
-        b = 1.0 / 6.0 - th2 / 120.0;
-    } else {
-        const double th = sqrt(th2);
-        a = (1.0 - cos(th)) / th2;
-        b = (th - sin(th)) / (th2 * th);
-    }
-    return m3_add(m3_add(m3_identity(), m3_scale(K, -a)), m3_scale(K2, b));
-}
-inline M3 so3_Jr_inv(const double* w) {
-    const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
-    const M3 K = hat(w), K2 = m3_mul(K, K);
-    double c;
-    if (th2 < 1e-8) {
-        c = 1.0 / 12.0 + th2 / 720.0;
-    } else {
-        const double th = sqrt(th2);
-        c = 1.0 / th2 - (1.0 + cos(th)) / (2.0 * th * sin(th));
-    }
-    return m3_add(m3_add(m3_identity(), m3_scale(K, 0.5)), m3_scale(K2, c));
-}
 
 // in-place Cholesky A = L L^T (lower, row-major n x n); false when not positive definite
 bool cholesky(double* A, int n) {
@@ -180,6 +48,22 @@ void chol_solve(const double* L, int n, double* b) {
         double s = b[i];
         for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
         b[i] = s / L[i * n + i];
+    }
+}
+// The same with the reciprocals of the diagonal taken once and multiplied in: the form the device-resident solver
+// (fullwindow_dev.hip) uses, where a division would sit on the dependency chain of every substitution step.
+void chol_solve_rcp(const double* L, int n, double* b) {
+    std::vector<double> rd(n);
+    for (int i = 0; i < n; ++i) rd[i] = 1.0 / L[i * n + i];
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * n + k] * b[k];
+        b[i] = s * rd[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
+        b[i] = s * rd[i];
     }
 }
 // cyclic Jacobi eigen-decomposition of a symmetric n x n matrix: A = V diag(ev) V^T, eigenvalues ascending
@@ -236,11 +120,6 @@ void sym_eig(const double* Ain, int n, double* ev, double* V) {
 constexpr double kGnorm = 9.805;                                        // IMUIntegrator.h:84
 constexpr double kAccN = 0.08, kGyrN = 0.004, kAccW = 2.0e-4, kGyrW = 2.0e-5;  // IMUIntegrator.h:79-82
 
-inline void set_block(double* M, int ld, int r0, int c0, const M3& B, double s = 1.0) {
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) M[(r0 + r) * ld + c0 + c] = s * B.a[3 * r + c];
-}
-
 // sqrt information of one pre-integration: LLT(covariance^-1).matrixL().transpose() (Estimator.cpp:1240-1242)
 bool imu_sqrt_info(const mml_imu_preint* pre, double* U /*15x15 upper*/) {
     double L[225];
@@ -261,69 +140,9 @@ bool imu_sqrt_info(const mml_imu_preint* pre, double* U /*15x15 upper*/) {
     return true;
 }
 
-// residual (15) and Jacobian (15 x 30, columns [PR_i 6 | VBias_i 9 | PR_j 6 | VBias_j 9]) BEFORE the sqrt information
-void imu_raw(const mml_imu_preint* pre, const double* g, const double* pri, const double* vbi, const double* prj,
-             const double* vbj, double* r, double* J) {
-    const double dt = pre->dtime, dt2 = dt * dt;
-    const M3 Ri = so3_exp(pri + 3), Rj = so3_exp(prj + 3), RiT = m3_t(Ri);
-    const double dbg[3] = {vbi[3] - pre->bg[0], vbi[4] - pre->bg[1], vbi[5] - pre->bg[2]};
-    const double dba[3] = {vbi[6] - pre->ba[0], vbi[7] - pre->ba[1], vbi[8] - pre->ba[2]};
-    auto Jb = [&](int r0, int c0) {
-        M3 B;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) B.a[3 * a + b] = pre->jacobian[(r0 + a) * 15 + c0 + b];
-        return B;
-    };
-    const M3 Jpbg = Jb(0, 9), Jpba = Jb(0, 12), Jrbg = Jb(3, 9), Jvbg = Jb(6, 9), Jvba = Jb(6, 12);
-    double a[3], b[3];
-    for (int k = 0; k < 3; ++k) {
-        a[k] = prj[k] - pri[k] - vbi[k] * dt - 0.5 * g[k] * dt2;
-        b[k] = vbj[k] - vbi[k] - g[k] * dt;
-    }
-    double Ra[3], Rb[3], t1[3], t2[3];
-    m3_vec(RiT, a, Ra);
-    m3_vec(RiT, b, Rb);
-    m3_vec(Jpbg, dbg, t1);
-    m3_vec(Jpba, dba, t2);
-    for (int k = 0; k < 3; ++k) r[k] = Ra[k] - (pre->dp[k] + t1[k] + t2[k]);
-    m3_vec(Jvbg, dbg, t1);
-    m3_vec(Jvba, dba, t2);
-    for (int k = 0; k < 3; ++k) r[6 + k] = Rb[k] - (pre->dv[k] + t1[k] + t2[k]);
-    double jd[3];
-    m3_vec(Jrbg, dbg, jd);
-    const M3 dR = quat_to_m3(pre->dq);
-    const M3 C = m3_mul(dR, so3_exp(jd));
-    const M3 E = m3_mul(m3_t(C), m3_mul(RiT, Rj));
-    so3_log(E, r + 3);
-    for (int k = 0; k < 6; ++k) r[9 + k] = vbj[3 + k] - vbi[3 + k];
-    if (!J) return;
-    memset(J, 0, sizeof(double) * 15 * 30);
-    const M3 Jri = so3_Jr(pri + 3), Jrj = so3_Jr(prj + 3), JrInv = so3_Jr_inv(r + 3);
-    // position rows
-    set_block(J, 30, 0, 0, RiT, -1.0);
-    set_block(J, 30, 0, 3, m3_mul(hat(Ra), Jri));
-    set_block(J, 30, 0, 6, RiT, -dt);
-    set_block(J, 30, 0, 9, Jpbg, -1.0);
-    set_block(J, 30, 0, 12, Jpba, -1.0);
-    set_block(J, 30, 0, 15, RiT);
-    // rotation rows
-    set_block(J, 30, 3, 3, m3_mul(JrInv, m3_mul(m3_mul(m3_t(Rj), Ri), Jri)), -1.0);
-    set_block(J, 30, 3, 9, m3_mul(JrInv, m3_mul(m3_t(E), m3_mul(so3_Jr(jd), Jrbg))), -1.0);
-    set_block(J, 30, 3, 18, m3_mul(JrInv, Jrj));
-    // velocity rows
-    set_block(J, 30, 6, 3, m3_mul(hat(Rb), Jri));
-    set_block(J, 30, 6, 6, RiT, -1.0);
-    set_block(J, 30, 6, 9, Jvbg, -1.0);
-    set_block(J, 30, 6, 12, Jvba, -1.0);
-    set_block(J, 30, 6, 21, RiT);
-    // bias rows
-    for (int k = 0; k < 6; ++k) {
-        J[(9 + k) * 30 + 9 + k] = -1.0;
-        J[(9 + k) * 30 + 24 + k] = 1.0;
-    }
-}
-
 }  // namespace
+
+bool mml_imu_sqrt_info(const mml_imu_preint* pre, double* U) { return imu_sqrt_info(pre, U); }
 
 extern "C" {
 
@@ -439,54 +258,8 @@ int mml_imu_factor(const mml_imu_preint* pre, const double* gravity, const doubl
 // ---- the full-window problem -------------------------------------------------------------------------------------------
 namespace {
 
-struct Prior {            // MarginalizationFactor on (para_PR[0], para_VBias[0]) after the address shift (:1552-1562)
-    bool valid = false;
-    int nres = 15;
-    double J[15 * 15];    // linearized_jacobians, columns [PR 6 | VBias 9]
-    double r0[15];        // linearized_residuals
-    double x0[15];        // keep_block_data
-};
-
-// MarginalizationFactor::Evaluate (ceresfunc.h:262-301): residual at x, the (constant) Jacobian is P.J
-void prior_residual(const Prior& P, const double* x15, double* r) {
-    double dx[15];
-    for (int k = 0; k < 3; ++k) dx[k] = x15[k] - P.x0[k];
-    const M3 E = m3_mul(m3_t(so3_exp(x15 + 3)), so3_exp(P.x0 + 3));  // exp(x)^-1 * exp(x0)  (:279)
-    so3_log(E, dx + 3);
-    for (int k = 6; k < 15; ++k) dx[k] = x15[k] - P.x0[k];
-    for (int i = 0; i < 15; ++i) {
-        double s = P.r0[i];
-        for (int k = 0; k < 15; ++k) s += P.J[i * 15 + k] * dx[k];
-        r[i] = s;
-    }
-}
-
-struct Eval {  // dense normal equations of the whole window at one x
-    std::vector<double> H, g;
-    double cost = 0;
-};
-
-}  // namespace
-
-struct mml_fullwindow {
-    int W = 0, n = 0;
-    mml_solve_opts opts;
-    std::vector<mml_imu_preint> imu;   // imu[f]: between frame f-1 and f (f >= 1)
-    std::vector<char> have_imu;
-    double gravity[3] = {0, 0, 0};
-    Prior prior;
-    // trust-region state (Ceres 2.1 TRADITIONAL_DOGLEG, same constants as mml_solve / tr_propose / tr_decide)
-    std::vector<double> x, xc, x_init, scale, diag, grad, gn, step;
-    Eval cur, cand;
-    double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0, x_norm = 0, model_change = 0, step_norm = 0;
-    int reuse = 0, num_invalid = 0, iter = 0, successful = 0, termination = 0, started = 0, done = 0;
-    double initial_cost = 0;
-};
-
-namespace {
-
 // adds the IMU factors and the prior, evaluated at x (W x 15: PR 6 | VBias 9), to the lidar records (W x 32)
-int assemble(const mml_fullwindow* s, const double* records, const double* x, Eval& e) {
+int assemble(const mml_fullwindow* s, const double* records, const double* x, MmlFwEval& e) {
     const int W = s->W, n = s->n;
     e.H.assign((size_t)n * n, 0.0);
     e.g.assign(n, 0.0);
@@ -588,7 +361,7 @@ int propose(mml_fullwindow* s) {
             }
             bool ok = cholesky(A.data(), n);
             if (ok) {
-                chol_solve(A.data(), n, b.data());
+                chol_solve_rcp(A.data(), n, b.data());
                 for (int a = 0; a < n; ++a)
                     if (!isfinite(b[a])) ok = false;
             }
@@ -806,7 +579,7 @@ int mml_fullwindow_step(mml_fullwindow* s, const double* records, double* x_eval
 int mml_fullwindow_normal_equations(const mml_fullwindow* s, const double* records, const double* x, double* H, double* g,
                                     double* cost) {
     if (!s || !records || !x || !H || !g || !cost) return MML_ERR_INVALID;
-    Eval e;
+    MmlFwEval e;
     int rc = assemble(s, records, x, e);
     if (rc != MML_OK) return rc;
     memcpy(H, e.H.data(), sizeof(double) * e.H.size());

@@ -260,6 +260,9 @@ class Estimator {
         bool valid = false;
     };
     double thres_dist = 25.0;  // Estimator.h:332, set by Estimate() (25 -> 10 -> 1, Estimator.cpp:1207,1377-1381)
+    // EstimateFullWindow: true = the joint ceres::Solve is one device-resident iteration (mml_fullwindow_solve, needs the
+    // window in consecutive slots); false = host iteration with one device evaluation per trust-region step
+    bool device_window_solve = true;
 
     // processPointToLine / processPointToPlanVec (Estimator.h:159-186, Estimator.cpp:148-365, 573-777) for the down-sampled
     // stacks of `slot` at lidar pose m4d = transformTobeMapped: kNN + model fit on the device (both kinds in one launch),
@@ -490,14 +493,22 @@ class Estimator {
                     r[28] = r[29] = r[30] = r[31] = 0;
                 }
             };
-            for (int guard = 0; guard < 200; ++guard) {
-                lidar_records();
-                const int rc = mml_fullwindow_step(fw, rec.data(), x.data());
-                if (rc < 0) {
+            if (consecutive && device_window_solve) {  // ceres::Solve as one device-resident iteration
+                const int rc = mml_fullwindow_solve(ctx_.get(), fw, frames[0]->slot, T_bl, x.data(), nullptr, nullptr);
+                if (rc != MML_OK) {
                     mml_fullwindow_destroy(fw);
-                    throw std::runtime_error("mml_fullwindow_step");
+                    check(ctx_.get(), rc, "mml_fullwindow_solve");
                 }
-                if (rc == 1) break;
+            } else {
+                for (int guard = 0; guard < 200; ++guard) {  // host iteration, one device evaluation per step
+                    lidar_records();
+                    const int rc = mml_fullwindow_step(fw, rec.data(), x.data());
+                    if (rc < 0) {
+                        mml_fullwindow_destroy(fw);
+                        throw std::runtime_error("mml_fullwindow_step");
+                    }
+                    if (rc == 1) break;
+                }
             }
             for (int f = 0; f < W; ++f) {  // double2vector (:952-964)
                 LidarFrame& l = *frames[f];

@@ -96,11 +96,16 @@ def _quat_from_rotvec(phi):
 class WindowEstimator:
     """Estimator::Estimate in full-window mode (windowSize == SLIDEWINDOWSIZE, Estimator.cpp:1143-1581): lidar factors
     of every frame (associated once, thres_dist 1, plan_weight_tan 3e-4, no loss), IMU factors between consecutive
-    frames, the marginalization prior of the previous call.  Association and the per-frame normal equations run on
-    the device; the 15 W dense trust-region iteration, the IMU factors and the marginalization are host code behind
-    the same C-ABI (mml_fullwindow_*)."""
+    frames, the marginalization prior of the previous call.  Association runs on the device.  solver="device" (the
+    default when the window sits in consecutive slots): the 15 W trust-region iteration with its IMU factors and
+    prior is one kernel launch (mml_fullwindow_solve); solver="host": the iteration is host code behind the same
+    C-ABI (mml_fullwindow_step) and every evaluation fetches the per-frame lidar normal equations from the device.
+    The marginalization is host code either way."""
 
-    def __init__(self, ctx, exTlb=None, gravity=(0.0, 0.0, -9.805), max_outer=5, inner_iters=10):
+    def __init__(self, ctx, exTlb=None, gravity=(0.0, 0.0, -9.805), max_outer=5, inner_iters=10, solver="device"):
+        if solver not in ("device", "host"):
+            raise ValueError("solver must be 'device' or 'host'")
+        self.solver = solver
         import importlib
         self.M = importlib.import_module(__package__)
         self.ctx = ctx
@@ -145,10 +150,15 @@ class WindowEstimator:
                 fw.set_imu(f, preints[f], self.gravity)
             if self.prior is not None:
                 fw.set_prior(self.prior)
-            for _ in range(20 * self.inner_iters):
-                done, x = fw.step(self._records(slots, x), x)
-                if done:
-                    break
+            if self.solver == "device" and all(s == slots[0] + f for f, s in enumerate(slots)):
+                x, _, evals = fw.solve_device(ctx, slots[0], self.T_bl, x)
+                info["evaluations"] = info.get("evaluations", 0) + evals
+            else:
+                for _ in range(20 * self.inner_iters):
+                    done, x = fw.step(self._records(slots, x), x)
+                    info["evaluations"] = info.get("evaluations", 0) + 1
+                    if done:
+                        break
             info["summaries"].append(fw.summary())
             for f, fr in enumerate(frames):                    # double2vector
                 fr["P"], fr["Q"] = x[f][0:3].copy(), _quat_from_rotvec(x[f][3:6])

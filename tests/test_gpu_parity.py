@@ -855,23 +855,25 @@ def test_odometry_replay_matches_oracle_loop(M, O, synth):
         c.close()
 
 
-def test_full_window_estimate_with_imu_matches_oracle_loop(M, O, synth, scene):
-    """SURVEY section 8(f) rank 1 at system level: Estimator::Estimate in full-window mode (5 frames, lidar factors from
-    the device, IMU factors, marginalization prior carried into the next call) against the same control flow driven by
-    the CPU oracle (C++ lidar restatement + numpy IMU / marginalization / trust region)."""
+@pytest.mark.parametrize("solver,W", [("host", 5), ("device", 5), ("device", 8)])
+def test_full_window_estimate_with_imu_matches_oracle_loop(M, O, synth, scene, solver, W):
+    """SURVEY section 8(f) rank 1 at system level: Estimator::Estimate in full-window mode (5 and 8 frames, lidar factors,
+    IMU factors, marginalization prior carried into the next call) against the same control flow driven by the CPU
+    oracle (C++ lidar restatement + numpy IMU / marginalization / trust region).  solver="host": the trust-region
+    iteration is host code fed by per-evaluation lidar records from the device (mml_fullwindow_step);
+    solver="device": the whole iteration is one kernel (mml_fullwindow_solve)."""
     sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
     if sys_path not in sys.path:
         sys.path.insert(0, sys_path)
     import imu_oracle as IO
     odometry = importlib.import_module("multi-modal-loam_amd.odometry")
-    W = 5
     G = synth.GRAVITY
     c = M.Context(max_scans=W + 1)
     try:
         c.map_set_local(0, scene["corner_map"])
         c.map_set_local(1, scene["surf_map"])
         tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
-        west = odometry.WindowEstimator(c, gravity=G)
+        west = odometry.WindowEstimator(c, gravity=G, solver=solver)
         prior_np = None
         rng = np.random.default_rng(17)
         for call, k0 in enumerate((10, 11)):               # two consecutive windows: the second consumes the prior
@@ -973,6 +975,78 @@ def test_full_window_estimate_with_imu_matches_oracle_loop(M, O, synth, scene):
             for f, k in enumerate(ks):
                 assert np.abs(xg[f][:3] - synth.pose_matrix(k)[:3, 3]).max() < 0.03
                 assert np.abs(xg[f][6:9] - synth.velocity_at(k)).max() < 0.25
+    finally:
+        c.close()
+
+
+def test_fullwindow_device_solve_matches_host_loop(M, synth, scene):
+    """mml_fullwindow_solve (trust-region loop in one kernel) against the mml_fullwindow_step loop on the same problem:
+    8 frames, IMU factors, a marginalization prior produced by a previous window, and a 3-frame window without IMU on
+    one pair (have_imu gaps).  The two share the arithmetic (imu_math.h, lidar_eval.h); what differs is libm vs device
+    sin / cos / atan and the order of the back substitution, so the iterates agree to round-off and the iteration counts
+    and termination codes are the same."""
+    odometry = importlib.import_module("multi-modal-loam_amd.odometry")
+    G = synth.GRAVITY
+    W = 8
+    c = M.Context(max_scans=W)
+    try:
+        c.map_set_local(0, scene["corner_map"])
+        c.map_set_local(1, scene["surf_map"])
+        rng = np.random.default_rng(5)
+        west = odometry.WindowEstimator(c, gravity=G, solver="host")
+        prior = None
+        for call, k0 in enumerate((20, 21)):
+            x0, pres = [], [None]
+            for f in range(W):
+                k = k0 + f
+                c.scan_upload(f, synth.velo_scan(k), synth.livox_scan(k))
+                c.extract(f, 1)
+                c.undistort(f, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+                c.downsample(f, 1)
+                T = perturbed(synth.pose_matrix(k), dt=rng.normal(0, 0.02, 3), rotvec=rng.normal(0, 0.003, 3))
+                x0.append(np.concatenate([T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_rotvec(), synth.velocity_at(k) + rng.normal(0, 0.02, 3),
+                                          rng.normal(0, 1e-4, 3), rng.normal(0, 1e-3, 3)]))
+                if f > 0:
+                    pres.append(M.imu_preintegrate(synth.imu_samples(k - 1, k), np.zeros(3), np.zeros(3)))
+                c.associate(f, 1, west._T_wl(x0[f])[None], 1.0)
+            x0 = np.stack(x0)
+            for Wsub, skip in ((W, ()), (3, (2,)), (1, ())):
+                def make():
+                    fw = M.FullWindowSolver(Wsub, max_iters=10, fixed=False, huber=0.0, w_tan=3e-4)
+                    for f in range(1, Wsub):
+                        if f not in skip:
+                            fw.set_imu(f, pres[f], G)
+                    if prior is not None:
+                        fw.set_prior(prior)
+                    return fw
+                fh = make()
+                xh = x0[:Wsub].copy()
+                evals_h = 0
+                for _ in range(200):
+                    done, xh = fh.step(c.linearize_window(0, Wsub, xh, west.T_bl, 3e-4, 0.0), xh)
+                    evals_h += 1
+                    if done:
+                        break
+                sh = fh.summary()
+                fd = make()
+                xd, sd, evals_d = fd.solve_device(c, 0, west.T_bl, x0[:Wsub])
+                assert (sd.iterations, sd.successful, sd.termination) == (sh.iterations, sh.successful, sh.termination)
+                assert evals_d == evals_h
+                assert abs(sd.initial_cost - sh.initial_cost) <= 1e-12 * sh.initial_cost
+                assert abs(sd.final_cost - sh.final_cost) <= 1e-9 * sh.final_cost
+                assert np.abs(xd - xh).max() < 1e-9, np.abs(xd - xh).max(0)
+                assert sh.successful >= 1 and np.abs(xh - x0[:Wsub]).max() > 1e-4      # the problem is not trivial
+                s2 = fd.summary()
+                assert (s2.iterations, s2.termination, s2.final_cost) == (sd.iterations, sd.termination, sd.final_cost)
+                if Wsub == W and call == 0:
+                    rec0 = M.pack_record(*c.linearize(0, xh[0][:6], west.T_bl, 3e-4, 0.0))
+                    ph, pd = fh.marginalize(rec0, xh), fd.marginalize(rec0, xd)
+                    Jh, Jd = np.array(ph.J).reshape(15, 15), np.array(pd.J).reshape(15, 15)     # sqrt factors: compare J^T J
+                    assert np.allclose(Jh.T @ Jh, Jd.T @ Jd, rtol=1e-6, atol=1e-9 * np.abs(Jh.T @ Jh).max())
+                    prior = ph
+        # a window that does not fit the slots is refused
+        with pytest.raises(M.MmlError):
+            M.FullWindowSolver(W).solve_device(c, 1, west.T_bl, x0)
     finally:
         c.close()
 
