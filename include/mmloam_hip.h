@@ -89,7 +89,11 @@ int mml_scan_upload(mml_ctx* ctx, int slot, const float* velo_xyzi, int n_velo,
  * the call (slot first_slot + i) has its n_velo[i] x (x, y, z, intensity) floats at velo_base + i * max_velo_points * 4
  * and its n_livox[i] CustomPoint records at livox_base + i * max_livox_points (max_* as given to mml_create, which must be
  * multiples of 64 for this entry point).  Two host-to-device copies for the whole batch instead of two per scan: at
- * 0.46 MB per copy the per-scan entry point reaches ~11 GB/s, this one the PCIe rate.  Asynchronous like mml_scan_upload. */
+ * 0.46 MB per copy the per-scan entry point reaches ~11 GB/s, this one the PCIe rate.  Asynchronous like mml_scan_upload,
+ * and on a copy stream of its own: the copies start after everything enqueued before the call, the next entry point that
+ * touches one of these slots waits for them, and work enqueued on OTHER slots runs concurrently with them -- a feeder
+ * that alternates two slot ranges (upload range B, then mml_step on range A, and vice versa) hides the PCIe time behind
+ * the kernels. */
 int mml_scan_upload_batch(mml_ctx* ctx, int first_slot, int count, const float* velo_base, const int* n_velo,
                           const mml_livox_point* livox_base, const int* n_livox);
 

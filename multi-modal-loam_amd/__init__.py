@@ -213,6 +213,8 @@ class Context:
             raise ValueError("staging arrays must hold count x max points per sensor")
         self._keep = getattr(self, "_keep", [])
         self._keep.append((v, l, nv, nl))
+        if len(self._keep) > 4 * self.cfg.max_scans + 8:
+            self._keep = self._keep[-8:]
         self._ck(lib().mml_scan_upload_batch(self._h, C.c_int(first), C.c_int(count), _p(v), _p(nv), _p(l), _p(nl)))
 
     def scan_upload_pointcloud2(self, slot, data, n_points, point_step, off_x, off_y, off_z, off_intensity, livox):

@@ -95,8 +95,13 @@ void mml_destroy(mml_ctx* ctx) {
         hipEventDestroy(pe.b);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
+    for (auto& u : ctx->uploads) hipEventDestroy(u.done);
+    for (auto e : ctx->upload_event_pool) hipEventDestroy(e);
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
+        if (ctx->lane_mark[l]) hipEventDestroy(ctx->lane_mark[l]);
         if (ctx->streams[l]) hipStreamDestroy(ctx->streams[l]);
+    }
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
@@ -141,9 +146,13 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
         int v = atoi(e_l);
         if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;
     }
-    for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
         if ((e = hipStreamCreateWithFlags(&ctx->streams[l], hipStreamNonBlocking)) != hipSuccess)
             return fail(e, "hipStreamCreate");
+        if ((e = hipEventCreateWithFlags(&ctx->lane_mark[l], hipEventDisableTiming)) != hipSuccess)
+            return fail(e, "hipEventCreate");
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     const size_t B = ctx->B, NV = ctx->NV, NL = ctx->NL, NT = ctx->NT, L = ctx->L, MF = ctx->MF, MM = ctx->MM;
 #define ALLOC(ptr, n)                                                  \
     if ((e = dalloc(&(ptr), (n))) != hipSuccess) return fail(e, #ptr); \
@@ -234,6 +243,10 @@ static int check_slots(mml_ctx* ctx, int first, int count) {
             ctx->err = "hipSetDevice failed";            \
             return MML_ERR_HIP;                          \
         }                                                \
+        if (!ctx->uploads.empty()) {                     \
+            rc_ = mml_uploads_wait(ctx, (first), (count)); \
+            if (rc_ != MML_OK) return rc_;               \
+        }                                                \
     } while (0)
 
 // copy a block of doubles to the device through the pinned ring (asynchronous, safe against reuse)
@@ -283,19 +296,38 @@ int mml_scan_upload_batch(mml_ctx* ctx, int first_slot, int count, const float* 
         any_l = any_l || n_livox[i] > 0;
     }
     MML_REQUIRE((!any_v || velo_base) && (!any_l || livox_base), MML_ERR_INVALID, "null point buffer");
+    // the copies go behind everything already enqueued on the lanes (a kernel may still be reading these slots) ...
+    hipStream_t cs = ctx->copy_stream;
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
+        MML_HIP(hipEventRecord(ctx->lane_mark[l], ctx->streams[l]));
+        MML_HIP(hipStreamWaitEvent(cs, ctx->lane_mark[l], 0));
+    }
     if (any_v)
         MML_HIP(hipMemcpyAsync(ctx->velo_in + (size_t)first_slot * ctx->NV, velo_base, sizeof(float4) * (size_t)count * ctx->NV,
-                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
+                               hipMemcpyHostToDevice, cs));
     if (any_l)
         MML_HIP(hipMemcpyAsync(ctx->livox_in + (size_t)first_slot * ctx->NL, livox_base, sizeof(mml_livox_point) * (size_t)count * ctx->NL,
-                               hipMemcpyHostToDevice, MML_STREAM(ctx)));
+                               hipMemcpyHostToDevice, cs));
     double* st = stage_alloc(ctx, (size_t)count);
     int* sti = reinterpret_cast<int*>(st);
     for (int i = 0; i < count; ++i) {
         ctx->h_n_in[2 * (first_slot + i)] = sti[2 * i] = n_velo[i];
         ctx->h_n_in[2 * (first_slot + i) + 1] = sti[2 * i + 1] = n_livox[i];
     }
-    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * (size_t)first_slot, sti, sizeof(int) * 2 * (size_t)count, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(ctx->d_n_in + 2 * (size_t)first_slot, sti, sizeof(int) * 2 * (size_t)count, hipMemcpyHostToDevice, cs));
+    // ... and whatever touches these slots next waits for them (CHECK_SLOTS -> mml_uploads_wait); work on other slots
+    // enqueued from now on runs concurrently with the copy
+    mml_ctx::Upload u;
+    u.first = first_slot;
+    u.count = count;
+    if (!ctx->upload_event_pool.empty()) {
+        u.done = ctx->upload_event_pool.back();
+        ctx->upload_event_pool.pop_back();
+    } else {
+        MML_HIP(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
+    }
+    MML_HIP(hipEventRecord(u.done, cs));
+    ctx->uploads.push_back(u);
     return MML_OK;
 }
 
@@ -1499,5 +1531,24 @@ void mml_stage_end(mml_ctx* ctx, int token) {
 
 int mml_sync_all(mml_ctx* ctx) {
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l) MML_HIP(hipStreamSynchronize(ctx->streams[l]));
+    MML_HIP(hipStreamSynchronize(ctx->copy_stream));
+    for (auto& u : ctx->uploads) ctx->upload_event_pool.push_back(u.done);
+    ctx->uploads.clear();
+    return MML_OK;
+}
+
+// Orders every lane behind the batch uploads still in flight on slots [first, first + count); finished uploads retire.
+int mml_uploads_wait(mml_ctx* ctx, int first, int count) {
+    for (size_t i = 0; i < ctx->uploads.size();) {
+        mml_ctx::Upload& u = ctx->uploads[i];
+        if (hipEventQuery(u.done) == hipSuccess) {
+            ctx->upload_event_pool.push_back(u.done);
+            ctx->uploads.erase(ctx->uploads.begin() + i);
+            continue;
+        }
+        if (u.first < first + count && first < u.first + u.count)
+            for (int l = 0; l < mml_ctx::MAX_LANES; ++l) MML_HIP(hipStreamWaitEvent(ctx->streams[l], u.done, 0));
+        ++i;
+    }
     return MML_OK;
 }

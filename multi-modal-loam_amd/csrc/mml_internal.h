@@ -62,6 +62,16 @@ struct mml_ctx {
     // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.
     static constexpr int MAX_LANES = 8;
     hipStream_t streams[MAX_LANES] = {};
+    // mml_scan_upload_batch copies on its own stream, so that the copy of one slot range runs under the kernels of
+    // another; an entry point that touches a slot range first makes the lanes wait for the uploads still in flight on it
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t lane_mark[MAX_LANES] = {};
+    struct Upload {
+        int first, count;
+        hipEvent_t done;
+    };
+    std::vector<Upload> uploads;
+    std::vector<hipEvent_t> upload_event_pool;
     int n_lanes = 1;
     int cur = 0;
     bool lanes_enabled = true;
@@ -203,6 +213,7 @@ struct mml_ctx {
 
 #define MML_STREAM(ctx) ((ctx)->streams[(ctx)->cur])
 int mml_sync_all(mml_ctx* ctx);
+int mml_uploads_wait(mml_ctx* ctx, int first, int count);
 
 #define MML_HIP(call)                                                                         \
     do {                                                                                      \

@@ -1265,6 +1265,81 @@ def test_scan_upload_batch_equals_per_scan_upload(M, synth):
         b.close()
 
 
+def test_overlapped_batch_upload_feeds_the_step_correctly(M, synth, scene):
+    """mml_scan_upload_batch copies on its own stream: the upload of one slot range is issued in front of the step on the
+    other range (the feeder of DESIGN.md section 5) and must neither be read too early nor overwrite scans a kernel still
+    reads.  Different scans go through the same slots round after round; every round's poses and feature stacks equal the
+    ones of the plain path (per-scan uploads, synchronised, one step)."""
+    h, rounds = 24, 3
+    nv, nl = 16 * 1800, 24000
+    c = M.Context(max_scans=2 * h, max_velo_points=28800, max_livox_points=24000)
+    r = M.Context(max_scans=h, max_velo_points=28800, max_livox_points=24000)
+    try:
+        for ctx in (c, r):
+            ctx.map_set_local(0, scene["corner_map"])
+            ctx.map_set_local(1, scene["surf_map"])
+        cfg = c.cfg
+        assert cfg.max_velo_points % 64 == 0 and cfg.max_livox_points % 64 == 0
+
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")        # the runtime the library already runs on
+        pinned_blocks = []
+
+        def pin(a):           # page-locked copy: only then is the host-to-device copy asynchronous
+            a = np.ascontiguousarray(a)
+            ptr = ctypes.c_void_p()
+            assert hip.hipHostMalloc(ctypes.byref(ptr), ctypes.c_size_t(a.nbytes), ctypes.c_uint(0)) == 0
+            pinned_blocks.append(ptr)
+            out = np.frombuffer((ctypes.c_uint8 * a.nbytes).from_address(ptr.value), dtype=a.dtype).reshape(a.shape)
+            out[...] = a
+            return out
+
+        def batch(k0):
+            vb = np.zeros((h, cfg.max_velo_points, 4), np.float32)
+            lb = np.zeros((h, cfg.max_livox_points), M.LIVOX_DTYPE)
+            nvs, nls = np.zeros(h, np.int32), np.zeros(h, np.int32)
+            scans = []
+            for s in range(h):
+                v, l = synth.velo_scan(k0 + s), synth.livox_scan(k0 + s)
+                vb[s, :len(v)], lb[s, :len(l)], nvs[s], nls[s] = v, l, len(v), len(l)
+                scans.append((v, l))
+            x = np.stack([np.concatenate([synth.pose_matrix(k0 + s)[:3, 3] + [0.02, -0.01, 0.01],
+                                          Rsc.from_matrix(synth.pose_matrix(k0 + s)[:3, :3]).as_rotvec()]) for s in range(h)])
+            return dict(vb=pin(vb), lb=pin(lb), nvs=nvs, nls=nls, scans=scans, x=x)
+
+        dR, dt = np.tile(np.eye(3).reshape(1, 9), (h, 1)), np.zeros((h, 3))
+        batches = [batch(3 + 5 * i) for i in range(2 * rounds + 1)]
+
+        def reference(bt):
+            for s, (v, l) in enumerate(bt["scans"]):
+                r.scan_upload(s, v, l)
+            r.synchronize()
+            x = r.step(0, h, dR, dt, np.eye(4), 25.0, 6, bt["x"])
+            return x, [r.features_download(s, 1) for s in (0, h - 1)]
+
+        up = lambda first, bt: c.scan_upload_batch(first, bt["vb"], bt["nvs"], bt["lb"], bt["nls"])
+        up(0, batches[0])
+        held = [0, None]                      # which batch each half holds
+        for rd in range(rounds):
+            for half in (0, 1):
+                nxt = 2 * rd + half + 1
+                up((1 - half) * h, batches[nxt])             # copy for the other half, in flight under the step below
+                held[1 - half] = nxt
+                bt = batches[held[half]]
+                x = c.step(half * h, h, dR, dt, np.eye(4), 25.0, 6, bt["x"])
+                feats = [c.features_download(half * h + s, 1) for s in (0, h - 1)]
+                xr, fr = reference(bt)
+                assert np.array_equal(x, xr), (rd, half, np.abs(x - xr).max())
+                for a, b in zip(feats, fr):
+                    assert np.array_equal(a, b)
+        c.synchronize()
+        for ptr in pinned_blocks:
+            hip.hipHostFree(ptr)
+    finally:
+        c.close()
+        r.close()
+
+
 def test_undistort_twice_reads_normal_x_as_one(M, O, synth):
     """RemoveLidarDistortion leaves normal_x = 1 behind (unionPoseEstimation.cpp:419); here that is a per-slot flag, not a
     store per point: a second call must see s = 1 for every point, downloads must report 1, and a re-extraction or an
