@@ -67,10 +67,11 @@ int mml_config_get(const mml_ctx* ctx, mml_config* out) {
 void mml_destroy(mml_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    mml_comm_destroy(ctx);
-    mml_fullwindow_dev_release(ctx);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l)
         if (ctx->streams[l]) hipStreamSynchronize(ctx->streams[l]);
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
+    mml_comm_destroy(ctx);
+    mml_fullwindow_dev_release(ctx);
     void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_meta,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue,
