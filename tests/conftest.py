@@ -46,6 +46,10 @@ def has_gpu():
 
 @pytest.fixture(scope="session")
 def scene(O, synth):
+    return build_scene(O, synth)
+
+
+def build_scene(O, synth):
     """Maps built from scans 0..7 of the synthetic room + down-sampled feature stacks of scans 10..13."""
     cm, sm = [], []
     for k in range(8):

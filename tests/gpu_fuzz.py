@@ -1,0 +1,160 @@
+"""Randomised parity campaign on a real device: the same comparisons as tests/test_gpu_parity.py (device through the C-ABI
+against the CPU oracle), over many fresh seeds instead of the few the suite pins.  Not collected by pytest (run by hand).
+
+    python tests/gpu_fuzz.py --seed 1 --lines 2000 --scans 60 --poses 40
+
+Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
+`scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
+then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
+pose perturbations.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
+is printed so that it can be replayed)."""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.spatial.transform import Rotation as Rsc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lines", type=int, default=500)
+    ap.add_argument("--scans", type=int, default=20)
+    ap.add_argument("--poses", type=int, default=12)
+    args = ap.parse_args()
+    M = importlib.import_module("multi-modal-loam_amd")
+    synth = importlib.import_module("multi-modal-loam_amd.synth")
+    import mml_oracle as O
+    O.build()
+    O.lib()
+    from conftest import fuzz_line, perturbed
+
+    rng = np.random.default_rng(args.seed)
+    ctx = M.Context(max_scans=4)
+    t0 = time.time()
+
+    # ---- lines ----------------------------------------------------------------------------------------------------------
+    counts = dict(n150=0, n100=0, n2=0, n300=0)
+    for trial in range(args.lines):
+        pts = fuzz_line(rng)
+        so, fo, flo = O.detect_feature_points(pts)
+        s, f, fl = ctx.detect_line(pts)
+        if not (np.array_equal(fl, flo) and np.array_equal(s, so) and np.array_equal(f, fo)):
+            bad = np.flatnonzero(fl != flo)[:8]
+            print("LINE MISMATCH seed %d trial %d n %d at %s device %s oracle %s" % (args.seed, trial, len(pts), bad, fl[bad], flo[bad]))
+            np.save("gpurun_out/fuzz_line_seed%d_trial%d.npy" % (args.seed, trial), pts)
+            return 1
+        counts["n150"] += int((flo == 150).sum())
+        counts["n100"] += int(((flo == 100) | (flo == 101)).sum())
+        counts["n2"] += int((flo == 2).sum())
+        counts["n300"] += int((flo == 300).sum())
+    print("lines: %d ok (%s) %.0f s" % (args.lines, counts, time.time() - t0), flush=True)
+
+    # ---- whole scans -----------------------------------------------------------------------------------------------------
+    t0 = time.time()
+    worst_ulp, n_pts = 0, 0
+    for trial in range(args.scans):
+        k = int(rng.integers(0, 5000))
+        v = synth.velo_scan(k).copy()
+        l = synth.livox_scan(k, motion=bool(rng.integers(0, 2))).copy()
+        for _ in range(int(rng.integers(0, 6))):           # dirt
+            kind = int(rng.integers(0, 7))
+            a = int(rng.integers(0, len(v) - 400))
+            n = int(rng.integers(1, 400))
+            if kind == 0:
+                v[a:a + n, int(rng.integers(0, 3))] = np.nan
+            elif kind == 1:
+                v[a::int(rng.integers(50, 200)), 2] = rng.uniform(20, 80)
+            elif kind == 2:
+                v[a:a + n, :3] *= rng.uniform(0.01, 0.2)
+            elif kind == 3:
+                v[a:a + n, :3] *= rng.uniform(5, 40)
+            elif kind == 4:
+                l["line"][int(rng.integers(0, 50))::int(rng.integers(20, 90))] = int(rng.integers(6, 9))
+            elif kind == 5:
+                l["x"][int(rng.integers(0, 50))::int(rng.integers(20, 90))] = rng.uniform(-1, 0.01)
+            else:
+                v[a:a + n] = v[a]
+        if rng.integers(0, 4) == 0:
+            v = v[:int(rng.integers(16, len(v)))]
+        if rng.integers(0, 4) == 0:
+            l = l[:int(rng.integers(3, len(l)))]
+        ctx.scan_upload(0, v, l)
+        ctx.extract(0, 1)
+        d = ctx.scan_download(0)
+        ev, el = O.extract_velo(v), O.extract_livox(l)
+        o = {key: np.concatenate([ev[key], el[key]]) for key in ("xyzi", "label", "reltime", "ring")}
+        ok = d["info"].n_points == len(o["xyzi"]) and all(np.array_equal(d[key], o[key]) for key in o)
+        if not ok:
+            print("SCAN MISMATCH seed %d trial %d k %d" % (args.seed, trial, k))
+            for key in o:
+                if len(d[key]) != len(o[key]):
+                    print("  ", key, "length", len(d[key]), len(o[key]))
+                elif not np.array_equal(d[key], o[key]):
+                    bad = np.flatnonzero(np.any(np.atleast_2d(d[key].T != o[key].T), axis=0))[:8]
+                    print("  ", key, "differs at", bad)
+            np.save("gpurun_out/fuzz_scan_seed%d_trial%d_v.npy" % (args.seed, trial), v)
+            np.save("gpurun_out/fuzz_scan_seed%d_trial%d_l.npy" % (args.seed, trial), l)
+            return 1
+        # undistortion with a random sweep motion, then the voxel filter of the labelled points
+        dR = Rsc.from_rotvec(rng.normal(0, 0.02, 3) * (0 if rng.integers(0, 5) == 0 else 1)).as_matrix()
+        dt = rng.normal(0, 0.05, 3)
+        ctx.undistort(0, 1, dR[None], dt[None])
+        ctx.downsample(0, 1)
+        d2 = ctx.scan_download(0)
+        ou = O.undistort(o["xyzi"][:, :3], o["reltime"], dR, dt)
+        ulp = np.abs(d2["xyzi"][:, :3].view(np.int32).astype(np.int64) - ou.view(np.int32).astype(np.int64))
+        worst_ulp = max(worst_ulp, int(ulp.max()) if len(ulp) else 0)
+        n_pts += len(ulp)
+        und = d2["xyzi"][:, :3]
+        vox_ok = (np.array_equal(ctx.features_download(0, 0), O.voxel_downsample(und[o["label"] == 1], 0.4)) and
+                  np.array_equal(ctx.features_download(0, 1), O.voxel_downsample(und[o["label"] == 2], 0.2)))
+        if worst_ulp > 1 or not vox_ok or not np.all(d2["reltime"] == 1.0):
+            print("UNDISTORT / VOXEL MISMATCH seed %d trial %d k %d ulp %d voxel_ok %s" % (args.seed, trial, k, worst_ulp, vox_ok))
+            return 1
+    print("scans: %d ok (%d points, worst undistort difference %d ulp) %.0f s" % (args.scans, n_pts, worst_ulp, time.time() - t0), flush=True)
+
+    # ---- association + Estimate from random perturbations --------------------------------------------------------------------
+    t0 = time.time()
+    from conftest import build_scene
+    scene = build_scene(O, synth)
+    ctx.map_set_local(0, scene["corner_map"])
+    ctx.map_set_local(1, scene["surf_map"])
+    for k, fr in enumerate(scene["frames"]):
+        ctx.scan_upload(k, fr["velo"], fr["livox"])
+    ctx.extract(0, 4)
+    ctx.undistort(0, 4, np.tile(np.eye(3).reshape(1, 9), (4, 1)), np.zeros((4, 3)))
+    ctx.downsample(0, 4)
+    worst = 0.0
+    for trial in range(args.poses):
+        T = np.stack([perturbed(fr["T_gt"], dt=rng.normal(0, 0.05, 3), rotvec=rng.normal(0, 0.01, 3)) for fr in scene["frames"]])
+        P0 = T[:, :3, 3]
+        Q0 = np.stack([Rsc.from_matrix(T[k][:3, :3]).as_quat() for k in range(4)])
+        ex = np.eye(4)
+        if trial % 2:
+            ex[:3, :3] = Rsc.from_rotvec(rng.normal(0, 0.01, 3)).as_matrix()
+            ex[:3, 3] = rng.normal(0, 0.03, 3)
+        Pg, Qg, info = ctx.estimate(0, 4, ex, P0, Q0)
+        for k, fr in enumerate(scene["frames"]):
+            Po, Qo, it, deg, _ = O.estimate_single(fr["corner"], fr["surf"], scene["corner_map"], scene["surf_map"], ex, P0[k], Q0[k])
+            dd = max(np.abs(Pg[k] - Po).max(), np.abs(Qg[k] - Qo).max())
+            worst = max(worst, dd)
+            if info[k].outer_iterations != it or info[k].is_degenerate != int(deg) or dd > 1e-7:
+                print("ESTIMATE MISMATCH seed %d trial %d frame %d: outer %d vs %d, degenerate %d vs %d, pose diff %.3g"
+                      % (args.seed, trial, k, info[k].outer_iterations, it, info[k].is_degenerate, int(deg), dd))
+                return 1
+    print("poses: %d x 4 ok (worst pose difference %.2e) %.0f s" % (args.poses, worst, time.time() - t0), flush=True)
+    ctx.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
