@@ -6,7 +6,8 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
+pose perturbations; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
 import importlib
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--lines", type=int, default=500)
     ap.add_argument("--scans", type=int, default=20)
     ap.add_argument("--poses", type=int, default=12)
+    ap.add_argument("--windows", type=int, default=10)
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -153,6 +155,102 @@ def main():
                 return 1
     print("poses: %d x 4 ok (worst pose difference %.2e) %.0f s" % (args.poses, worst, time.time() - t0), flush=True)
     ctx.close()
+
+    # ---- full-window problems (IMU factors, prior): trust-region loop on the device against the host loop -----------------
+    t0 = time.time()
+    odometry = importlib.import_module("multi-modal-loam_amd.odometry")
+    G = synth.GRAVITY
+    WMAX = 8
+    c = M.Context(max_scans=WMAX)
+    c.map_set_local(0, scene["corner_map"])
+    c.map_set_local(1, scene["surf_map"])
+    west = odometry.WindowEstimator(c, gravity=G, solver="host")
+    soft, loose, worst, terms = 0, 0, 0.0, {}
+    prior = None
+    for trial in range(args.windows):
+        k0 = int(rng.integers(5, 200))
+        W = int(rng.integers(1, WMAX + 1))
+        big = rng.integers(0, 4) == 0            # now and then a start far enough for rejected / invalid steps
+        lost = rng.integers(0, 12) == 0          # ... or a window 500 m away from the map: no lidar factor at all
+        x0, pres = [], [None]
+        for f in range(W):
+            k = k0 + f
+            c.scan_upload(f, synth.velo_scan(k), synth.livox_scan(k))
+            c.extract(f, 1)
+            c.undistort(f, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+            c.downsample(f, 1)
+            T = perturbed(synth.pose_matrix(k), dt=rng.normal(0, 0.3 if big else 0.02, 3) + (500.0 if lost else 0.0),
+                          rotvec=rng.normal(0, 0.05 if big else 0.003, 3))
+            x0.append(np.concatenate([T[:3, 3], Rsc.from_matrix(T[:3, :3]).as_rotvec(), synth.velocity_at(k) + rng.normal(0, 0.5 if big else 0.02, 3),
+                                      rng.normal(0, 1e-3, 3), rng.normal(0, 1e-2, 3)]))
+            if f > 0:
+                pres.append(M.imu_preintegrate(synth.imu_samples(k - 1, k), np.zeros(3), np.zeros(3)))
+            c.associate(f, 1, west._T_wl(x0[f])[None], 1.0)
+        x0 = np.stack(x0)
+        skip = set(int(v) for v in rng.integers(1, max(2, W), int(rng.integers(0, 3)))) if W > 2 else set()
+        use_prior = prior is not None and rng.integers(0, 2) == 0
+        if lost and rng.integers(0, 2) == 0:     # nothing constrains anything: gradient stop, or five invalid steps when fixed
+            skip, use_prior = set(range(1, W)), False
+        restart = (not lost) and rng.integers(0, 6) == 0   # a second solve from the converged state (parameter / function stop)
+        max_iters = int(rng.choice([1, 3, 10, 10, 10, 25]))
+        fixed = bool(rng.integers(0, 5) == 0)
+
+        def make():
+            fw = M.FullWindowSolver(W, max_iters=max_iters, fixed=fixed, huber=0.0, w_tan=3e-4)
+            for f in range(1, W):
+                if f not in skip:
+                    fw.set_imu(f, pres[f], G)
+            if use_prior:
+                fw.set_prior(prior)
+            return fw
+        if restart:
+            fw0 = make()
+            xs = x0.copy()
+            for _ in range(400):
+                done, xs = fw0.step(c.linearize_window(0, W, xs, west.T_bl, 3e-4, 0.0), xs)
+                if done:
+                    break
+            x0 = xs
+        fh = make()
+        xh = x0.copy()
+        evals_h = 0
+        for _ in range(400):
+            done, xh = fh.step(c.linearize_window(0, W, xh, west.T_bl, 3e-4, 0.0), xh)
+            evals_h += 1
+            if done:
+                break
+        sh = fh.summary()
+        fd = make()
+        xd, sd, evals_d = fd.solve_device(c, 0, west.T_bl, x0)
+        dd = float(np.abs(xd - xh).max())
+        same = (sd.iterations, sd.successful, sd.termination, evals_d) == (sh.iterations, sh.successful, sh.termination, evals_h)
+        terms[sh.termination] = terms.get(sh.termination, 0) + 1
+        if not same:
+            soft += 1          # a rounding-level difference flipped a decision: tolerated when the results still agree
+        worst = max(worst, dd)
+        loose += dd > 1e-8
+        # Windows with missing IMU factors or a prior taken from another window have directions the problem barely
+        # determines (velocity / bias of a frame no factor touches): there the two loops may sit 1e-6 apart at costs equal to
+        # 1e-12 -- the cost is held tightly, the states loosely.
+        # (costs: relative to the final cost, with a floor relative to where the solve started -- a window that converges to a
+        #  cost of 1e-11 from 1e+3 agrees to 1e-16 absolute, not to nine digits of 1e-11)
+        # A window far from the map that a foreign prior pulls on (cost ~1e9, not converged after 25 iterations) and a restart
+        # from the converged state with the tolerances off (rounding noise over a vanishing model decrease) are sensitive to
+        # the last bit of every sine: there the two loops are only required to stay close.
+        touchy = lost or restart or not same
+        cost_tol = (1e-7 * sh.final_cost + 1e-12 * sh.initial_cost + 1e-18) * (1e4 if touchy else 1)
+        if dd > (1e-1 if touchy else 1e-4) or abs(sd.final_cost - sh.final_cost) > cost_tol:
+            print("WINDOW MISMATCH seed %d trial %d W %d skip %s prior %s max_iters %d fixed %s: host (it %d ok %d term %d ev %d cost %.12g) "
+                  "device (it %d ok %d term %d ev %d cost %.12g) max |dx| %.3g"
+                  % (args.seed, trial, W, sorted(skip), use_prior, max_iters, fixed, sh.iterations, sh.successful, sh.termination, evals_h,
+                     sh.final_cost, sd.iterations, sd.successful, sd.termination, evals_d, sd.final_cost, dd))
+            return 1
+        if W >= 2 and 1 not in skip and rng.integers(0, 3) == 0:
+            rec0 = M.pack_record(*c.linearize(0, xh[0][:6], west.T_bl, 3e-4, 0.0))
+            prior = fh.marginalize(rec0, xh)
+    print("windows: %d ok (worst |dx| %.2e, %d above 1e-8, %d with a flipped decision, terminations %s) %.0f s"
+          % (args.windows, worst, loose, soft, terms, time.time() - t0), flush=True)
+    c.close()
     return 0
 
 
