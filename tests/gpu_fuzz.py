@@ -6,7 +6,7 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+pose perturbations; `solves` = factor records of random associations and the lidar-only window solve; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
 loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--scans", type=int, default=20)
     ap.add_argument("--poses", type=int, default=12)
     ap.add_argument("--windows", type=int, default=10)
+    ap.add_argument("--solves", type=int, default=10)
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -154,6 +155,59 @@ def main():
                       % (args.seed, trial, k, info[k].outer_iterations, it, info[k].is_degenerate, int(deg), dd))
                 return 1
     print("poses: %d x 4 ok (worst pose difference %.2e) %.0f s" % (args.poses, worst, time.time() - t0), flush=True)
+    # ---- association (factor records) + the lidar-only window solve, random thresholds / weights / window sizes -----------
+    t0 = time.time()
+    tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
+    for k, fr in enumerate(scene["frames"]):
+        ctx.features_upload(k, 0, fr["corner"])
+        ctx.features_upload(k, 1, fr["surf"])
+    worst, nfac, terms = 0.0, 0, {}
+    for trial in range(args.solves):
+        big = rng.integers(0, 3) == 0
+        T = np.stack([perturbed(fr["T_gt"], dt=rng.normal(0, 0.4 if big else 0.03, 3), rotvec=rng.normal(0, 0.06 if big else 0.004, 3))
+                      for fr in scene["frames"]])
+        thres = float(rng.choice([25.0, 10.0, 1.0]))
+        st = ctx.associate(0, 4, T, thres)
+        lfs, pfs = [], []
+        for k, fr in enumerate(scene["frames"]):
+            lf, lsrc = O.associate_lines(fr["corner"], tc, T[k], thres)
+            pf, psrc = O.associate_planes(fr["surf"], ts, T[k], thres)
+            gl, glsrc = ctx.factors_download(k, 0)
+            gp, gpsrc = ctx.factors_download(k, 1)
+            ol = np.concatenate([lf["point_ori"], lf["p1"], lf["p2"], lf["error"][:, None]], axis=1)
+            op = np.concatenate([pf["point_ori"], pf["point_proj"], pf["omega"], pf["error"][:, None]], axis=1)
+            if not (np.array_equal(glsrc, lsrc) and np.array_equal(gpsrc, psrc) and np.allclose(gl, ol, rtol=0, atol=1e-9)
+                    and np.allclose(gp, op, rtol=0, atol=1e-9) and st[k].n_line == len(lf) and st[k].n_plane == len(pf)):
+                print("ASSOCIATION MISMATCH seed %d trial %d frame %d thres %g" % (args.seed, trial, k, thres))
+                return 1
+            nfac += len(lf) + len(pf)
+            lfs.append(lf)
+            pfs.append(pf)
+        T_bl = np.eye(4)
+        if rng.integers(0, 2):
+            T_bl[:3, :3] = Rsc.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix()
+            T_bl[:3, 3] = rng.normal(0, 0.03, 3)
+        x0 = np.stack([np.concatenate([T[k][:3, 3], Rsc.from_matrix(T[k][:3, :3]).as_rotvec()]) for k in range(4)])
+        W = int(rng.choice([1, 2, 4]))
+        huber = float(rng.choice([0.0, 0.1 / 1.5e-3]))
+        w_tan = float(rng.choice([0.0, 3e-4]))
+        iters = int(rng.choice([1, 4, 10, 10, 30]))
+        fixed = bool(rng.integers(0, 4) == 0)
+        xg, sg, _ = ctx.solve(0, 4, x0, T_bl, window=W, max_iters=iters, fixed=fixed, huber=huber, w_tan=w_tan)
+        for p in range(4 // W):
+            sl = slice(p * W, (p + 1) * W)
+            xo, so, _ = O.solve_window(lfs[sl], pfs[sl], x0[sl], T_bl, iters, fixed=fixed, huber=huber, w_tan=w_tan)
+            dd = float(np.abs(xg[sl] - xo).max())
+            same = (sg[p].iterations, sg[p].termination) == (so["iterations"], so["termination"])
+            if not fixed:     # (iterations forced past convergence accept or reject steps of size 1e-12 on rounding noise)
+                same = same and sg[p].successful == so["successful"]
+            terms[so["termination"]] = terms.get(so["termination"], 0) + 1
+            worst = max(worst, dd)
+            if not same or dd > (1e-6 if fixed else 1e-8) or abs(sg[p].final_cost - so["final_cost"]) > 1e-9 * so["final_cost"] + 1e-18:
+                print("SOLVE MISMATCH seed %d trial %d problem %d W %d iters %d fixed %s huber %g w_tan %g: oracle %s device (%d %d %d) |dx| %.3g"
+                      % (args.seed, trial, p, W, iters, fixed, huber, w_tan, so, sg[p].iterations, sg[p].successful, sg[p].termination, dd))
+                return 1
+    print("solves: %d ok (%d factor records equal, worst |dx| %.2e, terminations %s) %.0f s" % (args.solves, nfac, worst, terms, time.time() - t0), flush=True)
     ctx.close()
 
     # ---- full-window problems (IMU factors, prior): trust-region loop on the device against the host loop -----------------
