@@ -6,7 +6,7 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations; `solves` = factor records of random associations and the lidar-only window solve; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+pose perturbations; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
 loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--poses", type=int, default=12)
     ap.add_argument("--windows", type=int, default=10)
     ap.add_argument("--solves", type=int, default=10)
+    ap.add_argument("--maps", type=int, default=2)
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -208,6 +209,36 @@ def main():
                       % (args.seed, trial, p, W, iters, fixed, huber, w_tan, so, sg[p].iterations, sg[p].successful, sg[p].termination, dd))
                 return 1
     print("solves: %d ok (%d factor records equal, worst |dx| %.2e, terminations %s) %.0f s" % (args.solves, nfac, worst, terms, time.time() - t0), flush=True)
+    # ---- local map upkeep: random walks of key scans through MapIncrementLocal (ring of 50, VoxelGrid of the merged map) --------
+    t0 = time.time()
+    checked = 0
+    for trial in range(args.maps):
+        c2 = M.Context(max_scans=2)
+        lm = O.LocalMap(window=50, leaf_corner=c2.cfg.leaf_corner, leaf_surf=c2.cfg.leaf_surf)
+        pos, yaw = rng.normal(0, 1, 3), 0.0
+        steps = int(rng.choice([8, 30, 70]))
+        for step in range(steps):
+            fr = scene["frames"][int(rng.integers(0, 4))]
+            thin_c, thin_s = (1.0, 1.0) if step < 4 else (rng.uniform(0.05, 0.5), rng.uniform(0.03, 0.3))
+            keep_c = fr["corner"][rng.random(len(fr["corner"])) < thin_c]
+            keep_s = fr["surf"][rng.random(len(fr["surf"])) < thin_s]
+            pos = pos + rng.normal(0, 0.3, 3) * [1, 1, 0.05]
+            yaw += rng.normal(0, 0.05)
+            T = perturbed(fr["T_gt"], dt=pos, rotvec=(rng.normal(0, 0.01), rng.normal(0, 0.01), yaw))
+            c2.features_upload(1, 0, keep_c)
+            c2.features_upload(1, 1, keep_s)
+            nc, ns = c2.map_increment_local(1, T)
+            lm.increment(keep_c, keep_s, T)
+            if step in (0, steps // 2, steps - 1) or rng.integers(0, 10) == 0:
+                for kind, n in ((0, nc), (1, ns)):
+                    want = lm.get(kind)
+                    got = c2.map_local_download(kind)
+                    if n != len(want) or got.tobytes() != want.tobytes():
+                        print("LOCAL MAP MISMATCH seed %d trial %d step %d kind %d: %d vs %d points" % (args.seed, trial, step, kind, n, len(want)))
+                        return 1
+                    checked += 1
+        c2.close()
+    print("maps: %d walks ok (%d map states equal byte for byte) %.0f s" % (args.maps, checked, time.time() - t0), flush=True)
     ctx.close()
 
     # ---- full-window problems (IMU factors, prior): trust-region loop on the device against the host loop -----------------
