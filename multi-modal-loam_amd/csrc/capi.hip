@@ -72,7 +72,7 @@ void mml_destroy(mml_ctx* ctx) {
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     mml_comm_destroy(ctx);
     mml_fullwindow_dev_release(ctx);
-    void* ptrs[] = {ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
+    void* ptrs[] = {ctx->wstate, ctx->wrec, ctx->waux, ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_meta,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue,
                     ctx->cb_n,     ctx->slot_flags, ctx->ln_line,  ctx->ln_label,

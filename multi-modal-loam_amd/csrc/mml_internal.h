@@ -57,6 +57,11 @@ struct mml_ctx {
     mml_config cfg;
     MmlComm* comm = nullptr;
     MmlFwDev* fwdev = nullptr;
+    // frame-parallel window solve (solve.hip): one state machine copy, 4 counters and two record buffers per slot
+    void* wstate = nullptr;
+    double* wrec = nullptr;
+    double* waux = nullptr;
+    bool window_frame_parallel = true;
     int device = 0;
     // `lanes`: independent HIP streams.  Entry points enqueue on lane `cur` (0 unless mml_step is pipelining
     // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.

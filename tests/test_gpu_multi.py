@@ -59,6 +59,36 @@ def test_window8_joint_solve_matches_oracle(M, O, scene, w_tan, huber):
         c.close()
 
 
+def test_frame_parallel_window_solve_equals_the_sequential_kernel(M, O, scene):
+    """mml_solve with window > 1 runs the frames of a window on W workgroups at once (rounds of k_window_round, the records
+    crossing through a double buffer); with a trace requested it runs k_solve, one workgroup taking the frames one after
+    the other.  Same functions, same records, same decisions: poses and summaries are equal bit for bit -- for every
+    window size, batched problems, tolerances on and off, and starts far enough for rejected steps."""
+    c, lfs, pfs, x0, T_bl = _window8(M, O, scene)
+    try:
+        rng = np.random.default_rng(4)
+        seen_reject = False
+        for trial in range(12):
+            W = (2, 4, 8, 3)[trial % 4]
+            count = (W8 // W) * W
+            x = x0[:count].copy()
+            if trial >= 4:
+                x[:, :3] += rng.normal(0, 0.25, (count, 3))
+                x[:, 3:] += rng.normal(0, 0.03, (count, 3))
+            kw = dict(window=W, max_iters=(10, 4, 25)[trial % 3], fixed=bool(trial % 5 == 2), huber=(0.0, 0.1 / 1.5e-3)[trial % 2],
+                      w_tan=(3e-4, 0.0)[trial % 2])
+            xa, sa, _ = c.solve(0, count, x, T_bl, **kw)                    # frame-parallel
+            xb, sb, _ = c.solve(0, count, x, T_bl, trace=True, **kw)        # sequential k_solve
+            assert np.array_equal(xa, xb), (trial, np.abs(xa - xb).max())
+            for a, b in zip(sa, sb):
+                assert (a.iterations, a.successful, a.termination, a.initial_cost, a.final_cost) == \
+                       (b.iterations, b.successful, b.termination, b.initial_cost, b.final_cost)
+                seen_reject = seen_reject or a.successful < a.iterations
+        assert seen_reject                                                  # rejected / invalid steps were part of it
+    finally:
+        c.close()
+
+
 def test_window_solve_allgather_world_size_one(M, O, scene):
     c, lfs, pfs, x0, T_bl = _window8(M, O, scene)
     try:
