@@ -716,6 +716,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     __shared__ TRState S;
     __shared__ double s_part[SOLVE_WAVES * 28];
     __shared__ double s_work[92];
+    __shared__ double s_wd[TRW_DOUBLES];
     const int prob = blockIdx.x;
     const int W = P.window;
     const int b0 = P.first + prob * W;
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
                            P.w_tan, P.huber, acc);
                 block_reduce28(acc, s_part, S.recc + 28 * f);
             }
-            if (tid == 0) tr_decide(S, W, P.fixed);
+            if (tid < 64) tr_decide_wave(S, s_wd, W, P.fixed);
         }
         __syncthreads();
         go = S.go;
