@@ -96,6 +96,7 @@ void mml_destroy(mml_ctx* ctx) {
         hipEventDestroy(pe.b);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    for (auto& g : ctx->win_graphs) hipGraphExecDestroy(g.exec);
     for (auto& u : ctx->uploads) hipEventDestroy(u.done);
     for (auto e : ctx->upload_event_pool) hipEventDestroy(e);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {

@@ -62,6 +62,14 @@ struct mml_ctx {
     double* wrec = nullptr;
     double* waux = nullptr;
     bool window_frame_parallel = true;
+    struct WinGraph {  // captured launch chain of one frame-parallel window solve
+        int first, count, W, max_iters, fixed;
+        double huber, w_tan;
+        hipStream_t stream;
+        const double* Tbl;
+        hipGraphExec_t exec;
+    };
+    std::vector<WinGraph> win_graphs;
     int device = 0;
     // `lanes`: independent HIP streams.  Entry points enqueue on lane `cur` (0 unless mml_step is pipelining
     // sub-batches); per-call scratch is sliced by slot index so lanes never share a byte.

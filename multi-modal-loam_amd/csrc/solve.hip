@@ -6,6 +6,7 @@
 // Each iteration makes ONE fused pass over the factors at the candidate point (cost + H + g), instead of Ceres'
 // cost-only pass followed by a Jacobian pass after acceptance.
 #include <math.h>
+#include <stdlib.h>
 
 #include "lidar_eval.h"
 #include "mml_internal.h"
@@ -1038,8 +1039,6 @@ static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W
     TRState* st = reinterpret_cast<TRState*>(ctx->wstate) + first;
     double* aux = ctx->waux + 4 * (size_t)first;
     double* rec[2] = {ctx->wrec + 32 * (size_t)first, ctx->wrec + 32 * ((size_t)ctx->B + first)};
-    MML_HIP(hipMemsetAsync(st, 0, sizeof(TRState) * (size_t)count, s));
-    MML_HIP(hipMemsetAsync(aux, 0, sizeof(double) * 4 * (size_t)count, s));
     WindowRoundParams P;
     P.first = first;
     P.n_local = 1;
@@ -1058,17 +1057,67 @@ static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W
     P.x_all = ctx->d_x + 6 * (size_t)first;
     P.state = st;
     P.aux = aux;
+    auto enqueue = [&]() -> hipError_t {
+        hipError_t e = hipMemsetAsync(st, 0, sizeof(TRState) * (size_t)count, s);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(aux, 0, sizeof(double) * 4 * (size_t)count, s);
+        if (e != hipSuccess) return e;
+        const int rounds = opts.max_num_iterations + 2;  // see mml_window_solve_allgather
+        for (int r = 0; r < rounds; ++r) {
+            P.round = r;
+            P.do_eval = r + 1 < rounds ? 1 : 0;
+            P.rec_in = rec[(r + 1) & 1];
+            P.rec_out = rec[r & 1];
+            hipLaunchKernelGGL(k_window_round, dim3(W, nprob), dim3(SOLVE_THREADS), 0, s, P);
+        }
+        hipLaunchKernelGGL(k_window_export, dim3(nprob), dim3(64), 0, s, first, W, st, aux, ctx->d_x, ctx->d_summ + 8 * (size_t)first);
+        return hipGetLastError();
+    };
     MmlStageScope t(ctx, "solve");
-    const int rounds = opts.max_num_iterations + 2;  // see mml_window_solve_allgather
-    for (int r = 0; r < rounds; ++r) {
-        P.round = r;
-        P.do_eval = r + 1 < rounds ? 1 : 0;
-        P.rec_in = rec[(r + 1) & 1];
-        P.rec_out = rec[r & 1];
-        hipLaunchKernelGGL(k_window_round, dim3(W, nprob), dim3(SOLVE_THREADS), 0, s, P);
+    // The chain is launch-bound (a dozen kernels of ~10 us that depend on each other): it is captured once per
+    // (slot range, window, options, stream) into a HIP graph and replayed, which removes the per-launch gaps.  Every
+    // pointer in it is a fixed function of the key.
+    static const bool use_graph = getenv("MML_NO_GRAPH") == nullptr;
+    if (use_graph) {
+        mml_ctx::WinGraph* g = nullptr;
+        for (auto& c : ctx->win_graphs)
+            if (c.first == first && c.count == count && c.W == W && c.max_iters == opts.max_num_iterations &&
+                c.fixed == opts.fixed_iterations && c.huber == opts.huber_delta && c.w_tan == opts.plan_weight_tan && c.stream == s &&
+                c.Tbl == d_Tbl)
+                g = &c;
+        if (!g && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            hipError_t e = enqueue();
+            hipGraph_t graph = nullptr;
+            hipError_t e2 = hipStreamEndCapture(s, &graph);
+            hipGraphExec_t exec = nullptr;
+            if (e == hipSuccess && e2 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                if (ctx->win_graphs.size() >= 16) {  // small cache: drop the oldest
+                    hipGraphExecDestroy(ctx->win_graphs.front().exec);
+                    ctx->win_graphs.erase(ctx->win_graphs.begin());
+                }
+                mml_ctx::WinGraph c;
+                c.first = first;
+                c.count = count;
+                c.W = W;
+                c.max_iters = opts.max_num_iterations;
+                c.fixed = opts.fixed_iterations;
+                c.huber = opts.huber_delta;
+                c.w_tan = opts.plan_weight_tan;
+                c.stream = s;
+                c.Tbl = d_Tbl;
+                c.exec = exec;
+                ctx->win_graphs.push_back(c);
+                g = &ctx->win_graphs.back();
+            }
+            if (graph) hipGraphDestroy(graph);
+            (void)hipGetLastError();
+        }
+        if (g) {
+            MML_HIP(hipGraphLaunch(g->exec, s));
+            return MML_OK;
+        }
     }
-    hipLaunchKernelGGL(k_window_export, dim3(nprob), dim3(64), 0, s, first, W, st, aux, ctx->d_x, ctx->d_summ + 8 * (size_t)first);
-    MML_HIP(hipGetLastError());
+    MML_HIP(enqueue());
     return MML_OK;
 }
 
