@@ -9,6 +9,7 @@
 //               fused behind the kNN in the same lane so the 5 neighbours never leave registers.
 // Compiled with -ffp-contract=off.
 #include <math.h>
+#include <stdlib.h>
 
 #include <cstring>
 #include <string.h>
@@ -606,6 +607,7 @@ struct AssocParams {
     double thres_d;  // gate, compared as in the reference: (double)d2[4] < thres_dist
     int map_m[2];
     int count;
+    int fresh_all;  // small batches: every feature goes to the 16-lane search of k_associate_hard from ring 0
     const int* work_off;
     int* hard_count;   // queue of features whose 5-NN search goes beyond ring 1
     int4* hard_list;
@@ -846,6 +848,8 @@ __device__ __forceinline__ int assoc_item(const AssocParams& P, int w) {
     return lo;
 }
 
+constexpr int HARD_REDO = 1 << 30;   // queue entry: search again in the local map (the cube-stage fit failed)
+constexpr int HARD_FRESH = 1 << 29;  // queue entry: nothing searched yet, start at ring 0 without a list
 // Search only: the model fit (double-precision eigen / QR code, ~150 registers) lives in k_associate_fit_all, so this
 // kernel keeps a small register footprint and enough wavefronts in flight to hide its dependent gathers.
 __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
@@ -871,6 +875,14 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
         const int stage = (cube != 5000 && P.have_g[kind] && P.cube_cnt[kind][cube] > (kind == 0 ? 100 : 50)) ? 0 : 1;
         if (cube == 5000 || isnan(sx) || isnan(sy) || isnan(sz) || (stage == 1 && !(P.map_m[kind] > 20))) {  // (:283 / :702)
             rec[1] = make_int4(0, 0, REC_NONE, 0);
+            continue;
+        }
+        if (P.fresh_all) {
+            // A handful of scans cannot fill the device with one lane per feature -- the ~80 candidates of rings 0-1 are then
+            // one lane's serial chain (74 us for one scan).  Sixteen lanes per feature share the rows instead.
+            const int hw = atomicAdd(P.hard_count, 1);
+            P.hard_list[hw] = make_int4(slot, kind, i, stage | (cube << 1) | HARD_FRESH);
+            rec[1] = make_int4(0, 0, REC_QUEUED, 0);
             continue;
         }
         // one call site per stage: each names ONE grid of the (wave-uniform) kind, so the grid descriptor stays in scalar
@@ -910,7 +922,6 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
 
 // Model fit of every feature pass 1 finished itself, one lane each.  A feature whose cube neighbourhood (stage 0) yields
 // no model is appended to the far-query list with the "search again in the local map" mark (:283 / :702).
-constexpr int HARD_REDO = 1 << 30;
 __global__ __launch_bounds__(128) void k_associate_fit_all(AssocParams P) {
     const int nitems = 2 * P.count;
     const int total = P.work_off[nitems];
@@ -978,6 +989,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
         const int w = w0 + group;
         bool live = w < total;
         int slot = 0, kind = 0, i = 0, b = P.first, stage = 1, cube = 0;
+        bool fresh = false;
         float sx = 0, sy = 0, sz = 0;
         Knn5 loc, best;
         knn_init(loc);
@@ -990,6 +1002,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
             i = e.z;
             stage = round == 1 ? 1 : (e.w & 1);
             cube = (e.w >> 1) & 0x3fff;
+            fresh = (e.w & HARD_FRESH) != 0;
             b = slot + P.first;
         }
         if (live) {
@@ -999,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
             sx = wx;
             sy = wy;
             sz = wz;
-            if (round == 0 && gl == 0) {  // the list pass 1 left after ring 1
+            if (round == 0 && gl == 0 && !fresh) {  // the list pass 1 left after ring 1
                 const float* hd = P.hard_knn + 10 * (size_t)w;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
@@ -1007,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
                 }
             }
         }
-        const int r0 = round == 0 ? 2 : 0;
+        const int r0 = (round == 0 && !fresh) ? 2 : 0;
         const float start_d5 = __shfl(knn_d(loc, 4), (threadIdx.x & 63) & ~15);  // the group's lane 0 (INFINITY unless round 0)
         // the entry's grid descriptor, selected field by field into registers once (a reference to one of four kernel
         // argument structs picked per lane is re-read from memory at every use)
@@ -1406,6 +1419,8 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     P.hard_list = ctx->hard_list + (size_t)first * ctx->MF * 2;
     P.hard_knn = ctx->hard_knn + (size_t)first * ctx->MF * 2 * 10;
     P.count = count;
+    static const bool no_group = getenv("MML_NO_GROUP_SEARCH") != nullptr;  // A/B switch for measurements
+    P.fresh_all = (count <= 8 && ctx->assoc_group_search && !no_group) ? 1 : 0;
     int* work_off = ctx->work_off + 2 * (size_t)first + ctx->cur;
     P.work_off = work_off;
     {

@@ -62,6 +62,7 @@ struct mml_ctx {
     double* wrec = nullptr;
     double* waux = nullptr;
     bool window_frame_parallel = true;
+    bool assoc_group_search = true;  // mml_associate on <= 8 slots: 16 lanes per feature from ring 0 (map_assoc.hip)
     struct WinGraph {  // captured launch chain of one frame-parallel window solve
         int first, count, W, max_iters, fixed;
         double huber, w_tan;
