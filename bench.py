@@ -637,7 +637,7 @@ def run_replay(args, rank, local_rank, world, dist):
     replay(False)  # warm-up pass (allocations of the map upkeep, code objects)
     # the timed region: the replay `reps` times over (every pass starts from an empty map and a fresh odometry object),
     # sized so that the default run times about 2 s
-    reps = max(1, args.steps // 4)
+    reps = max(1, (2 * args.steps) // 5)
     barrier()
     runs = [replay(True) for _ in range(reps)]
     barrier()
