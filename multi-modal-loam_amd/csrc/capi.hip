@@ -1033,6 +1033,18 @@ int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double*
         MML_HIP(hipMemcpyAsync(trace, ctx->d_trace + (size_t)first_slot * 6 * 64, sizeof(double) * (size_t)nprob * opts->max_num_iterations * 6 * window,
                                hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    if (window > 1 && !trace) {  // frame-parallel path: the first chunk of rounds ran; go on where a problem has not stopped
+        bool open = false;
+        for (int p = 0; p < nprob; ++p) open = open || hs[8 * p + 5] != 0.0;
+        if (open) {
+            const double* d_Tbl = ctx->d_pose_in + 64 * (size_t)(first_slot + count) - 16;
+            rc = mml_window_solve_continue(ctx, first_slot, count, window, d_Tbl, *opts);
+            if (rc != MML_OK) return rc;
+            MML_HIP(hipMemcpyAsync(x, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+            MML_HIP(hipMemcpyAsync(hs.data(), ctx->d_summ + 8 * (size_t)first_slot, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+            MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+        }
+    }
     if (summaries)
         for (int p = 0; p < nprob; ++p) {
             summaries[p].iterations = (int)hs[8 * p];

@@ -68,6 +68,7 @@ struct mml_ctx {
         double huber, w_tan;
         hipStream_t stream;
         const double* Tbl;
+        bool second;
         hipGraphExec_t exec;
     };
     std::vector<WinGraph> win_graphs;
@@ -279,6 +280,7 @@ int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_
 int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
                      bool want_trace);
+int mml_window_solve_continue(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts);
 int mml_feature_init(mml_ctx* ctx);
 void mml_fullwindow_dev_release(mml_ctx* ctx);
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);

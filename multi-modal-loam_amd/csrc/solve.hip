@@ -809,6 +809,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         o[1] = S.successful;
         o[3] = S.cost;
         o[4] = S.termination;
+        o[5] = 0;  // (finished: see k_window_export)
     }
 }
 
@@ -1021,6 +1022,7 @@ __global__ void k_window_export(int first, int W, const TRState* state, const do
         o[2] = aux[4 * (size_t)prob * W];
         o[3] = S.cost;
         o[4] = S.termination;
+        o[5] = S.go;  // still running: the caller enqueues the remaining rounds (mml_window_solve_continue)
     }
 }
 }  // namespace
@@ -1028,7 +1030,11 @@ __global__ void k_window_export(int first, int W, const TRState* state, const do
 // mml_solve with window > 1 on one GPU: the W frames of every problem are evaluated by W workgroups at once instead of one
 // after the other by a single workgroup (k_solve) -- the serial chain of an 8-frame window drops from 11 x 8 frame passes
 // to 12 rounds of one.  Same functions, same records, same decisions: the poses equal k_solve's bit for bit.
-static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W, const double* d_Tbl, mml_solve_opts opts) {
+// The rounds are enqueued in two chunks: [0, kFirstChunk) with the clean state in front -- enough for a solve that stops
+// within five iterations -- and, only when the exported `go` flag of some problem is still up, the rest.
+constexpr int kFirstChunk = 7;
+static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W, const double* d_Tbl, mml_solve_opts opts,
+                                       bool second_chunk) {
     if (!ctx->wstate) {
         MML_HIP(hipMalloc(&ctx->wstate, sizeof(TRState) * (size_t)ctx->B));
         MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->wrec), sizeof(double) * 2 * 32 * (size_t)ctx->B));
@@ -1057,13 +1063,16 @@ static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W
     P.x_all = ctx->d_x + 6 * (size_t)first;
     P.state = st;
     P.aux = aux;
+    const int rounds = opts.max_num_iterations + 2;  // see mml_window_solve_allgather
+    const int r_begin = second_chunk ? kFirstChunk : 0, r_end = second_chunk ? rounds : (rounds < kFirstChunk ? rounds : kFirstChunk);
     auto enqueue = [&]() -> hipError_t {
-        hipError_t e = hipMemsetAsync(st, 0, sizeof(TRState) * (size_t)count, s);
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(aux, 0, sizeof(double) * 4 * (size_t)count, s);
-        if (e != hipSuccess) return e;
-        const int rounds = opts.max_num_iterations + 2;  // see mml_window_solve_allgather
-        for (int r = 0; r < rounds; ++r) {
+        if (!second_chunk) {
+            hipError_t e = hipMemsetAsync(st, 0, sizeof(TRState) * (size_t)count, s);
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(aux, 0, sizeof(double) * 4 * (size_t)count, s);
+            if (e != hipSuccess) return e;
+        }
+        for (int r = r_begin; r < r_end; ++r) {
             P.round = r;
             P.do_eval = r + 1 < rounds ? 1 : 0;
             P.rec_in = rec[(r + 1) & 1];
@@ -1083,7 +1092,7 @@ static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W
         for (auto& c : ctx->win_graphs)
             if (c.first == first && c.count == count && c.W == W && c.max_iters == opts.max_num_iterations &&
                 c.fixed == opts.fixed_iterations && c.huber == opts.huber_delta && c.w_tan == opts.plan_weight_tan && c.stream == s &&
-                c.Tbl == d_Tbl)
+                c.Tbl == d_Tbl && c.second == second_chunk)
                 g = &c;
         if (!g && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             hipError_t e = enqueue();
@@ -1105,6 +1114,7 @@ static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W
                 c.w_tan = opts.plan_weight_tan;
                 c.stream = s;
                 c.Tbl = d_Tbl;
+                c.second = second_chunk;
                 c.exec = exec;
                 ctx->win_graphs.push_back(c);
                 g = &ctx->win_graphs.back();
@@ -1119,6 +1129,12 @@ static int launch_solve_frame_parallel(mml_ctx* ctx, int first, int count, int W
     }
     MML_HIP(enqueue());
     return MML_OK;
+}
+
+// the rounds after the first chunk, for the problems whose state machine has not stopped yet (a no-op for the others)
+int mml_window_solve_continue(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts) {
+    if (opts.max_num_iterations + 2 <= kFirstChunk) return MML_OK;
+    return launch_solve_frame_parallel(ctx, first, count, window, d_Tbl, opts, true);
 }
 
 // final pose / summary of the window state machine (device TRState -> host)
@@ -1148,7 +1164,7 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
                      bool want_trace) {
     MML_REQUIRE(window >= 1 && window <= MAXW && count % window == 0, MML_ERR_INVALID,
                 "window must be in [1,8] and divide count");
-    if (window > 1 && !want_trace && ctx->window_frame_parallel) return launch_solve_frame_parallel(ctx, first, count, window, d_Tbl, opts);
+    if (window > 1 && !want_trace && ctx->window_frame_parallel) return launch_solve_frame_parallel(ctx, first, count, window, d_Tbl, opts, false);
     SolveParams P;
     P.first = first;
     P.B = ctx->B;
