@@ -611,7 +611,7 @@ def run_replay(args, rank, local_rank, world, dist):
                 # the 8-scan sliding window: every frame re-associated at its current pose (thres_dist 1, full-window
                 # weights, Estimator.cpp:1203-1204) and solved jointly on the device
                 Tw = np.stack([poses[s] for s in range(W)])
-                ctx.associate(0, W, Tw, 1.0)
+                ctx.associate(0, W, Tw, 1.0, stats=False)      # enqueue only: the joint solve follows on the same stream
                 xw = np.stack([np.concatenate([Tw[s][:3, 3], Rsc.from_matrix(Tw[s][:3, :3]).as_rotvec()]) for s in range(W)])
                 xs, _, _ = ctx.solve(0, W, xw, T_bl, window=W, max_iters=10, huber=0.0, w_tan=3e-4)
                 for s in range(W):

@@ -403,8 +403,14 @@ class Context:
         self._ck(lib().mml_knn5(self._h, C.c_int(kind), _p(q), C.c_int(len(q)), C.c_float(md), _p(idx), _p(d2)))
         return idx, d2
 
-    def associate(self, first, count, T_wl, thres_dist):
+    def associate(self, first, count, T_wl, thres_dist, stats=True):
+        """stats=False: enqueue only (no read-back, no synchronisation) -- what a caller does that goes straight on to
+        mml_solve on the same slots."""
         T = _f64(T_wl).reshape(count, 16)
+        if not stats:
+            self._keep_T = T                              # the poses are staged before the call returns; kept anyway
+            self._ck(lib().mml_associate(self._h, C.c_int(first), C.c_int(count), _p(T), C.c_double(thres_dist), None))
+            return None
         st = (AssocStats * count)()
         self._ck(lib().mml_associate(self._h, C.c_int(first), C.c_int(count), _p(T), C.c_double(thres_dist), st))
         return list(st)

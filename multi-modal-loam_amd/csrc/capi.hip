@@ -33,6 +33,8 @@ double* stage_alloc(mml_ctx* ctx, size_t doubles) {
 
 }  // namespace
 
+double* mml_stage_alloc(mml_ctx* ctx, size_t doubles) { return stage_alloc(ctx, doubles); }
+
 extern "C" {
 
 void mml_config_default(mml_config* cfg, int max_scans) {
@@ -592,8 +594,8 @@ int mml_extract(mml_ctx* ctx, int first_slot, int count, const float* livox_extr
 int mml_scan_info_get(mml_ctx* ctx, int slot, mml_scan_info* info) {
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE(info != nullptr, MML_ERR_INVALID, "null info");
-    int h[8];
-    MML_HIP(hipMemcpyAsync(h, ctx->fu_info + 8 * slot, sizeof(h), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    int* h = reinterpret_cast<int*>(stage_alloc(ctx, 4));  // pinned: a pageable destination makes the copy a blocking staged one
+    MML_HIP(hipMemcpyAsync(h, ctx->fu_info + 8 * slot, sizeof(int) * 8, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     info->n_points = h[0];
     info->n_velo = h[1];
@@ -894,11 +896,11 @@ int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, d
     rc = mml_launch_associate(ctx, first_slot, count, d_T, thres_dist);
     if (rc != MML_OK) return rc;
     if (stats) {
-        std::vector<double> h(16 * (size_t)count);
-        MML_HIP(hipMemcpyAsync(h.data(), ctx->assoc_stats + 16 * (size_t)first_slot, sizeof(double) * h.size(),
+        double* h = stage_alloc(ctx, 16 * (size_t)count);  // pinned
+        MML_HIP(hipMemcpyAsync(h, ctx->assoc_stats + 16 * (size_t)first_slot, sizeof(double) * 16 * (size_t)count,
                                hipMemcpyDeviceToHost, MML_STREAM(ctx)));
         MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
-        for (int i = 0; i < count; ++i) finish_stats(h.data() + 16 * i, &stats[i]);
+        for (int i = 0; i < count; ++i) finish_stats(h + 16 * i, &stats[i]);
     }
     return MML_OK;
 }
@@ -1025,10 +1027,11 @@ int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double*
     int rc = solve_enqueue(ctx, first_slot, count, window, T_bl, opts, x, trace != nullptr);
     if (rc != MML_OK) return rc;
     const int nprob = count / window;
-    std::vector<double> hs(8 * (size_t)nprob);
-    MML_HIP(hipMemcpyAsync(x, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost,
+    double* hx = stage_alloc(ctx, 6 * (size_t)count + 8 * (size_t)nprob);  // pinned read-back area: poses, then summaries
+    double* hs = hx + 6 * (size_t)count;
+    MML_HIP(hipMemcpyAsync(hx, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost,
                            MML_STREAM(ctx)));
-    MML_HIP(hipMemcpyAsync(hs.data(), ctx->d_summ + 8 * (size_t)first_slot, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+    MML_HIP(hipMemcpyAsync(hs, ctx->d_summ + 8 * (size_t)first_slot, sizeof(double) * 8 * (size_t)nprob, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     if (trace)
         MML_HIP(hipMemcpyAsync(trace, ctx->d_trace + (size_t)first_slot * 6 * 64, sizeof(double) * (size_t)nprob * opts->max_num_iterations * 6 * window,
                                hipMemcpyDeviceToHost, MML_STREAM(ctx)));
@@ -1040,11 +1043,12 @@ int mml_solve(mml_ctx* ctx, int first_slot, int count, int window, const double*
             const double* d_Tbl = ctx->d_pose_in + 64 * (size_t)(first_slot + count) - 16;
             rc = mml_window_solve_continue(ctx, first_slot, count, window, d_Tbl, *opts);
             if (rc != MML_OK) return rc;
-            MML_HIP(hipMemcpyAsync(x, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
-            MML_HIP(hipMemcpyAsync(hs.data(), ctx->d_summ + 8 * (size_t)first_slot, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+            MML_HIP(hipMemcpyAsync(hx, ctx->d_x + 6 * (size_t)first_slot, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+            MML_HIP(hipMemcpyAsync(hs, ctx->d_summ + 8 * (size_t)first_slot, sizeof(double) * 8 * (size_t)nprob, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
             MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
         }
     }
+    memcpy(x, hx, sizeof(double) * 6 * count);
     if (summaries)
         for (int p = 0; p < nprob; ++p) {
             summaries[p].iterations = (int)hs[8 * p];

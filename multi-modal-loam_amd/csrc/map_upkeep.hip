@@ -444,10 +444,14 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
 int mml_downsample_redo_overflow(mml_ctx* ctx, int first, int count, std::vector<int>* redone) {
     if (ctx->NT > 65536) return MML_OK;  // those contexts took the global-sort path to begin with
     hipStream_t s = MML_STREAM(ctx);
-    std::vector<int> n0(count), n1(count), info(8 * (size_t)count);
-    MML_HIP(hipMemcpyAsync(n0.data(), ctx->ft_n + first, sizeof(int) * count, hipMemcpyDeviceToHost, s));
-    MML_HIP(hipMemcpyAsync(n1.data(), ctx->ft_n + ctx->B + first, sizeof(int) * count, hipMemcpyDeviceToHost, s));
-    MML_HIP(hipMemcpyAsync(info.data(), ctx->fu_info + 8 * (size_t)first, sizeof(int) * info.size(), hipMemcpyDeviceToHost, s));
+    // (pinned destinations: a device-to-host copy into pageable memory is a blocking staged copy, three of them cost more
+    //  than the down-sampling kernel of a single scan)
+    int* n0 = reinterpret_cast<int*>(mml_stage_alloc(ctx, 5 * (size_t)count + 2));
+    int* n1 = n0 + count;
+    int* info = n1 + count;
+    MML_HIP(hipMemcpyAsync(n0, ctx->ft_n + first, sizeof(int) * count, hipMemcpyDeviceToHost, s));
+    MML_HIP(hipMemcpyAsync(n1, ctx->ft_n + ctx->B + first, sizeof(int) * count, hipMemcpyDeviceToHost, s));
+    MML_HIP(hipMemcpyAsync(info, ctx->fu_info + 8 * (size_t)first, sizeof(int) * 8 * (size_t)count, hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));
     for (int c = 0; c < count; ++c) {
         if (n0[c] >= 0 && n1[c] >= 0) continue;
@@ -469,7 +473,7 @@ int mml_map_upkeep_increment(mml_ctx* ctx, int slot, const double* T_wl, int* n_
         int rc0 = ensure_vox_scratch(ctx, ring_pts);
         if (rc0 != MML_OK) return rc0;
     }
-    int n_feat[2];
+    int* n_feat = reinterpret_cast<int*>(mml_stage_alloc(ctx, 1));  // pinned
     MML_HIP(hipMemcpyAsync(&n_feat[0], ctx->ft_n + 0 * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, s));
     MML_HIP(hipMemcpyAsync(&n_feat[1], ctx->ft_n + 1 * ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));

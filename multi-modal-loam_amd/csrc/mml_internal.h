@@ -228,6 +228,7 @@ struct mml_ctx {
 
 #define MML_STREAM(ctx) ((ctx)->streams[(ctx)->cur])
 int mml_sync_all(mml_ctx* ctx);
+double* mml_stage_alloc(mml_ctx* ctx, size_t doubles);  // pinned staging ring (capi.hip): small read-backs land here
 int mml_uploads_wait(mml_ctx* ctx, int first, int count);
 
 #define MML_HIP(call)                                                                         \

@@ -30,7 +30,7 @@ def _window8(M, O, scene):
         lfs.append(O.associate_lines(fr["corner"], tc, Tf, 1.0)[0])
         pfs.append(O.associate_planes(fr["surf"], ts, Tf, 1.0)[0])
     T = np.stack(T)
-    c.associate(0, W8, T, 1.0)
+    assert c.associate(0, W8, T, 1.0, stats=False) is None     # enqueue only: the solves below follow on the same stream
     T_bl = np.eye(4)
     T_bl[:3, :3] = Rsc.from_rotvec([0.01, -0.02, 0.015]).as_matrix()
     T_bl[:3, 3] = [0.03, 0.01, -0.02]
