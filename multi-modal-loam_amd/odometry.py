@@ -142,8 +142,11 @@ class WindowEstimator:
         for it in range(self.max_outer):
             x = np.stack([np.concatenate([fr["P"], _rotvec_from_quat(fr["Q"]), fr["V"], fr["bg"], fr["ba"]]) for fr in frames])
             if it == 0:                                        # vLineFeatures / vPlanFeatures are empty only here
-                for f, s in enumerate(slots):
-                    ctx.associate(s, 1, self._T_wl(x[f])[None], self.thres_dist)
+                if all(s == slots[0] + f for f, s in enumerate(slots)):   # one enqueue for the whole window, no read-back
+                    ctx.associate(slots[0], W, np.stack([self._T_wl(x[f]) for f in range(W)]), self.thres_dist, stats=False)
+                else:
+                    for f, s in enumerate(slots):
+                        ctx.associate(s, 1, self._T_wl(x[f])[None], self.thres_dist, stats=False)
             q_before, t_before = frames[-1]["Q"].copy(), frames[-1]["P"].copy()
             fw = M.FullWindowSolver(W, max_iters=self.inner_iters, fixed=False, huber=0.0, w_tan=self.plan_weight_tan)
             for f in range(1, W):
