@@ -261,7 +261,8 @@ int mml_knn5(mml_ctx* ctx, int kind, const float* q, int nq, float max_d2, int* 
 /* ---- a11..a16: association + model fit -------------------------------------------------------------
  * Estimator::processPointToLine (Estimator.cpp:148-365) and processPointToPlanVec (:573-777) on the
  * local maps for `count` slots.  T_wl: count x 16 (transformTobeMapped, :1268-1270).  Factors stay on
- * the device. */
+ * the device.  stats (count entries) may be NULL: the call then only enqueues (T_wl is staged before it returns, nothing
+ * is read back, no synchronisation) -- what a caller does that goes straight on to mml_solve on the same slots. */
 typedef struct {
     int n_line, n_plane;        /* factors produced (vLineFeatures / vPlanFeatures sizes) */
     int n_line_used, n_plane_used; /* with |error| > 1e-5 (Estimator.cpp:1385,1396) */
