@@ -6,7 +6,7 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+pose perturbations; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
 loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--windows", type=int, default=10)
     ap.add_argument("--solves", type=int, default=10)
     ap.add_argument("--maps", type=int, default=2)
+    ap.add_argument("--dense", type=int, default=2)
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -156,6 +157,50 @@ def main():
                       % (args.seed, trial, k, info[k].outer_iterations, it, info[k].is_degenerate, int(deg), dd))
                 return 1
     print("poses: %d x 4 ok (worst pose difference %.2e) %.0f s" % (args.poses, worst, time.time() - t0), flush=True)
+    # ---- other ring layouts, scans beyond 64 k points and labelled clouds beyond the 8192-key LDS sort (global-sort path) ------
+    t0 = time.time()
+    npts = 0
+    for trial in range(args.dense):
+        n_rings = int(rng.choice([32, 64, 128]))
+        n_az = int(rng.choice([512, 900, 1800]))
+        pitch0 = float(rng.choice([-15.5, -25.0, -16.0]))
+        step = np.float32((abs(pitch0) * 2 + rng.uniform(-1, 3)) / (n_rings - 1))
+        far = float(rng.choice([50.0, 1000.0]))
+        scale = float(rng.choice([1.0, 1.0, 6.0]))       # x 6: most points beyond 50 m, all promoted to surf (:524)
+        v = synth.velo_scan(int(rng.integers(0, 3000)), n_rings=n_rings, n_az=n_az, pitch0=pitch0, pitch_step=step,
+                            noise=float(rng.choice([0.0, 0.002, 0.01]))).copy()
+        v[:, :3] *= scale
+        l = synth.livox_scan(int(rng.integers(0, 3000))) if rng.integers(0, 2) else None
+        kw = dict(n_rings=n_rings, pitch0=pitch0, pitch_step=step)
+        cfgd = M.default_config(1, n_rings=n_rings, pitch0_deg=pitch0, pitch_step_deg=step, far_th=far, max_velo_points=len(v),
+                                max_livox_points=24000 if l is not None else 64, max_features=1 << 18)
+        cd = M.Context(cfgd)
+        cd.scan_upload(0, v, l)
+        cd.extract(0, 1)
+        d = cd.scan_download(0)
+        ev = O.extract_velo(v, far=far, **kw)
+        parts = [ev] + ([O.extract_livox(l, far=far)] if l is not None else [])
+        o = {key: np.concatenate([e[key] for e in parts]) for key in ("xyzi", "label", "reltime", "ring")}
+        if not (d["info"].n_points == len(o["xyzi"]) and all(np.array_equal(d[key], o[key]) for key in o)):
+            print("DENSE SCAN MISMATCH seed %d trial %d rings %d az %d pitch0 %g step %g far %g scale %g" % (args.seed, trial, n_rings, n_az, pitch0, step, far, scale))
+            return 1
+        dR = Rsc.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix()
+        dt = rng.normal(0, 0.05, 3)
+        cd.undistort(0, 1, dR[None], dt[None])
+        cd.downsample(0, 1)
+        d2 = cd.scan_download(0)
+        ou = O.undistort(o["xyzi"][:, :3], o["reltime"], dR, dt)
+        ulp = np.abs(d2["xyzi"][:, :3].view(np.int32).astype(np.int64) - ou.view(np.int32).astype(np.int64))
+        und = d2["xyzi"][:, :3]
+        ok = (ulp.max() <= 1 and np.array_equal(cd.features_download(0, 0), O.voxel_downsample(und[o["label"] == 1], 0.4))
+              and np.array_equal(cd.features_download(0, 1), O.voxel_downsample(und[o["label"] == 2], 0.2)))
+        if not ok:
+            print("DENSE UNDISTORT / VOXEL MISMATCH seed %d trial %d rings %d az %d far %g scale %g ulp %d" % (args.seed, trial, n_rings, n_az, far, scale, ulp.max()))
+            return 1
+        npts += len(ulp)
+        cd.close()
+    print("dense: %d ok (%d points)  %.0f s" % (args.dense, npts, time.time() - t0), flush=True)
+
     # ---- association (factor records) + the lidar-only window solve, random thresholds / weights / window sizes -----------
     t0 = time.time()
     tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
