@@ -6,7 +6,7 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+pose perturbations; `cubes` = random trajectories through the global cube store; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
 loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--solves", type=int, default=10)
     ap.add_argument("--maps", type=int, default=2)
     ap.add_argument("--dense", type=int, default=2)
+    ap.add_argument("--cubes", type=int, default=2)
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -157,6 +158,51 @@ def main():
                       % (args.seed, trial, k, info[k].outer_iterations, it, info[k].is_degenerate, int(deg), dd))
                 return 1
     print("poses: %d x 4 ok (worst pose difference %.2e) %.0f s" % (args.poses, worst, time.time() - t0), flush=True)
+    # ---- global cube store: random trajectories through MapIncrement / MapMove, then the two-level association ---------------
+    t0 = time.time()
+    states = 0
+    for trial in range(args.cubes):
+        c2 = M.Context(max_scans=2)
+        cs = O.CubeStore()
+        pos = np.array([rng.uniform(0, 60), rng.uniform(0, 60), rng.uniform(-2, 8)])
+        yaw = 0.0
+        nsteps = int(rng.choice([4, 8, 14]))
+        for step in range(nsteps):
+            jump = rng.integers(0, 6) == 0
+            pos = pos + (rng.normal(0, 60, 3) * [1, 1, 0.1] if jump else rng.normal(0, 2.0, 3) * [1, 1, 0.1])
+            yaw += rng.normal(0, 0.1)
+            reps = int(rng.integers(0, 3))
+            cw, sw = [np.zeros((0, 3), np.float32)], [np.zeros((0, 3), np.float32)]
+            T = np.eye(4)
+            T[:3, :3] = Rsc.from_rotvec([0, 0, yaw]).as_matrix()
+            T[:3, 3] = pos
+            for r in range(reps):
+                fr = scene["frames"][int(rng.integers(0, 4))]
+                Tr = T.copy()
+                Tr[:3, 3] += rng.normal(0, 0.1, 3)
+                thin = rng.uniform(0.1, 1.0)
+                cf = fr["corner"][rng.random(len(fr["corner"])) < thin]
+                sf = fr["surf"][rng.random(len(fr["surf"])) < thin]
+                c2.features_upload(0, 0, cf)
+                c2.features_upload(0, 1, sf)
+                c2.map_global_append(0, Tr)
+                for feats, acc in ((cf, cw), (sf, sw)):
+                    x, y, z = (feats[:, i].astype(np.float64) for i in range(3))
+                    acc.append(np.stack([(((Tr[q, 0] * x + Tr[q, 1] * y) + Tr[q, 2] * z) + Tr[q, 3]).astype(np.float32) for q in range(3)], 1))
+                T = Tr
+            nc, ns = c2.map_global_increment(T)
+            cs.increment(np.concatenate(cw), np.concatenate(sw), T)
+            for kind, n in ((0, nc), (1, ns)):
+                gx, gc, gcen = c2.map_global_download(kind)
+                ox, oc, ocen = cs.get(kind)
+                order = np.argsort(gc, kind="stable")
+                if not (n == len(ox) and np.array_equal(gcen, ocen) and np.array_equal(gc[order], oc) and gx[order].tobytes() == ox.tobytes()):
+                    print("CUBE STORE MISMATCH seed %d trial %d step %d kind %d (%d vs %d points)" % (args.seed, trial, step, kind, n, len(ox)))
+                    return 1
+                states += 1
+        c2.close()
+    print("cubes: %d trajectories ok (%d store states equal) %.0f s" % (args.cubes, states, time.time() - t0), flush=True)
+
     # ---- other ring layouts, scans beyond 64 k points and labelled clouds beyond the 8192-key LDS sort (global-sort path) ------
     t0 = time.time()
     npts = 0
