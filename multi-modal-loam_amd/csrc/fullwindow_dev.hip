@@ -786,8 +786,8 @@ extern "C" int mml_fullwindow_solve(mml_ctx* ctx, mml_fullwindow* fw, int first_
         if (!fw->have_imu[f]) continue;
         p.have_imu[f] = 1;
         p.imu[f] = fw->imu[f];
-        MML_REQUIRE(mml_imu_sqrt_info(&fw->imu[f], p.U[f]), MML_ERR_STATE,
-                    "mml_fullwindow_solve: pre-integration covariance is not positive definite");
+        MML_REQUIRE(fw->U_ok[f], MML_ERR_STATE, "mml_fullwindow_solve: pre-integration covariance is not positive definite");
+        memcpy(p.U[f], &fw->U[225 * (size_t)f], sizeof(p.U[f]));
     }
     hipStream_t s = MML_STREAM(ctx);
     MmlStageScope t(ctx, "fullwindow");

@@ -23,6 +23,8 @@ struct mml_fullwindow {
     mml_solve_opts opts;
     std::vector<mml_imu_preint> imu;   // imu[f]: between frame f-1 and f (f >= 1)
     std::vector<char> have_imu;
+    std::vector<double> U;             // sqrt information of imu[f] (225 each), factored once in mml_fullwindow_set_imu
+    std::vector<char> U_ok;
     double gravity[3] = {0, 0, 0};
     MmlFwPrior prior;
     // trust-region state (Ceres 2.1 TRADITIONAL_DOGLEG, same constants as mml_solve / tr_propose / tr_decide)

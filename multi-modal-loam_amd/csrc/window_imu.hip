@@ -231,11 +231,22 @@ int mml_imu_preintegrate(const double* samples, int n, const double* bg, const d
     return MML_OK;
 }
 
+static void imu_factor_with_U(const mml_imu_preint* pre, const double* U, const double* gravity, const double* pri, const double* vbi,
+                              const double* prj, const double* vbj, double* residual, double* jacobian);
+
 int mml_imu_factor(const mml_imu_preint* pre, const double* gravity, const double* pri, const double* vbi, const double* prj,
                    const double* vbj, double* residual, double* jacobian) {
     if (!pre || !gravity || !pri || !vbi || !prj || !vbj || !residual) return MML_ERR_INVALID;
     double U[225];
     if (!imu_sqrt_info(pre, U)) return MML_ERR_STATE;
+    imu_factor_with_U(pre, U, gravity, pri, vbi, prj, vbj, residual, jacobian);
+    return MML_OK;
+}
+
+// the factor for a sqrt information that is already known (the full-window solver factors each covariance once, when the
+// pre-integration is handed over, instead of once per evaluation)
+static void imu_factor_with_U(const mml_imu_preint* pre, const double* U, const double* gravity, const double* pri, const double* vbi,
+                              const double* prj, const double* vbj, double* residual, double* jacobian) {
     double r[15], J[15 * 30];
     imu_raw(pre, gravity, pri, vbi, prj, vbj, r, jacobian ? J : nullptr);
     for (int i = 0; i < 15; ++i) {  // eResiduals.applyOnTheLeft(sqrt_information)
@@ -250,7 +261,6 @@ int mml_imu_factor(const mml_imu_preint* pre, const double* gravity, const doubl
                 for (int k = i; k < 15; ++k) s += U[i * 15 + k] * J[k * 30 + c];
                 jacobian[i * 30 + c] = s;
             }
-    return MML_OK;
 }
 
 }  // extern "C"
@@ -281,8 +291,8 @@ int assemble(const mml_fullwindow* s, const double* records, const double* x, Mm
         double r[15], J[15 * 30];
         const double* xi = x + 15 * (f - 1);
         const double* xj = x + 15 * f;
-        int rc = mml_imu_factor(&s->imu[f], s->gravity, xi, xi + 6, xj, xj + 6, r, J);
-        if (rc != MML_OK) return rc;
+        if (!s->U_ok[f]) return MML_ERR_STATE;
+        imu_factor_with_U(&s->imu[f], &s->U[225 * (size_t)f], s->gravity, xi, xi + 6, xj, xj + 6, r, J);
         const int base = 15 * (f - 1);  // the 30 columns are exactly the two consecutive frames
         for (int a = 0; a < 30; ++a) {
             double ga = 0;
@@ -488,6 +498,8 @@ mml_fullwindow* mml_fullwindow_create(int W, const mml_solve_opts* opts) {
     s->opts = *opts;
     s->imu.resize(W);
     s->have_imu.assign(W, 0);
+    s->U.assign(225 * (size_t)W, 0.0);
+    s->U_ok.assign(W, 0);
     const int n = s->n;
     s->x.assign(n, 0);
     s->xc.assign(n, 0);
@@ -505,6 +517,7 @@ int mml_fullwindow_set_imu(mml_fullwindow* s, int f, const mml_imu_preint* pre, 
     if (!s || !pre || !gravity || f < 1 || f >= s->W) return MML_ERR_INVALID;
     s->imu[f] = *pre;
     s->have_imu[f] = 1;
+    s->U_ok[f] = imu_sqrt_info(pre, &s->U[225 * (size_t)f]) ? 1 : 0;  // (a covariance that is not positive definite is reported by the solve)
     for (int k = 0; k < 3; ++k) s->gravity[k] = gravity[k];
     return MML_OK;
 }
@@ -618,7 +631,8 @@ int mml_fullwindow_marginalize(const mml_fullwindow* s, const double* lidar_reco
     }
     {
         double r[15], J[15 * 30];
-        int rc = mml_imu_factor(&s->imu[1], s->gravity, x, x + 6, x + 15, x + 21, r, J);
+        int rc = s->U_ok[1] ? MML_OK : MML_ERR_STATE;
+        if (rc == MML_OK) imu_factor_with_U(&s->imu[1], &s->U[225], s->gravity, x, x + 6, x + 15, x + 21, r, J);
         if (rc != MML_OK) return rc;
         for (int a = 0; a < 30; ++a) {
             for (int i = 0; i < 15; ++i) b[a] += J[i * 30 + a] * r[i];
