@@ -58,10 +58,14 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, co
     if (i >= NT) return;
     if (i < NV ? i >= cb_n[2 * b] : i - NV >= cb_n[2 * b + 1]) return;
     const double* dR = params + 12 * blockIdx.y;
-    float4 p = ln_pts[(size_t)b * NT + i];
-    const float s = (slot_flags[2 * b + 1] & 2) ? 1.0f : __int_as_float(ln_meta[(size_t)b * NT + i].y);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f* pp = reinterpret_cast<v4f*>(ln_pts + (size_t)b * NT + i);
+    const v4f raw = __builtin_nontemporal_load(pp);
+    float4 p = make_float4(raw.x, raw.y, raw.z, raw.w);
+    const float s = (slot_flags[2 * b + 1] & 2) ? 1.0f : __int_as_float(__builtin_nontemporal_load(&ln_meta[(size_t)b * NT + i].y));
     mml_und::undistort_point(dR, dR + 9, derived + 8 * blockIdx.y, s, p);
-    ln_pts[(size_t)b * NT + i] = p;
+    v4f outv = {p.x, p.y, p.z, p.w};
+    __builtin_nontemporal_store(outv, pp);
 }
 
 // ------------------------------------------------------------------------------------------------------------
