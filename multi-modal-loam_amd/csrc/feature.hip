@@ -120,6 +120,22 @@ __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int
     return m;
 }
 
+// streaming accesses of the bucketing passes: each byte is touched once per pass and the batch is far larger than the caches
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+typedef int v2i_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4 a) {
+    const v4f_nt v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(p));
+}
+__device__ __forceinline__ void nt_store2(int2* p, const int2 a) {
+    const v2i_nt v = {a.x, a.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2i_nt*>(p));
+}
+
 struct AssignAux {  // per slot, written by passes A / B
     int first_finite, last_finite, trig, kept_velo;
     float startOri, endOri;
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     int key = 0;
     if (i < n) {
         if (sensor == 0) {
-            const float4 p = P.velo_in[(size_t)b * P.NV + i];
+            const float4 p = nt_load4(P.velo_in + (size_t)b * P.NV + i);
             const bool fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
             int ring = 255;  // 255: non-finite (removed at :1133), 254: finite but outside the ring table (:1163-1166)
             float ori = 0.f;
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     uint32_t off_time = 0;
     if (valid) {
         if (sensor == 0) {
-            praw = P.velo_in[(size_t)b * P.NV + i];
+            praw = nt_load4(P.velo_in + (size_t)b * P.NV + i);
             out = make_float4(praw.x, praw.y, praw.z, 0.f);  // intensity zeroed, :1254-1256
         } else {
             const mml_livox_point q = P.livox_in[(size_t)b * P.NL + i];
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     const int line = (sensor == 0 ? 0 : P.n_rings) + key;
     const int dst = P.line_start[(size_t)b * P.L + line] + pos;
     const size_t g = (size_t)b * P.NT + dst;
-    P.ln_pts[g] = praw;
+    nt_store4(P.ln_pts + g, praw);
     float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
     if (sensor == 0) {
         const float startOri = a->startOri, endOri = a->endOri;
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     // its label still counts towards livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The
     // label byte is written by k_select for every point of a line, the line id follows from the line table: two
     // scattered stores per point in all (the pass is bound by their number, not by their bytes).
-    P.ln_meta[g] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
+    nt_store2(P.ln_meta + g, make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel)));
 }
 
 // locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
