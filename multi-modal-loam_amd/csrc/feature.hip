@@ -434,24 +434,46 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
     for (int k = tid; k < AB_WAVES * MAX_LINES; k += AB_THREADS) (&s_wcnt[0][0])[k] = 0;
-    __syncthreads();
+    // the block's offsets, the line starts and the per-slot constants are requested here, next to the points themselves: a
+    // lane's destination is then two LDS look-ups behind its key instead of two more dependent trips to memory (key ->
+    // block offset -> line start), which is what bounded the pass -- its lanes live as long as their longest load chain
+    __shared__ int s_cnt[MAX_LINES + 2];
+    __shared__ int s_ls[MAX_LINES];
+    const int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
+    for (int k = tid; k < nkeys; k += AB_THREADS) {
+        s_cnt[k] = cnt[k];
+        s_ls[k] = P.line_start[(size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings) + k];
+    }
+    if (tid < 2) s_cnt[MAX_LINES + tid] = cnt[MAX_LINES + tid];
+    const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);
+    // ... and so are the key and the record of the lane's own point (the record whether or not the key will call it valid:
+    // the few invalid ones cost nothing, and the load no longer waits for the key)
     const int region = sensor == 0 ? 0 : P.NV;
     int key = 255;
-    if (i < n) key = P.raw_line[(size_t)b * P.NT + region + i];
+    float4 praw = make_float4(0.f, 0.f, 0.f, 0.f);
+    mml_livox_point q;
+    q.x = q.y = q.z = 0.f;
+    q.reflectivity = 0;
+    q.offset_time = 0;
+    if (i < n) {
+        key = P.raw_line[(size_t)b * P.NT + region + i];
+        if (sensor == 0)
+            praw = nt_load4(P.velo_in + (size_t)b * P.NV + i);
+        else
+            q = P.livox_in[(size_t)b * P.NL + i];
+    }
+    __syncthreads();
     const bool valid = key < 254;
     if (!valid) key = 0;
     // the crop decision is geometric (lidars_extrinsic_cali.h:424-477), so the position of a point in the fused cloud
     // [velo kept ; livox kept] is known before any label is: the point goes straight there
     bool keep = false, near_ok = false;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 praw = out;
     uint32_t off_time = 0;
     if (valid) {
         if (sensor == 0) {
-            praw = nt_load4(P.velo_in + (size_t)b * P.NV + i);
             out = make_float4(praw.x, praw.y, praw.z, 0.f);  // intensity zeroed, :1254-1256
         } else {
-            const mml_livox_point q = P.livox_in[(size_t)b * P.NL + i];
             out = make_float4(q.x, q.y, q.z, (float)q.reflectivity);
             praw = out;
             off_time = q.offset_time;
@@ -465,16 +487,14 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     if (lane == 0) s_wvalid[wave] = __popcll(km);
     __syncthreads();
     if (!valid) return;
-    const int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
-    const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
-    int pos = cnt[key] + __popcll(eq & lt);
-    int fdst = (sensor == 0 ? 0 : a->kept_velo) + cnt[MAX_LINES + 1] + __popcll(km & lt);
+    const AssignAux* a = &aux;
+    int pos = s_cnt[key] + __popcll(eq & lt);
+    int fdst = (sensor == 0 ? 0 : a->kept_velo) + s_cnt[MAX_LINES + 1] + __popcll(km & lt);
     for (int w = 0; w < wave; ++w) {
         pos += s_wcnt[w][key];
         fdst += s_wvalid[w];
     }
-    const int line = (sensor == 0 ? 0 : P.n_rings) + key;
-    const int dst = P.line_start[(size_t)b * P.L + line] + pos;
+    const int dst = s_ls[key] + pos;
     const size_t g = (size_t)b * P.NT + dst;
     nt_store4(P.ln_pts + g, praw);
     float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
