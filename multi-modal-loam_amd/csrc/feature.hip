@@ -120,20 +120,13 @@ __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int
     return m;
 }
 
-// streaming accesses of the bucketing passes: each byte is touched once per pass and the batch is far larger than the caches
+// streaming loads of the bucketing passes: each raw record is touched once per pass and the batch is far larger than the caches
+// (the scattered stores stay plain: with 128 rings every lane of a wavefront writes to a different line, and a non-temporal
+//  16-byte store then reaches HBM alone -- 0.96 -> 2.68 ms at BASELINE configs[3])
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
-typedef int v2i_nt __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 nt_load4(const float4* p) {
     const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void nt_store4(float4* p, const float4 a) {
-    const v4f_nt v = {a.x, a.y, a.z, a.w};
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(p));
-}
-__device__ __forceinline__ void nt_store2(int2* p, const int2 a) {
-    const v2i_nt v = {a.x, a.y};
-    __builtin_nontemporal_store(v, reinterpret_cast<v2i_nt*>(p));
 }
 
 struct AssignAux {  // per slot, written by passes A / B
@@ -496,7 +489,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     }
     const int dst = s_ls[key] + pos;
     const size_t g = (size_t)b * P.NT + dst;
-    nt_store4(P.ln_pts + g, praw);
+    P.ln_pts[g] = praw;  // (plain stores: neighbouring lanes' pieces of a line are merged in the L2 before they reach HBM)
     float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
     if (sensor == 0) {
         const float startOri = a->startOri, endOri = a->endOri;
@@ -523,7 +516,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     // its label still counts towards livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The
     // label byte is written by k_select for every point of a line, the line id follows from the line table: two
     // scattered stores per point in all (the pass is bound by their number, not by their bytes).
-    nt_store2(P.ln_meta + g, make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel)));
+    P.ln_meta[g] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
 }
 
 // locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
