@@ -306,17 +306,27 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
         for (int kk = tid >> 6; kk <= nkeys + 1; kk += ASB_THREADS / 64) {
             const int k = kk < nkeys ? kk : MAX_LINES + (kk - nkeys);
             int acc = 0;
-            for (int b0 = 0; b0 < nblk; b0 += 64) {
-                const int blk = b0 + lane;
-                int* c = cnt0 + (size_t)(blk < nblk ? blk : 0) * BLK_STRIDE + k;
-                const int v = blk < nblk ? *c : 0;
-                int x = v;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int y = __shfl_up(x, o);
-                    if (lane >= o) x += y;
+            // eight chunks of 64 block records per round, their loads in flight together (a dense scan has 1024 blocks: one
+            // dependent load per chunk was 16 round trips to memory per key, 17 keys per wavefront)
+            for (int b0 = 0; b0 < nblk; b0 += 64 * 8) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int blk = b0 + 64 * u + lane;
+                    v[u] = blk < nblk ? cnt0[(size_t)blk * BLK_STRIDE + k] : 0;
                 }
-                if (blk < nblk) *c = acc + x - v;
-                acc += __shfl(x, 63);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int blk = b0 + 64 * u + lane;
+                    if (b0 + 64 * u >= nblk) break;  // wave-uniform
+                    int x = v[u];
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int y = __shfl_up(x, o);
+                        if (lane >= o) x += y;
+                    }
+                    if (blk < nblk) cnt0[(size_t)blk * BLK_STRIDE + k] = acc + x - v[u];
+                    acc += __shfl(x, 63);
+                }
             }
             if (lane == 0) s_tot[kk] = acc;
         }
