@@ -48,6 +48,7 @@ struct FeatParams {
     const int* n_in;
     uint8_t* raw_line;
     float* raw_ori;
+    int sensor_base;     // pass C launched per sensor: blockIdx.z + sensor_base
     float4* ln_pts;
     int2* ln_meta;       // (fused index, bits of the in-sweep time) of the bucketed point
     int* line_start;
@@ -300,36 +301,47 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
         s_last = -1;
     }
     __syncthreads();
-    // exclusive scan over blocks: one wavefront per key (+ one for the valid-point count), 64 blocks per step
+    // exclusive scan over blocks, per key (+ the valid-point and kept-point counts).  The block records are rows of
+    // BLK_STRIDE ints: a tile of 64 rows is brought into LDS with coalesced loads, scanned there -- one wavefront per key,
+    // one lane per row -- and written back the same way (lane-per-row accesses straight to memory touched one 64-byte sector
+    // per int: 3.9 ms per 1024 dense 128-ring scans).
     {
+        __shared__ int s_tile[64][BLK_STRIDE + 1];
+        __shared__ int s_acc[MAX_LINES + 2];
         const int lane = tid & 63;
-        for (int kk = tid >> 6; kk <= nkeys + 1; kk += ASB_THREADS / 64) {
-            const int k = kk < nkeys ? kk : MAX_LINES + (kk - nkeys);
-            int acc = 0;
-            // eight chunks of 64 block records per round, their loads in flight together (a dense scan has 1024 blocks: one
-            // dependent load per chunk was 16 round trips to memory per key, 17 keys per wavefront)
-            for (int b0 = 0; b0 < nblk; b0 += 64 * 8) {
-                int v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int blk = b0 + 64 * u + lane;
-                    v[u] = blk < nblk ? cnt0[(size_t)blk * BLK_STRIDE + k] : 0;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int blk = b0 + 64 * u + lane;
-                    if (b0 + 64 * u >= nblk) break;  // wave-uniform
-                    int x = v[u];
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int y = __shfl_up(x, o);
-                        if (lane >= o) x += y;
-                    }
-                    if (blk < nblk) cnt0[(size_t)blk * BLK_STRIDE + k] = acc + x - v[u];
-                    acc += __shfl(x, 63);
-                }
+        const int ncol = nkeys + 2;
+        for (int k = tid; k < ncol; k += ASB_THREADS) s_acc[k] = 0;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int rows = min(64, nblk - b0);
+            __syncthreads();
+            for (int idx = tid; idx < rows * ncol; idx += ASB_THREADS) {
+                const int r = idx / ncol, c = idx - r * ncol;
+                const int col = c < nkeys ? c : MAX_LINES + (c - nkeys);
+                s_tile[r][col] = cnt0[(size_t)(b0 + r) * BLK_STRIDE + col];
             }
-            if (lane == 0) s_tot[kk] = acc;
+            __syncthreads();
+            for (int kk = tid >> 6; kk < ncol; kk += ASB_THREADS / 64) {
+                const int k = kk < nkeys ? kk : MAX_LINES + (kk - nkeys);
+                const int base = s_acc[kk];
+                const int v = lane < rows ? s_tile[lane][k] : 0;
+                int x = v;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int y = __shfl_up(x, o);
+                    if (lane >= o) x += y;
+                }
+                if (lane < rows) s_tile[lane][k] = base + x - v;
+                const int tot = __shfl(x, 63);
+                if (lane == 0) s_acc[kk] = base + tot;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < rows * ncol; idx += ASB_THREADS) {
+                const int r = idx / ncol, c = idx - r * ncol;
+                const int col = c < nkeys ? c : MAX_LINES + (c - nkeys);
+                cnt0[(size_t)(b0 + r) * BLK_STRIDE + col] = s_tile[r][col];
+            }
         }
+        __syncthreads();
+        for (int k = tid; k < ncol; k += ASB_THREADS) s_tot[k] = s_acc[k];
     }
     __syncthreads();
     if (sensor == 0) {
@@ -425,11 +437,13 @@ __device__ __forceinline__ double livox_to_sec(uint32_t t) {  // ros::Time().fro
     return (double)sec + 1e-9 * (double)nsec;
 }
 
-__global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
+// pass C, lane-by-lane scatter: for sensors with few lines (16 rings: four consecutive raw points share a line, the
+// pieces of a line written by neighbouring lanes are merged in the L2)
+__global__ __launch_bounds__(AB_THREADS) void k_assign_c_direct(FeatParams P) {
     __shared__ int s_wcnt[AB_WAVES][MAX_LINES];
     __shared__ int s_wvalid[AB_WAVES];
     const int b = blockIdx.y + P.first;
-    const int sensor = blockIdx.z;
+    const int sensor = blockIdx.z + P.sensor_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n_in[2 * b + sensor];
     const int i = blockIdx.x * AB_THREADS + tid;
@@ -527,6 +541,152 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c(FeatParams P) {
     // label byte is written by k_select for every point of a line, the line id follows from the line table: two
     // scattered stores per point in all (the pass is bound by their number, not by their bytes).
     P.ln_meta[g] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
+}
+
+// Pass C for sensors with many lines (> 32): CB_SUB pass-A blocks per workgroup, the records staged in LDS in (line, rank)
+// order before they leave:
+// a dense scan has 128 rings and consecutive raw points belong to different rings, so a lane-by-lane scatter writes 16 isolated
+// bytes per lane (1.6 TB/s at BASELINE configs[3]); out of the staged order consecutive lanes write consecutive records of a
+// line -- runs of (points per line per workgroup) x 16 bytes.
+constexpr int CB_SUB = 4;
+constexpr int CB_THREADS = AB_THREADS * CB_SUB;
+constexpr int CB_WAVES = CB_THREADS / 64;
+__global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
+    __shared__ int s_wcnt[CB_WAVES][MAX_LINES];
+    __shared__ int s_wvalid[CB_WAVES];
+    __shared__ int s_cnt[CB_SUB][MAX_LINES + 2];
+    __shared__ int s_ls[MAX_LINES];
+    __shared__ int s_kstart[MAX_LINES + 1];  // where the run of each line starts in the staged order; [nkeys] = valid points
+    __shared__ float4 s_pt[CB_THREADS];
+    __shared__ int2 s_meta[CB_THREADS];
+    __shared__ int s_dst[CB_THREADS];
+    const int b = blockIdx.y + P.first;
+    const int sensor = blockIdx.z + P.sensor_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = wave / AB_WAVES;
+    const int n = P.n_in[2 * b + sensor];
+    const int i = blockIdx.x * CB_THREADS + tid;
+    if ((int)(blockIdx.x * CB_THREADS) >= n) return;
+    const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
+    const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
+    const int nblk = (n + AB_THREADS - 1) / AB_THREADS;
+    for (int k = tid; k < CB_WAVES * MAX_LINES; k += CB_THREADS) (&s_wcnt[0][0])[k] = 0;
+    // the blocks' offsets, the line starts and the per-slot constants are requested here, next to the points themselves: a
+    // lane's destination is then two LDS look-ups behind its key instead of two more dependent trips to memory (key ->
+    // block offset -> line start) -- the lanes of this pass live as long as their longest load chain
+    const int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + (size_t)blockIdx.x * CB_SUB) * BLK_STRIDE;
+    for (int k = tid; k < CB_SUB * nkeys; k += CB_THREADS) {
+        const int u = k / nkeys, kk = k - u * nkeys;
+        s_cnt[u][kk] = ((int)blockIdx.x * CB_SUB + u < nblk) ? cnt0[(size_t)u * BLK_STRIDE + kk] : 0;
+    }
+    for (int k = tid; k < nkeys; k += CB_THREADS) s_ls[k] = P.line_start[(size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings) + k];
+    if (tid < CB_SUB) s_cnt[tid][MAX_LINES + 1] = ((int)blockIdx.x * CB_SUB + tid < nblk) ? cnt0[(size_t)tid * BLK_STRIDE + MAX_LINES + 1] : 0;
+    const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);
+    // ... and so are the key and the record of the lane's own point (the record whether or not the key will call it valid:
+    // the few invalid ones cost nothing, and the load no longer waits for the key)
+    const int region = sensor == 0 ? 0 : P.NV;
+    int key = 255;
+    float4 praw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ori = 0.f;
+    mml_livox_point q;
+    q.x = q.y = q.z = 0.f;
+    q.reflectivity = 0;
+    q.offset_time = 0;
+    double timeSpan = 1.0;
+    if (i < n) {
+        key = P.raw_line[(size_t)b * P.NT + region + i];
+        if (sensor == 0) {
+            praw = nt_load4(P.velo_in + (size_t)b * P.NV + i);
+            ori = P.raw_ori[(size_t)b * P.NV + i];
+        } else {
+            q = P.livox_in[(size_t)b * P.NL + i];
+        }
+    }
+    if (sensor == 1) timeSpan = livox_to_sec(P.livox_in[(size_t)b * P.NL + n - 1].offset_time);  // :985
+    __syncthreads();
+    const bool valid = key < 254;
+    if (!valid) key = 0;
+    // the crop decision is geometric (lidars_extrinsic_cali.h:424-477), so the position of a point in the fused cloud
+    // [velo kept ; livox kept] is known before any label is: the point goes straight there
+    bool keep = false, near_ok = false;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t off_time = 0;
+    if (valid) {
+        if (sensor == 0) {
+            out = make_float4(praw.x, praw.y, praw.z, 0.f);  // intensity zeroed, :1254-1256
+        } else {
+            out = make_float4(q.x, q.y, q.z, (float)q.reflectivity);
+            praw = out;
+            off_time = q.offset_time;
+        }
+        crop_test(P, out.x, out.y, out.z, keep, near_ok);
+    }
+    const unsigned long long eq = match_key(valid, key, nbits);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long km = __ballot(keep);
+    if (valid && (eq & lt) == 0) s_wcnt[wave][key] = __popcll(eq);
+    if (lane == 0) s_wvalid[wave] = __popcll(km);
+    __syncthreads();
+    // staged order: lines ascending, inside a line the raw order.  The first wavefront scans the workgroup's line counts.
+    if (wave == 0) {
+        int carry = 0;
+        for (int k0 = 0; k0 < nkeys; k0 += 64) {
+            const int k = k0 + lane;
+            int c = 0;
+            if (k < nkeys)
+                for (int w = 0; w < CB_WAVES; ++w) c += s_wcnt[w][k];
+            int x = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            if (k < nkeys) s_kstart[k] = carry + x - c;
+            carry += __shfl(x, 63);
+        }
+        if (lane == 0) s_kstart[nkeys] = carry;
+    }
+    __syncthreads();
+    if (valid) {
+        const AssignAux* a = &aux;
+        int pos = s_cnt[sub][key] + __popcll(eq & lt);
+        int fdst = (sensor == 0 ? 0 : a->kept_velo) + s_cnt[sub][MAX_LINES + 1] + __popcll(km & lt);
+        for (int w = sub * AB_WAVES; w < wave; ++w) {
+            pos += s_wcnt[w][key];
+            fdst += s_wvalid[w];
+        }
+        float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
+        if (sensor == 0) {
+            const float startOri = a->startOri, endOri = a->endOri;
+            if (i <= a->trig) {  // :1169-1177
+                if (ori < startOri - M_PI / 2)
+                    ori += 2 * M_PI;
+                else if (ori > startOri + M_PI * 3 / 2)
+                    ori -= 2 * M_PI;
+            } else {  // :1178-1184
+                ori += 2 * M_PI;
+                if (ori < endOri - M_PI * 3 / 2)
+                    ori += 2 * M_PI;
+                else if (ori > endOri + M_PI / 2)
+                    ori -= 2 * M_PI;
+            }
+            rel = (ori - startOri) / (endOri - startOri);  // :1186
+        } else {
+            rel = livox_to_sec(off_time) / timeSpan;       // :995
+        }
+        // the point's rank inside its line, counted from the first of this workgroup's pass-A blocks
+        const int e = s_kstart[key] + (pos - s_cnt[0][key]);
+        s_pt[e] = praw;
+        // one 8-byte record per point: its index in the fused cloud (or -2 for a Livox point that only fails the far test --
+        // its label still counts towards livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The
+        // label byte is written by k_select for every point of a line, the line id follows from the line table.
+        s_meta[e] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
+        s_dst[e] = s_ls[key] + pos;
+    }
+    __syncthreads();
+    if (tid < s_kstart[nkeys]) {
+        const size_t g = (size_t)b * P.NT + s_dst[tid];
+        P.ln_pts[g] = s_pt[tid];
+        P.ln_meta[g] = s_meta[tid];
+    }
 }
 
 // locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
@@ -2007,6 +2167,7 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
 
 FeatParams make_params(mml_ctx* ctx, int first) {
     FeatParams P;
+    P.sensor_base = 0;
     P.first = first;
     P.NV = ctx->NV;
     P.NL = ctx->NL;
@@ -2078,7 +2239,15 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "assign_scatter");
-        hipLaunchKernelGGL(k_assign_c, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+        if (P.n_rings > 32) {  // dense scans: consecutive raw points belong to different rings
+            P.sensor_base = 0;
+            hipLaunchKernelGGL(k_assign_c_staged, dim3((P.nblk_v + CB_SUB - 1) / CB_SUB, count, 1), dim3(CB_THREADS), 0, s, P);
+            P.sensor_base = 1;
+            hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_l, count, 1), dim3(AB_THREADS), 0, s, P);
+            P.sensor_base = 0;
+        } else {
+            hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+        }
     }
     {
         MmlStageScope t(ctx, "stencil");
