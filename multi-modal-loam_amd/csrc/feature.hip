@@ -2040,20 +2040,12 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
     const uint32_t* lwv = reinterpret_cast<const uint32_t*>(P.ln_label + o);
     const uint32_t* lwl = reinterpret_cast<const uint32_t*>(P.ln_label + o + P.NV);
     const int wv = (cv + 3) / 4, wl = (cl + 3) / 4, words = wv + wl;
-    // consecutive chunk of whole 4-byte words per thread
-    const int per = (words + CROP_THREADS - 1) / CROP_THREADS;
-    const int w0 = tid * per, w1 = min(words, w0 + per);
-    int c[4] = {0, 0, 0, 0};  // corner, surf, velo corner, velo surf
-    // The label words are staged in LDS first when they fit (lds_words > 0): coalesced, all loads of a thread in flight
-    // together -- the per-thread chunks below are `per` words apart from lane to lane, and walking them in global memory
-    // is one dependent, uncoalesced load per word, twice.
+    // The label words go through LDS in chunks of `lds_words` (coalesced loads, all of a thread's loads in flight together);
+    // inside a chunk every thread owns a run of consecutive words, counts its labels, and after a workgroup scan emits the
+    // positions of its corner / surf points behind the running totals of the chunks before.  (A scan whose labels fit one
+    // chunk -- 52.8 k points -- makes one round; a dense 262 k-point scan used to walk its words in global memory, one
+    // dependent uncoalesced load per word, twice.)
     extern __shared__ uint32_t s_lab[];
-    const bool staged = words <= lds_words;
-    if (staged) {
-        for (int w = tid; w < words; w += CROP_THREADS) s_lab[w] = w < wv ? lwv[w] : lwl[w - wv];
-        __syncthreads();
-    }
-    auto word = [&](int w) -> uint32_t { return staged ? s_lab[w] : (w < wv ? lwv[w] : lwl[w - wv]); };
     // word w, byte q -> bucketed position (or -1 for the padding bytes behind a region)
     auto position = [&](int w, int q) -> int {
         if (w < wv) {
@@ -2063,62 +2055,78 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
         const int p = 4 * (w - wv) + q;
         return p < cl ? P.NV + p : -1;
     };
-    for (int w = w0; w < w1; ++w) {
-        const uint32_t v = word(w);
-        if (v == 0) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = position(w, q);
-            const int l = (v >> (8 * q)) & 255u;
-            if (p >= 0 && l) {
-                c[l == 1 ? 0 : 1] += 1;
-                if (p < P.NV) c[l == 1 ? 2 : 3] += 1;
-            }
-        }
-    }
-    // exclusive scan over threads (corner, surf) + totals (all four)
-    int inc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int x = c[k];
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        inc[k] = x;
-        if (lane == 63) s_w[wave][k] = x;
-    }
-    __syncthreads();
-    int base[2] = {0, 0};
-    for (int w = 0; w < wave; ++w) {
-        base[0] += s_w[w][0];
-        base[1] += s_w[w][1];
-    }
-    if (tid < 4) {
-        int t = 0;
-        for (int w = 0; w < CROP_THREADS / 64; ++w) t += s_w[w][tid];
-        s_tot[tid] = t;
-    }
-    __syncthreads();
-    int d1 = base[0] + inc[0] - c[0], d2 = base[1] + inc[1] - c[1];
-    if (c[0] | c[1]) {
+    int run1 = 0, run2 = 0;        // corner / surf points listed by the chunks before
+    int tot[4] = {0, 0, 0, 0};     // corner, surf, velo corner, velo surf
+    for (int c0 = 0; c0 < words; c0 += lds_words) {
+        const int cw = min(lds_words, words - c0);
+        __syncthreads();  // the previous chunk has been read
+        for (int w = tid; w < cw; w += CROP_THREADS) s_lab[w] = (c0 + w) < wv ? lwv[c0 + w] : lwl[c0 + w - wv];
+        __syncthreads();
+        const int per = (cw + CROP_THREADS - 1) / CROP_THREADS;
+        const int w0 = min(cw, tid * per), w1 = min(cw, w0 + per);
+        int c[4] = {0, 0, 0, 0};
         for (int w = w0; w < w1; ++w) {
-            const uint32_t v = word(w);
+            const uint32_t v = s_lab[w];
             if (v == 0) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int p = position(w, q);
+                const int p = position(c0 + w, q);
                 const int l = (v >> (8 * q)) & 255u;
-                if (p >= 0 && l == 1) {
-                    if (d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)p;
-                    ++d1;
-                } else if (p >= 0 && l == 2) {
-                    if (d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)p;
-                    ++d2;
+                if (p >= 0 && l) {
+                    c[l == 1 ? 0 : 1] += 1;
+                    if (p < P.NV) c[l == 1 ? 2 : 3] += 1;
                 }
             }
         }
+        // exclusive scan over threads (corner, surf) + totals (all four)
+        int inc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int x = c[k];
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            inc[k] = x;
+            if (lane == 63) s_w[wave][k] = x;
+        }
+        __syncthreads();
+        int base[2] = {0, 0};
+        for (int w = 0; w < wave; ++w) {
+            base[0] += s_w[w][0];
+            base[1] += s_w[w][1];
+        }
+        int ctot[4] = {0, 0, 0, 0};
+        for (int w = 0; w < CROP_THREADS / 64; ++w) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ctot[k] += s_w[w][k];
+        }
+        int d1 = run1 + base[0] + inc[0] - c[0], d2 = run2 + base[1] + inc[1] - c[1];
+        if (c[0] | c[1]) {
+            for (int w = w0; w < w1; ++w) {
+                const uint32_t v = s_lab[w];
+                if (v == 0) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = position(c0 + w, q);
+                    const int l = (v >> (8 * q)) & 255u;
+                    if (p >= 0 && l == 1) {
+                        if (d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)p;
+                        ++d1;
+                    } else if (p >= 0 && l == 2) {
+                        if (d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)p;
+                        ++d2;
+                    }
+                }
+            }
+        }
+        run1 += ctot[0];
+        run2 += ctot[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += ctot[k];
     }
+    if (tid < 4) s_tot[tid] = tot[tid];
+    __syncthreads();
     int* info = P.fu_info + 8 * b;
     const int livox_corner = info[4] + s_tot[0] - s_tot[2];  // info[4/5] hold k_select's count of labelled points beyond far_th
     __syncthreads();
@@ -2272,9 +2280,9 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "crop_compact");
-        // label staging: the whole fused cloud of a slot when that leaves two workgroups per CU (<= 64 KB), else none
+        // label staging: the whole fused cloud of a slot when that leaves two workgroups per CU (<= 64 KB), else 64 KB chunks
         const int lab_words = (ctx->NT + 3) / 4;
-        const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 0;
+        const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 16 * 1024;
         hipLaunchKernelGGL(k_crop, dim3(count), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
     }
     MML_HIP(hipGetLastError());
@@ -2319,7 +2327,7 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
     hipStream_t s = MML_STREAM(ctx);
     hipLaunchKernelGGL(k_decode_xyzinormal, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, d_raw, n, n_velo, slot, P);
     const int lab_words = (ctx->NT + 3) / 4;
-    const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 0;
+    const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 16 * 1024;
     hipLaunchKernelGGL(k_crop, dim3(1), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
     MML_HIP(hipGetLastError());
     return MML_OK;
