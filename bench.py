@@ -72,10 +72,10 @@ CONFIGS = {
             pitch0=-15.0, pitch_step=2.0, livox=24000, map_points=200000, gn_iters=10, slots=2048, scans_per_step=32768,
             max_features=0, distinct=64),
     3: dict(name="BASELINE configs[3]: 128-ring x 2048 dense scan (262144 pts)", n_rings=128, n_az=2048, pitch0=-25.0,
-            pitch_step=40.0 / 127.0, livox=0, map_points=2000000, gn_iters=10, slots=1024, scans_per_step=4096,
+            pitch_step=40.0 / 127.0, livox=0, map_points=2000000, gn_iters=10, slots=1024, scans_per_step=5120,
             max_features=1 << 16, distinct=8),
     4: dict(name="BASELINE configs[4]: 240k-pt fused scan (128 x 1687 + Livox 24000)", n_rings=128, n_az=1687, pitch0=-25.0,
-            pitch_step=40.0 / 127.0, livox=24000, map_points=10000000, gn_iters=20, slots=512, scans_per_step=4096,
+            pitch_step=40.0 / 127.0, livox=24000, map_points=10000000, gn_iters=20, slots=512, scans_per_step=5120,
             max_features=1 << 16, distinct=8),
 }
 
