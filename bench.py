@@ -178,7 +178,7 @@ def make_scan(synth, cfg, k, motion=True):
 
 def make_context(M, cfg, slots, device, args, map_points):
     nv = cfg["n_rings"] * cfg["n_az"]
-    kw = dict(max_scans=slots, max_velo_points=nv, max_livox_points=max(cfg["livox"], 64), n_rings=cfg["n_rings"],
+    kw = dict(max_scans=slots, max_velo_points=nv, max_livox_points=cfg["livox"], n_rings=cfg["n_rings"],
               pitch0_deg=cfg["pitch0"], pitch_step_deg=cfg["pitch_step"], max_map_points=max(int(map_points * 1.05), 1 << 16),
               cell_corner=args.cell_corner, cell_surf=args.cell_surf)
     if cfg["max_features"]:

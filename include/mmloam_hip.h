@@ -160,9 +160,11 @@ int mml_gicp_align(mml_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * livox_corner_num > 100 the slot's Livox surf cloud (source) is aligned to its Velodyne surf cloud (target) -- every
  * frame, _extrin_cnt never advances (:199,307) -- extrinsic_inout = extri_mtx is updated if the alignment converged
  * (*refreshed), and with apply != 0 the Livox part of the fused cloud is transformed with the (updated or kept) matrix
- * (pcl::transformPointCloud, :312).  With livox_corner_num <= 100 nothing happens, as in the reference.  Deviation: the
- * surf clouds are taken from the fused cloud, so Livox surf points beyond far_th (kept by the reference's
- * removeNearPointCloud, :925) are not part of the source.  Synchronous. */
+ * (pcl::transformPointCloud, :312).  With livox_corner_num <= 100 nothing happens, as in the reference.  The two surf
+ * clouds are the reference's: label-2 points in the order of each sensor's raw cloud (:1024-1031, :1242-1252), the
+ * Velodyne one cropped near + far (:1287-1293), the Livox one near only (removeNearPointCloud, :925 -- its labelled points
+ * beyond far_th are part of the source although they are not part of the fused cloud).  MML_ERR_STATE when the slot holds
+ * an uploaded or already undistorted cloud: the refresh belongs between mml_extract and mml_undistort.  Synchronous. */
 int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, int apply, int* refreshed, mml_gicp_info* info);
 
 /* ---- a1..a8: feature extraction -----------------------------------------------------------------

@@ -214,6 +214,7 @@ class Context:
         self._keep = getattr(self, "_keep", [])
         self._keep.append((v, l, nv, nl))
         if len(self._keep) > 4 * self.cfg.max_scans + 8:
+            self.synchronize()  # the copies are asynchronous: nothing may be released while one is still in flight
             self._keep = self._keep[-8:]
         self._ck(lib().mml_scan_upload_batch(self._h, C.c_int(first), C.c_int(count), _p(v), _p(nv), _p(l), _p(nl)))
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void tri_set_e(Tri3& t, int i, double v) {
 }
 
 __device__ void eig3_sym(double m00, double m10, double m11, double m20, double m21, double m22, double* ev,
-                         double* v2, double* v0 = nullptr) {
+                         double* v2, double* v0 = nullptr, double* v1 = nullptr) {
     double scale = fabs(m00);
     scale = fmax(scale, fabs(m10));
     scale = fmax(scale, fabs(m11));
@@ -198,6 +198,11 @@ __device__ void eig3_sym(double m00, double m10, double m11, double m20, double 
         v0[0] = q00;
         v0[1] = q10;
         v0[2] = q20;
+    }
+    if (v1) {  // ... and of the middle one
+        v1[0] = q01;
+        v1[1] = q11;
+        v1[2] = q21;
     }
 }
 

@@ -36,7 +36,8 @@ enum : unsigned {
     A_RFLAT = 1u << 10,    // right half-window flat (:597) -> stride 4
     A_C150 = 1u << 11,     // included-angle test passes (:644)
     A_F5_SHIFT = 12,       // 2 bits: 0 none, 1 -> flag 100, 2 -> flag 101 (:677-802)
-    A_NEAR = 1u << 14      // r^2 < thLidarNearestDis^2 (:824)
+    A_NEAR = 1u << 14,     // r^2 < thLidarNearestDis^2 (:824)
+    A_VIS = 1u << 15       // visited by the stride-1-or-4 walk of :543-650 (k_stencil resolves the walk per line)
 };
 
 struct CropBlk;
@@ -97,7 +98,6 @@ __device__ __forceinline__ void dnormalize(D3& a) {
 
 constexpr int ASSIGN_THREADS = 1024;
 constexpr int ASSIGN_WAVES = ASSIGN_THREADS / MML_WAVE;
-constexpr int STENCIL_PTS = 1024;  // bucketed positions per k_stencil workgroup (256 threads, 4 rounds)
 constexpr int MAX_LINES = 160;  // n_rings + n_livox_lines upper bound
 constexpr int BLK_STRIDE = MAX_LINES + 2;  // per-block record: key histogram | valid points | points kept by the crop
 
@@ -111,6 +111,10 @@ constexpr int BLK_STRIDE = MAX_LINES + 2;  // per-block record: key histogram | 
 constexpr int AB_THREADS = 256;
 constexpr int AB_WAVES = AB_THREADS / 64;
 
+// number of set bits of a wave mask below the calling lane (v_mbcnt: no lane mask to keep in registers)
+__device__ __forceinline__ int lower_count(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int nbits) {
     unsigned long long m = __ballot(valid);
     for (int bit = 0; bit < nbits; ++bit) {
@@ -151,9 +155,6 @@ __global__ void k_assign_init(FeatParams P, int count) {
         a->last_finite = -1;
         a->trig = 0x7fffffff;
         P.slot_flags[2 * (P.first + t)] = 0;  // an extracted cloud, not undistorted yet
-        int* info = P.fu_info + 8 * (P.first + t);
-        info[4] = 0;  // livox corner / surf: k_select adds the labelled points beyond far_th, k_crop the kept ones
-        info[5] = 0;
         P.brk_cnt[P.first + t] = 0;   // the stencil's two queues start empty
         P.redo_cnt[P.first + t] = 0;
     }
@@ -797,10 +798,111 @@ struct WinRegs {
     __device__ __forceinline__ float4 operator[](int k) const { return p[k]; }
     __device__ __forceinline__ float seg(int o) const { return seg_sq(p[5 + o], p[5 + o + 1]); }
 };
+// The included-angle test of :615-644 for a point whose two half-windows are flat: true when the point is a plane-intersection
+// corner (flag 150 if the stride walk visits it).  `decided` = false (FAST only): the float pre-decision was not certain.
+template <bool FAST, typename WIN>
+__device__ __forceinline__ bool c150_point(const WIN q, bool& decided_out) {
+#define PT(o) q[5 + (o)]
+    // :615-644: cc = |cos| between the weighted sums of the unit vectors to the four neighbours on either
+    // side; flag 150 needs cc < 0.5 and both outermost neighbours farther than 5 cm.
+    // (1) float pre-decision of cc >= 0.5 (the common case on a plane: cc ~ 1), accepted only when the
+    //     squared form is 1e-3 away from the threshold and neither sum nearly cancels;
+    // (2) the same squared form in double (v_rsq_f64 + Newton) with a 1e-10 band;
+    // (3) the reference expression.
+    bool c150 = false, decided = false;
+    decided_out = false;
+    {
+        float lx = 0.f, ly = 0.f, lz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, za4 = 0.f, zb4 = 0.f;
+#pragma unroll
+        for (int k = 1; k < 5; k++) {
+            const float ax = PT(-k).x - PT(0).x, ay = PT(-k).y - PT(0).y, az = PT(-k).z - PT(0).z;
+            const float bx = PT(k).x - PT(0).x, by = PT(k).y - PT(0).y, bz = PT(k).z - PT(0).z;
+            const float za = fmaf(az, az, fmaf(ay, ay, ax * ax)), zb = fmaf(bz, bz, fmaf(by, by, bx * bx));
+            const float wa = (k / 10.0f) * (za > 0.f ? __builtin_amdgcn_rsqf(za) : 1.f);
+            const float wb = (k / 10.0f) * (zb > 0.f ? __builtin_amdgcn_rsqf(zb) : 1.f);
+            lx = fmaf(wa, ax, lx);
+            ly = fmaf(wa, ay, ly);
+            lz = fmaf(wa, az, lz);
+            rx = fmaf(wb, bx, rx);
+            ry = fmaf(wb, by, ry);
+            rz = fmaf(wb, bz, rz);
+            if (k == 4) {
+                za4 = za;
+                zb4 = zb;
+            }
+        }
+        const float dt = fmaf(lz, rz, fmaf(ly, ry, lx * rx));
+        const float n1 = fmaf(lz, lz, fmaf(ly, ly, lx * lx)), n2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+        const float rhs = 0.25f * (n1 * n2), df = fmaf(dt, dt, -rhs);
+        const bool inr = (n1 > 0.25f) & (n2 > 0.25f) & (n1 < 4.f) & (n2 < 4.f);
+        // cc >= 0.5 for sure: not a 150 point.  cc < 0.5 for sure: the 5 cm test on the outermost
+        // neighbours decides, in float when neither squared distance is within 1e-5 of 0.0025.
+        const bool ge = (df > 1e-3f * rhs) & inr, lt = (df < -1e-3f * rhs) & inr;
+        const bool k4 = (fabsf(za4 - 0.0025f) > 2.5e-8f) & (fabsf(zb4 - 0.0025f) > 2.5e-8f);
+        decided = ge | (lt & k4);
+        c150 = lt & (za4 > 0.0025f) & (zb4 > 0.0025f);
+    }
+    if (!decided) {
+    if constexpr (FAST) return false;  // decided stays false
+    D3 nl = d3(0, 0, 0), nr = d3(0, 0, 0);
+    double last2 = 0, cur2 = 0;
+#pragma unroll
+    for (int k = 1; k < 5; k++) {
+        const D3 tl = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+        const D3 tr = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+        const double zl = ddot(tl, tl), zr = ddot(tr, tr);
+        const double il = zl > 0.0 ? rsqrt_nr(zl) : 1.0, ir = zr > 0.0 ? rsqrt_nr(zr) : 1.0;
+        const double wl = (k / 10.0) * il, wr = (k / 10.0) * ir;
+        nl.x += wl * tl.x;
+        nl.y += wl * tl.y;
+        nl.z += wl * tl.z;
+        nr.x += wr * tr.x;
+        nr.y += wr * tr.y;
+        nr.z += wr * tr.z;
+        if (k == 4) {
+            last2 = zl;
+            cur2 = zr;
+        }
+    }
+    bool ca;
+    const bool cc_ge = abs_cos_gt(ddot(nl, nr), ddot(nl, nl), ddot(nr, nr), 0.25, ca);  // cc > 0.5
+    const bool cl = fabs(last2 - 0.0025) > 1e-12, cr = fabs(cur2 - 0.0025) > 1e-12;
+    c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
+    if (!(ca && cl && cr)) {  // reference expression (:615-644)
+        D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < 5; k++) {
+            D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
+            dnormalize(tmp);
+            norm_left.x += (k / 10.0) * tmp.x;
+            norm_left.y += (k / 10.0) * tmp.y;
+            norm_left.z += (k / 10.0) * tmp.z;
+        }
+#pragma unroll
+        for (int k = 1; k < 5; k++) {
+            D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
+            dnormalize(tmp);
+            norm_right.x += (k / 10.0) * tmp.x;
+            norm_right.y += (k / 10.0) * tmp.y;
+            norm_right.z += (k / 10.0) * tmp.z;
+        }
+        double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
+        D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
+        D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
+        double last_dis = dnorm(last_tmp);
+        double current_dis = dnorm(current_tmp);
+        c150 = cc < 0.5 && last_dis > 0.05 && current_dis > 0.05;
+    }
+    }
+    decided_out = true;
+    return c150;
+#undef PT
+}
+
 // W: the window, indexable -5..5 around its centre (an LDS pointer in the fast kernel, registers in the redo kernel).
 // SECTION(): in the fast kernel the window is re-read from LDS section by section, so that no more than one section's
 // points are live in registers at a time.
-template <bool FAST, typename WIN>
+template <bool FAST, bool WITH150, typename WIN>
 __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float& curv, float& refl, bool& brk) {
 #define PT(o) q[5 + (o)]
 #define SECTION()                               \
@@ -815,6 +917,7 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
     float diffX = 0, diffY = 0, diffZ = 0;
     const float dis2 = PT(0).x * PT(0).x + PT(0).y * PT(0).y + PT(0).z * PT(0).z;
     const float dis = sqrtf(dis2);  // == (float)sqrt((double)dis2): IEEE float sqrt
+    bool unsure = false;
     // :421-422 fabs(cos) > 0.966 for both neighbours.  Float pre-decision (error ~1e-6 of the cosine, accepted only
     // when the squared form is more than 1e-3 away from the threshold), then the double squared form, then the
     // reference expression.
@@ -832,8 +935,11 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
         gn = en > 0.f;
         const bool sure = (fabsf(el) > 1e-3f * rl) & (fabsf(en) > 1e-3f * rn) & (rl < 1e30f) & (rn < 1e30f) &
                           (rl > 1e-30f) & (rn > 1e-30f);
-        if (!sure) {
-            if constexpr (FAST) return false;
+        if constexpr (FAST) {
+            // (the fast kernel finishes the point anyway -- its flatness bits, exact float tests, feed the stride walk -- and
+            //  reports it as uncertain at the end)
+            unsure = !sure;
+        } else if (!sure) {
             const D3 pt_cur = d3(PT(0).x, PT(0).y, PT(0).z);
             const D3 dl = d3((double)PT(-1).x - pt_cur.x, (double)PT(-1).y - pt_cur.y, (double)PT(-1).z - pt_cur.z);
             const D3 dn = d3((double)PT(1).x - pt_cur.x, (double)PT(1).y - pt_cur.y, (double)PT(1).z - pt_cur.z);
@@ -923,98 +1029,13 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
         if (lflat) attr |= A_LFLAT;
         if (rflat) attr |= A_RFLAT;
         SECTION();
-        if (lflat && rflat) {
-            // :615-644: cc = |cos| between the weighted sums of the unit vectors to the four neighbours on either
-            // side; flag 150 needs cc < 0.5 and both outermost neighbours farther than 5 cm.
-            // (1) float pre-decision of cc >= 0.5 (the common case on a plane: cc ~ 1), accepted only when the
-            //     squared form is 1e-3 away from the threshold and neither sum nearly cancels;
-            // (2) the same squared form in double (v_rsq_f64 + Newton) with a 1e-10 band;
-            // (3) the reference expression.
-            bool c150 = false, decided = false;
-            {
-                float lx = 0.f, ly = 0.f, lz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, za4 = 0.f, zb4 = 0.f;
-#pragma unroll
-                for (int k = 1; k < 5; k++) {
-                    const float ax = PT(-k).x - PT(0).x, ay = PT(-k).y - PT(0).y, az = PT(-k).z - PT(0).z;
-                    const float bx = PT(k).x - PT(0).x, by = PT(k).y - PT(0).y, bz = PT(k).z - PT(0).z;
-                    const float za = fmaf(az, az, fmaf(ay, ay, ax * ax)), zb = fmaf(bz, bz, fmaf(by, by, bx * bx));
-                    const float wa = (k / 10.0f) * (za > 0.f ? __builtin_amdgcn_rsqf(za) : 1.f);
-                    const float wb = (k / 10.0f) * (zb > 0.f ? __builtin_amdgcn_rsqf(zb) : 1.f);
-                    lx = fmaf(wa, ax, lx);
-                    ly = fmaf(wa, ay, ly);
-                    lz = fmaf(wa, az, lz);
-                    rx = fmaf(wb, bx, rx);
-                    ry = fmaf(wb, by, ry);
-                    rz = fmaf(wb, bz, rz);
-                    if (k == 4) {
-                        za4 = za;
-                        zb4 = zb;
-                    }
-                }
-                const float dt = fmaf(lz, rz, fmaf(ly, ry, lx * rx));
-                const float n1 = fmaf(lz, lz, fmaf(ly, ly, lx * lx)), n2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
-                const float rhs = 0.25f * (n1 * n2), df = fmaf(dt, dt, -rhs);
-                const bool inr = (n1 > 0.25f) & (n2 > 0.25f) & (n1 < 4.f) & (n2 < 4.f);
-                // cc >= 0.5 for sure: not a 150 point.  cc < 0.5 for sure: the 5 cm test on the outermost
-                // neighbours decides, in float when neither squared distance is within 1e-5 of 0.0025.
-                const bool ge = (df > 1e-3f * rhs) & inr, lt = (df < -1e-3f * rhs) & inr;
-                const bool k4 = (fabsf(za4 - 0.0025f) > 2.5e-8f) & (fabsf(zb4 - 0.0025f) > 2.5e-8f);
-                decided = ge | (lt & k4);
-                c150 = lt & (za4 > 0.0025f) & (zb4 > 0.0025f);
+        if constexpr (WITH150) {
+            if (lflat && rflat) {
+                bool decided;
+                const bool c150 = c150_point<FAST>(q, decided);
+                if (!decided) return false;  // (FAST only)
+                if (c150) attr |= A_C150;
             }
-            if (!decided) {
-            if constexpr (FAST) return false;
-            D3 nl = d3(0, 0, 0), nr = d3(0, 0, 0);
-            double last2 = 0, cur2 = 0;
-#pragma unroll
-            for (int k = 1; k < 5; k++) {
-                const D3 tl = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
-                const D3 tr = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
-                const double zl = ddot(tl, tl), zr = ddot(tr, tr);
-                const double il = zl > 0.0 ? rsqrt_nr(zl) : 1.0, ir = zr > 0.0 ? rsqrt_nr(zr) : 1.0;
-                const double wl = (k / 10.0) * il, wr = (k / 10.0) * ir;
-                nl.x += wl * tl.x;
-                nl.y += wl * tl.y;
-                nl.z += wl * tl.z;
-                nr.x += wr * tr.x;
-                nr.y += wr * tr.y;
-                nr.z += wr * tr.z;
-                if (k == 4) {
-                    last2 = zl;
-                    cur2 = zr;
-                }
-            }
-            bool ca;
-            const bool cc_ge = abs_cos_gt(ddot(nl, nr), ddot(nl, nl), ddot(nr, nr), 0.25, ca);  // cc > 0.5
-            const bool cl = fabs(last2 - 0.0025) > 1e-12, cr = fabs(cur2 - 0.0025) > 1e-12;
-            c150 = !cc_ge && last2 > 0.0025 && cur2 > 0.0025;
-            if (!(ca && cl && cr)) {  // reference expression (:615-644)
-                D3 norm_left = d3(0, 0, 0), norm_right = d3(0, 0, 0);
-#pragma unroll
-                for (int k = 1; k < 5; k++) {
-                    D3 tmp = d3(PT(-k).x - PT(0).x, PT(-k).y - PT(0).y, PT(-k).z - PT(0).z);
-                    dnormalize(tmp);
-                    norm_left.x += (k / 10.0) * tmp.x;
-                    norm_left.y += (k / 10.0) * tmp.y;
-                    norm_left.z += (k / 10.0) * tmp.z;
-                }
-#pragma unroll
-                for (int k = 1; k < 5; k++) {
-                    D3 tmp = d3(PT(k).x - PT(0).x, PT(k).y - PT(0).y, PT(k).z - PT(0).z);
-                    dnormalize(tmp);
-                    norm_right.x += (k / 10.0) * tmp.x;
-                    norm_right.y += (k / 10.0) * tmp.y;
-                    norm_right.z += (k / 10.0) * tmp.z;
-                }
-                double cc = fabs(ddot(norm_left, norm_right) / (dnorm(norm_left) * dnorm(norm_right)));
-                D3 last_tmp = d3(PT(-4).x - PT(0).x, PT(-4).y - PT(0).y, PT(-4).z - PT(0).z);
-                D3 current_tmp = d3(PT(4).x - PT(0).x, PT(4).y - PT(0).y, PT(4).z - PT(0).z);
-                double last_dis = dnorm(last_tmp);
-                double current_dis = dnorm(current_tmp);
-                c150 = cc < 0.5 && last_dis > 0.05 && current_dis > 0.05;
-            }
-            }
-            if (c150) attr |= A_C150;
         }
     }
     // ---- :651-806 break points ----
@@ -1032,63 +1053,274 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
     if (dis2 < thLidarNearestDis * thLidarNearestDis) attr |= A_NEAR;
 #undef PT
 #undef SECTION
-    return true;
+    return !unsure;
 }
 
-__global__ __launch_bounds__(256) void k_stencil(FeatParams P) {
+// Transfer table of the stride-1-or-4 walk (:543-650) over 8 positions.  row[RFLAT byte]: low word = for each offset e = 0..3 of
+// the first visited position the visited byte (bits 8e..8e+7); high word = the offset into the next byte, already multiplied by 8
+// (bits 8e..8e+7) -- so that the walk state IS the bit offset of both fields and a step is two bit-field extracts.  A compile-time
+// constant.  The walk of a 64-point window fetches its eight rows at once and chains them in registers; the entry offset of a
+// window is the exit of its predecessor.
+struct alignas(16) WalkTab {
+    unsigned long long row[256];
+};
+constexpr WalkTab make_walk_tab() {
+    WalkTab t{};
+    for (int m8 = 0; m8 < 256; ++m8) {
+        unsigned long long r = 0;
+        for (int e = 0; e < 4; ++e) {
+            int pos = e;
+            unsigned v = 0;
+            while (pos < 8) {
+                v |= 1u << pos;
+                pos += ((m8 >> pos) & 1) ? 4 : 1;
+            }
+            r |= (unsigned long long)v << (8 * e);
+            r |= (unsigned long long)(8 * (pos - 8)) << (32 + 8 * e);
+        }
+        t.row[m8] = r;
+    }
+    return t;
+}
+__device__ const WalkTab g_walk_tab = make_walk_tab();
+
+#ifdef MML_ST_TIMING
+// phase clocks of one k_stencil workgroup (line MML_ST_TIMING of the 8th slot of the launch): cycles spent up to each mark, summed
+// over the tiles of the line
+__device__ unsigned long long g_st_dbg[16];
+#define ST_MARK(id)                                                       \
+    do {                                                                  \
+        if (st_dbg) {                                                     \
+            const unsigned long long now_ = clock64();                    \
+            g_st_dbg[id] += now_ - st_prev;                               \
+            st_prev = now_;                                               \
+        }                                                                 \
+    } while (0)
+extern "C" int mml_debug_st_timing(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_st_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#else
+#define ST_MARK(id)
+#endif
+
+// One WAVEFRONT per scan line (four lines per workgroup, nothing shared between them: no workgroup barrier anywhere), the line
+// in tiles of ST_TILE positions -- four rounds of one point per lane through the wavefront's LDS tile of the points and of the
+// squared segment lengths.  Per tile:
+//   1. every order-independent predicate except the included-angle test (float pre-decisions; uncertain points -> redo queue)
+//   2. the stride walk of :543-650 over the tile -- it depends only on the RFLAT bits just computed (four ballots, in scalar
+//      registers): lane (w, e) walks window w entered at offset e through the transfer table, the windows are chained with
+//      four lane reads, the exit offset is carried to the next tile in a scalar register
+//   3. the included-angle test (eight normalisations, a third of the old kernel) only for the points the walk visits and
+//      whose half-windows are both flat -- on a plane the walk strides by 4, so that is every fourth point --, compacted into
+//      a list and evaluated with all lanes busy; then the attribute words are written.
+// A wavefront's serial stretches (tile loads in flight, the walk's dependent chain) are covered by the other wavefronts of
+// the SIMD, which are at other points of other lines: the workgroup-per-line form of this kernel lost a quarter of its time
+// to three wavefronts waiting at a barrier for the one that walks.
+constexpr int ST_TILE = 256;
+constexpr int ST_LINES = 4;  // lines (wavefronts) per workgroup
+__global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
+    __shared__ unsigned long long s_row[256];  // the transfer table (2 KB): eight look-ups per window walk
+    for (int k = threadIdx.x; k < 256; k += 64 * ST_LINES) s_row[k] = g_walk_tab.row[k];
+    __syncthreads();  // (the only workgroup barrier: before any wavefront leaves)
     const int b = blockIdx.y + P.first;
-    // the STENCIL_PTS + 10 points this workgroup's windows cover, read once (lines are contiguous in ln_pts, so the
-    // window of position p is [p - 5, p + 5] whatever its line)
-    __shared__ float4 s_pt[STENCIL_PTS + 10];
-    const int p_first = blockIdx.x * STENCIL_PTS;
-    for (int k = threadIdx.x; k < STENCIL_PTS + 10; k += 256) {
-        const int gp = p_first - 5 + k;
-        s_pt[k] = (gp >= 0 && gp < P.NT) ? P.ln_pts[(size_t)b * P.NT + gp] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    LineTab tab;
-    load_line_tab(P, b, tab);
-    __syncthreads();
-    __shared__ float s_sq[STENCIL_PTS + 10];
-    for (int k = threadIdx.x; k < STENCIL_PTS + 9; k += 256) s_sq[k] = seg_sq(s_pt[k], s_pt[k + 1]);
-    __syncthreads();
-    for (int rep = 0; rep < STENCIL_PTS / 256; ++rep) {
-    const int tp = rep * 256 + threadIdx.x, p = p_first + tp;
-    if (__builtin_amdgcn_readfirstlane(p) >= P.NT) break;
-    int line, i, n, start;
-    const bool found = find_line(P, tab, p < P.NT ? p : P.NT - 1, line, i, n, start);  // (whole wavefront takes part)
-    const bool live = p < P.NT && found;
+    const int wave_id = threadIdx.x >> 6;
+    const int line = blockIdx.x * ST_LINES + wave_id;
+    if (line >= P.L) return;
+    const int n = P.line_len[(size_t)b * P.L + line];
+    if (n <= 0) return;
+    const int start = P.line_start[(size_t)b * P.L + line];
     const size_t base = (size_t)b * P.NT + start;
-    unsigned attr = 0;
-    float curv = 0.f, refl = 0.f;
-    bool brk = false, redo = false;
-    if (live && i >= 5 && i < n - 5) {
-        redo = !stencil_point<true>(WinTile{s_pt + tp, s_sq + tp}, attr, curv, refl, brk);
-        brk = brk && !redo;
+    __shared__ float4 s_pt_all[ST_LINES][ST_TILE + 10];
+    __shared__ float s_sq_all[ST_LINES][ST_TILE + 10];
+    __shared__ unsigned short s_attr_all[ST_LINES][ST_TILE];
+    float4* s_pt = s_pt_all[wave_id];
+    float* s_sq = s_sq_all[wave_id];
+    unsigned short* s_attr = s_attr_all[wave_id];
+    unsigned short* s_list = reinterpret_cast<unsigned short*>(s_sq);  // (the segment lengths are dead once the rounds are done)
+#ifdef MML_ST_TIMING
+    const bool st_dbg = (threadIdx.x & 63) == 0 && line == MML_ST_TIMING && blockIdx.y == 517;
+    unsigned long long st_prev = clock64();
+#endif
+    // Every phase of the tile loop derives its lane number and addresses from its own opaque copy of the thread index: the
+    // compiler otherwise keeps the loop-invariant values of ALL phases in registers across the whole loop
+#define PHASE_IDS()                               \
+    int lane = threadIdx.x & 63;                  \
+    asm volatile("" : "+v"(lane))
+#define WAVE_SYNC()                                        \
+    do {                                                   \
+        __builtin_amdgcn_wave_barrier();                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    } while (0)
+    unsigned carry = 0;  // offset of the first visited position in the tile's first byte (wave-uniform)
+    for (int t0 = 0; t0 < n; t0 += ST_TILE) {
+        WAVE_SYNC();  // the previous tile has been consumed
+        ST_MARK(0);
+        {
+            PHASE_IDS();
+            // the ST_TILE + 10 points the tile's windows cover, read once, and the squared length of every segment between
+            // consecutive points (each is tested by six windows).  Every lane requests its point AND the successor (the second
+            // request is served from the lines the first one brings in), all requests of the phase in flight together.
+            constexpr int NLD = (ST_TILE + 10 + 63) / 64;
+            float4 pa[NLD], pb[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int gp = t0 - 5 + lane + 64 * u;
+                const bool in_tile = lane + 64 * u < ST_TILE + 10;
+                pa[u] = (in_tile && gp >= 0 && gp < n) ? P.ln_pts[base + gp] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pb[u] = (in_tile && gp + 1 >= 0 && gp + 1 < n) ? P.ln_pts[base + gp + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int k = lane + 64 * u;
+                if (k < ST_TILE + 10) s_pt[k] = pa[u];
+                if (k < ST_TILE + 9) s_sq[k] = seg_sq(pa[u], pb[u]);
+            }
+        }
+        WAVE_SYNC();
+        ST_MARK(1);
+        unsigned redo_bits = 0;
+        unsigned long long rmask[4] = {0ull, 0ull, 0ull, 0ull};
+        {
+            PHASE_IDS();
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) {
+                if (t0 + rep * 64 >= n) break;  // wave-uniform
+                int tp = rep * 64 + lane;
+                asm volatile("" : "+v"(tp));
+                const int i = t0 + tp;
+                const bool live = i < n;
+                unsigned attr = 0;
+                float curv = 0.f, refl = 0.f;
+                bool brk = false, redo = false;
+                if (live && i >= 5 && i < n - 5) {
+                    redo = !stencil_point<true, false>(WinTile{s_pt + tp, s_sq + tp}, attr, curv, refl, brk);
+                    brk = brk && !redo;
+                    if (redo) attr &= A_LFLAT | A_RFLAT;  // (exact float tests, always decided: the walk needs them now)
+                }
+                // (addresses of the stores below from a fresh copy of the index: none of them stays live across the stencil above)
+                int tq = tp;
+                asm volatile("" : "+v"(tq));
+                const int iq = t0 + tq;
+                if (live && !redo) {
+                    P.ln_curv[base + iq] = curv;
+                    P.ln_refl[base + iq] = refl;
+                }
+                s_attr[tq] = (unsigned short)attr;
+                if (redo) redo_bits |= 1u << rep;
+                rmask[rep] = __ballot(attr & A_RFLAT);
+                // wave-aggregated append to the slot's break-point queue
+                const unsigned long long bm = __ballot(brk);
+                if (bm) {
+                    int first = 0;
+                    if (lane == (int)__ffsll((long long)bm) - 1) first = atomicAdd(&P.brk_cnt[b], __popcll(bm));
+                    first = __shfl(first, (int)__ffsll((long long)bm) - 1);
+                    if (brk) P.brk_queue[(size_t)b * P.NT + first + lower_count(bm)] = (unsigned)(start + iq);
+                }
+                // ... and to its redo queue
+                const unsigned long long rm = __ballot(redo);
+                if (rm) {
+                    int first = 0;
+                    if (lane == (int)__ffsll((long long)rm) - 1) first = atomicAdd(&P.redo_cnt[b], __popcll(rm));
+                    first = __shfl(first, (int)__ffsll((long long)rm) - 1);
+                    if (redo) P.redo_queue[(size_t)b * P.NT + first + lower_count(rm)] = (unsigned)(start + iq);
+                }
+            }
+        }
+        ST_MARK(2);
+        // ---- the walk over this tile: lane (w, e), w < 4, = window w entered at offset e ----
+        unsigned long long vmask[4] = {0ull, 0ull, 0ull, 0ull};
+#ifndef MML_ST_NOWALK
+        {
+            PHASE_IDS();
+            const int w = (lane >> 2) & 3;
+            const unsigned long long m = w == 0 ? rmask[0] : (w == 1 ? rmask[1] : (w == 2 ? rmask[2] : rmask[3]));
+            unsigned long long row[8];
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) row[sb] = s_row[(unsigned)(m >> (8 * sb)) & 255u];
+            // state = 8 x (offset of the first visited position in the byte) = bit offset of this entry's fields in a row
+            unsigned st = 8u * (lane & 3), vlo, vhi;
+            if (t0 == 0) {  // (wave-uniform) the walk starts at index 5: positions 5, 6, 7 of the line's first byte by hand
+                const unsigned r5 = (unsigned)(m >> 5) & 1u, r6 = (unsigned)(m >> 6) & 1u, r7 = (unsigned)(m >> 7) & 1u;
+                const unsigned v6 = r5 ^ 1u, v7 = v6 & (r6 ^ 1u);
+                const unsigned first_vis = (1u << 5) | (v6 << 6) | (v7 << 7);
+                const unsigned first_exit = v7 ? (r7 ? 3u : 0u) : (v6 ? 2u : 1u);
+                const bool hand = w == 0;
+                vlo = hand ? first_vis : __builtin_amdgcn_ubfe((unsigned)row[0], st, 8u);
+                st = hand ? 8u * first_exit : __builtin_amdgcn_ubfe((unsigned)(row[0] >> 32), st, 8u);
+            } else {
+                vlo = __builtin_amdgcn_ubfe((unsigned)row[0], st, 8u);
+                st = __builtin_amdgcn_ubfe((unsigned)(row[0] >> 32), st, 8u);
+            }
+#pragma unroll
+            for (int sb = 1; sb < 4; ++sb) {
+                vlo |= __builtin_amdgcn_ubfe((unsigned)row[sb], st, 8u) << (8 * sb);
+                st = __builtin_amdgcn_ubfe((unsigned)(row[sb] >> 32), st, 8u);
+            }
+            vhi = __builtin_amdgcn_ubfe((unsigned)row[4], st, 8u);
+            st = __builtin_amdgcn_ubfe((unsigned)(row[4] >> 32), st, 8u);
+#pragma unroll
+            for (int sb = 5; sb < 8; ++sb) {
+                vhi |= __builtin_amdgcn_ubfe((unsigned)row[sb], st, 8u) << (8 * (sb - 4));
+                st = __builtin_amdgcn_ubfe((unsigned)(row[sb] >> 32), st, 8u);
+            }
+            // chain the four windows: the entry offset of a window is the exit of its predecessor for ITS entry offset
+            unsigned e = carry;  // (8 x offset)
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const int src = ww * 4 + (int)(e >> 3);
+                vmask[ww] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, src) << 32) |
+                            (unsigned)__builtin_amdgcn_readlane((int)vlo, src);
+                e = (unsigned)__builtin_amdgcn_readlane((int)st, src);
+            }
+            carry = e;
+        }
+#endif
+        ST_MARK(3);
+        // ---- list of the points that need the included-angle test, the test, the attribute words ----
+        {
+            PHASE_IDS();
+            int n150 = 0;
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) {
+                if (t0 + rep * 64 >= n) break;
+                const int tp = rep * 64 + lane, i = t0 + tp;
+                const unsigned attr = s_attr[tp];
+                const bool vis = ((vmask[rep] >> lane) & 1ull) && i >= 5 && i < n - 5;
+                if (vis) s_attr[tp] = (unsigned short)(attr | A_VIS);
+                const bool want = vis && (attr & A_LFLAT) && (attr & A_RFLAT) && !((redo_bits >> rep) & 1u);
+                const unsigned long long wm = __ballot(want);
+                if (want) s_list[n150 + lower_count(wm)] = (unsigned short)tp;
+                n150 += __popcll(wm);
+            }
+            WAVE_SYNC();
+#ifdef MML_ST_NO150
+            n150 = 0;
+#endif
+            for (int e = lane; e < n150; e += 64) {
+                const int tp = s_list[e];
+                bool decided;
+                const bool c150 = c150_point<true>(WinTile{s_pt + tp, s_sq + tp}, decided);
+                if (!decided)  // (about one point in a thousand) the whole point again, with the full decision chain
+                    P.redo_queue[(size_t)b * P.NT + atomicAdd(&P.redo_cnt[b], 1)] = (unsigned)(start + t0 + tp);
+                else if (c150)
+                    s_attr[tp] = (unsigned short)(s_attr[tp] | A_C150);
+            }
+            WAVE_SYNC();
+            ST_MARK(4);
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) {
+                const int tp = rep * 64 + lane, i = t0 + tp;
+                if (i < n) P.ln_attr[base + i] = ((redo_bits >> rep) & 1u) ? (unsigned short)(s_attr[tp] & A_VIS) : s_attr[tp];
+            }
+        }
+        ST_MARK(5);
     }
-    if (live && !redo) {
-        P.ln_curv[base + i] = curv;
-        P.ln_refl[base + i] = refl;
-        P.ln_attr[base + i] = (uint16_t)attr;
-    }
-    // wave-aggregated append to the slot's break-point queue
-    const unsigned long long bm = __ballot(brk);
-    if (bm) {
-        const int lane = threadIdx.x & 63;
-        int first = 0;
-        if (lane == (int)__ffsll((long long)bm) - 1) first = atomicAdd(&P.brk_cnt[b], __popcll(bm));
-        first = __shfl(first, (int)__ffsll((long long)bm) - 1);
-        if (brk) P.brk_queue[(size_t)b * P.NT + first + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(start + i);
-    }
-    // ... and to its redo queue
-    const unsigned long long rm = __ballot(redo);
-    if (rm) {
-        const int lane = threadIdx.x & 63;
-        int first = 0;
-        if (lane == (int)__ffsll((long long)rm) - 1) first = atomicAdd(&P.redo_cnt[b], __popcll(rm));
-        first = __shfl(first, (int)__ffsll((long long)rm) - 1);
-        if (redo) P.redo_queue[(size_t)b * P.NT + first + __popcll(rm & ((1ull << lane) - 1ull))] = (unsigned)(start + i);
-    }
-    }
+#undef PHASE_IDS
+#undef WAVE_SYNC
 }
 
 // the points whose float pre-decisions were not certain, one per lane, with the full decision chain
@@ -1104,10 +1336,10 @@ __global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {
         unsigned attr = 0;
         float curv = 0.f, refl = 0.f;
         bool brk = false;
-        stencil_point<false>(WinRegs{q}, attr, curv, refl, brk);
+        stencil_point<false, true>(WinRegs{q}, attr, curv, refl, brk);
         P.ln_curv[pos] = curv;
         P.ln_refl[pos] = refl;
-        P.ln_attr[pos] = (uint16_t)attr;
+        P.ln_attr[pos] = (uint16_t)(attr | (P.ln_attr[pos] & A_VIS));  // (the walk's bit is k_stencil's)
         if (brk) P.brk_queue[(size_t)b * P.NT + atomicAdd(&P.brk_cnt[b], 1)] = pos_in_slot;
     }
 }
@@ -1328,9 +1560,8 @@ __device__ __forceinline__ void p2_acc(const uint2 o, unsigned me, unsigned mk, 
 // and live in registers afterwards: the kernel is bound by the latency of dependent phases, not by bytes, and every
 // global load removed from a phase removes a full HBM round trip from the critical path of the workgroup.
 // K == 0: any length, per-point state in a global scratch, attributes re-read where needed.
-template <int K, typename WP, typename U64P, typename ByteP>
-__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, WP W, WP R, U64P wmask,
-                                            U64P wvis, ByteP wexit, ByteP wsel, int* s_sp,
+template <int K, typename WP>
+__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, WP W, WP R, int* s_sp,
                                             unsigned long long (*s_pm)[3], unsigned long long* s_minE,
                                             unsigned long long* s_minG, unsigned char* s_bfirst,
                                             unsigned char* s_list, int* s_cnt, int* s_flag, unsigned short* s_walk) {
@@ -1816,87 +2047,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     __syncthreads();  // R is dead from here on: the window tables of the cached form live in its storage
 
     SEL_MARK(8);
-    // ---- phase 4: stride walk of :543-650, window transfer functions ------------------------------------------------
-    const int nw = (n + 63) / 64;
-    // transfer table of the stride walk over 8 positions: (RFLAT byte, entry offset 0..3) -> visited byte | exit << 8
-    // (built here: until now its storage held the window state masks of the dependency rounds)
-    for (int t = tid; t < 1024; t += SELP_THREADS) {
-        const unsigned m8 = (unsigned)t >> 2;
-        int pos = t & 3;
-        unsigned v = 0;
-        while (pos < 8) {
-            v |= 1u << pos;
-            pos += ((m8 >> pos) & 1u) ? 4 : 1;
-        }
-        s_walk[t] = (unsigned short)(v | ((unsigned)(pos - 8) << 8));
-    }
-    if constexpr (CACHED) {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) {
-            const int i = tid + k * SELP_THREADS;
-            if ((i & ~63) >= n) break;  // wave-uniform
-            const unsigned long long m = __ballot(i < n && (r_attr[k] & A_RFLAT));
-            if (lane == 0) wmask[i >> 6] = m;
-        }
-    } else {
-        for (int w0 = (tid >> 6) * 64; w0 < n; w0 += SELP_THREADS) {
-            const int i = w0 + lane;
-            const unsigned long long m = __ballot(i < n && (attr[i] & A_RFLAT));
-            if (lane == 0) wmask[w0 >> 6] = m;
-        }
-    }
-    __syncthreads();
-    for (int t = tid; t < nw * 4; t += SELP_THREADS) {
-        const int w = t >> 2;
-        const unsigned long long m = wmask[w];
-        unsigned long long vis = 0;
-        int ent = t & 3, sb = 0;
-        if (w == 0) {  // the walk starts at index 5: the first byte by hand
-            int pos = 5;
-            while (pos < 8) {
-                vis |= 1ull << pos;
-                pos += ((m >> pos) & 1ull) ? 4 : 1;
-            }
-            ent = pos - 8;
-            sb = 1;
-        }
-        for (; sb < 8; ++sb) {  // one table look-up per 8 positions instead of up to 8 dependent steps
-            const unsigned tv = s_walk[(((unsigned)(m >> (8 * sb)) & 255u) << 2) + ent];
-            vis |= (unsigned long long)(tv & 255u) << (8 * sb);
-            ent = (int)(tv >> 8);
-        }
-        wvis[t] = vis;
-        wexit[t] = (unsigned char)ent;
-    }
-    __syncthreads();
-    SEL_MARK(9);
-    // entry offset of every window = composition of the exit tables of the windows before it: a prefix scan over
-    // maps {0..3} -> {0..3} (2 bits per entry), 64 windows per pass of the first wavefront
-    if (tid < 64) {
-        unsigned carry = 0;
-        for (int w0 = 0; w0 < nw; w0 += 64) {
-            const int w = w0 + lane;
-            unsigned f = 0xE4u;  // identity: e -> e
-            if (w < nw) f = (unsigned)wexit[w * 4] | ((unsigned)wexit[w * 4 + 1] << 2) | ((unsigned)wexit[w * 4 + 2] << 4) |
-                            ((unsigned)wexit[w * 4 + 3] << 6);
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned g = __shfl_up(f, o);  // windows before mine, applied first
-                if (lane >= o) {
-                    unsigned h = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h |= ((f >> (2 * ((g >> (2 * e)) & 3u))) & 3u) << (2 * e);
-                    f = h;
-                }
-            }
-            const unsigned before = __shfl_up(f, 1);
-            const unsigned entry = lane == 0 ? carry : ((before >> (2 * carry)) & 3u);
-            if (w < nw) wsel[w] = (unsigned char)entry;
-            carry = (__shfl(f, 63) >> (2 * carry)) & 3u;
-        }
-    }
-    __syncthreads();
-
+    // (phase 4, the stride walk of :543-650, is resolved by k_stencil: attribute bit A_VIS)
     SEL_MARK(10);
     // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
     uint8_t* lnlab = P.ln_label + base;
@@ -1921,9 +2072,8 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         if ((me >> I_F_SHIFT) & 4u) f = 1;  // marked by a point of a later partition (:503,516 of the next partitions)
         const bool inner = i >= 5 && i < n - 5;
         if (inner) {
-            const int w = i >> 6;
-            const bool visited = (wvis[w * 4 + wsel[w]] >> (i & 63)) & 1ull;
-            if (visited && (at & A_LFLAT) && (at & A_RFLAT) && (at & A_C150)) f = 150;
+            // visited by the stride walk and the included-angle test passes (the test implies both half-windows flat)
+            if ((at & (A_VIS | A_C150)) == (A_VIS | A_C150)) f = 150;
             const unsigned f5 = (at >> A_F5_SHIFT) & 3u;
             if (f5 == 1) f = 100;
             if (f5 == 2) f = 101;
@@ -1936,8 +2086,8 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
                 const int gi = CACHED ? r_gidx[k] : gidx[i].x;
                 if (gi >= 0)
                     labv = lab;
-                else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940
-                    atomicAdd(&P.fu_info[8 * b + 3 + lab], 1);
+                else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940 and part of the
+                    labv = lab | 0x80;  // surf cloud the GICP refresh aligns (:296-312); k_crop counts these, nobody lists them
             }
         }
         lnlab[i] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
@@ -1971,28 +2121,15 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     const size_t base = (size_t)b * P.NT + start;
     constexpr int cap = K * SELP_THREADS;
     if (n <= cap) {
-        constexpr int nwin = cap / 64;
         unsigned* W = reinterpret_cast<unsigned*>(smem) + 8;  // 4 pad records in front, 4 behind
         unsigned* R = reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8);
-        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(R);  // tables reuse R (45 B per window)
-        unsigned long long* wvis = wmask + nwin;
-        unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * nwin);
-        unsigned char* wsel = wexit + 4 * nwin;
-        select_body<K>(P, b, n, base, W, R, wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+        select_body<K>(P, b, n, base, W, R, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
     } else {
         // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
         const size_t BNT = (size_t)P.B * P.NT;
         // (+8 * line + 8 words: room for the pad records of every line in front of this one)
         unsigned* W = P.sel_scratch + 2 * base + 16 * ((size_t)b * (P.L + 2) + line + 1);
-        const int nwin = (n + 63) / 64;
-        uintptr_t wp = reinterpret_cast<uintptr_t>(P.sel_scratch + 2 * BNT + 16 * (size_t)(P.L + 2) * P.B + 2 * base);
-        wp = (wp + 7) & ~uintptr_t(7);
-        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wp);
-        unsigned long long* wvis = wmask + nwin;
-        unsigned char* wexit = reinterpret_cast<unsigned char*>(wvis + 4 * (size_t)nwin);
-        unsigned char* wsel = wexit + 4 * (size_t)nwin;
-        select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), wmask, wvis, wexit, wsel, s_sp, s_pm, s_minE,
-                       s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+        select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
     }
 }
 
@@ -2057,6 +2194,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
     };
     int run1 = 0, run2 = 0;        // corner / surf points listed by the chunks before
     int tot[4] = {0, 0, 0, 0};     // corner, surf, velo corner, velo surf
+    int far_c = 0, far_s = 0;      // this thread's labelled Livox points beyond far_th (label byte with bit 7 set)
     for (int c0 = 0; c0 < words; c0 += lds_words) {
         const int cw = min(lds_words, words - c0);
         __syncthreads();  // the previous chunk has been read
@@ -2073,8 +2211,13 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
                 const int p = position(c0 + w, q);
                 const int l = (v >> (8 * q)) & 255u;
                 if (p >= 0 && l) {
-                    c[l == 1 ? 0 : 1] += 1;
-                    if (p < P.NV) c[l == 1 ? 2 : 3] += 1;
+                    if (l & 0x80) {
+                        far_c += (l & 3) == 1;
+                        far_s += (l & 3) == 2;
+                    } else {
+                        c[l == 1 ? 0 : 1] += 1;
+                        if (p < P.NV) c[l == 1 ? 2 : 3] += 1;
+                    }
                 }
             }
         }
@@ -2125,18 +2268,29 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
 #pragma unroll
         for (int k = 0; k < 4; ++k) tot[k] += ctot[k];
     }
+    // the labelled Livox points beyond far_th: workgroup totals
+    __shared__ int s_far[2];
+    if (tid < 2) s_far[tid] = 0;
     if (tid < 4) s_tot[tid] = tot[tid];
     __syncthreads();
-    int* info = P.fu_info + 8 * b;
-    const int livox_corner = info[4] + s_tot[0] - s_tot[2];  // info[4/5] hold k_select's count of labelled points beyond far_th
+    for (int d = 32; d > 0; d >>= 1) {
+        far_c += __shfl_xor(far_c, d);
+        far_s += __shfl_xor(far_s, d);
+    }
+    if (lane == 0 && (far_c | far_s)) {
+        atomicAdd(&s_far[0], far_c);
+        atomicAdd(&s_far[1], far_s);
+    }
     __syncthreads();
+    int* info = P.fu_info + 8 * b;
+    const int livox_corner = s_far[0] + s_tot[0] - s_tot[2];
     if (tid == 0) {
         info[0] = n;          // fused points
         info[1] = nv;         // ... of which velodyne
         info[2] = s_tot[2];   // velo corner / surf after near+far crop (:1287-1300)
         info[3] = s_tot[3];
         info[4] = livox_corner;                      // livox corner / surf after the near crop only (:925-940)
-        info[5] = info[5] + s_tot[1] - s_tot[3];
+        info[5] = s_far[1] + s_tot[1] - s_tot[3];
         info[6] = s_tot[0];   // all kept corner- / surf-labelled points (label split, Estimator.cpp:995-1003)
         info[7] = s_tot[1];
     }
@@ -2235,7 +2389,6 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     FeatParams P = make_params(ctx, first);
     P.extr = have_extrinsic ? ctx->d_extr : nullptr;
     hipStream_t s = MML_STREAM(ctx);
-    const int pblocks = (ctx->NT + STENCIL_PTS - 1) / STENCIL_PTS;
     {
         MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
@@ -2250,16 +2403,18 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         if (P.n_rings > 32) {  // dense scans: consecutive raw points belong to different rings
             P.sensor_base = 0;
             hipLaunchKernelGGL(k_assign_c_staged, dim3((P.nblk_v + CB_SUB - 1) / CB_SUB, count, 1), dim3(CB_THREADS), 0, s, P);
-            P.sensor_base = 1;
-            hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_l, count, 1), dim3(AB_THREADS), 0, s, P);
-            P.sensor_base = 0;
+            if (P.nblk_l > 0) {  // (a context without a Livox region, max_livox_points = 0: a zero-sized grid is not a launch)
+                P.sensor_base = 1;
+                hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_l, count, 1), dim3(AB_THREADS), 0, s, P);
+                P.sensor_base = 0;
+            }
         } else {
             hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
         }
     }
     {
         MmlStageScope t(ctx, "stencil");
-        hipLaunchKernelGGL(k_stencil, dim3(pblocks, count), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_stencil, dim3((ctx->L + ST_LINES - 1) / ST_LINES, count), dim3(64 * ST_LINES), 0, s, P);  // one wavefront per scan line
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
     }
@@ -2340,11 +2495,10 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     hipStream_t s = MML_STREAM(ctx);
     const int t = (n > ctx->L ? n : ctx->L);
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
-    const int pblocks = (n + STENCIL_PTS - 1) / STENCIL_PTS;
     MML_HIP(hipMemsetAsync(ctx->brk_cnt, 0, sizeof(int), s));
     MML_HIP(hipMemsetAsync(ctx->brk_cnt + ctx->B, 0, sizeof(int), s));
-    if (pblocks > 0) {
-        hipLaunchKernelGGL(k_stencil, dim3(pblocks, 1), dim3(256), 0, s, P);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_stencil, dim3(1, 1), dim3(64 * ST_LINES), 0, s, P);  // line 0 holds the whole input
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, 1), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, 1), dim3(256), 0, s, P);
     }

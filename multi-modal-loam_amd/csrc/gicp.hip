@@ -10,7 +10,7 @@
 //   k_gicp_cov   one lane per point: exact 20-NN in its own cloud by brute force over LDS tiles (the clouds are a few
 //                hundred to a few thousand surf points -- the search grid of the association would cost more to build
 //                than the N^2 distance tests), top-20 list as sorted 64-bit (distance, index) keys in registers, second
-//                moments in neighbour order, symmetric eigen-solver, covariance U diag(1, 1, 1e-3) U^T
+//                moments in neighbour order, symmetric eigen-solver, covariance = sum of v_k u_k u_k^T as PCL forms it (v = 1, 1, 1e-3)
 //   k_gicp_corr  one lane per source point: transform with the current estimate, exact 1-NN in the target, Mahalanobis
 //                matrix (R C1 R^T + C2)^-1
 //   k_gicp_bfgs  ONE workgroup: the whole inner BFGS minimisation of f(x) = 1/m sum res^T M res over x = (t, roll, pitch, yaw).
@@ -97,15 +97,21 @@ __global__ __launch_bounds__(256) void k_gicp_cov(const float4* __restrict__ pts
     c20 = c20 / kk - mean[2] * mean[0];
     c21 = c21 / kk - mean[2] * mean[1];
     c22 = c22 / kk - mean[2] * mean[2];
-    double ev[3], u2[3], u0[3];
-    eig3_sym(c00, c10, c11, c20, c21, c22, ev, u2, u0);
-    // U diag(1, 1, eps) U^T with U orthonormal = I - (1 - eps) u0 u0^T (u0: eigenvector of the smallest eigenvalue)
+    double ev[3], u2[3], u0[3], u1[3];
+    eig3_sym(c00, c10, c11, c20, c21, c22, ev, u2, u0, u1);
+    // PCL (gicp.hpp computeCovariances): cov = sum_k v_k col_k col_k^T over the columns of U in the SVD's order -- singular values
+    // descending --, v = 1, 1, gicp_epsilon; each term is (v col[r]) col[s], added to the matrix one k after the other
     double* o = cov + 9 * (size_t)i;
-    const double w = 1.0 - GICP_EPS;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) o[3 * r + s] = (r == s ? 1.0 : 0.0) - w * u0[r] * u0[s];
+        for (int s = 0; s < 3; ++s) {
+            double a = 0.0;
+            a += (1.0 * u2[r]) * u2[s];
+            a += (1.0 * u1[r]) * u1[s];
+            a += (GICP_EPS * u0[r]) * u0[s];
+            o[3 * r + s] = a;
+        }
 }
 
 __device__ __forceinline__ void tf_pt(const float* T, float x, float y, float z, float* o) {
@@ -197,62 +203,64 @@ __device__ void apply_state(const double* x, float* T) {  // GeneralizedIterativ
     T[15] = 1.f;
 }
 
+constexpr int EV_CH = 512;            // correspondences per LDS chunk of an objective evaluation
+constexpr int EV_ROW = EV_CH + 1;     // row stride of the term table (odd number of 8-byte words: the 13 summing lanes hit 13 banks)
 struct EvalCtx {
     const float4* src;
     const float4* tgt;
     const int* corr;
     const double* maha;
     int m;
-    double* s_red;  // LDS: waves x 13, then 13 totals
+    double* s_terms;  // LDS: 13 rows x EV_ROW terms of the current chunk
+    double* s_tot;    // LDS: the 13 totals
 };
 
-__device__ __forceinline__ double shfl_xor_d(double v, int o) {
-    const unsigned lo = __shfl_xor((unsigned)__double2loint(v), o), hi = __shfl_xor((unsigned)__double2hiint(v), o);
-    return __hiloint2double((int)hi, (int)lo);
-}
-
-// OptimizationFunctorWithIndices::operator() / fdf: every thread returns the same f and (optionally) gradient
+// OptimizationFunctorWithIndices::operator() / fdf: every thread returns the same f and (optionally) gradient.
+// PCL adds the m terms of every sum one after the other; so does this: the terms of a chunk of correspondences are formed in
+// parallel into an LDS table and ONE lane per sum adds them in correspondence order (the 13 sums on 13 lanes at once), so
+// that f and the gradient equal the sequential loop's bit for bit -- the line search compares objective values that differ
+// in their last bits near the flat minimum of a cross-sensor alignment, and a strided pass with a tree reduction decides
+// some of those comparisons the other way (round 2: matrices equal to 5e-3 only).
 __device__ double gicp_eval(const EvalCtx& E, const double* x, double* g) {
     float T[16];
     apply_state(x, T);
-    double acc[13];
+    const int nsum = g ? 13 : 1;
+    double run = 0;
+    for (int c0 = 0; c0 < E.m; c0 += EV_CH) {
+        const int cnt = min(EV_CH, E.m - c0);
+        for (int j = threadIdx.x; j < cnt; j += BF_THREADS) {
+            const int i = c0 + j;
+            const float4 ps = E.src[i], pt = E.tgt[E.corr[i]];
+            float pp[3];
+            tf_pt(T, ps.x, ps.y, ps.z, pp);
+            const double res[3] = {(double)(pp[0] - pt.x), (double)(pp[1] - pt.y), (double)(pp[2] - pt.z)};
+            const double* M = E.maha + 9 * (size_t)i;
+            double tmp[3];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) acc[k] = 0;
-    for (int i = threadIdx.x; i < E.m; i += BF_THREADS) {
-        const float4 ps = E.src[i], pt = E.tgt[E.corr[i]];
-        float pp[3];
-        tf_pt(T, ps.x, ps.y, ps.z, pp);
-        const double res[3] = {(double)(pp[0] - pt.x), (double)(pp[1] - pt.y), (double)(pp[2] - pt.z)};
-        const double* M = E.maha + 9 * (size_t)i;
-        double tmp[3];
+            for (int r = 0; r < 3; ++r) tmp[r] = (M[3 * r] * res[0] + M[3 * r + 1] * res[1]) + M[3 * r + 2] * res[2];
+            E.s_terms[j] = (res[0] * tmp[0] + res[1] * tmp[1]) + res[2] * tmp[2];
+            if (g) {
+                const double p3[3] = {(double)ps.x, (double)ps.y, (double)ps.z};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) tmp[r] = (M[3 * r] * res[0] + M[3 * r + 1] * res[1]) + M[3 * r + 2] * res[2];
-        acc[0] += (res[0] * tmp[0] + res[1] * tmp[1]) + res[2] * tmp[2];
-        const double p3[3] = {(double)ps.x, (double)ps.y, (double)ps.z};
+                for (int r = 0; r < 3; ++r) {
+                    E.s_terms[(1 + r) * EV_ROW + j] = tmp[r];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            acc[1 + r] += tmp[r];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[4 + 3 * r + c] += p3[r] * tmp[c];
+                    for (int c = 0; c < 3; ++c) E.s_terms[(4 + 3 * r + c) * EV_ROW + j] = p3[r] * tmp[c];
+                }
+            }
         }
+        __syncthreads();
+        if ((int)threadIdx.x < nsum) {
+            const double* row = E.s_terms + threadIdx.x * EV_ROW;
+            for (int j = 0; j < cnt; ++j) run += row[j];
+        }
+        __syncthreads();
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        double v = acc[k];
-        for (int o = 32; o > 0; o >>= 1) v += shfl_xor_d(v, o);
-        if (lane == 0) E.s_red[wave * 13 + k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 13) {
-        double v = E.s_red[threadIdx.x];
-        for (int w = 1; w < BF_THREADS / 64; ++w) v += E.s_red[w * 13 + threadIdx.x];
-        E.s_red[(BF_THREADS / 64) * 13 + threadIdx.x] = v;
-    }
+    if ((int)threadIdx.x < nsum) E.s_tot[threadIdx.x] = run;
     __syncthreads();
     double tot[13];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) tot[k] = E.s_red[(BF_THREADS / 64) * 13 + k];
+    for (int k = 0; k < 13; ++k) tot[k] = k < nsum ? E.s_tot[k] : 0.0;
     __syncthreads();
     const double m = (double)E.m;
     if (g) {
@@ -568,13 +576,14 @@ __device__ int bfgs_iterate(Bfgs& B, const EvalCtx& E) {
 
 __global__ __launch_bounds__(BF_THREADS) void k_gicp_bfgs(const float4* src, const float4* tgt, const int* corr, const double* maha, int m,
                                                          GicpState* st) {
-    __shared__ double s_red[(BF_THREADS / 64 + 1) * 13];
+    __shared__ double s_terms[13 * EV_ROW];
+    __shared__ double s_tot[13];
     if (st->converged || st->failed) return;
     if (m < 4) {  // NotEnoughPointsException: the outer loop ends unconverged
         if (threadIdx.x == 0) st->failed = 1;
         return;
     }
-    EvalCtx E{src, tgt, corr, maha, m, s_red};
+    EvalCtx E{src, tgt, corr, maha, m, s_terms, s_tot};
     float T[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) T[c] = st->T[c];
@@ -641,33 +650,49 @@ __global__ void k_gicp_init(GicpState* st) {
     }
 }
 
-// the slot's surf clouds: label list of kind 1 = ascending bucketed positions, Velodyne lines below NV, Livox lines from NV
-__global__ void k_gicp_gather(const float4* ln_pts, const unsigned* list, int nsel, int NV, float4* velo, float4* livox, int* counts) {
-    __shared__ int s_split;
-    if (threadIdx.x == 0) {  // every block finds the split for itself (log2(nsel) loads)
-        int lo = 0, hi = nsel;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((int)list[mid] < NV)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        s_split = lo;
-        if (blockIdx.x == 0) {
-            counts[0] = lo;
-            counts[1] = nsel - lo;
-        }
-    }
+// The slot's surf clouds as the feature node builds them (unionFeatureExtract.cpp:1024-1031, :1242-1252): the points labelled 2 in
+// the order of the sensor's RAW cloud, the Velodyne one cropped near + far (:1287-1293), the Livox one near only (:925) --
+// its labelled points beyond far_th carry bit 7 in their label byte.  One wavefront per sensor walks the raw line ids in
+// order and rebuilds every point's bucketed position (line start + rank among the earlier points of its line), which is
+// where its label and its coordinates live.  Not a hot path: one slot, once per refresh.
+__global__ __launch_bounds__(64) void k_gicp_gather_raw(const uint8_t* raw_line, const int* n_in, const int* line_start, const uint8_t* label,
+                                                       const float4* ln_pts, int NV, int n_rings, float4* velo, float4* livox, int* counts) {
+    __shared__ int s_run[256];
+    const int sensor = blockIdx.x, lane = threadIdx.x;
+    const int n = n_in[sensor], region = sensor == 0 ? 0 : NV;
+    for (int k = lane; k < 256; k += 64) s_run[k] = 0;
     __syncthreads();
-    const int split = s_split;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nsel; i += gridDim.x * blockDim.x) {
-        const float4 p = ln_pts[list[i]];
-        if (i < split)
-            velo[i] = p;
-        else
-            livox[i - split] = p;
+    float4* out = sensor == 0 ? velo : livox;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int n_out = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const int key = i < n ? (int)raw_line[region + i] : 255;
+        const bool valid = key < 254;
+        unsigned long long eq = __ballot(valid);  // lanes holding the same line id as mine
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (key >> bit) & 1;
+            const unsigned long long bm = __ballot(valid && set);
+            eq &= set ? bm : ~bm;
+        }
+        int pos = 0;
+        if (valid) pos = s_run[key] + __popcll(eq & lt);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (eq & lt) == 0) s_run[key] += __popcll(eq);
+        __builtin_amdgcn_wave_barrier();
+        bool take = false;
+        int p = 0;
+        if (valid) {
+            p = line_start[(sensor == 0 ? 0 : n_rings) + key] + pos;
+            const unsigned l = label[p];
+            take = (l & 3u) == 2u && l < (sensor == 0 ? 0x80u : 0x100u);
+        }
+        const unsigned long long wm = __ballot(take);
+        if (take) out[n_out + __popcll(wm & lt)] = ln_pts[p];
+        n_out += __popcll(wm);
     }
+    if (lane == 0) counts[sensor] = n_out;
 }
 
 __global__ void k_gicp_apply(float4* pts, int n, const float* T) {  // pcl::transformPointCloud, float (PCL 1.8.1)
@@ -771,23 +796,25 @@ extern "C" int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, 
     hipStream_t s = MML_STREAM(ctx);
     if (refreshed) *refreshed = 0;
     if (info) memset(info, 0, sizeof(*info));
-    int fi[8];
+    int fi[8], cb[2], fl[2];  // counters; valid points per sensor region of the slot's storage; the slot's state flags
     MML_HIP(hipMemcpyAsync(fi, ctx->fu_info + 8 * (size_t)slot, sizeof(fi), hipMemcpyDeviceToHost, s));
-    MML_HIP(hipStreamSynchronize(s));
-    if (!(fi[4] > 100)) return MML_OK;  // union_msg.livox_corner_num > 100 (unionFeatureExtract.cpp:302)
-    const int nsel = fi[7];
-    int cb[2];  // valid points per sensor region of the slot's storage
     MML_HIP(hipMemcpyAsync(cb, ctx->cb_n + 2 * (size_t)slot, sizeof(cb), hipMemcpyDeviceToHost, s));
+    MML_HIP(hipMemcpyAsync(fl, ctx->slot_flags + 2 * (size_t)slot, sizeof(fl), hipMemcpyDeviceToHost, s));
     MML_HIP(hipStreamSynchronize(s));
+    // the refresh belongs to the feature node: it aligns the surf clouds of the EXTRACTED scan (raw coordinates, raw order)
+    MML_REQUIRE((fl[0] & 3) == 0, MML_ERR_STATE,
+                "mml_gicp_refresh: the slot holds an uploaded or undistorted cloud (call it after mml_extract, before mml_undistort)");
+    if (!(fi[4] > 100)) return MML_OK;  // union_msg.livox_corner_num > 100 (unionFeatureExtract.cpp:302)
     Scratch S;
-    bool ok = S.take((void**)&S.src, sizeof(float4) * (size_t)(nsel + 1)) && S.take((void**)&S.tgt, sizeof(float4) * (size_t)(nsel + 1)) &&
+    bool ok = S.take((void**)&S.src, sizeof(float4) * (size_t)(cb[1] + 1)) && S.take((void**)&S.tgt, sizeof(float4) * (size_t)(cb[0] + 1)) &&
               S.take((void**)&S.counts, sizeof(int) * 2) && S.take((void**)&S.dT, sizeof(float) * 16);
     MML_REQUIRE(ok, MML_ERR_HIP, "mml_gicp_refresh: device allocation failed");
     int cnt[2] = {0, 0};
-    if (nsel > 0) {
-        const unsigned* list = reinterpret_cast<const unsigned*>(ctx->vx_keys) + ((size_t)slot * 2 + 1) * ctx->VX_CAP;
-        hipLaunchKernelGGL(k_gicp_gather, dim3((nsel + 255) / 256), dim3(256), 0, s, ctx->ln_pts + (size_t)slot * ctx->NT, list, nsel, ctx->NV,
-                           S.tgt, S.src, S.counts);
+    {
+        const size_t o = (size_t)slot * ctx->NT;
+        hipLaunchKernelGGL(k_gicp_gather_raw, dim3(2), dim3(64), 0, s, ctx->raw_line + o, ctx->d_n_in + 2 * (size_t)slot,
+                           ctx->line_start + (size_t)slot * ctx->L, ctx->ln_label + o, ctx->ln_pts + o, ctx->NV, ctx->cfg.n_rings, S.tgt, S.src,
+                           S.counts);
         MML_HIP(hipMemcpyAsync(cnt, S.counts, sizeof(cnt), hipMemcpyDeviceToHost, s));
         MML_HIP(hipStreamSynchronize(s));
     }

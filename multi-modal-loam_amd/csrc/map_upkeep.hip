@@ -371,12 +371,29 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
     const int nseg = 2 * count;
     // scratch for the worst case (every point of every slot labelled), allocated on first use
     const size_t cap = (size_t)ctx->B * ctx->NT;
-    if (!ctx->seg_keys) {
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_keys), sizeof(unsigned long long) * 2 * cap));
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_vals), sizeof(unsigned) * 2 * cap));
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_cat), sizeof(float4) * cap));
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_flag), sizeof(int) * 2 * (cap + 1)));
-        MML_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->seg_meta), sizeof(int) * (8 * (size_t)ctx->B * 2 + 16) * mml_ctx::MAX_LANES));
+    if (!ctx->seg_meta) {  // seg_meta is set last: it marks the scratch as complete
+        const hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&ctx->seg_keys), sizeof(unsigned long long) * 2 * cap);
+        const hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&ctx->seg_vals), sizeof(unsigned) * 2 * cap);
+        const hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&ctx->seg_cat), sizeof(float4) * cap);
+        const hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&ctx->seg_flag), sizeof(int) * 2 * (cap + 1));
+        int* meta_buf = nullptr;
+        const hipError_t e5 = hipMalloc(reinterpret_cast<void**>(&meta_buf), sizeof(int) * (8 * (size_t)ctx->B * 2 + 16) * mml_ctx::MAX_LANES);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+            // all or nothing: a later call must not find a half-allocated scratch and launch on null buffers
+            (void)hipFree(ctx->seg_keys);
+            (void)hipFree(ctx->seg_vals);
+            (void)hipFree(ctx->seg_cat);
+            (void)hipFree(ctx->seg_flag);
+            (void)hipFree(meta_buf);
+            ctx->seg_keys = nullptr;
+            ctx->seg_vals = nullptr;
+            ctx->seg_cat = nullptr;
+            ctx->seg_flag = nullptr;
+            (void)hipGetLastError();
+            ctx->err = "mml_downsample_big: out of device memory for the global-sort scratch";
+            return MML_ERR_HIP;
+        }
+        ctx->seg_meta = meta_buf;
     }
     // lanes work on disjoint slot ranges: each gets the part of the scratch that its slots' points can fill
     const size_t base = (size_t)first * ctx->NT;

@@ -132,7 +132,8 @@ struct mml_ctx {
     uint8_t* ln_line = nullptr;   // B * NT  ring / Livox line (normal_y) of an UPLOADED cloud (an extracted one has its line table)
     int* slot_flags = nullptr;    // B * 2   [0] bit 0: filled by mml_cloud_upload, bit 1: undistorted (in-sweep time reads 1);
                                   //         [1] bit 1 as it was when the current mml_undistort started
-    uint8_t* ln_label = nullptr;  // B * NT  0 none / 1 corner / 2 surf (normal_z), non-zero only for kept points
+    uint8_t* ln_label = nullptr;  // B * NT  0 none / 1 corner / 2 surf (normal_z) for kept points; 0x81 / 0x82 for labelled Livox
+                                  //         points beyond far_th (counted in livox_*_num and aligned by the GICP refresh, not fused)
     int* fu_info = nullptr;  // B * 8: n_points, n_velo, vc, vs, lc, ls, fused corner, fused surf
 
     // down-sampled feature stacks: kind 0 corner, 1 surf

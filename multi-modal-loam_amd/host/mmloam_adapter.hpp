@@ -68,14 +68,17 @@ class Context {
             mml_config_default(&c, max_scans);
         int rc = mml_create(&c, device, &ctx_);
         if (rc != MML_OK) throw std::runtime_error("mml_create failed (no HIP device? there is no CPU fallback)");
+        cfg_ = c;
     }
     ~Context() { mml_destroy(ctx_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     mml_ctx* get() const { return ctx_; }
+    const mml_config& config() const { return cfg_; }
 
    private:
     mml_ctx* ctx_ = nullptr;
+    mml_config cfg_;
 };
 
 // ---- feature_extraction (unionFeatureExtract.cpp:143-1320), hot-path members only -----------------------------------
@@ -198,9 +201,14 @@ inline void RemoveLidarDistortion(Context& ctx, int slot, const Matrix3d& dRlc, 
 
 // A labelled cloud that arrived over /union_feature_cloud (velo_combine followed by livox_combine, the merge of
 // unionPoseEstimation.cpp:746-757) -> scan slot: pcl::fromROSMsg on the device.  n_velo = velo_combine's size.
+// n_velo = -1 (the caller does not know the split, as the reference's RemoveLidarDistortion does not): the cloud fills the
+// Velodyne region first and spills the rest into the Livox region, so a merged cloud of up to max_velo_points +
+// max_livox_points is accepted; the velo_* / livox_* label counts and mml_gicp_refresh are then not meaningful for the slot
+// (undistortion, down-sampling and the estimator do not depend on the split).
 inline void uploadCloud(Context& ctx, int slot, const PointCloud& cloud, int n_velo = -1) {
     const int n = (int)cloud.size();
-    check(ctx.get(), mml_cloud_upload(ctx.get(), slot, reinterpret_cast<const uint8_t*>(cloud.data()), n, n_velo < 0 ? n : n_velo),
+    if (n_velo < 0) n_velo = n < ctx.config().max_velo_points ? n : ctx.config().max_velo_points;
+    check(ctx.get(), mml_cloud_upload(ctx.get(), slot, reinterpret_cast<const uint8_t*>(cloud.data()), n, n_velo),
           "mml_cloud_upload");
 }
 

@@ -75,12 +75,14 @@ void covariances(const float* pts, int n, std::vector<M3>& out) {
             }
         double ev[3], U[9];
         eig3_sym(c, ev, U);  // ascending eigenvalues, eigenvectors in the columns of U (row-major)
-        // singular values sorted descending in the SVD: the two largest -> 1, the smallest -> gicp_epsilon
+        // PCL (gicp.hpp computeCovariances): cov += v * col * col^T for k = 0, 1, 2 over the columns of the SVD's U, singular
+        // values descending: the two largest -> 1, the smallest -> gicp_epsilon.  Column 2 of U here = largest eigenvalue.
         M3& o = out[i];
-        for (int col = 0; col < 3; ++col) {
-            const double v = col == 0 ? GICP_EPS : 1.0;  // column 0 = smallest eigenvalue
+        for (int k = 0; k < 3; ++k) {
+            const int col = 2 - k;
+            const double v = k == 2 ? GICP_EPS : 1.0;
             for (int r = 0; r < 3; ++r)
-                for (int s = 0; s < 3; ++s) o.m[3 * r + s] += v * U[3 * r + col] * U[3 * s + col];
+                for (int s = 0; s < 3; ++s) o.m[3 * r + s] += (v * U[3 * r + col]) * U[3 * s + col];
         }
     }
 }

@@ -219,7 +219,7 @@ def main():
         l = synth.livox_scan(int(rng.integers(0, 3000))) if rng.integers(0, 2) else None
         kw = dict(n_rings=n_rings, pitch0=pitch0, pitch_step=step)
         cfgd = M.default_config(1, n_rings=n_rings, pitch0_deg=pitch0, pitch_step_deg=step, far_th=far, max_velo_points=len(v),
-                                max_livox_points=24000 if l is not None else 64, max_features=1 << 18)
+                                max_livox_points=24000 if l is not None else 0, max_features=1 << 18)
         cd = M.Context(cfgd)
         cd.scan_upload(0, v, l)
         cd.extract(0, 1)

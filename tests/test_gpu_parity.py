@@ -178,6 +178,29 @@ def test_extract_other_ring_layout(M, O, synth):
     c.close()
 
 
+def test_extract_velodyne_only_context(M, O, synth):
+    """A context without a Livox region (max_livox_points = 0): dense (64-ring, staged scatter) and 16-ring sensors.
+    The dense path used to launch its Livox scatter on an empty grid, which fails the whole extract."""
+    for rings, n_az, pitch0, step in ((64, 600, -25.0, np.float32(40.0 / 63.0)), (16, 900, -15.0, np.float32(2.0))):
+        v = synth.velo_scan(77, n_rings=rings, n_az=n_az, pitch0=pitch0, pitch_step=float(step))
+        c = M.Context(max_scans=2, max_velo_points=len(v), max_livox_points=0, n_rings=rings, pitch0_deg=pitch0,
+                      pitch_step_deg=step)
+        try:
+            c.scan_upload(1, v, None)
+            c.extract(1, 1)
+            d = c.scan_download(1)
+            o = O.extract_velo(v, n_rings=rings, pitch0=pitch0, pitch_step=step)
+            assert np.array_equal(d["xyzi"], o["xyzi"]) and np.array_equal(d["label"], o["label"])
+            assert np.array_equal(d["ring"], o["ring"]) and np.array_equal(d["reltime"], o["reltime"])
+            assert (d["label"] == 1).sum() > 10 and (d["label"] == 2).sum() > 100
+            c.undistort(1, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+            c.downsample(1, 1)
+            xyz = o["xyzi"][:, :3]
+            assert np.array_equal(c.features_download(1, 1), O.voxel_downsample(xyz[o["label"] == 2], 0.2))
+        finally:
+            c.close()
+
+
 def test_extract_livox_extrinsic_and_far_labels(M, O, synth):
     """unionFeatureExtract.cpp:302-318: the Livox part is moved by the extrinsic (pcl::transformPointCloud, float)
     only when livox_corner_num > 100; :925-940: that count includes labelled points beyond far_th, which are not
@@ -1182,9 +1205,9 @@ def test_gicp_align_matches_oracle(M, O, synth):
             okg, Tg, info = c.gicp_align(s_, t_)
             oko, To, ito, evo, fo = O.gicp_align(s_, t_)
             assert okg and oko
-            # same algorithm, same float transformation; the objective sums differ in their order of addition only
-            assert np.abs(Tg - To).max() < 2e-5, np.abs(Tg - To).max()
-            assert info.outer_iterations == ito and abs(info.objective - fo) <= 1e-6 * max(fo, 1e-9) + 1e-12
+            assert np.abs(Tg - To).max() <= 1e-6, np.abs(Tg - To).max()
+            assert info.outer_iterations == ito and info.objective_evaluations == evo
+            assert abs(info.objective - fo) <= 1e-9 * max(fo, 1e-9) + 1e-15
             assert (info.n_source, info.n_target) == (len(s_), len(t_))
         # two different samplings of the room (Livox surf vs Velodyne surf) and clouds beyond one LDS tile: the minimum is
         # flat, the objective is evaluated with a float transformation (as in PCL), and 10 outer iterations stop short of
@@ -1194,8 +1217,10 @@ def test_gicp_align_matches_oracle(M, O, synth):
             okg, Tg, info = c.gicp_align(s_, t_)
             oko, To, ito, evo, fo = O.gicp_align(s_, t_)
             assert okg and oko and 1 <= info.outer_iterations <= 10
-            assert np.abs(Tg - To).max() < 5e-3, np.abs(Tg - To).max()
-            assert abs(info.objective - fo) <= 0.02 * fo
+            # the objective and gradient sums are taken in correspondence order on both sides: same iterates
+            assert np.abs(Tg - To).max() <= 1e-6, np.abs(Tg - To).max()
+            assert info.outer_iterations == ito and info.objective_evaluations == evo
+            assert abs(info.objective - fo) <= 1e-9 * fo
         okg, Tg, _ = c.gicp_align(src, vs)
         assert np.abs(Tg - Tt).max() < 1e-4                              # and it actually recovers the displacement
         T0 = np.eye(4, dtype=np.float32)
@@ -1209,36 +1234,48 @@ def test_gicp_align_matches_oracle(M, O, synth):
 
 def test_gicp_refresh_on_a_slot(M, O, synth):
     """unionCloudHandler's refresh (unionFeatureExtract.cpp:302-318) on the extracted cloud of a slot: Livox surf -> Velodyne
-    surf, extri_mtx updated, Livox part of the fused cloud transformed; skipped when livox_corner_num <= 100."""
-    c = M.Context(max_scans=2)
-    try:
-        v, l = synth.velo_scan(14), synth.livox_scan(14)
-        c.scan_upload(0, v, l)
-        c.scan_upload(1, v, l[:3000])                                   # too few Livox corners for the refresh
-        c.extract(0, 2)
-        before = [c.scan_download(s) for s in range(2)]
-        assert before[0]["info"].livox_corner_num > 100 and before[1]["info"].livox_corner_num <= 100
-        nv = before[0]["info"].n_velo
-        lab, xyz = before[0]["label"], before[0]["xyzi"][:, :3]
-        vs, ls = xyz[:nv][lab[:nv] == 2], xyz[nv:][lab[nv:] == 2]
-        ok, T, info = c.gicp_refresh(0, np.eye(4), apply=True)
-        oko, To, ito, _, _ = O.gicp_align(ls, vs)
-        assert ok and oko and np.abs(T - To).max() < 5e-3            # (cross-sensor case: see test_gicp_align_matches_oracle)
-        assert (info.n_source, info.n_target) == (len(ls), len(vs))
-        after = c.scan_download(0)
-        assert np.array_equal(after["xyzi"][:nv], before[0]["xyzi"][:nv]) and np.array_equal(after["label"], lab)
-        p = before[0]["xyzi"][nv:, :3]
-        exp = np.stack([T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1] + T[r, 2] * p[:, 2] + T[r, 3] for r in range(3)], 1)   # float, PCL's order
-        assert np.array_equal(after["xyzi"][nv:, :3], exp.astype(np.float32))
-        assert np.array_equal(after["xyzi"][nv:, 3], before[0]["xyzi"][nv:, 3])
-        T1 = np.eye(4, dtype=np.float32)
-        T1[2, 3] = 0.125
-        ok, T, _ = c.gicp_refresh(1, T1, apply=True)
-        assert not ok and np.array_equal(T, T1)
-        a1 = c.scan_download(1)
-        assert np.array_equal(a1["xyzi"], before[1]["xyzi"])             # nothing applied either (:302)
-    finally:
-        c.close()
+    surf, extri_mtx updated, Livox part of the fused cloud transformed; skipped when livox_corner_num <= 100.  The source is
+    the reference's livoSurfPtr: label-2 Livox points in raw order, near-cropped ONLY (:925) -- with far_th = 6 m most of it lies
+    beyond the fused cloud.  The oracle's input comes from the oracle's own extraction, not from the device cloud."""
+    v, l = synth.velo_scan(14), synth.livox_scan(14)
+    for far in (50.0, 6.0):
+        c = M.Context(max_scans=2, far_th=far)
+        try:
+            c.scan_upload(0, v, l)
+            c.scan_upload(1, v, l[:3000])                                   # too few Livox corners for the refresh
+            c.extract(0, 2)
+            before = [c.scan_download(s) for s in range(2)]
+            assert before[0]["info"].livox_corner_num > 100 and before[1]["info"].livox_corner_num <= 100
+            nv = before[0]["info"].n_velo
+            lab = before[0]["label"]
+            ev, el_near = O.extract_velo(v, far=far), O.extract_livox(l, far=1e9)
+            vs = ev["xyzi"][ev["label"] == 2][:, :3].copy()                  # veloSurfPtr: near + far crop (:1287-1293)
+            ls = el_near["xyzi"][el_near["label"] == 2][:, :3].copy()        # livoSurfPtr: near crop only (:925)
+            n_fused_ls = int((lab[nv:] == 2).sum())
+            assert (len(ls) > n_fused_ls) == (far < 50.0)
+            ok, T, info = c.gicp_refresh(0, np.eye(4), apply=True)
+            oko, To, ito, evo, fo = O.gicp_align(ls, vs)
+            assert (info.n_source, info.n_target) == (len(ls), len(vs))
+            assert ok and oko and np.abs(T - To).max() <= 1e-6, np.abs(T - To).max()
+            assert info.outer_iterations == ito and info.objective_evaluations == evo
+            after = c.scan_download(0)
+            assert np.array_equal(after["xyzi"][:nv], before[0]["xyzi"][:nv]) and np.array_equal(after["label"], lab)
+            p = before[0]["xyzi"][nv:, :3]
+            exp = np.stack([T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1] + T[r, 2] * p[:, 2] + T[r, 3] for r in range(3)], 1)   # float, PCL's order
+            assert np.array_equal(after["xyzi"][nv:, :3], exp.astype(np.float32))
+            assert np.array_equal(after["xyzi"][nv:, 3], before[0]["xyzi"][nv:, 3])
+            T1 = np.eye(4, dtype=np.float32)
+            T1[2, 3] = 0.125
+            ok, T, _ = c.gicp_refresh(1, T1, apply=True)
+            assert not ok and np.array_equal(T, T1)
+            a1 = c.scan_download(1)
+            assert np.array_equal(a1["xyzi"], before[1]["xyzi"])             # nothing applied either (:302)
+            # the refresh belongs between extract and undistort: an undistorted slot is refused
+            c.undistort(1, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+            with pytest.raises(Exception):
+                c.gicp_refresh(1, T1, apply=True)
+        finally:
+            c.close()
 
 
 def test_scan_upload_batch_equals_per_scan_upload(M, synth):
