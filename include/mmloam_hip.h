@@ -384,6 +384,23 @@ int mml_comm_broadcast_features(mml_ctx* ctx, int slot, int root);
  * kNN grids there.  Collective; synchronises the ctx. */
 int mml_comm_broadcast_local_map(mml_ctx* ctx, int root);
 
+/* ---- loopback group: the N-rank path on ONE device (test / bring-up entry points) -------------------------------------
+ * RCCL refuses two ranks on one device, so the rank > 0 side of the three exchanges above -- the section offsets of the
+ * gather buffers, "linearise only my frames", a broadcast whose root is another rank -- cannot run through mml_comm_init on
+ * a single-GPU box.  A loopback group makes n_ranks contexts of ONE process on ONE device the ranks 0 .. n_ranks-1
+ * (ctxs[r] = rank r) of a communicator whose collectives are executed by the calling thread as device-to-device copies
+ * between the ranks' buffers; kernels, buffers and the device-resident state machine are those of the RCCL path.  Each
+ * call drives ALL ranks (it is the collective).  Not a deployment mode: no overlap, every exchange drains the streams. */
+int mml_comm_init_loopback(mml_ctx** ctxs, int n_ranks);
+/* mml_window_solve_allgather for every rank of the group: rank r owns window frames [r * n_local, (r + 1) * n_local) in
+ * its slots [first_slot[r], first_slot[r] + n_local).  x_window_in: W x 6 starting poses; x_window_out: n_ranks x W x 6,
+ * the window as EVERY rank ends up holding it (they must be identical); summaries (may be NULL): n_ranks. */
+int mml_window_solve_allgather_loopback(mml_ctx** ctxs, int n_ranks, const int* first_slot, int n_local, const double* T_bl,
+                                        const mml_solve_opts* opts, const double* x_window_in, double* x_window_out,
+                                        mml_solve_summary* summaries);
+int mml_comm_broadcast_features_loopback(mml_ctx** ctxs, int n_ranks, int slot, int root);
+int mml_comm_broadcast_local_map_loopback(mml_ctx** ctxs, int n_ranks, int root);
+
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the ctx stream. */
 #define MML_MAX_STAGES 32

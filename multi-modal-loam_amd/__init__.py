@@ -74,6 +74,42 @@ class WindowTiming(C.Structure):
 COMM_ID_BYTES = 128
 
 
+class LoopbackGroup:
+    """N contexts of this process on one device as the ranks 0 .. N-1 of a communicator whose collectives are device copies
+    (mml_comm_*_loopback): the N-rank path of the C-ABI on a single GPU.  Every call drives all ranks."""
+
+    def __init__(self, contexts):
+        self.ctxs = list(contexts)
+        self.n = len(self.ctxs)
+        self._arr = (C.c_void_p * self.n)(*[c._h for c in self.ctxs])
+        self._ck(lib().mml_comm_init_loopback(self._arr, C.c_int(self.n)), "mml_comm_init_loopback")
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            errs = [lib().mml_last_error(c._h).decode() for c in self.ctxs]
+            raise MmlError(rc, what + ": " + " | ".join(e for e in errs if e))
+
+    def window_solve(self, first_slots, n_local, x_window, T_bl, max_iters=10, fixed=False, huber=0.0, w_tan=3e-4):
+        """Returns (n_ranks x W x 6 poses as every rank holds them, per-rank summaries)."""
+        W = self.n * n_local
+        x = _f64(x_window).reshape(W, 6).copy()
+        out = np.zeros((self.n, W, 6))
+        fs = np.ascontiguousarray(first_slots, dtype=np.int32)
+        opts = SolveOpts(max_iters, 1 if fixed else 0, huber, w_tan)
+        summ = (SolveSummary * self.n)()
+        self._ck(lib().mml_window_solve_allgather_loopback(self._arr, C.c_int(self.n), _p(fs), C.c_int(n_local), _p(_f64(T_bl).reshape(16)),
+                                                           C.byref(opts), _p(x), _p(out), summ), "mml_window_solve_allgather_loopback")
+        return out, list(summ)
+
+    def broadcast_features(self, slot, root):
+        self._ck(lib().mml_comm_broadcast_features_loopback(self._arr, C.c_int(self.n), C.c_int(slot), C.c_int(root)),
+                 "mml_comm_broadcast_features_loopback")
+
+    def broadcast_local_map(self, root):
+        self._ck(lib().mml_comm_broadcast_local_map_loopback(self._arr, C.c_int(self.n), C.c_int(root)),
+                 "mml_comm_broadcast_local_map_loopback")
+
+
 def comm_unique_id():
     """ncclGetUniqueId through the C-ABI: called by one rank, handed to mml_comm_init of every rank."""
     buf = (C.c_uint8 * COMM_ID_BYTES)()

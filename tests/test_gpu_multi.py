@@ -127,3 +127,97 @@ def test_window_solve_allgather_world_size_one(M, O, scene):
             c.comm_info()
     finally:
         c.close()
+
+
+def _rank_contexts(M, scene, n_ranks, n_local, x0, first_slots):
+    """The 8-frame window of _window8 split over n_ranks contexts on this device: rank r holds window frames
+    [r n_local, (r + 1) n_local) in ITS slots first_slots[r] ..., associated at the window's starting poses."""
+    ctxs = []
+    rng = np.random.default_rng(8)
+    T = [perturbed(scene["frames"][f % 4]["T_gt"], dt=rng.normal(0, 0.02, 3), rotvec=rng.normal(0, 0.003, 3)) for f in range(W8)]
+    assert np.allclose(np.stack([pose_to_x(t) for t in T]), x0)          # the same frames and poses as _window8
+    for r in range(n_ranks):
+        c = M.Context(max_scans=first_slots[r] + n_local)
+        c.map_set_local(0, scene["corner_map"])
+        c.map_set_local(1, scene["surf_map"])
+        for k in range(n_local):
+            f = r * n_local + k
+            fr = scene["frames"][f % 4]
+            c.features_upload(first_slots[r] + k, 0, fr["corner"])
+            c.features_upload(first_slots[r] + k, 1, fr["surf"])
+        c.associate(first_slots[r], n_local, np.stack(T[r * n_local:(r + 1) * n_local]), 1.0, stats=False)
+        ctxs.append(c)
+    return ctxs
+
+
+@pytest.mark.parametrize("n_ranks,n_local", [(2, 4), (8, 1), (4, 2)])
+def test_window_solve_ranks_on_one_device(M, O, scene, n_ranks, n_local):
+    """The rank > 0 side of mml_window_solve_allgather on a single GPU: N contexts as the N ranks of a loopback group (the
+    all-gather = device copies between the ranks' gather buffers; kernels, buffers, state machine as in the RCCL path).
+    Every rank linearises only ITS frames into ITS section of the record buffer, all advance the same dogleg -- and every
+    rank must end with the poses of mml_solve(window = 8) on one context, bit for bit (Estimator.cpp:1265-1299,1425-1432)."""
+    ref, lfs, pfs, x0, T_bl = _window8(M, O, scene)
+    first_slots = [(r * 3) % 2 for r in range(n_ranks)]                  # ranks keep their frames in different slots
+    ctxs = _rank_contexts(M, scene, n_ranks, n_local, x0, first_slots)
+    try:
+        grp = M.LoopbackGroup(ctxs)
+        assert [c.comm_info() for c in ctxs] == [(n_ranks, r) for r in range(n_ranks)]
+        for fixed, huber, w_tan in ((False, 0.0, 3e-4), (True, 0.1 / 1.5e-3, 0.0)):
+            xs, ss, _ = ref.solve(0, W8, x0, T_bl, window=W8, max_iters=10, fixed=fixed, huber=huber, w_tan=w_tan)
+            xr, sr = grp.window_solve(first_slots, n_local, x0, T_bl, max_iters=10, fixed=fixed, huber=huber, w_tan=w_tan)
+            for r in range(n_ranks):
+                assert np.array_equal(xr[r], xs), (r, np.abs(xr[r] - xs).max())
+                assert (sr[r].iterations, sr[r].successful, sr[r].termination) == (ss[0].iterations, ss[0].successful, ss[0].termination)
+                assert sr[r].initial_cost == ss[0].initial_cost and sr[r].final_cost == ss[0].final_cost
+        # a start far enough away for rejected steps
+        xf = x0.copy()
+        xf[:, :3] += np.random.default_rng(3).normal(0, 0.25, (W8, 3))
+        xs, ss, _ = ref.solve(0, W8, xf, T_bl, window=W8, max_iters=25, huber=0.0, w_tan=3e-4)
+        xr, sr = grp.window_solve(first_slots, n_local, xf, T_bl, max_iters=25, huber=0.0, w_tan=3e-4)
+        assert all(np.array_equal(xr[r], xs) for r in range(n_ranks)) and sr[-1].iterations == ss[0].iterations
+        # the RCCL entry point refuses a loopback group instead of touching a null communicator
+        with pytest.raises(M.MmlError):
+            ctxs[0].window_solve_allgather(first_slots[0], n_local, x0[:n_local], T_bl)
+    finally:
+        for c in ctxs:
+            c.close()
+        ref.close()
+
+
+def test_broadcasts_from_another_rank_on_one_device(M, O, scene):
+    """mml_comm_broadcast_features / _local_map with root != rank (Estimator.cpp:1083-1085, 1125-1130: the key scan's features
+    and the local map reach every replica): three ranks, root 1; ranks 0 and 2 start without a map."""
+    ctxs = [M.Context(max_scans=3) for _ in range(3)]
+    try:
+        root = ctxs[1]
+        root.map_set_local(0, scene["corner_map"])
+        root.map_set_local(1, scene["surf_map"])
+        fr = scene["frames"][1]
+        root.features_upload(2, 0, fr["corner"])
+        root.features_upload(2, 1, fr["surf"])
+        other = scene["frames"][2]
+        for c in (ctxs[0], ctxs[2]):                                      # something else in the slot: it must be replaced
+            c.features_upload(2, 0, other["corner"][:50])
+            c.features_upload(2, 1, other["surf"][:70])
+        grp = M.LoopbackGroup(ctxs)
+        grp.broadcast_features(2, 1)
+        for c in ctxs:
+            assert np.array_equal(c.features_download(2, 0), fr["corner"]) and np.array_equal(c.features_download(2, 1), fr["surf"])
+        with pytest.raises(M.MmlError):
+            grp.broadcast_local_map(0)                                    # rank 0 has no map to give
+        grp.broadcast_local_map(1)
+        q = fr["surf"][:200]
+        i1, d1 = root.knn5(1, q)
+        ic, dc = root.knn5(0, fr["corner"][:100])
+        for c in (ctxs[0], ctxs[2]):
+            i, d = c.knn5(1, q)
+            assert np.array_equal(i, i1) and np.array_equal(d, d1)
+            i, d = c.knn5(0, fr["corner"][:100])
+            assert np.array_equal(i, ic) and np.array_equal(d, dc)
+        # and the replicas register like the root does
+        T = np.stack([perturbed(fr["T_gt"], dt=[0.02, -0.01, 0.01], rotvec=[0.002, 0.001, -0.003])])
+        st = [c.associate(2, 1, T, 1.0) for c in ctxs]
+        assert st[0][0].n_line == st[1][0].n_line == st[2][0].n_line and st[0][0].n_plane == st[1][0].n_plane == st[2][0].n_plane
+    finally:
+        for c in ctxs:
+            c.close()
