@@ -39,6 +39,110 @@ MML_HD M3 m3_add(const M3& A, const M3& B) {
     return C;
 }
 
+// ---- sin / cos / atan written out once for both sides -----------------------------------------------------------------------
+// The host iteration and the device-resident one must take the same decisions, and the last bit of a sine decides some of them
+// (a step accepted or rejected at a model decrease of 1e-16): libm on the host and the device math library agree to an ulp,
+// not to the bit.  These are the classic fdlibm kernels (k_sin.c, k_cos.c, s_atan.c: minimax polynomials, Cody-Waite reduction
+// by pi/2 in two pieces -- arguments here are rotation angles, a few pi at most), plain double arithmetic in a fixed order and
+// compiled without contraction on both sides: identical results by construction, within an ulp of the libm values.
+MML_HD double mml_ksin(double x) {  // |x| <= pi/4
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+MML_HD double mml_kcos(double x) {  // |x| <= pi/4
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs(x);
+    if (ax < 0.3) return 1.0 - (0.5 * z - z * r);
+    const double qx = ax > 0.78125 ? 0.28125 : 0.25 * ax;
+    const double hz = 0.5 * z - qx, a = 1.0 - qx;
+    return a - (hz - z * r);
+}
+// x = n * pi/2 + y, |y| <= pi/4 (+ rounding); returns n mod 4
+MML_HD int mml_rem_pio2(double x, double& y) {
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    if (fabs(x) <= 0.78539816339744830962) {
+        y = x;
+        return 0;
+    }
+    const double fn = rint(x * invpio2);
+    const double r = x - fn * pio2_1, w = fn * pio2_1t;
+    y = r - w;
+    return (int)((long long)fn & 3);
+}
+MML_HD double mml_sin(double x) {
+    double y;
+    switch (mml_rem_pio2(x, y)) {
+        case 0: return mml_ksin(y);
+        case 1: return mml_kcos(y);
+        case 2: return -mml_ksin(y);
+        default: return -mml_kcos(y);
+    }
+}
+MML_HD double mml_cos(double x) {
+    double y;
+    switch (mml_rem_pio2(x, y)) {
+        case 0: return mml_kcos(y);
+        case 1: return -mml_ksin(y);
+        case 2: return -mml_kcos(y);
+        default: return mml_ksin(y);
+    }
+}
+MML_HD double mml_atan(double xin) {
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+                 aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+                 aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+    if (!(xin == xin)) return xin;
+    const bool neg = xin < 0.0;
+    double x = fabs(xin);
+    if (x >= 73786976294838206464.0) {  // 2^66: atan = +-pi/2
+        const double z = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
+        return neg ? -z : z;
+    }
+    double hi = 0.0, lo = 0.0;
+    int id = -1;
+    if (x < 0.4375) {
+        if (x < 1.862645149230957e-09) return xin;  // 2^-29
+    } else if (x < 1.1875) {
+        if (x < 0.6875) {
+            id = 0;
+            hi = 4.63647609000806093515e-01;
+            lo = 2.26987774529616870924e-17;
+            x = (2.0 * x - 1.0) / (2.0 + x);
+        } else {
+            id = 1;
+            hi = 7.85398163397448278999e-01;
+            lo = 3.06161699786838301793e-17;
+            x = (x - 1.0) / (x + 1.0);
+        }
+    } else if (x < 2.4375) {
+        id = 2;
+        hi = 9.82793723247329054082e-01;
+        lo = 1.39033110312309984516e-17;
+        x = (x - 1.5) / (1.0 + 1.5 * x);
+    } else {
+        id = 3;
+        hi = 1.57079632679489655800e+00;
+        lo = 6.12323399573676603587e-17;
+        x = -1.0 / x;
+    }
+    const double z = x * x, w = z * z;
+    const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) {
+        const double r = x - x * (s1 + s2);
+        return neg ? -r : r;
+    }
+    const double r = hi - ((x * (s1 + s2) - lo) - x);
+    return neg ? -r : r;
+}
+
 // Sophus::SO3d::exp (so3.hpp:585-622, epsilon 1e-10 on theta^2): rotation vector -> unit quaternion (x, y, z, w)
 MML_HD void so3_exp_q(const double* w, double* q) {
     const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
@@ -49,8 +153,8 @@ MML_HD void so3_exp_q(const double* w, double* q) {
         real = 1.0 - 0.125 * th2 + (1.0 / 384.0) * th4;
     } else {
         const double th = sqrt(th2), h = 0.5 * th;
-        imag = sin(h) / th;
-        real = cos(h);
+        imag = mml_sin(h) / th;
+        real = mml_cos(h);
     }
     q[0] = imag * w[0];
     q[1] = imag * w[1];
@@ -105,7 +209,7 @@ MML_HD void so3_log_q(const double* q, double* w) {
         if (fabs(qw) < 1e-10)
             two_atan = (qw > 0 ? M_PI : -M_PI) / n;
         else
-            two_atan = 2.0 * atan(n / qw) / n;
+            two_atan = 2.0 * mml_atan(n / qw) / n;
     }
     w[0] = two_atan * q[0];
     w[1] = two_atan * q[1];
@@ -128,8 +232,8 @@ MML_HD M3 so3_Jr(const double* w) {
         b = 1.0 / 6.0 - th2 / 120.0;
     } else {
         const double th = sqrt(th2);
-        a = (1.0 - cos(th)) / th2;
-        b = (th - sin(th)) / (th2 * th);
+        a = (1.0 - mml_cos(th)) / th2;
+        b = (th - mml_sin(th)) / (th2 * th);
     }
     return m3_add(m3_add(m3_identity(), m3_scale(K, -a)), m3_scale(K2, b));
 }
@@ -141,7 +245,7 @@ MML_HD M3 so3_Jr_inv(const double* w) {
         c = 1.0 / 12.0 + th2 / 720.0;
     } else {
         const double th = sqrt(th2);
-        c = 1.0 / th2 - (1.0 + cos(th)) / (2.0 * th * sin(th));
+        c = 1.0 / th2 - (1.0 + mml_cos(th)) / (2.0 * th * mml_sin(th));
     }
     return m3_add(m3_add(m3_identity(), m3_scale(K, 0.5)), m3_scale(K2, c));
 }

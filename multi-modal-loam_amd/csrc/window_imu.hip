@@ -51,7 +51,10 @@ void chol_solve(const double* L, int n, double* b) {
     }
 }
 // The same with the reciprocals of the diagonal taken once and multiplied in: the form the device-resident solver
-// (fullwindow_dev.hip) uses, where a division would sit on the dependency chain of every substitution step.
+// (fullwindow_dev.hip) uses, where a division would sit on the dependency chain of every substitution step.  The terms of a
+// row are subtracted in the order a column-by-column (right-looking) substitution meets them -- ascending k forwards,
+// DESCENDING k backwards, "the columns become known from the last one down" -- which is the device's order: the two
+// iterations then hold bit-identical steps.
 void chol_solve_rcp(const double* L, int n, double* b) {
     std::vector<double> rd(n);
     for (int i = 0; i < n; ++i) rd[i] = 1.0 / L[i * n + i];
@@ -62,7 +65,7 @@ void chol_solve_rcp(const double* L, int n, double* b) {
     }
     for (int i = n - 1; i >= 0; --i) {
         double s = b[i];
-        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
+        for (int k = n - 1; k > i; --k) s -= L[k * n + i] * b[k];
         b[i] = s * rd[i];
     }
 }
