@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 BAG_RATE_HZ = 10.0      # mm_lio_full.launch:21 (10 Hz Velodyne, one union message per sweep)
+VALU_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md): the VALU issue peak is CUs x 4 SIMDs x clock / 4
 
 # Algorithmic bytes per unit for every stage (DESIGN.md section "Kernels"): N fused points, F features per scan.
 # The SURVEY 8(d) figures: extraction 20 B/pt in total, undistort 28 B/pt, association 112 B/feature,
@@ -376,16 +377,44 @@ def run_throughput(args, rank, local_rank, world, dist):
     dom = max(stage_ms, key=stage_ms.get)
     alg_bytes = STAGE_BYTES.get(dom, lambda *a: 0)(n_v, n_l, nf, gn_iters)
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-    traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "traffic_r02.json" if args.config == 1 else "traffic_r02_config%d.json" % args.config)
-    if os.path.exists(tr_file):
+    # PMC evidence of the same command, committed under profiles/ by tools/profile_round.sh (separate rocprofv3 passes):
+    # HBM traffic per launch (FETCH_SIZE / WRITE_SIZE) and VALU wave-instructions per launch (SQ_INSTS_VALU)
+    suffix = "" if args.config == 1 else "_config%d" % args.config
+    traffic, traffic_file = None, None
+    for tag in ("r03", "r02"):
+        tr_file = os.path.join(ROOT, "profiles", "traffic_%s%s.json" % (tag, suffix))
+        if os.path.exists(tr_file):
+            try:
+                tr = json.load(open(tr_file))
+                if tr.get(dom) is not None:
+                    traffic = tr[dom] * KB / float(tr.get("scans_per_launch", KB))
+                    traffic_file = os.path.relpath(tr_file, ROOT)
+                    break
+            except Exception:
+                pass
+    # Issue-bound kernels: a wave64 VALU instruction occupies a SIMD for 4 cycles, so the device issues at most
+    # CUs x 4 SIMDs x clock / 4 wave-instructions per second (6.14e11 at 256 CUs, 2.4 GHz); the fraction of that peak the
+    # dominant stage reaches says how much of its time is instruction issue -- for such a kernel THIS is the roof, not HBM.
+    issue = None
+    sq_file = os.path.join(ROOT, "profiles", "sq_r03%s.json" % suffix)
+    if os.path.exists(sq_file):
         try:
-            tr = json.load(open(tr_file))
-            traffic = tr.get(dom)
-            if traffic is not None:
-                traffic = traffic * KB / float(tr.get("scans_per_launch", KB))
+            sq = json.load(open(sq_file))
+            if dom in sq and stage_ms[dom] > 0:
+                wi = sq[dom]["valu_wave_instr"] * KB / float(sq.get("scans_per_launch", KB))
+                peak = cus * 4 * VALU_CLOCK_HZ / 4.0
+                issue = {"valu_wave_instr_per_launch": wi, "achieved": wi / (stage_ms[dom] * 1e-3), "peak": peak,
+                         "unit": "wave-instructions/s", "frac": wi / (stage_ms[dom] * 1e-3) / peak,
+                         "source": os.path.relpath(sq_file, ROOT)}
         except Exception:
-            traffic = None
+            issue = None
+    hbm_frac = achieved / HBM_PEAK_GBPS
+    bound = "valu-issue" if issue is not None and issue["frac"] > max(hbm_frac, 0.5) else "hbm"
+    # the practical HBM roof of THIS box: a device-to-device copy (read + write counted), next to the 8 TB/s of the data sheet
+    try:
+        copy_gbps = float(ctx.copy_bandwidth(1 << 30, 10))
+    except Exception:
+        copy_gbps = None
     bytes_per_scan = 48 * (n_v + n_l) / KB + 112 * nf / KB + 72 * nf / KB * gn_iters
     total_scans = world * batch * args.steps
     value = total_scans / elapsed
@@ -548,8 +577,10 @@ def run_throughput(args, rank, local_rank, world, dist):
                        "algorithmic_bytes_per_scan": bytes_per_scan, "max_pose_err_vs_gt_m": gt_err,
                        "timed_region_s": elapsed},
             "value_with_upload": with_upload,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_file, "issue": issue,
+                         "measured_copy_GBps": copy_gbps,
+                         "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
                          "avg_launch_ms": stage_ms[dom], "algorithmic_bytes_per_launch": alg_bytes,
                          "scans_per_launch": KB, "timing": "HIP events, %d single-stream steps after the timed region" % args.kernel_steps,
                          "whole_path_frac": bytes_per_scan * value / world / 1e9 / HBM_PEAK_GBPS,
