@@ -1235,10 +1235,14 @@ def test_gicp_align_matches_oracle(M, O, synth):
 def test_gicp_refresh_on_a_slot(M, O, synth):
     """unionCloudHandler's refresh (unionFeatureExtract.cpp:302-318) on the extracted cloud of a slot: Livox surf -> Velodyne
     surf, extri_mtx updated, Livox part of the fused cloud transformed; skipped when livox_corner_num <= 100.  The source is
-    the reference's livoSurfPtr: label-2 Livox points in raw order, near-cropped ONLY (:925) -- with far_th = 6 m most of it lies
-    beyond the fused cloud.  The oracle's input comes from the oracle's own extraction, not from the device cloud."""
+    the reference's livoSurfPtr: label-2 Livox points in raw order, near-cropped ONLY (:925) -- with far_th = 8 m a good part of it
+    lies beyond the fused cloud (and the alignment runs all 10 outer iterations, ~800 objective evaluations: still equal to the
+    oracle's, matrix, iteration and evaluation counts).  The oracle's input comes from the oracle's own extraction, not from the
+    device cloud.  (At far_th = 6 m only 180 target points are left, the alignment does not settle, and after ~900 evaluations the
+    last-bit differences between the device's and libm's sin / cos / atan2 / asin -- the only arithmetic the two sides do not share
+    -- have grown into different matrices: not a test case.)"""
     v, l = synth.velo_scan(14), synth.livox_scan(14)
-    for far in (50.0, 6.0):
+    for far in (50.0, 8.0):
         c = M.Context(max_scans=2, far_th=far)
         try:
             c.scan_upload(0, v, l)
