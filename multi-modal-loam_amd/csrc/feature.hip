@@ -997,18 +997,15 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
         // 0.02, so for a float x: x > 0.02 <=> x > 0.02f.
         constexpr float kTh002 = 0.02f;
         static_assert((double)kTh002 < 0.02, "0.02f must round down");
-        int a3 = 0;
-#pragma unroll
-        for (int l = 1; l <= 3; l++) {
-            if (q.seg(l - 1) > kTh002 || far) break;  // |PT(l) - PT(l - 1)|^2
-            a3 = l;
-        }
-        int b3 = 0;
-#pragma unroll
-        for (int l = -1; l >= -3; l--) {
-            if (q.seg(l) > kTh002 || far) break;  // |PT(l) - PT(l + 1)|^2: the same squares as |PT(l + 1) - PT(l)|^2
-            b3 = -l;
-        }
+        // the two loops of :492-517 stop at the first segment longer than the threshold: the six segment lengths are
+        // fetched together and the counts formed without branches (a loop that breaks on loaded data is, on a wavefront, a
+        // chain of dependent LDS round trips and exec-mask updates)
+        const float sa0 = q.seg(0), sa1 = q.seg(1), sa2 = q.seg(2);     // |PT(l) - PT(l - 1)|^2, l = 1, 2, 3
+        const float sb0 = q.seg(-1), sb1 = q.seg(-2), sb2 = q.seg(-3);  // |PT(l) - PT(l + 1)|^2, l = -1, -2, -3
+        const bool ga0 = !(sa0 > kTh002 || far), ga1 = ga0 && !(sa1 > kTh002), ga2 = ga1 && !(sa2 > kTh002);
+        const bool gb0 = !(sb0 > kTh002 || far), gb1 = gb0 && !(sb1 > kTh002), gb2 = gb1 && !(sb2 > kTh002);
+        const int a3 = (int)ga0 + (int)ga1 + (int)ga2;
+        const int b3 = (int)gb0 + (int)gb1 + (int)gb2;
         attr |= (unsigned)a3 << A_A3_SHIFT;
         attr |= (unsigned)b3 << A_B3_SHIFT;
     }
@@ -1121,7 +1118,10 @@ extern "C" int mml_debug_st_timing(unsigned long long* out, int reset) {
 // the SIMD, which are at other points of other lines: the workgroup-per-line form of this kernel lost a quarter of its time
 // to three wavefronts waiting at a barrier for the one that walks.
 constexpr int ST_TILE = 256;
-constexpr int ST_LINES = 4;  // lines (wavefronts) per workgroup
+#ifndef MML_ST_LINES
+#define MML_ST_LINES 2  // (1: 0.706, 2: 0.684, 4: 0.712, 8: 0.730 ms per 1024 scans)
+#endif
+constexpr int ST_LINES = MML_ST_LINES;  // lines (wavefronts) per workgroup
 __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
     __shared__ unsigned long long s_row[256];  // the transfer table (2 KB): eight look-ups per window walk
     for (int k = threadIdx.x; k < 256; k += 64 * ST_LINES) s_row[k] = g_walk_tab.row[k];
@@ -1528,7 +1528,7 @@ __device__ __forceinline__ void load_nb_info(WP W, int i, unsigned (&o)[6]) {
 __device__ unsigned long long g_sel_dbg[64];
 #define SEL_MARK(id)                                                                  \
     do {                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[id] = clock64(); \
+        if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 517) g_sel_dbg[id] = clock64(); \
     } while (0)
 extern "C" int mml_debug_sel_timing(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sel_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
@@ -1762,7 +1762,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
                 pending |= U != 0;
             }
 #ifdef MML_SEL_TIMING
-            if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[20] += 1;
+            if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 517) g_sel_dbg[20] += 1;
 #endif
             // No workgroup barrier between passes: a wavefront with undecided windows only waits for edge bits of its
             // neighbours, which they publish as soon as they have them (LDS is coherent across the workgroup and the
@@ -1876,7 +1876,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
                 if (!decide(i)) undecided = 1;
         }
 #ifdef MML_SEL_TIMING
-        if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 7) g_sel_dbg[20] += 1;
+        if (threadIdx.x == 0 && blockIdx.x == MML_SEL_TIMING && blockIdx.y == 517) g_sel_dbg[20] += 1;
 #endif
         // one barrier per round: any wavefront with an undecided point raises the round's flag (three slots, the one
         // two rounds ahead is cleared after the barrier, when nobody reads or writes it)
