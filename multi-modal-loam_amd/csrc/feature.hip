@@ -2164,6 +2164,9 @@ static int select_round_cap(int want) {
 // multiple of 64, so both regions start on a word); the sweeps walk the concatenation of the two regions word by word.
 // The lists hold bucketed positions (ascending: the Velodyne part is a prefix); the fused order the reference sums a
 // voxel's points in is restored by the voxel sort, which carries the fused index in its key.
+#ifndef MML_CROP_WORDS
+#define MML_CROP_WORDS 16384
+#endif
 constexpr int CROP_THREADS = 512;  // (1024-thread workgroups wait long for wave slots next to other lanes' kernels)
 __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, int lds_words) {
     __shared__ int s_w[CROP_THREADS / 64][4];
@@ -2435,9 +2438,9 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "crop_compact");
-        // label staging: the whole fused cloud of a slot when that leaves two workgroups per CU (<= 64 KB), else 64 KB chunks
+        // label staging in chunks of at most MML_CROP_WORDS words
         const int lab_words = (ctx->NT + 3) / 4;
-        const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 16 * 1024;
+        const int lds_words = lab_words <= MML_CROP_WORDS ? lab_words : MML_CROP_WORDS;
         hipLaunchKernelGGL(k_crop, dim3(count), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
     }
     MML_HIP(hipGetLastError());
@@ -2482,7 +2485,7 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
     hipStream_t s = MML_STREAM(ctx);
     hipLaunchKernelGGL(k_decode_xyzinormal, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, d_raw, n, n_velo, slot, P);
     const int lab_words = (ctx->NT + 3) / 4;
-    const int lds_words = lab_words * 4 <= 64 * 1024 ? lab_words : 16 * 1024;
+    const int lds_words = lab_words <= MML_CROP_WORDS ? lab_words : MML_CROP_WORDS;
     hipLaunchKernelGGL(k_crop, dim3(1), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
     MML_HIP(hipGetLastError());
     return MML_OK;

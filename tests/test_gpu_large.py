@@ -37,7 +37,7 @@ def _map_from(M, O, synth, c, ks, n_az, livox):
     return O.voxel_downsample(np.concatenate(cm), 0.4), O.voxel_downsample(np.concatenate(sm), 0.2)
 
 
-def test_config4_128x2048_scan_2m_map(M, O, synth):
+def test_configs3_128x2048_scan_2m_map(M, O, synth):
     n_az = 2048
     c = M.Context(max_scans=2, max_velo_points=128 * n_az, max_livox_points=64, n_rings=128, pitch0_deg=PITCH0,
                   pitch_step_deg=STEP, max_features=1 << 16, max_map_points=(1 << 21) + (1 << 18))
@@ -86,7 +86,7 @@ def test_config4_128x2048_scan_2m_map(M, O, synth):
         c.close()
 
 
-def test_config5_240k_scans_10m_map_properties(M, O, synth):
+def test_configs4_240k_scans_10m_map_properties(M, O, synth):
     n_az = 1687
     B = 4
     c = M.Context(max_scans=B, max_velo_points=128 * n_az, max_livox_points=24000, n_rings=128, pitch0_deg=PITCH0,
