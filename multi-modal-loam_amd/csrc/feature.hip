@@ -78,6 +78,8 @@ struct FeatParams {
     int* brk_cnt;         // [B]
     unsigned* redo_queue;  // [B][NT] positions whose float pre-decisions were not certain (k_stencil_redo)
     int* redo_cnt;         // [B]
+    unsigned char* st_exit;  // [B][st_stride] k_stencil, segment mode: the stride walk's exit offsets of every tile, for the four entries
+    int st_stride;
 };
 
 struct D3 {
@@ -1122,13 +1124,22 @@ constexpr int ST_TILE = 256;
 #define MML_ST_LINES 2  // (1: 0.706, 2: 0.684, 4: 0.712, 8: 0.730 ms per 1024 scans)
 #endif
 constexpr int ST_LINES = MML_ST_LINES;  // lines (wavefronts) per workgroup
+constexpr int ST_SEGMENT_MAX_SLOTS = 16;  // batches up to this size take the segment mode (below)
+// MODE 0: a wavefront walks its whole line, tile after tile (grid: lines / ST_LINES x slots) -- the form for batches, where there
+//         are thousands of lines to fill the device with.
+// MODE 1 + MODE 2: segment mode for a handful of scans (the live one-scan call, the single-line entry point), where a 4 000-point
+//         line walked tile by tile is 16 serial round trips on an otherwise empty device: every TILE gets a wavefront (grid: tiles
+//         x lines / ST_LINES x slots).  Launch 1 runs the rounds and records, per tile, where the stride walk leaves it for each of
+//         the four offsets it may enter at (one byte); launch 2 composes the bytes of the tiles before its own into its entry
+//         offset, reloads the tile (it is in the L2), walks it, and runs the included-angle pass.  Same results as MODE 0.
+template <int MODE>
 __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
     __shared__ unsigned long long s_row[256];  // the transfer table (2 KB): eight look-ups per window walk
     for (int k = threadIdx.x; k < 256; k += 64 * ST_LINES) s_row[k] = g_walk_tab.row[k];
     __syncthreads();  // (the only workgroup barrier: before any wavefront leaves)
-    const int b = blockIdx.y + P.first;
+    const int b = (MODE == 0 ? blockIdx.y : blockIdx.z) + P.first;
     const int wave_id = threadIdx.x >> 6;
-    const int line = blockIdx.x * ST_LINES + wave_id;
+    const int line = (MODE == 0 ? blockIdx.x : blockIdx.y) * ST_LINES + wave_id;
     if (line >= P.L) return;
     const int n = P.line_len[(size_t)b * P.L + line];
     if (n <= 0) return;
@@ -1155,10 +1166,17 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
         __builtin_amdgcn_wave_barrier();                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     } while (0)
-    unsigned carry = 0;  // offset of the first visited position in the tile's first byte (wave-uniform)
-    for (int t0 = 0; t0 < n; t0 += ST_TILE) {
+    unsigned carry = 0;  // 8 x offset of the first visited position in the tile's first byte (wave-uniform)
+    unsigned char* tile_exit = P.st_exit + (size_t)b * P.st_stride + (start >> 8) + line;  // (segment mode) this line's tiles
+    const int t_first = MODE == 0 ? 0 : (int)blockIdx.x * ST_TILE, t_step = MODE == 0 ? ST_TILE : (int)gridDim.x * ST_TILE;
+    for (int t0 = t_first; t0 < n; t0 += t_step) {
         WAVE_SYNC();  // the previous tile has been consumed
         ST_MARK(0);
+        if constexpr (MODE == 2) {  // entry offset = the exits of the tiles before this one, composed
+            unsigned c = 0;
+            for (int u = 0; u < t0 / ST_TILE; ++u) c = 8u * ((tile_exit[u] >> (c >> 2)) & 3u);
+            carry = c;
+        }
         {
             PHASE_IDS();
             // the ST_TILE + 10 points the tile's windows cover, read once, and the squared length of every segment between
@@ -1184,7 +1202,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
         ST_MARK(1);
         unsigned redo_bits = 0;
         unsigned long long rmask[4] = {0ull, 0ull, 0ull, 0ull};
-        {
+        if constexpr (MODE != 2) {
             PHASE_IDS();
 #pragma unroll
             for (int rep = 0; rep < 4; ++rep) {
@@ -1229,6 +1247,16 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                     if (redo) P.redo_queue[(size_t)b * P.NT + first + lower_count(rm)] = (unsigned)(start + iq);
                 }
             }
+        } else {  // the rounds ran in launch 1: the flatness bits come back with the attribute words
+            PHASE_IDS();
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) {
+                if (t0 + rep * 64 >= n) break;
+                const int tp = rep * 64 + lane, i = t0 + tp;
+                const unsigned attr = i < n ? (unsigned)P.ln_attr[base + i] : 0u;
+                s_attr[tp] = (unsigned short)attr;
+                rmask[rep] = __ballot(attr & A_RFLAT);
+            }
         }
         ST_MARK(2);
         // ---- the walk over this tile: lane (w, e), w < 4, = window w entered at offset e ----
@@ -1268,18 +1296,42 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                 st = __builtin_amdgcn_ubfe((unsigned)(row[sb] >> 32), st, 8u);
             }
             // chain the four windows: the entry offset of a window is the exit of its predecessor for ITS entry offset
-            unsigned e = carry;  // (8 x offset)
+            if constexpr (MODE == 1) {
+                // segment mode, launch 1: where the walk leaves this tile for each of the four offsets it may enter at
+                unsigned summary = 0;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const int src = ww * 4 + (int)(e >> 3);
-                vmask[ww] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, src) << 32) |
-                            (unsigned)__builtin_amdgcn_readlane((int)vlo, src);
-                e = (unsigned)__builtin_amdgcn_readlane((int)st, src);
+                for (int c = 0; c < 4; ++c) {
+                    unsigned e = 8u * c;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) e = (unsigned)__builtin_amdgcn_readlane((int)st, ww * 4 + (int)(e >> 3));
+                    summary |= (e >> 3) << (2 * c);
+                }
+                if (lane == 0) tile_exit[t0 / ST_TILE] = (unsigned char)summary;
+                (void)vlo;
+                (void)vhi;
+            } else {
+                unsigned e = carry;  // (8 x offset)
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const int src = ww * 4 + (int)(e >> 3);
+                    vmask[ww] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, src) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)vlo, src);
+                    e = (unsigned)__builtin_amdgcn_readlane((int)st, src);
+                }
+                carry = e;
             }
-            carry = e;
         }
 #endif
         ST_MARK(3);
+        if constexpr (MODE == 1) {  // the attribute words as the rounds left them (launch 2 reads the flatness bits back)
+            PHASE_IDS();
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) {
+                const int tp = rep * 64 + lane, i = t0 + tp;
+                if (i < n) P.ln_attr[base + i] = s_attr[tp];
+            }
+            continue;
+        }
         // ---- list of the points that need the included-angle test, the test, the attribute words ----
         {
             PHASE_IDS();
@@ -2383,6 +2435,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.brk_cnt = ctx->brk_cnt;
     P.redo_queue = ctx->redo_queue;
     P.redo_cnt = ctx->brk_cnt + ctx->B;
+    P.st_exit = ctx->st_exit;
+    P.st_stride = ctx->NT / 256 + ctx->L + 8;
     return P;
 }
 
@@ -2417,7 +2471,14 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "stencil");
-        hipLaunchKernelGGL(k_stencil, dim3((ctx->L + ST_LINES - 1) / ST_LINES, count), dim3(64 * ST_LINES), 0, s, P);  // one wavefront per scan line
+        if (count > ST_SEGMENT_MAX_SLOTS) {  // one wavefront per scan line
+            hipLaunchKernelGGL(k_stencil<0>, dim3((ctx->L + ST_LINES - 1) / ST_LINES, count), dim3(64 * ST_LINES), 0, s, P);
+        } else {  // a handful of scans: one wavefront per tile, two launches
+            const int nominal = 2 * (ctx->NT / (ctx->L > 0 ? ctx->L : 1)) + ST_TILE;
+            const dim3 grid((nominal + ST_TILE - 1) / ST_TILE, (ctx->L + ST_LINES - 1) / ST_LINES, count);
+            hipLaunchKernelGGL(k_stencil<1>, grid, dim3(64 * ST_LINES), 0, s, P);
+            hipLaunchKernelGGL(k_stencil<2>, grid, dim3(64 * ST_LINES), 0, s, P);
+        }
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
     }
@@ -2501,7 +2562,11 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     MML_HIP(hipMemsetAsync(ctx->brk_cnt, 0, sizeof(int), s));
     MML_HIP(hipMemsetAsync(ctx->brk_cnt + ctx->B, 0, sizeof(int), s));
     if (n > 0) {
-        hipLaunchKernelGGL(k_stencil, dim3(1, 1), dim3(64 * ST_LINES), 0, s, P);  // line 0 holds the whole input
+        // line 0 holds the whole input: one wavefront per tile (up to 256 of them, longer lines loop)
+        const int tiles = (n + ST_TILE - 1) / ST_TILE;
+        const dim3 grid(tiles < 256 ? tiles : 256, 1, 1);
+        hipLaunchKernelGGL(k_stencil<1>, grid, dim3(64 * ST_LINES), 0, s, P);
+        hipLaunchKernelGGL(k_stencil<2>, grid, dim3(64 * ST_LINES), 0, s, P);
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, 1), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, 1), dim3(256), 0, s, P);
     }
