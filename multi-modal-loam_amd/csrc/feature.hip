@@ -18,6 +18,7 @@
 // (left-to-right, float), double expressions follow Eigen's (x0+x1)+x2 reduction order.  libm calls on
 // float arguments follow the "double libm, round on assignment" convention documented in DESIGN.md.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mml_internal.h"
 
@@ -78,6 +79,7 @@ struct FeatParams {
     int* brk_cnt;         // [B]
     unsigned* redo_queue;  // [B][NT] positions whose float pre-decisions were not certain (k_stencil_redo)
     int* redo_cnt;         // [B]
+    uint8_t* sel_done;       // [B][L] 1: the line's flags and labels were written by k_select_part, k_select skips it
     unsigned char* st_exit;  // [B][st_stride] k_stencil, segment mode: the stride walk's exit offsets of every tile, for the four entries
     int st_stride;
 };
@@ -2169,6 +2171,7 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     const int line = blockIdx.x + P.line0;
     const int n = P.line_len[(size_t)b * P.L + line];
     if (n <= 0) return;
+    if (P.sel_done && P.sel_done[(size_t)b * P.L + line]) return;  // done by k_select_part
     const int start = P.line_start[(size_t)b * P.L + line];
     const size_t base = (size_t)b * P.NT + start;
     constexpr int cap = K * SELP_THREADS;
@@ -2183,6 +2186,389 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
         unsigned* W = P.sel_scratch + 2 * base + 16 * ((size_t)b * (P.L + 2) + line + 1);
         select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
     }
+}
+
+// ---- a4 + a5 + a8 once more, for lines whose partitions hold 3 .. 64 points: one partition per LANE ---------------------------
+// k_select above resolves the state machine with one point per lane: every relation between a point and its six neighbours is
+// recomputed by the point's lane (~450 wave-instructions per 64 points, at the issue limit).  The same relations, transposed:
+// the 50 partitions of a line are 50 lanes of ONE wavefront, and everything a partition knows about its points is a set of
+// 64-bit masks private to its lane -- candidate, mark ranges (a >= d, b >= d), "point k - d is visited before point k" --, so
+// that one 64-bit operation is one relation of all the partition's points at once:
+//   neighbour k - d can suppress k        Pm_d = ((A_d << d) | edge) & G_d & C
+//   neighbour k + d can suppress k        Pp_d = (B_d >> d) & ~(G_d >> d) & C        (never from a later partition)
+//   a dependency step                     anyS = OR_d Pm_d & (S << d | edge)  |  Pp_d & (S >> d);   toN = U & anyS; ...
+// with three edge bits travelling from a lane to the next per step (a partition only ever waits for the one before it).
+// Phase A builds the bit planes of the line with one point per lane (ballots; the order bits G_d from lane shuffles of the
+// curvature keys), phase B is the partition-per-lane part (dependency steps, :521-539 in closed form as in k_select: reflect
+// top-3, ranks, first promotable point, with loops over the few set bits that need a key), phase C turns the result planes back
+// into flags / labels with one point per lane.  Lines outside 161 <= n <= 3211 (a partition of fewer than 3 or more than 64
+// points) are left to k_select (per-line flag sel_done).
+#ifdef MML_SP_TIMING
+__device__ unsigned long long g_sp_dbg[16];
+#define SP_MARK(id)                                                       \
+    do {                                                                  \
+        if (sp_dbg) {                                                     \
+            const unsigned long long now_ = clock64();                    \
+            g_sp_dbg[id] += now_ - sp_prev;                               \
+            sp_prev = now_;                                               \
+        }                                                                 \
+    } while (0)
+extern "C" int mml_debug_sp_timing(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_sp_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#else
+#define SP_MARK(id)
+#endif
+constexpr int SP_LINES = 4;     // lines (wavefronts) per workgroup
+constexpr int SP_MAXWIN = 52;   // 64-point windows of a line of at most 3211 points (+ 1 zero window)
+enum { PL_C = 0, PL_AN, PL_FR, PL_RF, PL_A0, PL_A1, PL_B0, PL_B1, PL_G1, PL_G2, PL_G3, PL_R0, PL_R1, PL_R2, PL_COUNT };
+__device__ __forceinline__ unsigned long long sp_bits(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int d) {
+    const unsigned lo = __shfl_up((unsigned)v, d), hi = __shfl_up((unsigned)(v >> 32), d);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int n_lines_launch) {
+    __shared__ unsigned long long s_plane_all[SP_LINES][PL_COUNT][SP_MAXWIN];
+    const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y + P.first;
+    const int line = P.line0 + blockIdx.x * SP_LINES + wave_id;
+    if ((int)(blockIdx.x * SP_LINES + wave_id) >= n_lines_launch) return;
+    const int n = P.line_len[(size_t)b * P.L + line];
+    const int range = n - 11;
+    const bool eligible = range >= 150 && range <= 3200;  // every partition holds 3 .. 64 points
+    if (lane == 0) P.sel_done[(size_t)b * P.L + line] = eligible ? 1 : 0;
+    if (!eligible) return;
+    const int start = P.line_start[(size_t)b * P.L + line];
+    const size_t base = (size_t)b * P.NT + start;
+    const uint16_t* attr = P.ln_attr + base;
+    const float* curv = P.ln_curv + base;
+    const float* refl = P.ln_refl + base;
+    unsigned long long(*pl)[SP_MAXWIN] = s_plane_all[wave_id];
+    const int nwin = (n + 63) >> 6;
+#ifdef MML_SP_TIMING
+    const bool sp_dbg = lane == 0 && line == MML_SP_TIMING && blockIdx.y == 517;
+    unsigned long long sp_prev = clock64();
+#endif
+#define SP_SYNC()                                          \
+    do {                                                   \
+        __builtin_amdgcn_wave_barrier();                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    } while (0)
+    // ---- phase A: bit planes of the line, one point per lane ------------------------------------------------------------
+    const int T = (attr[n - 6] & A_W2) ? 2 : 3;  // thNumCurvSize as the last stencil iteration left it (:492,505)
+    for (int k = lane; k < 3 * SP_MAXWIN; k += 64) (&pl[PL_R0][0])[k] = 0ull;       // the three result planes
+    if (lane < PL_R0) pl[lane][nwin] = 0ull;                                         // the zero window behind the line
+    unsigned tail0 = 0, tail1 = 0, tail2 = 0;  // curvature keys of the three points before the window (wave-uniform)
+    // (eight windows per turn, their sixteen loads in flight together: this wavefront's life is a chain of memory round trips,
+    //  and four other wavefronts per SIMD cover only so many of them)
+    for (int w4 = 0; w4 < nwin; w4 += 8) {
+        unsigned at4[8], key4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 64 * (w4 + u) + lane;
+            const bool in = i < n;
+            at4[u] = in ? (unsigned)attr[i] : 0u;
+            key4[u] = in ? __float_as_uint(curv[i]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = w4 + u;
+            if (w >= nwin) break;
+            const int i = 64 * w + lane;
+            const unsigned at = at4[u], key = key4[u];
+            const bool inpart = i >= 5 && i <= n - 7;
+            const bool cand = inpart && (at & A_CAND3);
+            const unsigned a = cand ? min((at >> A_A3_SHIFT) & 3u, (unsigned)T) : 0u, bb = cand ? min((at >> A_B3_SHIFT) & 3u, (unsigned)T) : 0u;
+            // "point i - d is visited before point i" inside a partition: key (curvature bits, index) ascending, ties to the lower index
+            const unsigned k1 = __shfl_up(key, 1), k2 = __shfl_up(key, 2), k3 = __shfl_up(key, 3);
+            const unsigned p1 = lane >= 1 ? k1 : tail2, p2 = lane >= 2 ? k2 : (lane == 1 ? tail2 : tail1),
+                           p3 = lane >= 3 ? k3 : (lane == 2 ? tail2 : (lane == 1 ? tail1 : tail0));
+            const unsigned long long m_c = __ballot(cand), m_an = __ballot(inpart && (at & A_ANGLE)), m_fr = __ballot(inpart && (at & A_FAR)),
+                                     m_rf = __ballot(inpart && (at & A_REFL)), m_a0 = __ballot(a & 1u), m_a1 = __ballot(a & 2u),
+                                     m_b0 = __ballot(bb & 1u), m_b1 = __ballot(bb & 2u), m_g1 = __ballot(p1 <= key), m_g2 = __ballot(p2 <= key),
+                                     m_g3 = __ballot(p3 <= key);
+            if (lane == 0) {
+                pl[PL_C][w] = m_c;
+                pl[PL_AN][w] = m_an;
+                pl[PL_FR][w] = m_fr;
+                pl[PL_RF][w] = m_rf;
+                pl[PL_A0][w] = m_a0;
+                pl[PL_A1][w] = m_a1;
+                pl[PL_B0][w] = m_b0;
+                pl[PL_B1][w] = m_b1;
+                pl[PL_G1][w] = m_g1;
+                pl[PL_G2][w] = m_g2;
+                pl[PL_G3][w] = m_g3;
+            }
+            tail0 = (unsigned)__builtin_amdgcn_readlane((int)key, 61);
+            tail1 = (unsigned)__builtin_amdgcn_readlane((int)key, 62);
+            tail2 = (unsigned)__builtin_amdgcn_readlane((int)key, 63);
+        }
+    }
+    SP_SYNC();
+    SP_MARK(0);
+    // ---- phase B: one partition per lane ------------------------------------------------------------------------------------
+    {
+        const bool act = lane < 50;
+        const int pj = act ? lane : 49;
+        const int sp = 5 + range * pj / 50, spn = 5 + range * (pj + 1) / 50, L = spn - sp;  // 3 <= L <= 64
+        const unsigned long long maskL = sp_bits(L);
+        const int w0 = sp >> 6, off = sp & 63;
+        auto extract = [&](int plane) -> unsigned long long {
+            const unsigned long long lo = pl[plane][w0] >> off, hi = off ? (pl[plane][w0 + 1] << (64 - off)) : 0ull;
+            return act ? ((lo | hi) & maskL) : 0ull;
+        };
+        const unsigned long long C = extract(PL_C), AN = extract(PL_AN), FR = extract(PL_FR), RF = extract(PL_RF);
+        const unsigned long long a0 = extract(PL_A0), a1 = extract(PL_A1), b0 = extract(PL_B0), b1 = extract(PL_B1);
+        const unsigned long long A1 = a0 | a1, A2 = a1, A3 = a1 & a0, B1 = b0 | b1, B2 = b1, B3 = b1 & b0;
+        // order bits: inside the partition from the keys; a point of the partition before is always visited first
+        const unsigned long long G1 = extract(PL_G1) | 1ull, G2 = extract(PL_G2) | 3ull, G3 = extract(PL_G3) | 7ull;
+        // edges: which of the LAST d points of the partition before cover my first points (a >= d), which of the FIRST d
+        // points of the partition behind cover my last points (b >= d)
+        const unsigned tA = (unsigned)((A1 >> (L - 1)) & 1ull) | ((unsigned)((A2 >> (L - 2)) & 3ull) << 1) | ((unsigned)((A3 >> (L - 3)) & 7ull) << 3);
+        const unsigned hB = (unsigned)(B1 & 1ull) | ((unsigned)(B2 & 3ull) << 1) | ((unsigned)(B3 & 7ull) << 3);
+        unsigned pA = __shfl_up(tA, 1), nB = __shfl_down(hB, 1);
+        if (lane == 0 || !act) pA = 0;
+        if (lane >= 49) nB = 0;
+        const unsigned long long inA1 = pA & 1u, inA2 = (pA >> 1) & 3u, inA3 = (pA >> 3) & 7u;          // bits 0 .. d-1
+        const unsigned long long inB1 = (unsigned long long)(nB & 1u) << (L - 1), inB2 = (unsigned long long)((nB >> 1) & 3u) << (L - 2),
+                                 inB3 = (unsigned long long)((nB >> 3) & 7u) << (L - 3);                // bits L-d .. L-1
+        // static relations
+        const unsigned long long Cm1 = ((A1 << 1) | inA1) & maskL, Cm2 = ((A2 << 2) | inA2) & maskL, Cm3 = ((A3 << 3) | inA3) & maskL;
+        const unsigned long long Cw1 = B1 >> 1, Cw2 = B2 >> 2, Cw3 = B3 >> 3;  // covered from k + d inside the partition
+        const unsigned long long Pm1 = Cm1 & G1 & C, Pm2 = Cm2 & G2 & C, Pm3 = Cm3 & G3 & C;
+        const unsigned long long Pp1 = Cw1 & ~(G1 >> 1) & C, Pp2 = Cw2 & ~(G2 >> 2) & C, Pp3 = Cw3 & ~(G3 >> 3) & C;
+        const unsigned long long has_pred = Pm1 | Pm2 | Pm3 | Pp1 | Pp2 | Pp3;
+        unsigned long long S = C & ~has_pred, U = C & has_pred;
+        SP_MARK(1);
+        // dependency steps: a partition's first three points wait for the last three of the partition before
+        for (int guard = 0; guard < 4096; ++guard) {
+            const unsigned e = (unsigned)((S >> (L - 3)) & 7ull) | ((unsigned)((U >> (L - 3)) & 7ull) << 3);
+            unsigned pe = __shfl_up(e, 1);
+            if (lane == 0) pe = 0;
+            const unsigned long long pS = pe & 7u, pU = (pe >> 3) & 7u;  // bit j <-> point L' - 3 + j of the partition before
+            const unsigned long long S1 = (S << 1) | (pS >> 2), S2 = (S << 2) | (pS >> 1), S3 = (S << 3) | pS;
+            const unsigned long long U1 = (U << 1) | (pU >> 2), U2 = (U << 2) | (pU >> 1), U3 = (U << 3) | pU;
+            const unsigned long long anyS = (Pm1 & S1) | (Pm2 & S2) | (Pm3 & S3) | (Pp1 & (S >> 1)) | (Pp2 & (S >> 2)) | (Pp3 & (S >> 3));
+            const unsigned long long anyU = (Pm1 & U1) | (Pm2 & U2) | (Pm3 & U3) | (Pp1 & (U >> 1)) | (Pp2 & (U >> 2)) | (Pp3 & (U >> 3));
+            const unsigned long long toN = U & anyS, toS = U & ~anyS & ~anyU;
+            S |= toS;
+            U &= ~(toN | toS);
+            if (!__any((toN | toS) != 0ull)) break;
+        }
+        SP_MARK(2);
+        // value held when :521-539 runs: 1 when a pick of the same or an earlier partition marks me (it cannot have come before
+        // my own pick, or I would not be picked), else 3 for a pick; marks from the partition behind land after :521-539
+        const unsigned e2 = (unsigned)((S >> (L - 3)) & 7ull) | ((unsigned)(S & 7ull) << 3);
+        unsigned pe2 = __shfl_up(e2, 1), ne2 = __shfl_down(e2, 1);
+        if (lane == 0) pe2 = 0;
+        if (lane >= 49) ne2 = 0;
+        const unsigned long long pS = pe2 & 7u, nS = (ne2 >> 3) & 7u;  // nS bit j <-> point j of the partition behind
+        const unsigned long long covL = (Cm1 & ((S << 1) | (pS >> 2))) | (Cm2 & ((S << 2) | (pS >> 1))) | (Cm3 & ((S << 3) | pS)) | (Cw1 & (S >> 1)) |
+                                        (Cw2 & (S >> 2)) | (Cw3 & (S >> 3));
+        const unsigned long long covLater = (inB1 & ((nS & 1ull) << (L - 1))) | (inB2 & ((nS & 3ull) << (L - 2))) | (inB3 & ((nS & 7ull) << (L - 3)));
+        const unsigned long long is3 = S & ~covL;
+        // ---- :521-539 in closed form (as in k_select) ----
+        // the three first reflect candidates in reflect order
+        unsigned long long inBm = 0ull, bfirst = 0ull;
+        {
+            unsigned long long best[3] = {~0ull, ~0ull, ~0ull};
+            unsigned long long m = RF;
+            while (m) {  // four candidates per turn, their keys requested together
+                int kk[4];
+                float rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    kk[u] = m ? (int)__ffsll((long long)m) - 1 : -1;
+                    m &= m - 1;
+                    rv[u] = refl[sp + (kk[u] >= 0 ? kk[u] : 0)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (kk[u] < 0) continue;
+                    unsigned long long x = ((unsigned long long)refl_key(rv[u]) << 32) | (unsigned)(sp + kk[u]);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const unsigned long long cur = best[r];
+                        const bool lt = x < cur;
+                        best[r] = lt ? x : cur;
+                        x = lt ? cur : x;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (best[r] != ~0ull) inBm |= 1ull << ((int)(unsigned)best[r] - sp);
+            SP_MARK(3);
+            // does a pick's reflect visit come before its own curvature visit?  (only read for a pick that holds 3 or is a
+            // grazing point): ranks in both orders over the whole partition
+            // Counted with one POINT per lane (a partition has at most 64): the picks of all partitions are taken four at a
+            // time -- the owning lanes broadcast partition and pick, lanes 0 .. L-1 fetch that partition's keys, two ballots
+            // give the two ranks -- instead of every owner walking its partition alone, a chain of dependent loads that the
+            // whole wavefront waited for (31 % of the kernel).
+            unsigned long long need = inBm & (is3 | AN);
+            for (;;) {
+                // next pick of my own partition (if any), then the wavefront's list of lanes that have one
+                const int myk = need ? (int)__ffsll((long long)need) - 1 : -1;
+                unsigned long long owners = __ballot(myk >= 0);
+                if (!owners) break;
+                int src[4], pk[4], psp[4], pL[4];
+                unsigned ck[4], rk[4];
+                float cv[4], rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    src[u] = owners ? (int)__ffsll((long long)owners) - 1 : -1;
+                    owners &= owners - 1;
+                    const int o = src[u] >= 0 ? src[u] : 0;
+                    pk[u] = __shfl(myk, o);
+                    psp[u] = __shfl(sp, o);
+                    pL[u] = __shfl(L, o);
+                    const int q = min(lane, pL[u] - 1);
+                    cv[u] = curv[psp[u] + q];
+                    rv[u] = refl[psp[u] + q];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ck[u] = __float_as_uint(cv[u]);
+                    rk[u] = refl_key(rv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (src[u] < 0) continue;  // wave-uniform
+                    const unsigned mk = __shfl(ck[u], pk[u]), mr = __shfl(rk[u], pk[u]);
+                    const bool in = lane < pL[u];
+                    const int rc = __popcll(__ballot(in && ((ck[u] < mk) || (ck[u] == mk && lane < pk[u]))));
+                    const int rr = __popcll(__ballot(in && ((rk[u] < mr) || (rk[u] == mr && lane < pk[u]))));
+                    if (lane == src[u]) {
+                        if (rr < rc) bfirst |= 1ull << pk[u];
+                        need &= need - 1;
+                    }
+                }
+            }
+        }
+        SP_MARK(4);
+        const unsigned long long eff3 = is3 & ~(inBm & bfirst);
+        const unsigned long long Gm = AN | (eff3 & FR);
+        unsigned long long first = 0ull;
+        {
+            unsigned long long minE = ~0ull, minG = ~0ull;
+            auto min_key = [&](unsigned long long m) -> unsigned long long {  // four keys per turn, requested together
+                unsigned long long best = ~0ull;
+                while (m) {
+                    int kk[4];
+                    float cv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        kk[u] = m ? (int)__ffsll((long long)m) - 1 : -1;
+                        m &= m - 1;
+                        cv[u] = curv[sp + (kk[u] >= 0 ? kk[u] : 0)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long ck = kk[u] >= 0 ? (((unsigned long long)__float_as_uint(cv[u]) << 32) | (unsigned)(sp + kk[u])) : ~0ull;
+                        best = ck < best ? ck : best;
+                    }
+                }
+                return best;
+            };
+            minE = min_key(eff3);
+            minG = min_key(Gm);
+            if (minE != ~0ull && !(minG < minE)) first = 1ull << ((int)(unsigned)minE - sp);
+        }
+        SP_MARK(5);
+        const unsigned long long picked = Gm | first;
+        const unsigned long long two_after_300 = inBm & picked & AN & bfirst;
+        const unsigned long long F2 = ((picked & ~inBm) | two_after_300) & ~covLater;
+        const unsigned long long F300 = inBm & ~two_after_300 & ~covLater;
+        const unsigned long long F1 = covLater | (covL & ~picked & ~inBm);
+        const unsigned long long F3 = is3 & ~picked & ~inBm & ~covLater;
+        // result planes: code 1 -> flag 1, 2 -> 2, 3 -> 3, 4 -> 300
+        unsigned long long r0 = F1 | F3, r1 = F2 | F3, r2 = F300;
+        // the points in front of the first and behind the last partition can only be marked (flag 1)
+        unsigned long long head1 = 0ull, tail1m = 0ull;  // bit j <-> point sp - 1 - j / point spn + j
+        if (lane == 0) {
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k + j < 3; ++k) {
+                    const int d = k + j + 1;
+                    const unsigned long long Bd = d == 1 ? B1 : (d == 2 ? B2 : B3);
+                    if ((S >> k) & (Bd >> k) & 1ull) head1 |= 1ull << j;
+                }
+        }
+        if (lane == 49) {
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k + j < 3; ++k) {
+                    const int d = k + j + 1;
+                    const unsigned long long Ad = d == 1 ? A1 : (d == 2 ? A2 : A3);
+                    if ((S >> (L - 1 - k)) & (Ad >> (L - 1 - k)) & 1ull) tail1m |= 1ull << j;
+                }
+        }
+        if (act) {
+            auto scatter = [&](int plane, unsigned long long v) {
+                if (v == 0ull) return;
+                atomicOr(&pl[plane][w0], v << off);
+                if (off && (v >> (64 - off))) atomicOr(&pl[plane][w0 + 1], v >> (64 - off));
+            };
+            scatter(PL_R0, r0);
+            scatter(PL_R1, r1);
+            scatter(PL_R2, r2);
+            if (lane == 0)
+                for (int j = 0; j < 3; ++j)
+                    if ((head1 >> j) & 1ull) atomicOr(&pl[PL_R0][(sp - 1 - j) >> 6], 1ull << ((sp - 1 - j) & 63));
+            if (lane == 49)
+                for (int j = 0; j < 3; ++j)
+                    if ((tail1m >> j) & 1ull) atomicOr(&pl[PL_R0][(spn + j) >> 6], 1ull << ((spn + j) & 63));
+        }
+    }
+    SP_SYNC();
+    SP_MARK(6);
+    // ---- phase C: flags and labels, one point per lane -----------------------------------------------------------------
+    uint8_t* lnlab = P.ln_label + base;
+    const int2* gidx = P.ln_meta + base;
+    for (int w4 = 0; w4 < nwin; w4 += 4) {
+        unsigned at4[4];
+        int gi4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(64 * (w4 + u) + lane, n - 1);
+            at4[u] = attr[i];
+            gi4[u] = gidx[i].x;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = w4 + u, i = 64 * w + lane;
+            if (w >= nwin || i >= n) continue;
+            const unsigned long long r0 = pl[PL_R0][w], r1 = pl[PL_R1][w], r2 = pl[PL_R2][w];
+            const unsigned code = (unsigned)((r0 >> lane) & 1ull) | ((unsigned)((r1 >> lane) & 1ull) << 1) | ((unsigned)((r2 >> lane) & 1ull) << 2);
+            int f = code == 4u ? 300 : (int)code;
+            const unsigned at = at4[u];
+            const bool inner = i >= 5 && i < n - 5;
+            if (inner) {
+                if ((at & (A_VIS | A_C150)) == (A_VIS | A_C150)) f = 150;
+                const unsigned f5 = (at >> A_F5_SHIFT) & 3u;
+                if (f5 == 1) f = 100;
+                if (f5 == 2) f = 101;
+            }
+            if (P.ln_final) P.ln_final[base + i] = (uint16_t)f;
+            int labv = 0;
+            if (inner && !(at & A_NEAR)) {
+                const int lab = (f == 2) ? 2 : ((f == 100 || f == 150) ? 1 : 0);
+                if (lab) {
+                    const int gi = gi4[u];
+                    if (gi >= 0)
+                        labv = lab;
+                    else if (gi == -2)
+                        labv = lab | 0x80;
+                }
+            }
+            lnlab[i] = (uint8_t)labv;
+        }
+    }
+    SP_MARK(7);
+#undef SP_SYNC
 }
 
 // K (points per thread in LDS-resident lines) variants of k_select
@@ -2435,6 +2821,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.brk_cnt = ctx->brk_cnt;
     P.redo_queue = ctx->redo_queue;
     P.redo_cnt = ctx->brk_cnt + ctx->B;
+    P.sel_done = ctx->select_part ? ctx->sel_done : nullptr;
     P.st_exit = ctx->st_exit;
     P.st_stride = ctx->NT / 256 + ctx->L + 8;
     return P;
@@ -2486,6 +2873,8 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         MmlStageScope t(ctx, "select");
         // rings and Livox lines have different nominal lengths: each group runs the variant whose LDS block fits it, so the
         // short rings do not pay (in occupancy) for the long Livox lines
+        if (ctx->select_part)  // lines whose partitions hold 3 .. 64 points: one partition per lane; the rest falls through to k_select
+            hipLaunchKernelGGL(k_select_part, dim3((ctx->L + SP_LINES - 1) / SP_LINES, count), dim3(64 * SP_LINES), 0, s, P, ctx->L);
         FeatParams Pv = P;
         Pv.sel_cap = ctx->sel_cap_velo;
         hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(ctx->cfg.n_rings, count), dim3(SELP_THREADS),
@@ -2570,12 +2959,17 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, 1), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, 1), dim3(256), 0, s, P);
     }
+    if (ctx->select_part) hipLaunchKernelGGL(k_select_part, dim3(1, 1), dim3(64 * SP_LINES), 0, s, P, 1);
     hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
 
 int mml_feature_init(mml_ctx* ctx) {
+    {
+        const char* e = getenv("MML_SELECT_PART");  // measurement switch: 0 = every line through k_select
+        ctx->select_part = !(e && atoi(e) == 0);
+    }
     // LDS budget of k_select: twice the nominal ring length / the nominal Livox line length + 2 %, rounded up to a
     // whole number of points per thread (the default 16 x 1800 + 6 x 4000 layout gets 4096 points = 51.6 KB, three
     // workgroups per CU); longer lines take the global-scratch form of the same code

@@ -122,6 +122,8 @@ struct mml_ctx {
     unsigned* brk_queue = nullptr;  // B * NT: queued break-point candidates of k_stencil
     int* brk_cnt = nullptr;         // 2 B: break-point queue sizes, then redo queue sizes
     unsigned* redo_queue = nullptr; // B * NT: points k_stencil left to k_stencil_redo
+    uint8_t* sel_done = nullptr;       // B * L: lines finished by k_select_part
+    bool select_part = true;
     unsigned char* st_exit = nullptr;  // B * (NT / 256 + L + 8): k_stencil segment mode, exit offsets of the stride walk per tile
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
