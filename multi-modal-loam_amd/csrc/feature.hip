@@ -2223,31 +2223,47 @@ extern "C" int mml_debug_sp_timing(unsigned long long* out, int reset) {
 #else
 #define SP_MARK(id)
 #endif
-constexpr int SP_LINES = 4;     // lines (wavefronts) per workgroup
-constexpr int SP_MAXWIN = 52;   // 64-point windows of a line of at most 3211 points (+ 1 zero window)
-enum { PL_C = 0, PL_AN, PL_FR, PL_RF, PL_A0, PL_A1, PL_B0, PL_B1, PL_G1, PL_G2, PL_G3, PL_R0, PL_R1, PL_R2, PL_COUNT };
-__device__ __forceinline__ unsigned long long sp_bits(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
-__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int d) {
-    const unsigned lo = __shfl_up((unsigned)v, d), hi = __shfl_up((unsigned)(v >> 32), d);
-    return ((unsigned long long)hi << 32) | lo;
+typedef unsigned long long u64m;
+typedef unsigned __int128 u128m;
+enum { PL_C = 0, PL_AN, PL_FR, PL_RF, PL_A0, PL_A1, PL_B0, PL_B1, PL_G1, PL_G2, PL_G3, PL_COUNT };
+enum { PL_R0 = PL_C, PL_R1 = PL_AN, PL_R2 = PL_FR };  // the result planes take the place of three input planes once those are read
+__device__ __forceinline__ int m_ffs(u64m v) { return v ? (int)__ffsll((long long)v) - 1 : -1; }
+__device__ __forceinline__ int m_ffs(u128m v) {
+    const u64m lo = (u64m)v, hi = (u64m)(v >> 64);
+    return lo ? (int)__ffsll((long long)lo) - 1 : (hi ? 64 + (int)__ffsll((long long)hi) - 1 : -1);
 }
-__global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int n_lines_launch) {
-    __shared__ unsigned long long s_plane_all[SP_LINES][PL_COUNT][SP_MAXWIN];
+template <typename M>
+__device__ __forceinline__ M m_bits(int nbits) {
+    return nbits >= (int)(8 * sizeof(M)) ? ~(M)0 : (((M)1 << nbits) - (M)1);
+}
+// M = 64-bit masks: partitions of up to 64 points (lines of 161 .. 3211 points: the rings); M = 128-bit masks: up to 128 points
+// (.. 6411: the Livox lines).  WAVES = lines (wavefronts) per workgroup, MAXWIN = 64-point windows of the longest line + 2.
+template <typename M, int WAVES, int MAXWIN>
+__global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_lines_launch) {
+    constexpr int MBITS = (int)(8 * sizeof(M));
+    constexpr bool WIDE = MBITS > 64;
+    __shared__ u64m s_plane_all[WAVES][PL_COUNT][MAXWIN];
     const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y + P.first;
-    const int line = P.line0 + blockIdx.x * SP_LINES + wave_id;
-    if ((int)(blockIdx.x * SP_LINES + wave_id) >= n_lines_launch) return;
+    const int line = P.line0 + blockIdx.x * WAVES + wave_id;
+    if ((int)(blockIdx.x * WAVES + wave_id) >= n_lines_launch) return;
     const int n = P.line_len[(size_t)b * P.L + line];
     const int range = n - 11;
-    const bool eligible = range >= 150 && range <= 3200;  // every partition holds 3 .. 64 points
-    if (lane == 0) P.sel_done[(size_t)b * P.L + line] = eligible ? 1 : 0;
+    const bool eligible = range >= 150 && range <= 50 * MBITS;  // every partition holds 3 .. MBITS points
+    // per-line flag for k_select: the narrow form (launched first) resets it, the wide form takes what the narrow one left
+    if constexpr (!WIDE) {
+        if (lane == 0) P.sel_done[(size_t)b * P.L + line] = eligible ? 1 : 0;
+    } else {
+        if (P.sel_done[(size_t)b * P.L + line]) return;
+        if (eligible && lane == 0) P.sel_done[(size_t)b * P.L + line] = 1;
+    }
     if (!eligible) return;
     const int start = P.line_start[(size_t)b * P.L + line];
     const size_t base = (size_t)b * P.NT + start;
     const uint16_t* attr = P.ln_attr + base;
     const float* curv = P.ln_curv + base;
     const float* refl = P.ln_refl + base;
-    unsigned long long(*pl)[SP_MAXWIN] = s_plane_all[wave_id];
+    u64m(*pl)[MAXWIN] = s_plane_all[wave_id];
     const int nwin = (n + 63) >> 6;
 #ifdef MML_SP_TIMING
     const bool sp_dbg = lane == 0 && line == MML_SP_TIMING && blockIdx.y == 517;
@@ -2260,11 +2276,13 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
     } while (0)
     // ---- phase A: bit planes of the line, one point per lane ------------------------------------------------------------
     const int T = (attr[n - 6] & A_W2) ? 2 : 3;  // thNumCurvSize as the last stencil iteration left it (:492,505)
-    for (int k = lane; k < 3 * SP_MAXWIN; k += 64) (&pl[PL_R0][0])[k] = 0ull;       // the three result planes
-    if (lane < PL_R0) pl[lane][nwin] = 0ull;                                         // the zero window behind the line
+    if (lane < PL_COUNT) {                        // the zero windows behind the line
+        pl[lane][nwin] = 0ull;
+        pl[lane][nwin + 1] = 0ull;
+    }
     unsigned tail0 = 0, tail1 = 0, tail2 = 0;  // curvature keys of the three points before the window (wave-uniform)
     // (eight windows per turn, their sixteen loads in flight together: this wavefront's life is a chain of memory round trips,
-    //  and four other wavefronts per SIMD cover only so many of them)
+    //  and the few other wavefronts of the SIMD cover only so many of them)
     for (int w4 = 0; w4 < nwin; w4 += 8) {
         unsigned at4[8], key4[8];
 #pragma unroll
@@ -2287,10 +2305,9 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
             const unsigned k1 = __shfl_up(key, 1), k2 = __shfl_up(key, 2), k3 = __shfl_up(key, 3);
             const unsigned p1 = lane >= 1 ? k1 : tail2, p2 = lane >= 2 ? k2 : (lane == 1 ? tail2 : tail1),
                            p3 = lane >= 3 ? k3 : (lane == 2 ? tail2 : (lane == 1 ? tail1 : tail0));
-            const unsigned long long m_c = __ballot(cand), m_an = __ballot(inpart && (at & A_ANGLE)), m_fr = __ballot(inpart && (at & A_FAR)),
-                                     m_rf = __ballot(inpart && (at & A_REFL)), m_a0 = __ballot(a & 1u), m_a1 = __ballot(a & 2u),
-                                     m_b0 = __ballot(bb & 1u), m_b1 = __ballot(bb & 2u), m_g1 = __ballot(p1 <= key), m_g2 = __ballot(p2 <= key),
-                                     m_g3 = __ballot(p3 <= key);
+            const u64m m_c = __ballot(cand), m_an = __ballot(inpart && (at & A_ANGLE)), m_fr = __ballot(inpart && (at & A_FAR)),
+                       m_rf = __ballot(inpart && (at & A_REFL)), m_a0 = __ballot(a & 1u), m_a1 = __ballot(a & 2u), m_b0 = __ballot(bb & 1u),
+                       m_b1 = __ballot(bb & 2u), m_g1 = __ballot(p1 <= key), m_g2 = __ballot(p2 <= key), m_g3 = __ballot(p3 <= key);
             if (lane == 0) {
                 pl[PL_C][w] = m_c;
                 pl[PL_AN][w] = m_an;
@@ -2315,85 +2332,91 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
     {
         const bool act = lane < 50;
         const int pj = act ? lane : 49;
-        const int sp = 5 + range * pj / 50, spn = 5 + range * (pj + 1) / 50, L = spn - sp;  // 3 <= L <= 64
-        const unsigned long long maskL = sp_bits(L);
+        const int sp = 5 + range * pj / 50, spn = 5 + range * (pj + 1) / 50, L = spn - sp;  // 3 <= L <= MBITS
+        const M maskL = m_bits<M>(L);
         const int w0 = sp >> 6, off = sp & 63;
-        auto extract = [&](int plane) -> unsigned long long {
-            const unsigned long long lo = pl[plane][w0] >> off, hi = off ? (pl[plane][w0 + 1] << (64 - off)) : 0ull;
-            return act ? ((lo | hi) & maskL) : 0ull;
+        auto extract = [&](int plane) -> M {
+            const u64m x0 = pl[plane][w0], x1 = pl[plane][w0 + 1];
+            M v = (M)((x0 >> off) | (off ? (x1 << (64 - off)) : 0ull));
+            if constexpr (WIDE) {
+                const u64m x2 = pl[plane][w0 + 2];
+                v |= (M)((x1 >> off) | (off ? (x2 << (64 - off)) : 0ull)) << 64;
+            }
+            return act ? (v & maskL) : (M)0;
         };
-        const unsigned long long C = extract(PL_C), AN = extract(PL_AN), FR = extract(PL_FR), RF = extract(PL_RF);
-        const unsigned long long a0 = extract(PL_A0), a1 = extract(PL_A1), b0 = extract(PL_B0), b1 = extract(PL_B1);
-        const unsigned long long A1 = a0 | a1, A2 = a1, A3 = a1 & a0, B1 = b0 | b1, B2 = b1, B3 = b1 & b0;
+        const M C = extract(PL_C), AN = extract(PL_AN), FR = extract(PL_FR), RF = extract(PL_RF);
+        const M a0 = extract(PL_A0), a1 = extract(PL_A1), b0 = extract(PL_B0), b1 = extract(PL_B1);
+        const M A1 = a0 | a1, A2 = a1, A3 = a1 & a0, B1 = b0 | b1, B2 = b1, B3 = b1 & b0;
         // order bits: inside the partition from the keys; a point of the partition before is always visited first
-        const unsigned long long G1 = extract(PL_G1) | 1ull, G2 = extract(PL_G2) | 3ull, G3 = extract(PL_G3) | 7ull;
+        const M G1 = extract(PL_G1) | (M)1, G2 = extract(PL_G2) | (M)3, G3 = extract(PL_G3) | (M)7;
+        SP_SYNC();  // every lane has read its planes: three of them now become the (zeroed) result planes
+        for (int k = lane; k < 3 * MAXWIN; k += 64) (&pl[PL_R0][0])[k] = 0ull;
         // edges: which of the LAST d points of the partition before cover my first points (a >= d), which of the FIRST d
         // points of the partition behind cover my last points (b >= d)
-        const unsigned tA = (unsigned)((A1 >> (L - 1)) & 1ull) | ((unsigned)((A2 >> (L - 2)) & 3ull) << 1) | ((unsigned)((A3 >> (L - 3)) & 7ull) << 3);
-        const unsigned hB = (unsigned)(B1 & 1ull) | ((unsigned)(B2 & 3ull) << 1) | ((unsigned)(B3 & 7ull) << 3);
+        const unsigned tA = (unsigned)((A1 >> (L - 1)) & (M)1) | ((unsigned)((A2 >> (L - 2)) & (M)3) << 1) | ((unsigned)((A3 >> (L - 3)) & (M)7) << 3);
+        const unsigned hB = (unsigned)(B1 & (M)1) | ((unsigned)(B2 & (M)3) << 1) | ((unsigned)(B3 & (M)7) << 3);
         unsigned pA = __shfl_up(tA, 1), nB = __shfl_down(hB, 1);
         if (lane == 0 || !act) pA = 0;
         if (lane >= 49) nB = 0;
-        const unsigned long long inA1 = pA & 1u, inA2 = (pA >> 1) & 3u, inA3 = (pA >> 3) & 7u;          // bits 0 .. d-1
-        const unsigned long long inB1 = (unsigned long long)(nB & 1u) << (L - 1), inB2 = (unsigned long long)((nB >> 1) & 3u) << (L - 2),
-                                 inB3 = (unsigned long long)((nB >> 3) & 7u) << (L - 3);                // bits L-d .. L-1
+        const M inA1 = (M)(pA & 1u), inA2 = (M)((pA >> 1) & 3u), inA3 = (M)((pA >> 3) & 7u);                                 // bits 0 .. d-1
+        const M inB1 = (M)(nB & 1u) << (L - 1), inB2 = (M)((nB >> 1) & 3u) << (L - 2), inB3 = (M)((nB >> 3) & 7u) << (L - 3);  // bits L-d .. L-1
         // static relations
-        const unsigned long long Cm1 = ((A1 << 1) | inA1) & maskL, Cm2 = ((A2 << 2) | inA2) & maskL, Cm3 = ((A3 << 3) | inA3) & maskL;
-        const unsigned long long Cw1 = B1 >> 1, Cw2 = B2 >> 2, Cw3 = B3 >> 3;  // covered from k + d inside the partition
-        const unsigned long long Pm1 = Cm1 & G1 & C, Pm2 = Cm2 & G2 & C, Pm3 = Cm3 & G3 & C;
-        const unsigned long long Pp1 = Cw1 & ~(G1 >> 1) & C, Pp2 = Cw2 & ~(G2 >> 2) & C, Pp3 = Cw3 & ~(G3 >> 3) & C;
-        const unsigned long long has_pred = Pm1 | Pm2 | Pm3 | Pp1 | Pp2 | Pp3;
-        unsigned long long S = C & ~has_pred, U = C & has_pred;
+        const M Cm1 = ((A1 << 1) | inA1) & maskL, Cm2 = ((A2 << 2) | inA2) & maskL, Cm3 = ((A3 << 3) | inA3) & maskL;
+        const M Cw1 = B1 >> 1, Cw2 = B2 >> 2, Cw3 = B3 >> 3;  // covered from k + d inside the partition
+        const M Pm1 = Cm1 & G1 & C, Pm2 = Cm2 & G2 & C, Pm3 = Cm3 & G3 & C;
+        const M Pp1 = Cw1 & ~(G1 >> 1) & C, Pp2 = Cw2 & ~(G2 >> 2) & C, Pp3 = Cw3 & ~(G3 >> 3) & C;
+        const M has_pred = Pm1 | Pm2 | Pm3 | Pp1 | Pp2 | Pp3;
+        M S = C & ~has_pred, U = C & has_pred;
         SP_MARK(1);
         // dependency steps: a partition's first three points wait for the last three of the partition before
         for (int guard = 0; guard < 4096; ++guard) {
-            const unsigned e = (unsigned)((S >> (L - 3)) & 7ull) | ((unsigned)((U >> (L - 3)) & 7ull) << 3);
+            const unsigned e = (unsigned)((S >> (L - 3)) & (M)7) | ((unsigned)((U >> (L - 3)) & (M)7) << 3);
             unsigned pe = __shfl_up(e, 1);
             if (lane == 0) pe = 0;
-            const unsigned long long pS = pe & 7u, pU = (pe >> 3) & 7u;  // bit j <-> point L' - 3 + j of the partition before
-            const unsigned long long S1 = (S << 1) | (pS >> 2), S2 = (S << 2) | (pS >> 1), S3 = (S << 3) | pS;
-            const unsigned long long U1 = (U << 1) | (pU >> 2), U2 = (U << 2) | (pU >> 1), U3 = (U << 3) | pU;
-            const unsigned long long anyS = (Pm1 & S1) | (Pm2 & S2) | (Pm3 & S3) | (Pp1 & (S >> 1)) | (Pp2 & (S >> 2)) | (Pp3 & (S >> 3));
-            const unsigned long long anyU = (Pm1 & U1) | (Pm2 & U2) | (Pm3 & U3) | (Pp1 & (U >> 1)) | (Pp2 & (U >> 2)) | (Pp3 & (U >> 3));
-            const unsigned long long toN = U & anyS, toS = U & ~anyS & ~anyU;
+            const M pS = (M)(pe & 7u), pU = (M)((pe >> 3) & 7u);  // bit j <-> point L' - 3 + j of the partition before
+            const M S1 = (S << 1) | (pS >> 2), S2 = (S << 2) | (pS >> 1), S3 = (S << 3) | pS;
+            const M U1 = (U << 1) | (pU >> 2), U2 = (U << 2) | (pU >> 1), U3 = (U << 3) | pU;
+            const M anyS = (Pm1 & S1) | (Pm2 & S2) | (Pm3 & S3) | (Pp1 & (S >> 1)) | (Pp2 & (S >> 2)) | (Pp3 & (S >> 3));
+            const M anyU = (Pm1 & U1) | (Pm2 & U2) | (Pm3 & U3) | (Pp1 & (U >> 1)) | (Pp2 & (U >> 2)) | (Pp3 & (U >> 3));
+            const M toN = U & anyS, toS = U & ~anyS & ~anyU;
             S |= toS;
             U &= ~(toN | toS);
-            if (!__any((toN | toS) != 0ull)) break;
+            if (!__any((toN | toS) != (M)0)) break;
         }
         SP_MARK(2);
         // value held when :521-539 runs: 1 when a pick of the same or an earlier partition marks me (it cannot have come before
         // my own pick, or I would not be picked), else 3 for a pick; marks from the partition behind land after :521-539
-        const unsigned e2 = (unsigned)((S >> (L - 3)) & 7ull) | ((unsigned)(S & 7ull) << 3);
+        const unsigned e2 = (unsigned)((S >> (L - 3)) & (M)7) | ((unsigned)(S & (M)7) << 3);
         unsigned pe2 = __shfl_up(e2, 1), ne2 = __shfl_down(e2, 1);
         if (lane == 0) pe2 = 0;
         if (lane >= 49) ne2 = 0;
-        const unsigned long long pS = pe2 & 7u, nS = (ne2 >> 3) & 7u;  // nS bit j <-> point j of the partition behind
-        const unsigned long long covL = (Cm1 & ((S << 1) | (pS >> 2))) | (Cm2 & ((S << 2) | (pS >> 1))) | (Cm3 & ((S << 3) | pS)) | (Cw1 & (S >> 1)) |
-                                        (Cw2 & (S >> 2)) | (Cw3 & (S >> 3));
-        const unsigned long long covLater = (inB1 & ((nS & 1ull) << (L - 1))) | (inB2 & ((nS & 3ull) << (L - 2))) | (inB3 & ((nS & 7ull) << (L - 3)));
-        const unsigned long long is3 = S & ~covL;
+        const M pS = (M)(pe2 & 7u), nS = (M)((ne2 >> 3) & 7u);  // nS bit j <-> point j of the partition behind
+        const M covL = (Cm1 & ((S << 1) | (pS >> 2))) | (Cm2 & ((S << 2) | (pS >> 1))) | (Cm3 & ((S << 3) | pS)) | (Cw1 & (S >> 1)) | (Cw2 & (S >> 2)) |
+                       (Cw3 & (S >> 3));
+        const M covLater = (inB1 & ((nS & (M)1) << (L - 1))) | (inB2 & ((nS & (M)3) << (L - 2))) | (inB3 & ((nS & (M)7) << (L - 3)));
+        const M is3 = S & ~covL;
         // ---- :521-539 in closed form (as in k_select) ----
         // the three first reflect candidates in reflect order
-        unsigned long long inBm = 0ull, bfirst = 0ull;
+        M inBm = (M)0, bfirst = (M)0;
         {
-            unsigned long long best[3] = {~0ull, ~0ull, ~0ull};
-            unsigned long long m = RF;
-            while (m) {  // four candidates per turn, their keys requested together
+            u64m best[3] = {~0ull, ~0ull, ~0ull};
+            M m = RF;
+            while (m != (M)0) {  // four candidates per turn, their keys requested together
                 int kk[4];
                 float rv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    kk[u] = m ? (int)__ffsll((long long)m) - 1 : -1;
-                    m &= m - 1;
+                    kk[u] = m_ffs(m);
+                    m &= m - (M)1;
                     rv[u] = refl[sp + (kk[u] >= 0 ? kk[u] : 0)];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (kk[u] < 0) continue;
-                    unsigned long long x = ((unsigned long long)refl_key(rv[u]) << 32) | (unsigned)(sp + kk[u]);
+                    u64m x = ((u64m)refl_key(rv[u]) << 32) | (unsigned)(sp + kk[u]);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        const unsigned long long cur = best[r];
+                        const u64m cur = best[r];
                         const bool lt = x < cur;
                         best[r] = lt ? x : cur;
                         x = lt ? cur : x;
@@ -2402,23 +2425,20 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                if (best[r] != ~0ull) inBm |= 1ull << ((int)(unsigned)best[r] - sp);
+                if (best[r] != ~0ull) inBm |= (M)1 << ((int)(unsigned)best[r] - sp);
             SP_MARK(3);
             // does a pick's reflect visit come before its own curvature visit?  (only read for a pick that holds 3 or is a
-            // grazing point): ranks in both orders over the whole partition
-            // Counted with one POINT per lane (a partition has at most 64): the picks of all partitions are taken four at a
-            // time -- the owning lanes broadcast partition and pick, lanes 0 .. L-1 fetch that partition's keys, two ballots
-            // give the two ranks -- instead of every owner walking its partition alone, a chain of dependent loads that the
-            // whole wavefront waited for (31 % of the kernel).
-            unsigned long long need = inBm & (is3 | AN);
+            // grazing point): ranks in both orders over the whole partition.  Counted with one POINT per lane: the picks of all
+            // partitions are taken four at a time -- the owning lanes broadcast partition and pick, the lanes fetch that
+            // partition's keys (64 per pass), two ballots per pass give the two ranks -- instead of every owner walking its
+            // partition alone, a chain of dependent loads that the whole wavefront waited for (31 % of the kernel).
+            M need = inBm & (is3 | AN);
             for (;;) {
-                // next pick of my own partition (if any), then the wavefront's list of lanes that have one
-                const int myk = need ? (int)__ffsll((long long)need) - 1 : -1;
-                unsigned long long owners = __ballot(myk >= 0);
+                const int myk = m_ffs(need);  // next pick of my own partition (if any)
+                u64m owners = __ballot(myk >= 0);
                 if (!owners) break;
                 int src[4], pk[4], psp[4], pL[4];
-                unsigned ck[4], rk[4];
-                float cv[4], rv[4];
+                float mcv[4], mrv[4], cv[4][WIDE ? 2 : 1], rv[4][WIDE ? 2 : 1];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     src[u] = owners ? (int)__ffsll((long long)owners) - 1 : -1;
@@ -2427,100 +2447,113 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
                     pk[u] = __shfl(myk, o);
                     psp[u] = __shfl(sp, o);
                     pL[u] = __shfl(L, o);
-                    const int q = min(lane, pL[u] - 1);
-                    cv[u] = curv[psp[u] + q];
-                    rv[u] = refl[psp[u] + q];
-                }
+                    mcv[u] = curv[psp[u] + max(pk[u], 0)];
+                    mrv[u] = refl[psp[u] + max(pk[u], 0)];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ck[u] = __float_as_uint(cv[u]);
-                    rk[u] = refl_key(rv[u]);
+                    for (int h = 0; h < (WIDE ? 2 : 1); ++h) {
+                        const int q = min(lane + 64 * h, pL[u] - 1);
+                        cv[u][h] = curv[psp[u] + q];
+                        rv[u][h] = refl[psp[u] + q];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (src[u] < 0) continue;  // wave-uniform
-                    const unsigned mk = __shfl(ck[u], pk[u]), mr = __shfl(rk[u], pk[u]);
-                    const bool in = lane < pL[u];
-                    const int rc = __popcll(__ballot(in && ((ck[u] < mk) || (ck[u] == mk && lane < pk[u]))));
-                    const int rr = __popcll(__ballot(in && ((rk[u] < mr) || (rk[u] == mr && lane < pk[u]))));
+                    const unsigned mk = __float_as_uint(mcv[u]), mr = refl_key(mrv[u]);
+                    int rc = 0, rr = 0;
+#pragma unroll
+                    for (int h = 0; h < (WIDE ? 2 : 1); ++h) {
+                        const int q = lane + 64 * h;
+                        const bool in = q < pL[u];
+                        const unsigned kq = __float_as_uint(cv[u][h]), rq = refl_key(rv[u][h]);
+                        rc += __popcll(__ballot(in && ((kq < mk) || (kq == mk && q < pk[u]))));
+                        rr += __popcll(__ballot(in && ((rq < mr) || (rq == mr && q < pk[u]))));
+                    }
                     if (lane == src[u]) {
-                        if (rr < rc) bfirst |= 1ull << pk[u];
-                        need &= need - 1;
+                        if (rr < rc) bfirst |= (M)1 << pk[u];
+                        need &= need - (M)1;
                     }
                 }
             }
         }
         SP_MARK(4);
-        const unsigned long long eff3 = is3 & ~(inBm & bfirst);
-        const unsigned long long Gm = AN | (eff3 & FR);
-        unsigned long long first = 0ull;
+        const M eff3 = is3 & ~(inBm & bfirst);
+        const M Gm = AN | (eff3 & FR);
+        M first = (M)0;
         {
-            unsigned long long minE = ~0ull, minG = ~0ull;
-            auto min_key = [&](unsigned long long m) -> unsigned long long {  // four keys per turn, requested together
-                unsigned long long best = ~0ull;
-                while (m) {
+            auto min_key = [&](M m) -> u64m {  // four keys per turn, requested together
+                u64m best = ~0ull;
+                while (m != (M)0) {
                     int kk[4];
                     float cv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        kk[u] = m ? (int)__ffsll((long long)m) - 1 : -1;
-                        m &= m - 1;
+                        kk[u] = m_ffs(m);
+                        m &= m - (M)1;
                         cv[u] = curv[sp + (kk[u] >= 0 ? kk[u] : 0)];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const unsigned long long ck = kk[u] >= 0 ? (((unsigned long long)__float_as_uint(cv[u]) << 32) | (unsigned)(sp + kk[u])) : ~0ull;
+                        const u64m ck = kk[u] >= 0 ? (((u64m)__float_as_uint(cv[u]) << 32) | (unsigned)(sp + kk[u])) : ~0ull;
                         best = ck < best ? ck : best;
                     }
                 }
                 return best;
             };
-            minE = min_key(eff3);
-            minG = min_key(Gm);
-            if (minE != ~0ull && !(minG < minE)) first = 1ull << ((int)(unsigned)minE - sp);
+            const u64m minE = min_key(eff3), minG = min_key(Gm);
+            if (minE != ~0ull && !(minG < minE)) first = (M)1 << ((int)(unsigned)minE - sp);
         }
         SP_MARK(5);
-        const unsigned long long picked = Gm | first;
-        const unsigned long long two_after_300 = inBm & picked & AN & bfirst;
-        const unsigned long long F2 = ((picked & ~inBm) | two_after_300) & ~covLater;
-        const unsigned long long F300 = inBm & ~two_after_300 & ~covLater;
-        const unsigned long long F1 = covLater | (covL & ~picked & ~inBm);
-        const unsigned long long F3 = is3 & ~picked & ~inBm & ~covLater;
+        const M picked = Gm | first;
+        const M two_after_300 = inBm & picked & AN & bfirst;
+        const M F2 = ((picked & ~inBm) | two_after_300) & ~covLater;
+        const M F300 = inBm & ~two_after_300 & ~covLater;
+        const M F1 = covLater | (covL & ~picked & ~inBm);
+        const M F3 = is3 & ~picked & ~inBm & ~covLater;
         // result planes: code 1 -> flag 1, 2 -> 2, 3 -> 3, 4 -> 300
-        unsigned long long r0 = F1 | F3, r1 = F2 | F3, r2 = F300;
+        const M r0 = F1 | F3, r1 = F2 | F3, r2 = F300;
         // the points in front of the first and behind the last partition can only be marked (flag 1)
-        unsigned long long head1 = 0ull, tail1m = 0ull;  // bit j <-> point sp - 1 - j / point spn + j
+        unsigned head1 = 0, tail1m = 0;  // bit j <-> point sp - 1 - j / point spn + j
         if (lane == 0) {
             for (int j = 0; j < 3; ++j)
                 for (int k = 0; k + j < 3; ++k) {
                     const int d = k + j + 1;
-                    const unsigned long long Bd = d == 1 ? B1 : (d == 2 ? B2 : B3);
-                    if ((S >> k) & (Bd >> k) & 1ull) head1 |= 1ull << j;
+                    const M Bd = d == 1 ? B1 : (d == 2 ? B2 : B3);
+                    if ((unsigned)((S >> k) & (Bd >> k) & (M)1)) head1 |= 1u << j;
                 }
         }
         if (lane == 49) {
             for (int j = 0; j < 3; ++j)
                 for (int k = 0; k + j < 3; ++k) {
                     const int d = k + j + 1;
-                    const unsigned long long Ad = d == 1 ? A1 : (d == 2 ? A2 : A3);
-                    if ((S >> (L - 1 - k)) & (Ad >> (L - 1 - k)) & 1ull) tail1m |= 1ull << j;
+                    const M Ad = d == 1 ? A1 : (d == 2 ? A2 : A3);
+                    if ((unsigned)((S >> (L - 1 - k)) & (Ad >> (L - 1 - k)) & (M)1)) tail1m |= 1u << j;
                 }
         }
+        SP_SYNC();  // (the result planes have been zeroed by every lane)
         if (act) {
-            auto scatter = [&](int plane, unsigned long long v) {
-                if (v == 0ull) return;
-                atomicOr(&pl[plane][w0], v << off);
-                if (off && (v >> (64 - off))) atomicOr(&pl[plane][w0 + 1], v >> (64 - off));
+            auto scatter = [&](int plane, M v) {
+                if (v == (M)0) return;
+                const u64m lo = (u64m)v;
+                if (lo << off) atomicOr(&pl[plane][w0], lo << off);
+                u64m mid = off ? (lo >> (64 - off)) : 0ull;
+                if constexpr (WIDE) {
+                    const u64m hi = (u64m)(v >> 64);
+                    mid |= hi << off;
+                    const u64m top = off ? (hi >> (64 - off)) : 0ull;
+                    if (top) atomicOr(&pl[plane][w0 + 2], top);
+                }
+                if (mid) atomicOr(&pl[plane][w0 + 1], mid);
             };
             scatter(PL_R0, r0);
             scatter(PL_R1, r1);
             scatter(PL_R2, r2);
             if (lane == 0)
                 for (int j = 0; j < 3; ++j)
-                    if ((head1 >> j) & 1ull) atomicOr(&pl[PL_R0][(sp - 1 - j) >> 6], 1ull << ((sp - 1 - j) & 63));
+                    if ((head1 >> j) & 1u) atomicOr(&pl[PL_R0][(sp - 1 - j) >> 6], 1ull << ((sp - 1 - j) & 63));
             if (lane == 49)
                 for (int j = 0; j < 3; ++j)
-                    if ((tail1m >> j) & 1ull) atomicOr(&pl[PL_R0][(spn + j) >> 6], 1ull << ((spn + j) & 63));
+                    if ((tail1m >> j) & 1u) atomicOr(&pl[PL_R0][(spn + j) >> 6], 1ull << ((spn + j) & 63));
         }
     }
     SP_SYNC();
@@ -2541,7 +2574,7 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
         for (int u = 0; u < 4; ++u) {
             const int w = w4 + u, i = 64 * w + lane;
             if (w >= nwin || i >= n) continue;
-            const unsigned long long r0 = pl[PL_R0][w], r1 = pl[PL_R1][w], r2 = pl[PL_R2][w];
+            const u64m r0 = pl[PL_R0][w], r1 = pl[PL_R1][w], r2 = pl[PL_R2][w];
             const unsigned code = (unsigned)((r0 >> lane) & 1ull) | ((unsigned)((r1 >> lane) & 1ull) << 1) | ((unsigned)((r2 >> lane) & 1ull) << 2);
             int f = code == 4u ? 300 : (int)code;
             const unsigned at = at4[u];
@@ -2570,6 +2603,9 @@ __global__ __launch_bounds__(64 * SP_LINES) void k_select_part(FeatParams P, int
     SP_MARK(7);
 #undef SP_SYNC
 }
+// the two forms: partitions of up to 64 points (rings), up to 128 (Livox lines)
+constexpr int SP_LINES = 4, SP_LINES_WIDE = 2;
+constexpr int SP_MAXWIN = 53, SP_MAXWIN_WIDE = 103;  // (3211 + 63) / 64 + 2, (6411 + 63) / 64 + 2
 
 // K (points per thread in LDS-resident lines) variants of k_select
 typedef void (*select_fn)(FeatParams);
@@ -2874,7 +2910,12 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         // rings and Livox lines have different nominal lengths: each group runs the variant whose LDS block fits it, so the
         // short rings do not pay (in occupancy) for the long Livox lines
         if (ctx->select_part)  // lines whose partitions hold 3 .. 64 points: one partition per lane; the rest falls through to k_select
-            hipLaunchKernelGGL(k_select_part, dim3((ctx->L + SP_LINES - 1) / SP_LINES, count), dim3(64 * SP_LINES), 0, s, P, ctx->L);
+        {
+            hipLaunchKernelGGL((k_select_part<u64m, SP_LINES, SP_MAXWIN>), dim3((ctx->L + SP_LINES - 1) / SP_LINES, count), dim3(64 * SP_LINES), 0, s,
+                               P, ctx->L);
+            hipLaunchKernelGGL((k_select_part<u128m, SP_LINES_WIDE, SP_MAXWIN_WIDE>), dim3((ctx->L + SP_LINES_WIDE - 1) / SP_LINES_WIDE, count),
+                               dim3(64 * SP_LINES_WIDE), 0, s, P, ctx->L);
+        }
         FeatParams Pv = P;
         Pv.sel_cap = ctx->sel_cap_velo;
         hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(ctx->cfg.n_rings, count), dim3(SELP_THREADS),
@@ -2959,7 +3000,10 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
         hipLaunchKernelGGL(k_stencil_redo, dim3(4, 1), dim3(256), 0, s, P);
         hipLaunchKernelGGL(k_stencil_break, dim3(2, 1), dim3(256), 0, s, P);
     }
-    if (ctx->select_part) hipLaunchKernelGGL(k_select_part, dim3(1, 1), dim3(64 * SP_LINES), 0, s, P, 1);
+    if (ctx->select_part) {
+        hipLaunchKernelGGL((k_select_part<u64m, SP_LINES, SP_MAXWIN>), dim3(1, 1), dim3(64 * SP_LINES), 0, s, P, 1);
+        hipLaunchKernelGGL((k_select_part<u128m, SP_LINES_WIDE, SP_MAXWIN_WIDE>), dim3(1, 1), dim3(64 * SP_LINES_WIDE), 0, s, P, 1);
+    }
     hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
     MML_HIP(hipGetLastError());
     return MML_OK;
