@@ -18,6 +18,8 @@
 // (left-to-right, float), double expressions follow Eigen's (x0+x1)+x2 reduction order.  libm calls on
 // float arguments follow the "double libm, round on assignment" convention documented in DESIGN.md.
 #include <math.h>
+
+#include <algorithm>
 #include <stdlib.h>
 
 #include "mml_internal.h"
@@ -80,6 +82,8 @@ struct FeatParams {
     unsigned* redo_queue;  // [B][NT] positions whose float pre-decisions were not certain (k_stencil_redo)
     int* redo_cnt;         // [B]
     uint8_t* sel_done;       // [B][L] 1: the line's flags and labels were written by k_select_part, k_select skips it
+    int* sel_list;           // [2][B * L][2] (slot, line) of the lines k_select_part left to k_select: rings | Livox lines
+    int* sel_list_cnt;       // [B][2] list lengths of the launch that starts at slot `first`
     unsigned char* st_exit;  // [B][st_stride] k_stencil, segment mode: the stride walk's exit offsets of every tile, for the four entries
     int st_stride;
 };
@@ -2155,8 +2159,11 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
 // LDS of the cached form: W pairs with 4 pad records either side | R (reflect keys; later the window tables)
 __host__ __device__ inline size_t select_lds_bytes(int cap) { return (size_t)(cap + 8) * 8 + (size_t)cap * 4; }
 
+// list_kind < 0: one workgroup per (line, slot) of the grid.  list_kind 0 / 1: behind k_select_part, the (normally empty) list of the
+// ring / Livox lines that kernel left over, walked by a small grid -- a full grid of workgroups that only find their line done
+// still has to wait for 512 wave slots and 29-53 KB of LDS each, and held its stream for longer than the real work took.
 template <int K>
-__global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
+__global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P, int list_kind) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_pm[50][3];
     __shared__ unsigned long long s_minE[50], s_minG[50];
@@ -2167,25 +2174,43 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P) {
     // only the global-scratch form (lines beyond the LDS budget) uses these two; its dynamic LDS block is otherwise idle
     unsigned char* s_bfirst = smem;
     unsigned char* s_list = smem + 160;
-    const int b = blockIdx.y + P.first;
-    const int line = blockIdx.x + P.line0;
-    const int n = P.line_len[(size_t)b * P.L + line];
-    if (n <= 0) return;
-    if (P.sel_done && P.sel_done[(size_t)b * P.L + line]) return;  // done by k_select_part
-    const int start = P.line_start[(size_t)b * P.L + line];
-    const size_t base = (size_t)b * P.NT + start;
-    constexpr int cap = K * SELP_THREADS;
-    if (n <= cap) {
-        unsigned* W = reinterpret_cast<unsigned*>(smem) + 8;  // 4 pad records in front, 4 behind
-        unsigned* R = reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8);
-        select_body<K>(P, b, n, base, W, R, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
-    } else {
-        // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
-        const size_t BNT = (size_t)P.B * P.NT;
-        // (+8 * line + 8 words: room for the pad records of every line in front of this one)
-        unsigned* W = P.sel_scratch + 2 * base + 16 * ((size_t)b * (P.L + 2) + line + 1);
-        select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+    const int n_list = list_kind < 0 ? 1 : P.sel_list_cnt[2 * P.first + list_kind];
+    const int* list = P.sel_list + 2 * ((size_t)(list_kind < 0 ? 0 : list_kind) * P.B + P.first) * P.L;
+    for (int e = list_kind < 0 ? 0 : (int)blockIdx.x; e < n_list; e += gridDim.x) {
+        const int b = list_kind < 0 ? (int)blockIdx.y + P.first : list[2 * e];
+        const int line = list_kind < 0 ? (int)blockIdx.x + P.line0 : list[2 * e + 1];
+        const int n = P.line_len[(size_t)b * P.L + line];
+        if (n <= 0) continue;
+        if (list_kind < 0 && P.sel_done && P.sel_done[(size_t)b * P.L + line]) return;  // done by k_select_part
+        __syncthreads();  // (list mode: the previous line's LDS state has been read)
+        const int start = P.line_start[(size_t)b * P.L + line];
+        const size_t base = (size_t)b * P.NT + start;
+        constexpr int cap = K * SELP_THREADS;
+        if (n <= cap) {
+            unsigned* W = reinterpret_cast<unsigned*>(smem) + 8;  // 4 pad records in front, 4 behind
+            unsigned* R = reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8);
+            select_body<K>(P, b, n, base, W, R, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+        } else {
+            // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
+            // (+8 * line + 8 words: room for the pad records of every line in front of this one)
+            unsigned* W = P.sel_scratch + 2 * base + 16 * ((size_t)b * (P.L + 2) + line + 1);
+            select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+        }
+        if (list_kind < 0) break;
     }
+}
+
+// the lines of a launch that k_select_part did not take, as two lists (rings, Livox lines) for k_select
+__global__ void k_select_list(FeatParams P, int count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * P.L) return;
+    const int b = P.first + t / P.L, line = t % P.L;
+    if (P.line_len[(size_t)b * P.L + line] <= 0 || P.sel_done[(size_t)b * P.L + line]) return;
+    const int kind = line < P.n_rings ? 0 : 1;
+    const int at = atomicAdd(&P.sel_list_cnt[2 * P.first + kind], 1);
+    int* list = P.sel_list + 2 * ((size_t)kind * P.B + P.first) * P.L;
+    list[2 * at] = b;
+    list[2 * at + 1] = line;
 }
 
 // ---- a4 + a5 + a8 once more, for lines whose partitions hold 3 .. 64 points: one partition per LANE ---------------------------
@@ -2608,7 +2633,7 @@ constexpr int SP_LINES = 4, SP_LINES_WIDE = 2;
 constexpr int SP_MAXWIN = 53, SP_MAXWIN_WIDE = 103;  // (3211 + 63) / 64 + 2, (6411 + 63) / 64 + 2
 
 // K (points per thread in LDS-resident lines) variants of k_select
-typedef void (*select_fn)(FeatParams);
+typedef void (*select_fn)(FeatParams, int);
 static select_fn select_variant(int cap) {
     switch (cap / SELP_THREADS) {
         case 2: return k_select<2>;
@@ -2858,6 +2883,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.redo_queue = ctx->redo_queue;
     P.redo_cnt = ctx->brk_cnt + ctx->B;
     P.sel_done = ctx->select_part ? ctx->sel_done : nullptr;
+    P.sel_list = ctx->sel_list;
+    P.sel_list_cnt = ctx->sel_list_cnt;
     P.st_exit = ctx->st_exit;
     P.st_stride = ctx->NT / 256 + ctx->L + 8;
     return P;
@@ -2909,22 +2936,29 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         MmlStageScope t(ctx, "select");
         // rings and Livox lines have different nominal lengths: each group runs the variant whose LDS block fits it, so the
         // short rings do not pay (in occupancy) for the long Livox lines
-        if (ctx->select_part)  // lines whose partitions hold 3 .. 64 points: one partition per lane; the rest falls through to k_select
-        {
+        FeatParams Pv = P;
+        Pv.sel_cap = ctx->sel_cap_velo;
+        FeatParams Pl = P;
+        Pl.line0 = ctx->cfg.n_rings;
+        if (ctx->select_part) {
+            // lines whose partitions hold 3 .. 64 / .. 128 points: one partition per lane; what is left over (short, very long or
+            // ragged lines) is listed and goes through k_select, a small grid walking the two lists
+            MML_HIP(hipMemsetAsync(ctx->sel_list_cnt + 2 * (size_t)first, 0, 2 * sizeof(int), s));
             hipLaunchKernelGGL((k_select_part<u64m, SP_LINES, SP_MAXWIN>), dim3((ctx->L + SP_LINES - 1) / SP_LINES, count), dim3(64 * SP_LINES), 0, s,
                                P, ctx->L);
             hipLaunchKernelGGL((k_select_part<u128m, SP_LINES_WIDE, SP_MAXWIN_WIDE>), dim3((ctx->L + SP_LINES_WIDE - 1) / SP_LINES_WIDE, count),
                                dim3(64 * SP_LINES_WIDE), 0, s, P, ctx->L);
-        }
-        FeatParams Pv = P;
-        Pv.sel_cap = ctx->sel_cap_velo;
-        hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(ctx->cfg.n_rings, count), dim3(SELP_THREADS),
-                           select_lds_bytes(ctx->sel_cap_velo), s, Pv);
-        if (ctx->L > ctx->cfg.n_rings) {
-            FeatParams Pl = P;
-            Pl.line0 = ctx->cfg.n_rings;
-            hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(ctx->L - ctx->cfg.n_rings, count), dim3(SELP_THREADS),
-                               select_lds_bytes(ctx->sel_cap), s, Pl);
+            hipLaunchKernelGGL(k_select_list, dim3((count * ctx->L + 255) / 256), dim3(256), 0, s, P, count);
+            const int rows_v = std::min(ctx->cfg.n_rings * count, 256), rows_l = std::min((ctx->L - ctx->cfg.n_rings) * count, 128);
+            hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(rows_v), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap_velo), s, Pv, 0);
+            if (rows_l > 0)
+                hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(rows_l), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, Pl, 1);
+        } else {
+            hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(ctx->cfg.n_rings, count), dim3(SELP_THREADS),
+                               select_lds_bytes(ctx->sel_cap_velo), s, Pv, -1);
+            if (ctx->L > ctx->cfg.n_rings)
+                hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(ctx->L - ctx->cfg.n_rings, count), dim3(SELP_THREADS),
+                                   select_lds_bytes(ctx->sel_cap), s, Pl, -1);
         }
     }
     {
@@ -3004,7 +3038,8 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
         hipLaunchKernelGGL((k_select_part<u64m, SP_LINES, SP_MAXWIN>), dim3(1, 1), dim3(64 * SP_LINES), 0, s, P, 1);
         hipLaunchKernelGGL((k_select_part<u128m, SP_LINES_WIDE, SP_MAXWIN_WIDE>), dim3(1, 1), dim3(64 * SP_LINES_WIDE), 0, s, P, 1);
     }
-    hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P);
+    // (direct mode: the workgroup finds its line done by k_select_part, or does it)
+    hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(1, 1), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, P, -1);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }

@@ -124,6 +124,8 @@ struct mml_ctx {
     unsigned* redo_queue = nullptr; // B * NT: points k_stencil left to k_stencil_redo
     uint8_t* sel_done = nullptr;       // B * L: lines finished by k_select_part
     bool select_part = true;
+    int* sel_list = nullptr;           // 2 * B * L * 2 ints: (slot, line) lists of the lines left to k_select (rings | Livox lines)
+    int* sel_list_cnt = nullptr;       // 2 B ints
     unsigned char* st_exit = nullptr;  // B * (NT / 256 + L + 8): k_stencil segment mode, exit offsets of the stride walk per tile
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)
