@@ -2457,15 +2457,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
             // partitions are taken four at a time -- the owning lanes broadcast partition and pick, the lanes fetch that
             // partition's keys (64 per pass), two ballots per pass give the two ranks -- instead of every owner walking its
             // partition alone, a chain of dependent loads that the whole wavefront waited for (31 % of the kernel).
+            constexpr int RK = WIDE ? 4 : 8;  // picks per turn
             M need = inBm & (is3 | AN);
             for (;;) {
                 const int myk = m_ffs(need);  // next pick of my own partition (if any)
                 u64m owners = __ballot(myk >= 0);
                 if (!owners) break;
-                int src[4], pk[4], psp[4], pL[4];
-                float mcv[4], mrv[4], cv[4][WIDE ? 2 : 1], rv[4][WIDE ? 2 : 1];
+                int src[RK], pk[RK], psp[RK], pL[RK];
+                float mcv[RK], mrv[RK], cv[RK][WIDE ? 2 : 1], rv[RK][WIDE ? 2 : 1];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RK; ++u) {
                     src[u] = owners ? (int)__ffsll((long long)owners) - 1 : -1;
                     owners &= owners - 1;
                     const int o = src[u] >= 0 ? src[u] : 0;
@@ -2482,7 +2483,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RK; ++u) {
                     if (src[u] < 0) continue;  // wave-uniform
                     const unsigned mk = __float_as_uint(mcv[u]), mr = refl_key(mrv[u]);
                     int rc = 0, rr = 0;
@@ -2586,17 +2587,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
     // ---- phase C: flags and labels, one point per lane -----------------------------------------------------------------
     uint8_t* lnlab = P.ln_label + base;
     const int2* gidx = P.ln_meta + base;
-    for (int w4 = 0; w4 < nwin; w4 += 4) {
-        unsigned at4[4];
-        int gi4[4];
+    for (int w4 = 0; w4 < nwin; w4 += 8) {
+        unsigned at4[8];
+        int gi4[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int i = min(64 * (w4 + u) + lane, n - 1);
             at4[u] = attr[i];
             gi4[u] = gidx[i].x;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int w = w4 + u, i = 64 * w + lane;
             if (w >= nwin || i >= n) continue;
             const u64m r0 = pl[PL_R0][w], r1 = pl[PL_R1][w], r2 = pl[PL_R2][w];
