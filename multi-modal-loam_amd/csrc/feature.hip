@@ -63,6 +63,7 @@ struct FeatParams {
     int* blk_cnt;        // [B][2][nblk_max][BLK_STRIDE] per-block histograms / exclusive offsets
     int* assign_aux;     // AssignAux per slot
     int nblk_v, nblk_l, nblk_max, ring_bits, line_bits;
+    int asb_stride;      // row stride of k_assign_b's LDS tile
     CropBlk* crop_cnt;   // [B][nblk_t] per-block counts / exclusive offsets of the crop passes
     unsigned* label_idx; // [B][2][cap] fused-cloud indices of the corner / surf labelled points
     int nblk_t;
@@ -315,10 +316,14 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
     // one lane per row -- and written back the same way (lane-per-row accesses straight to memory touched one 64-byte sector
     // per int: 3.9 ms per 1024 dense 128-ring scans).
     {
-        __shared__ int s_tile[64][BLK_STRIDE + 1];
+        // (the tile is sized by the launch for the sensor's real number of columns, compact: 64 x 19 ints at 16 rings instead
+        //  of 64 x 163 -- with 42 KB of LDS per workgroup this one-workgroup-per-slot kernel waited ~0.5 ms per 512-slot launch
+        //  for room next to the other lanes' kernels, and its lane's scatter pass with it)
+        extern __shared__ int s_tile_dyn[];
         __shared__ int s_acc[MAX_LINES + 2];
         const int lane = tid & 63;
         const int ncol = nkeys + 2;
+        const int tstride = P.asb_stride;  // >= max(n_rings, n_lines) + 2, odd
         for (int k = tid; k < ncol; k += ASB_THREADS) s_acc[k] = 0;
         for (int b0 = 0; b0 < nblk; b0 += 64) {
             const int rows = min(64, nblk - b0);
@@ -326,19 +331,18 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
             for (int idx = tid; idx < rows * ncol; idx += ASB_THREADS) {
                 const int r = idx / ncol, c = idx - r * ncol;
                 const int col = c < nkeys ? c : MAX_LINES + (c - nkeys);
-                s_tile[r][col] = cnt0[(size_t)(b0 + r) * BLK_STRIDE + col];
+                s_tile_dyn[r * tstride + c] = cnt0[(size_t)(b0 + r) * BLK_STRIDE + col];
             }
             __syncthreads();
             for (int kk = tid >> 6; kk < ncol; kk += ASB_THREADS / 64) {
-                const int k = kk < nkeys ? kk : MAX_LINES + (kk - nkeys);
                 const int base = s_acc[kk];
-                const int v = lane < rows ? s_tile[lane][k] : 0;
+                const int v = lane < rows ? s_tile_dyn[lane * tstride + kk] : 0;
                 int x = v;
                 for (int o = 1; o < 64; o <<= 1) {
                     const int y = __shfl_up(x, o);
                     if (lane >= o) x += y;
                 }
-                if (lane < rows) s_tile[lane][k] = base + x - v;
+                if (lane < rows) s_tile_dyn[lane * tstride + kk] = base + x - v;
                 const int tot = __shfl(x, 63);
                 if (lane == 0) s_acc[kk] = base + tot;
             }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
             for (int idx = tid; idx < rows * ncol; idx += ASB_THREADS) {
                 const int r = idx / ncol, c = idx - r * ncol;
                 const int col = c < nkeys ? c : MAX_LINES + (c - nkeys);
-                cnt0[(size_t)(b0 + r) * BLK_STRIDE + col] = s_tile[r][col];
+                cnt0[(size_t)(b0 + r) * BLK_STRIDE + col] = s_tile_dyn[r * tstride + c];
             }
         }
         __syncthreads();
@@ -2865,6 +2869,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     while ((1 << P.ring_bits) < ctx->cfg.n_rings) ++P.ring_bits;
     P.line_bits = 1;
     while ((1 << P.line_bits) < ctx->cfg.n_livox_lines) ++P.line_bits;
+    P.asb_stride = (ctx->cfg.n_rings > ctx->cfg.n_livox_lines ? ctx->cfg.n_rings : ctx->cfg.n_livox_lines) + 2;
+    P.asb_stride |= 1;
     P.crop_cnt = reinterpret_cast<CropBlk*>(ctx->crop_cnt);
     P.label_idx = reinterpret_cast<unsigned*>(ctx->vx_keys);
     P.nblk_t = (ctx->NT + 255) / 256;
@@ -2904,7 +2910,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     }
     {
         MmlStageScope t(ctx, "assign_scan");
-        hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(ASB_THREADS), 0, s, P);
+        hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(ASB_THREADS), sizeof(int) * 64 * (size_t)P.asb_stride, s, P);
     }
     {
         MmlStageScope t(ctx, "assign_scatter");

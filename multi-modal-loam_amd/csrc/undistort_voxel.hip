@@ -69,15 +69,13 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-constexpr int VX_THREADS = 1024;
-constexpr int VX_WAVES = VX_THREADS / 64;
 constexpr int VX_TAIL = 64;
 
 // Bitonic sort of npad = KPT * VX_THREADS keys, ascending, element e = tid + VX_THREADS * k held by thread tid in
 // key[k].  The partner of element e at distance j is e ^ j: for j >= VX_THREADS that is another register of the same
 // thread, for j < 64 another lane of the same wavefront (two 32-bit shuffles), and only the four distances in between
 // go through LDS -- 22 barrier-separated exchanges for 8192 keys instead of 91.
-template <int KPT, int DK>
+template <int VX_THREADS, int KPT, int DK>
 __device__ __forceinline__ void bitonic_reg_step(unsigned long long (&key)[KPT], int k, int tid) {
     if constexpr (DK < KPT) {
 #pragma unroll
@@ -94,7 +92,7 @@ __device__ __forceinline__ void bitonic_reg_step(unsigned long long (&key)[KPT],
         }
     }
 }
-template <int KPT>
+template <int VX_THREADS, int KPT>
 __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT], unsigned long long* lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int NP = KPT * VX_THREADS;
@@ -105,11 +103,11 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
             if (j >= VX_THREADS) {
                 const int dk = j / VX_THREADS;  // 1, 2 or 4: register distance (compile-time in each branch)
                 if (dk == 1)
-                    bitonic_reg_step<KPT, 1>(key, k, tid);
+                    bitonic_reg_step<VX_THREADS, KPT, 1>(key, k, tid);
                 else if (dk == 2)
-                    bitonic_reg_step<KPT, 2>(key, k, tid);
+                    bitonic_reg_step<VX_THREADS, KPT, 2>(key, k, tid);
                 else
-                    bitonic_reg_step<KPT, 4>(key, k, tid);
+                    bitonic_reg_step<VX_THREADS, KPT, 4>(key, k, tid);
             } else if (j < 64) {
 #pragma unroll
                 for (int a = 0; a < KPT; ++a) {
@@ -145,10 +143,12 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 }
 
 // One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
-__global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
+template <int VX_THREADS>
+__global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
                                                      const float4* ln_pts, const int2* ln_meta,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
+    constexpr int VX_WAVES = VX_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int s_wtot[VX_WAVES];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     __shared__ int s_nout;
 
     const int b = blockIdx.x + first;
-    const int kind = blockIdx.y;
+    const int kind = blockIdx.y + kind0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* px = ln_pts + (size_t)b * NT;
     const int2* gx = ln_meta + (size_t)b * NT;
@@ -247,22 +247,22 @@ __global__ __launch_bounds__(VX_THREADS, 8) void k_voxel(int first, int NT, int 
     // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
     if (cnt <= VX_THREADS) {
         unsigned long long k1[1] = {make_key(tid)};
-        bitonic_sort_regs<1>(k1, keys);
+        bitonic_sort_regs<VX_THREADS, 1>(k1, keys);
     } else if (cnt <= 2 * VX_THREADS) {
         unsigned long long k2[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) k2[a] = make_key(tid + VX_THREADS * a);
-        bitonic_sort_regs<2>(k2, keys);
+        bitonic_sort_regs<VX_THREADS, 2>(k2, keys);
     } else if (cnt <= 4 * VX_THREADS) {
         unsigned long long k4[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) k4[a] = make_key(tid + VX_THREADS * a);
-        bitonic_sort_regs<4>(k4, keys);
+        bitonic_sort_regs<VX_THREADS, 4>(k4, keys);
     } else {
         unsigned long long k8[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a) k8[a] = make_key(tid + VX_THREADS * a);
-        bitonic_sort_regs<8>(k8, keys);
+        bitonic_sort_regs<VX_THREADS, 8>(k8, keys);
     }
     // 4. one lane per voxel head: centroid in input order (AccumulatorXYZ: float sum, then / n)
     if (tid == 0) {
@@ -349,13 +349,21 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     if (ctx->NT > 65536) return mml_downsample_big(ctx, first, count);  // labelled clouds beyond the LDS sort
     // `cap` labelled points per (slot, kind) fit the LDS sort; a slot with more gets ft_n = -1 here and is redone through
     // the global-sort path by mml_downsample_redo_overflow (the label lists hold every labelled point: stride VX_CAP)
-    const int cap = MML_VOXEL_LDS_CAP;
-    int npad = 1;
-    while (npad < cap) npad <<= 1;
-    size_t lds = (size_t)npad * sizeof(unsigned long long);
-    hipLaunchKernelGGL(k_voxel, dim3(count, 2), dim3(VX_THREADS), lds, MML_STREAM(ctx), first, ctx->NT, ctx->MF, ctx->B,
-                       cap, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf,
-                       ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+    // The corner lists are an order of magnitude shorter than the surf lists (hundreds against thousands of points): they get a
+    // 256-thread workgroup with room for 2048 keys (16 KB), so that only the surf half of the launch is made of 1024-thread
+    // workgroups holding 64 KB of keys -- two per CU, and in the pipelined step they wait for that room.
+    const int cap_surf = MML_VOXEL_LDS_CAP, cap_corner = MML_VOXEL_LDS_CAP < 2048 ? MML_VOXEL_LDS_CAP : 2048;
+    auto pad = [](int cap) {
+        int npad = 1;
+        while (npad < cap) npad <<= 1;
+        return (size_t)npad * sizeof(unsigned long long);
+    };
+    hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), pad(cap_corner), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
+                       ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0], ctx->ft_xyz[1],
+                       ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+    hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 1, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
+                       ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0], ctx->ft_xyz[1],
+                       ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
