@@ -124,14 +124,19 @@ constexpr int AB_WAVES = AB_THREADS / 64;
 __device__ __forceinline__ int lower_count(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// (the key of an invalid lane must be 0.  Per key bit: one compare for the ballot, the lane's bit spread to a word (v_bfe_i32),
+//  and mask &= ~(ballot ^ spread) on the two halves -- six vector instructions; the obvious `m &= set ? bm : ~bm` compiled to
+//  eleven, a quarter of the bucketing passes' instructions at 16 rings)
 __device__ __forceinline__ unsigned long long match_key(bool valid, int key, int nbits) {
-    unsigned long long m = __ballot(valid);
+    const unsigned long long vm = __ballot(valid);
+    unsigned mlo = (unsigned)vm, mhi = (unsigned)(vm >> 32);
     for (int bit = 0; bit < nbits; ++bit) {
-        const bool set = (key >> bit) & 1;
-        const unsigned long long bm = __ballot(valid && set);
-        m &= set ? bm : ~bm;
+        const int e = __builtin_amdgcn_sbfe(key, bit, 1);  // -1 where the bit is set
+        const unsigned long long bm = __ballot(e != 0);
+        mlo &= ~((unsigned)bm ^ (unsigned)e);
+        mhi &= ~((unsigned)(bm >> 32) ^ (unsigned)e);
     }
-    return m;
+    return ((unsigned long long)mhi << 32) | mlo;
 }
 
 // streaming loads of the bucketing passes: each raw record is touched once per pass and the batch is far larger than the caches
@@ -171,12 +176,34 @@ __global__ void k_assign_init(FeatParams P, int count) {
 
 // getVeloFeature per-point part (:1133, :1154-1168) -- ring id through a float estimate of the pitch, the reference
 // expression (double atan) only when the estimate is within 2e-4 ring widths of a rounding boundary.
+// (the estimate is built from the raw v_rsq / v_rcp instructions and an eight-term odd polynomial: |error| < 4e-7 rad in all,
+//  2.3e-5 degrees, which the guard band below covers five times over for any ring spacing; the IEEE sqrtf / two divisions /
+//  atanf it replaces were 70 of the pass's 163 vector instructions per point)
+__device__ __forceinline__ float atan_est(float a) {
+    const float aa = fabsf(a);
+    const bool inv = aa > 1.0f;
+    const float t = inv ? __builtin_amdgcn_rcpf(aa) : aa;
+    const float z = t * t;
+    float p = -0.004054564982652664f;  // least-squares fit of atan(t) / t on [0, 1], evaluated in float: 1.35e-7 rad
+    p = __builtin_fmaf(p, z, 0.021862952038645744f);
+    p = __builtin_fmaf(p, z, -0.0559123232960701f);
+    p = __builtin_fmaf(p, z, 0.0964219719171524f);
+    p = __builtin_fmaf(p, z, -0.1390862911939621f);
+    p = __builtin_fmaf(p, z, 0.19946566224098206f);
+    p = __builtin_fmaf(p, z, -0.33329859375953674f);
+    p = __builtin_fmaf(p, z, 0.9999993443489075f);
+    float r = p * t;
+    r = inv ? 1.57079637f - r : r;
+    return copysignf(r, a);
+}
 __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pitch_step, int R) {
-    const float rxy = sqrtf(p.x * p.x + p.y * p.y);
-    const float est = atanf(p.z / rxy) * 57.29577951308232f;
-    const double t = (double)((est - pitch0) / pitch_step) + 0.5;
+    const float inv_step = __builtin_amdgcn_rcpf(pitch_step);                  // (lane-uniform)
+    const float guard = __builtin_fmaf(1.2e-4f, fabsf(inv_step), 2e-4f);      // ring widths: 2e-4 + 1.2e-4 degrees
+    const float rr = __builtin_fmaf(p.x, p.x, p.y * p.y);
+    const float est = atan_est(p.z * __builtin_amdgcn_rsqf(rr)) * 57.29577951308232f;
+    const float t = __builtin_fmaf(est - pitch0, inv_step, 0.5f);
     int scanID;
-    if (fabs(t - rint(t)) > 2e-4 && fabs(t) < 1e6) {
+    if (fabsf(t - rintf(t)) > guard && fabsf(t) < 1e6f) {
         scanID = (int)t;
     } else {
         const float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;
@@ -204,16 +231,16 @@ __device__ __forceinline__ float neg_atan2_f(float yf, float xf) {
         const bool big = a > 0.41421356237309503;
         const double t = big ? fast_div(a - 1.0, a + 1.0) : a;
         const double z = t * t;
-        double p = 2.25838847748916528e-02;
-        p = __builtin_fma(p, z, -4.46976301461388392e-02);
-        p = __builtin_fma(p, z, 5.73167296507084492e-02);
-        p = __builtin_fma(p, z, -6.64873778438867108e-02);
-        p = __builtin_fma(p, z, 7.69095714550778464e-02);
-        p = __builtin_fma(p, z, -9.09084591627817573e-02);
-        p = __builtin_fma(p, z, 1.11111093716489140e-01);
-        p = __builtin_fma(p, z, -1.42857142603585840e-01);
-        p = __builtin_fma(p, z, 1.99999999998416944e-01);
-        p = __builtin_fma(p, z, -3.33333333333330928e-01);
+        double p = mml_und::sconst(2.25838847748916528e-02);
+        p = __builtin_fma(p, z, mml_und::sconst(-4.46976301461388392e-02));
+        p = __builtin_fma(p, z, mml_und::sconst(5.73167296507084492e-02));
+        p = __builtin_fma(p, z, mml_und::sconst(-6.64873778438867108e-02));
+        p = __builtin_fma(p, z, mml_und::sconst(7.69095714550778464e-02));
+        p = __builtin_fma(p, z, mml_und::sconst(-9.09084591627817573e-02));
+        p = __builtin_fma(p, z, mml_und::sconst(1.11111093716489140e-01));
+        p = __builtin_fma(p, z, mml_und::sconst(-1.42857142603585840e-01));
+        p = __builtin_fma(p, z, mml_und::sconst(1.99999999998416944e-01));
+        p = __builtin_fma(p, z, mml_und::sconst(-3.33333333333330928e-01));
         double r = (big ? 0.78539816339744831 : 0.0) + __builtin_fma(t * z, p, t);
         if (ay > ax) r = 1.5707963267948966 - r;
         if (x < 0.0) r = 3.141592653589793 - r;
@@ -241,7 +268,8 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     if ((int)blockIdx.x >= nblk) return;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
-    for (int k = tid; k < nkeys; k += AB_THREADS) s_bcnt[k] = 0;
+    static_assert(MAX_LINES <= AB_THREADS, "one key per thread");
+    if (tid < nkeys) s_bcnt[tid] = 0;
     if (tid == 0) {
         s_valid = 0;
         s_keep = 0;
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
     __syncthreads();
     int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
-    for (int k = tid; k < nkeys; k += AB_THREADS) cnt[k] = s_bcnt[k];
+    if (tid < nkeys) cnt[tid] = s_bcnt[tid];
     if (tid == 0) {
         cnt[MAX_LINES] = s_valid;
         cnt[MAX_LINES + 1] = s_keep;
@@ -463,16 +491,16 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c_direct(FeatParams P) {
     if ((int)(blockIdx.x * AB_THREADS) >= n) return;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
-    for (int k = tid; k < AB_WAVES * MAX_LINES; k += AB_THREADS) (&s_wcnt[0][0])[k] = 0;
+    for (int k = lane; k < nkeys; k += 64) s_wcnt[wave][k] = 0;  // (a wavefront's own row)
     // the block's offsets, the line starts and the per-slot constants are requested here, next to the points themselves: a
     // lane's destination is then two LDS look-ups behind its key instead of two more dependent trips to memory (key ->
     // block offset -> line start), which is what bounded the pass -- its lanes live as long as their longest load chain
     __shared__ int s_cnt[MAX_LINES + 2];
     __shared__ int s_ls[MAX_LINES];
     const int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
-    for (int k = tid; k < nkeys; k += AB_THREADS) {
-        s_cnt[k] = cnt[k];
-        s_ls[k] = P.line_start[(size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings) + k];
+    if (tid < nkeys) {
+        s_cnt[tid] = cnt[tid];
+        s_ls[tid] = P.line_start[(size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings) + tid];
     }
     if (tid < 2) s_cnt[MAX_LINES + tid] = cnt[MAX_LINES + tid];
     const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);

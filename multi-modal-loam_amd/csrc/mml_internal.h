@@ -13,6 +13,16 @@
 #include "mmloam_hip.h"
 
 #define MML_WAVE 64
+
+namespace mml_und {
+// A double literal as a scalar-register operand.  gfx950 has no 64-bit literal in VOP3: left alone the compiler materialises
+// each constant of a polynomial with two v_mov_b32 next to its FMA (three vector instructions per term in kernels that are
+// bound by vector issue); from an SGPR pair the term is ONE v_fma_f64 and the two s_mov_b32 go to the scalar unit.
+__device__ __forceinline__ double sconst(double v) {
+    asm("" : "+s"(v));
+    return v;
+}
+}  // namespace mml_und
 #define MML_VOXEL_LDS_CAP 8192  // labelled points per (slot, kind) that k_voxel sorts in LDS; more go the global-sort way
 
 // ---- factor records kept on the device (SoA would save little: every field is read once per GN pass) ----

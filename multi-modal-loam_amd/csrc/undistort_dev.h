@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "mml_internal.h"
+
 namespace mml_und {
 
 struct Q4 {
@@ -123,20 +125,20 @@ __device__ __forceinline__ void undistort_point(const double* dR, const double* 
         // their Taylor polynomials (truncation < 1e-18 for theta < 0.5).  Like the other fast forms the result is
         // only trusted away from float rounding boundaries (below).
         const double x = t * theta, z = x * x;
-        double ps = -1.0 / 1307674368000.0;
-        ps = __builtin_fma(ps, z, 1.0 / 6227020800.0);
-        ps = __builtin_fma(ps, z, -1.0 / 39916800.0);
-        ps = __builtin_fma(ps, z, 1.0 / 362880.0);
-        ps = __builtin_fma(ps, z, -1.0 / 5040.0);
-        ps = __builtin_fma(ps, z, 1.0 / 120.0);
-        ps = __builtin_fma(ps, z, -1.0 / 6.0);
+        double ps = sconst(-1.0 / 1307674368000.0);
+        ps = __builtin_fma(ps, z, sconst(1.0 / 6227020800.0));
+        ps = __builtin_fma(ps, z, sconst(-1.0 / 39916800.0));
+        ps = __builtin_fma(ps, z, sconst(1.0 / 362880.0));
+        ps = __builtin_fma(ps, z, sconst(-1.0 / 5040.0));
+        ps = __builtin_fma(ps, z, sconst(1.0 / 120.0));
+        ps = __builtin_fma(ps, z, sconst(-1.0 / 6.0));
         const double sn = __builtin_fma(x * z, ps, x);
-        double pc = -1.0 / 87178291200.0;
-        pc = __builtin_fma(pc, z, 1.0 / 479001600.0);
-        pc = __builtin_fma(pc, z, -1.0 / 3628800.0);
-        pc = __builtin_fma(pc, z, 1.0 / 40320.0);
-        pc = __builtin_fma(pc, z, -1.0 / 720.0);
-        pc = __builtin_fma(pc, z, 1.0 / 24.0);
+        double pc = sconst(-1.0 / 87178291200.0);
+        pc = __builtin_fma(pc, z, sconst(1.0 / 479001600.0));
+        pc = __builtin_fma(pc, z, sconst(-1.0 / 3628800.0));
+        pc = __builtin_fma(pc, z, sconst(1.0 / 40320.0));
+        pc = __builtin_fma(pc, z, sconst(-1.0 / 720.0));
+        pc = __builtin_fma(pc, z, sconst(1.0 / 24.0));
         pc = __builtin_fma(pc, z, -0.5);
         aw = __builtin_fma(z, pc, 1.0);
         const double k = (qw < 0.0 ? -dv[6] : dv[6]) * sn;
@@ -164,18 +166,21 @@ __device__ __forceinline__ void undistort_point(const double* dR, const double* 
         az *= inv_n;
         aw *= inv_n;
     }
+    // (this is the guarded form: its double result only has to be within `tol` of the reference expression, so the products
+    //  are fused -- two thirds of the instructions of the separate multiplies and adds the reference order needs)
     const double vx = p.x, vy = p.y, vz = p.z;
-    double ux = ay * vz - az * vy, uy = az * vx - ax * vz, uz = ax * vy - ay * vx;
+    double ux = __builtin_fma(ay, vz, -(az * vy)), uy = __builtin_fma(az, vx, -(ax * vz)), uz = __builtin_fma(ax, vy, -(ay * vx));
     ux += ux;
     uy += uy;
     uz += uz;
-    const double cx = ay * uz - az * uy, cy = az * ux - ax * uz, cz = ax * uy - ay * ux;
-    const double wx = (((vx + aw * ux) + cx) + s * dt[0]) - dt[0];
-    const double wy = (((vy + aw * uy) + cy) + s * dt[1]) - dt[1];
-    const double wz = (((vz + aw * uz) + cz) + s * dt[2]) - dt[2];
-    const double ox = (dR[0] * wx + dR[3] * wy) + dR[6] * wz;
-    const double oy = (dR[1] * wx + dR[4] * wy) + dR[7] * wz;
-    const double oz = (dR[2] * wx + dR[5] * wy) + dR[8] * wz;
+    const double cx = __builtin_fma(ay, uz, -(az * uy)), cy = __builtin_fma(az, ux, -(ax * uz)), cz = __builtin_fma(ax, uy, -(ay * ux));
+    const double sm1 = (double)s - 1.0;  // exact
+    const double wx = __builtin_fma(sm1, dt[0], __builtin_fma(aw, ux, vx) + cx);
+    const double wy = __builtin_fma(sm1, dt[1], __builtin_fma(aw, uy, vy) + cy);
+    const double wz = __builtin_fma(sm1, dt[2], __builtin_fma(aw, uz, vz) + cz);
+    const double ox = __builtin_fma(dR[6], wz, __builtin_fma(dR[3], wy, dR[0] * wx));
+    const double oy = __builtin_fma(dR[7], wz, __builtin_fma(dR[4], wy, dR[1] * wx));
+    const double oz = __builtin_fma(dR[8], wz, __builtin_fma(dR[5], wy, dR[2] * wx));
     const double tol = 1e-13 * (((fabs(vx) + fabs(vy)) + fabs(vz)) + ((fabs(dt[0]) + fabs(dt[1])) + fabs(dt[2])) + 1e-30);
     if (float_round_safe(ox, tol) & float_round_safe(oy, tol) & float_round_safe(oz, tol)) {
         p.x = ox;
