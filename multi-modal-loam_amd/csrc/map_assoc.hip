@@ -147,17 +147,32 @@ __device__ __forceinline__ void knn_init(Knn5& k) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) k.key[i] = KNN_EMPTY;
 }
-// sorted insert: the new key sinks to its place, the largest of the six falls off (no branches past the reject test)
+// Sorted insert by rank: lt_s = (x < key[s]) is monotone in s for a sorted list, so the new list is
+//   key[s] = lt_s ? (lt_{s-1} ? key[s-1] : x) : key[s]
+// -- five compares and two selects per word, 23 vector instructions and no dependent chain.  A wavefront runs the insert as
+// soon as ONE of its lanes has a candidate below its fifth key, which is the case for nearly every candidate of the first rings
+// (a lane takes ~5 (1 + ln(n / 5)) of n candidates), so the insert is most of what a candidate costs; the sinking form
+// (compare, two selects, compare, two selects per stage) compiled to 38.
+__device__ __forceinline__ unsigned long long sel64(bool c, unsigned long long a, unsigned long long b) {
+    // (two v_cndmask; written on the halves and marked unpredictable so that no pass turns a select of a select into branches)
+    const unsigned lo = __builtin_unpredictable(c) ? (unsigned)a : (unsigned)b;
+    const unsigned hi = __builtin_unpredictable(c) ? (unsigned)(a >> 32) : (unsigned)(b >> 32);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void knn_insert_key(Knn5& k, unsigned long long x) {
+    const bool lt0 = x < k.key[0], lt1 = x < k.key[1], lt2 = x < k.key[2], lt3 = x < k.key[3], lt4 = x < k.key[4];
+    const unsigned long long c1 = sel64(lt0, k.key[0], x), c2 = sel64(lt1, k.key[1], x), c3 = sel64(lt2, k.key[2], x),
+                             c4 = sel64(lt3, k.key[3], x);
+    k.key[4] = sel64(lt4, c4, k.key[4]);
+    k.key[3] = sel64(lt3, c3, k.key[3]);
+    k.key[2] = sel64(lt2, c2, k.key[2]);
+    k.key[1] = sel64(lt1, c1, k.key[1]);
+    k.key[0] = sel64(lt0, x, k.key[0]);
+}
 __device__ __forceinline__ void knn_insert(Knn5& k, float dd, int ii) {
-    unsigned long long x = knn_key(dd, ii);
+    const unsigned long long x = knn_key(dd, ii);
     if (!(x < k.key[4])) return;
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const unsigned long long cur = k.key[s];
-        const bool lt = x < cur;
-        k.key[s] = lt ? x : cur;
-        x = lt ? cur : x;
-    }
+    knn_insert_key(k, x);
 }
 
 // tags / mytag: when the grid carries cube tags (global map, a12) only points of the query's cube take part: the
@@ -171,19 +186,20 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, const
         int tg[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u, e - 1);
+            const unsigned i = (unsigned)min(i0 + u, e - 1);  // (unsigned: a 32-bit offset from the scalar base, no 64-bit address arithmetic)
             p[u] = pts[i];
             tg[u] = tags ? (int)tags[i] : mytag;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u >= e || tg[u] != mytag) continue;
             float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
             float r = 0;
             r += dx * dx;
             r += dy * dy;
             r += dz * dz;
-            knn_insert(k, r, (int)__float_as_uint(p[u].w));
+            // a candidate that does not take part carries a key that never enters
+            const unsigned long long x = (i0 + u >= e || tg[u] != mytag) ? ~0ull : knn_key(r, (int)__float_as_uint(p[u].w));
+            if (x < k.key[4]) knn_insert_key(k, x);
         }
     }
 }
