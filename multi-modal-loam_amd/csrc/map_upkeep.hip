@@ -459,7 +459,7 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
 // redone one by one through the global-sort filter.  Synchronises the stream (the marks are read back).  A slot whose
 // overflow is a real capacity limit (more voxels than max_features) keeps its mark.
 int mml_downsample_redo_overflow(mml_ctx* ctx, int first, int count, std::vector<int>* redone) {
-    if (ctx->NT > 65536) return MML_OK;  // those contexts took the global-sort path to begin with
+    if (ctx->NT > (1 << 20)) return MML_OK;  // those contexts took the global-sort path to begin with
     hipStream_t s = MML_STREAM(ctx);
     // (pinned destinations: a device-to-host copy into pageable memory is a blocking staged copy, three of them cost more
     //  than the down-sampling kernel of a single scan)
@@ -472,7 +472,7 @@ int mml_downsample_redo_overflow(mml_ctx* ctx, int first, int count, std::vector
     MML_HIP(hipStreamSynchronize(s));
     for (int c = 0; c < count; ++c) {
         if (n0[c] >= 0 && n1[c] >= 0) continue;
-        if (info[8 * c + 6] <= MML_VOXEL_LDS_CAP && info[8 * c + 7] <= MML_VOXEL_LDS_CAP) continue;  // not a sort overflow
+        if (info[8 * c + 6] <= mml_voxel_cap_corner(ctx) && info[8 * c + 7] <= MML_VOXEL_LDS_CAP) continue;  // not a sort overflow
         int rc = mml_downsample_big(ctx, first + c, 1);
         if (rc != MML_OK) return rc;
         if (redone) redone->push_back(first + c);

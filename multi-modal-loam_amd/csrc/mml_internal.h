@@ -281,6 +281,8 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
 int mml_launch_time_offset(mml_ctx* ctx, MmlGrid& g, float4* d_velo4, const float* d_velo_xyz, int n_velo, const float* d_tf,
                            const float* d_livox_xyz, int n_livox, int res, int sliced, int nwin, float* d_nn, double* d_err);
 int mml_launch_downsample(mml_ctx* ctx, int first, int count);
+// labelled corner points per (slot, kind) that the LDS sort of k_voxel takes (surf: MML_VOXEL_LDS_CAP)
+inline int mml_voxel_cap_corner(const mml_ctx* ctx) { return (ctx->NT > 65536 || MML_VOXEL_LDS_CAP < 2048) ? MML_VOXEL_LDS_CAP : 2048; }
 int mml_build_grid(mml_ctx* ctx, int kind, const float* h_xyz, int m);
 int mml_build_grid_device(mml_ctx* ctx, int kind, int m);
 int mml_downsample_big(mml_ctx* ctx, int first, int count);

@@ -142,7 +142,10 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
     __syncthreads();
 }
 
-// One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx << 32 | sequence number).
+// One workgroup per (slot, kind).  LDS: keys[cap] (u64: voxel idx | fused index | where to find the point).
+// Two key layouts: scans up to 65536 points carry (voxel 32 | fused index 16 | bucketed position 16); larger ones (up to 2^20
+// points: 128 x 2048 rings) carry (voxel 31 | fused index 20 | place in the label list 13) and find the position through the
+// list -- their labelled clouds are no larger than a small scan's, only their indices are wider.
 template <int VX_THREADS>
 __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
                                                      const float4* ln_pts, const int2* ln_meta,
@@ -167,6 +170,9 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
     // the labelled points of this (slot, kind): their bucketed positions, listed by the crop pass
     unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * list_stride;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool wide = NT > 65536;
+    const int vshift = wide ? 33 : 32;
+    auto key_pos = [&](unsigned long long k) -> unsigned { return wide ? seq2idx[(unsigned)k & 0x1fffu] : (unsigned)k & 0xffffu; };
 
     // 1. the labelled points were listed by the crop pass (feature.hip k_crop_c) in fused-cloud order; min / max of
     //    their coordinates (getMinMax3D)
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
         const int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
+        if (wide) return ((unsigned long long)(unsigned)idx << 33) | ((unsigned long long)(unsigned)gx[pos].x << 13) | (unsigned)sidx;
         return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos].x << 16) | pos;
     };
     // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
@@ -275,8 +282,8 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         bool head = false;
         unsigned vox = 0;
         if (s < cnt) {
-            vox = (unsigned)(keys[s] >> 32);
-            head = (s == 0) || ((unsigned)(keys[s - 1] >> 32) != vox);
+            vox = (unsigned)(keys[s] >> vshift);
+            head = (s == 0) || ((unsigned)(keys[s - 1] >> vshift) != vox);
         }
         // the points of this chunk (and VX_TAIL beyond it, for runs that cross into the next chunk) are fetched by their
         // own lanes, all gathers in flight together, so that the sequential per-voxel sums below read LDS instead of
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         for (int t = tid; t < VX_THREADS + VX_TAIL; t += VX_THREADS) {
             const int e = c0 + t;
             if (e < cnt) {
-                const float4 p = px[(unsigned)(keys[e] & 0xffffu)];
+                const float4 p = px[key_pos(keys[e])];
                 s_stage[0][t] = p.x;
                 s_stage[1][t] = p.y;
                 s_stage[2][t] = p.z;
@@ -299,14 +306,14 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         if (head && dst < MF) {
             float sx = 0, sy = 0, sz = 0;
             int e = s;
-            while (e < cnt && (unsigned)(keys[e] >> 32) == vox) {
+            while (e < cnt && (unsigned)(keys[e] >> vshift) == vox) {
                 const int t = e - c0;
                 if (t < VX_THREADS + VX_TAIL) {
                     sx += s_stage[0][t];
                     sy += s_stage[1][t];
                     sz += s_stage[2][t];
                 } else {  // a voxel with more than VX_TAIL points across the chunk edge
-                    const float4 p = px[(unsigned)(keys[e] & 0xffffu)];
+                    const float4 p = px[key_pos(keys[e])];
                     sx += p.x;
                     sy += p.y;
                     sz += p.z;
@@ -346,24 +353,31 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
 
 int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     MmlStageScope t(ctx, "voxel_downsample");
-    if (ctx->NT > 65536) return mml_downsample_big(ctx, first, count);  // labelled clouds beyond the LDS sort
+    if (ctx->NT > (1 << 20)) return mml_downsample_big(ctx, first, count);  // indices beyond the key layouts of k_voxel
     // `cap` labelled points per (slot, kind) fit the LDS sort; a slot with more gets ft_n = -1 here and is redone through
     // the global-sort path by mml_downsample_redo_overflow (the label lists hold every labelled point: stride VX_CAP)
     // The corner lists are an order of magnitude shorter than the surf lists (hundreds against thousands of points): they get a
     // 256-thread workgroup with room for 2048 keys (16 KB), so that only the surf half of the launch is made of 1024-thread
-    // workgroups holding 64 KB of keys -- two per CU, and in the pipelined step they wait for that room.
-    const int cap_surf = MML_VOXEL_LDS_CAP, cap_corner = MML_VOXEL_LDS_CAP < 2048 ? MML_VOXEL_LDS_CAP : 2048;
+    // workgroups holding 64 KB of keys -- two per CU, and in the pipelined step they wait for that room.  (Scans beyond 65536
+    // points -- 128 rings: up to 12 800 corner candidates -- get the large workgroup for both kinds.)
+    const int cap_surf = MML_VOXEL_LDS_CAP, cap_corner = mml_voxel_cap_corner(ctx);
     auto pad = [](int cap) {
         int npad = 1;
         while (npad < cap) npad <<= 1;
         return (size_t)npad * sizeof(unsigned long long);
     };
-    hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), pad(cap_corner), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
-                       ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0], ctx->ft_xyz[1],
-                       ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
-    hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 1, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
-                       ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0], ctx->ft_xyz[1],
-                       ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+    if (cap_corner == cap_surf) {
+        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 2), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
+                           ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+    } else {
+        hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), pad(cap_corner), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
+                           ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 1, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
+                           ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+    }
     MML_HIP(hipGetLastError());
     return MML_OK;
 }

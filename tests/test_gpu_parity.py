@@ -1187,6 +1187,50 @@ def test_dense_labelled_cloud_takes_the_global_sort_path(M, O, synth):
 
 
 
+def test_corner_list_beyond_the_small_sort(M, O, synth):
+    """The corner lists go through a 256-thread sort of up to 2048 keys: a rough scene with more corner-labelled points than
+    that (and fewer than 8192 surf points) is redone through the global-sort filter, in mml_downsample and inside mml_step."""
+    kw = dict(n_rings=32, pitch0=-15.5, pitch_step=1.0)
+    cfg = M.default_config(2, n_rings=32, pitch0_deg=-15.5, pitch_step_deg=1.0, far_th=1000.0, max_velo_points=57600,
+                           max_livox_points=64, max_features=32768)
+    c = M.Context(cfg)
+    try:
+        scans = [synth.velo_scan(3, n_az=1800, noise=0.03, **kw), synth.velo_scan(4, n_az=1800, **kw)]
+        ev = [O.extract_velo(v, far=1000.0, **kw) for v in scans]
+        n_corner, n_surf = (ev[0]["label"] == 1).sum(), (ev[0]["label"] == 2).sum()
+        assert 2048 < n_corner < 8192 and n_surf < 8192
+        for s, v in enumerate(scans):
+            c.scan_upload(s, v, None)
+        c.extract(0, 2)
+        dR, dt = np.tile(np.eye(3).reshape(1, 9), (2, 1)), np.zeros((2, 3))
+        c.undistort(0, 2, dR, dt)
+        c.downsample(0, 2)
+        feats = []
+        for s in range(2):
+            xyz, lab = ev[s]["xyzi"][:, :3], ev[s]["label"]
+            cf, sf = c.features_download(s, 0), c.features_download(s, 1)
+            assert np.array_equal(cf, O.voxel_downsample(xyz[lab == 1], 0.4))
+            assert np.array_equal(sf, O.voxel_downsample(xyz[lab == 2], 0.2))
+            feats.append((cf, sf))
+        c.map_set_local(0, feats[0][0])
+        c.map_set_local(1, feats[0][1])
+        x0 = np.tile(np.array([0.03, -0.02, 0.01, 0.002, -0.001, 0.004]), (2, 1))
+        x = c.step(0, 2, dR, dt, np.eye(4), 25.0, 10, x0)
+        assert np.abs(x[0][:3]).max() < 5e-3  # registered back onto itself
+        c.extract(0, 2)
+        c.undistort(0, 2, dR, dt)
+        c.downsample(0, 2)
+        T = np.stack([np.eye(4)] * 2)
+        for s in range(2):
+            T[s][:3, :3] = Rsc.from_rotvec(x0[s][3:]).as_matrix()
+            T[s][:3, 3] = x0[s][:3]
+        c.associate(0, 2, T, 25.0)
+        xs, _, _ = c.solve(0, 2, x0, np.eye(4), window=1, max_iters=10, fixed=True, huber=0.1 / 1.5e-3, w_tan=0.0)
+        assert np.array_equal(xs, x)
+    finally:
+        c.close()
+
+
 # ---- SURVEY 8(f) rank 4: the GICP extrinsic refresh ------------------------------------------------------------------
 def test_gicp_align_matches_oracle(M, O, synth):
     c = M.Context(max_scans=1)
