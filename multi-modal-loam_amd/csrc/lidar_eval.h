@@ -75,6 +75,21 @@ __device__ void make_pose(const double* x, const double* T_bl, Pose& P) {
         }
 }
 
+// sqrt(x) and 1 / sqrt(x) together: v_rsq_f64 and two coupled Goldschmidt steps (nine instructions, ~1e-16 relative; the IEEE
+// sqrt() and operator/ of the compiler are 28 and 14 -- a plane factor had three of each, 126 of its ~330 instructions).  The
+// solvers are held to the oracle by tolerances (1e-9 on the iteration trace, 1e-11 on H and g), and to each other bit for bit:
+// every device solver evaluates its factors through this header.
+__device__ __forceinline__ void sqrt_pair(double x, double& root, double& inv_root) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    root = __builtin_fma(g, r, g);
+    inv_root = 2.0 * __builtin_fma(h, r, h);
+}
+
 // ceres/loss_function.cc HuberLoss::Evaluate
 __device__ __forceinline__ void huber(double s, double a, double& rho0, double& rho1) {
     rho0 = s;
@@ -82,9 +97,10 @@ __device__ __forceinline__ void huber(double s, double a, double& rho0, double& 
     if (a > 0) {
         double bb = a * a;
         if (s > bb) {
-            double r = sqrt(s);
+            double r, ir;
+            sqrt_pair(s, r, ir);
             rho0 = 2.0 * a * r - bb;
-            rho1 = fmax(2.2250738585072014e-308, a / r);
+            rho1 = fmax(2.2250738585072014e-308, a * ir);
         }
     }
 }
@@ -131,21 +147,23 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
         Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
         Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
         Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
-        const double l12 = sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz));
+        double l12, il12, a012, ia012, s12, is12, rs, sm14;
+        sqrt_pair((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz), l12, il12);
         const double c0 = (Pw[0] - ax) * (Pw[1] - by) - (Pw[0] - bx) * (Pw[1] - ay);
         const double c1 = (Pw[0] - ax) * (Pw[2] - bz) - (Pw[0] - bx) * (Pw[2] - az);
         const double c2 = (Pw[1] - ay) * (Pw[2] - bz) - (Pw[1] - by) * (Pw[2] - az);
-        const double a012 = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
-        const double ld2 = a012 / l12;
+        sqrt_pair(c0 * c0 + c1 * c1 + c2 * c2, a012, ia012);
+        const double ld2 = a012 * il12;
         const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
-        const double rs = sqrt(sqrt(s));
-        const double weight = 1.0 - 0.9 * fabs(ld2) / rs;
+        sqrt_pair(s, s12, is12);        // s^(1/2), s^(-1/2)
+        sqrt_pair(s12, rs, sm14);       // s^(1/4), s^(-1/4)
+        const double weight = 1.0 - 0.9 * fabs(ld2) * sm14;
         const double r = ka * weight * ld2;
         // gradient of ld wrt P: ((a-b) x u_hat) / l12, u = (c2, -c1, c0)
-        const double ux = c2 / a012, uy = -c1 / a012, uz = c0 / a012;
+        const double ux = c2 * ia012, uy = -c1 * ia012, uz = c0 * ia012;
         const double dx = ax - bx, dy = ay - by, dz = az - bz;
-        double gl[3] = {(dy * uz - dz * uy) / l12, (dz * ux - dx * uz) / l12, (dx * uy - dy * ux) / l12};
-        const double sm14 = 1.0 / rs, sm54 = sm14 / s;
+        double gl[3] = {(dy * uz - dz * uy) * il12, (dz * ux - dx * uz) * il12, (dx * uy - dy * ux) * il12};
+        const double sm54 = sm14 * (is12 * is12);
         double gr[3];
         for (int c = 0; c < 3; ++c) {
             double gw = (-0.9) * (sm14 * gl[c] + (fabs(ld2) * (-0.5) * sm54) * Pw[c]);
@@ -173,13 +191,15 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
         Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
         Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
         const double d[3] = {Pw[0] - f.proj[0], Pw[1] - f.proj[1], Pw[2] - f.proj[2]};
-        const double nd = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        double nd, ind, s12, is12, rs, sm14;
+        sqrt_pair((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], nd, ind);
         const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
-        const double rs = sqrt(sqrt(s));
-        const double weight = 1.0 - 0.9 * nd / rs;
-        const double sm14 = 1.0 / rs, sm54 = sm14 / s;
+        sqrt_pair(s, s12, is12);   // s^(1/2), s^(-1/2)
+        sqrt_pair(s12, rs, sm14);  // s^(1/4), s^(-1/4)
+        const double weight = 1.0 - 0.9 * nd * sm14;
+        const double sm54 = sm14 * (is12 * is12);
         double gw[3];
-        for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * ((sm14 / nd) * d[c] + (nd * (-0.5) * sm54) * Pw[c]);
+        for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * ((sm14 * ind) * d[c] + (nd * (-0.5) * sm54) * Pw[c]);
         // e = weight * d ;  de/dP = weight I + d gw^T ;  row^T de/dP = weight row + (row . d) gw
         const double w[3] = {f.omega[0], f.omega[1], f.omega[2]};
         double rows[3][3];
@@ -197,10 +217,11 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
             else
                 h[2] = 1;
             double t0 = w[1] * h[2] - w[2] * h[1], t1 = w[2] * h[0] - w[0] * h[2], t2 = w[0] * h[1] - w[1] * h[0];
-            double n = sqrt((t0 * t0 + t1 * t1) + t2 * t2);
-            t0 /= n;
-            t1 /= n;
-            t2 /= n;
+            double n, in;
+            sqrt_pair((t0 * t0 + t1 * t1) + t2 * t2, n, in);
+            t0 *= in;
+            t1 *= in;
+            t2 *= in;
             rows[1][0] = kb * t0;
             rows[1][1] = kb * t1;
             rows[1][2] = kb * t2;

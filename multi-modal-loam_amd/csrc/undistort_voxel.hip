@@ -147,7 +147,7 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 // points: 128 x 2048 rings) carry (voxel 31 | fused index 20 | place in the label list 13) and find the position through the
 // list -- their labelled clouds are no larger than a small scan's, only their indices are wider.
 template <int VX_THREADS>
-__global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int NT, int MF, int B, int cap, int list_stride, const int* fu_info,
+__global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int NT, int MF, int B, int cap_y0, int cap_y1, int list_stride, const int* fu_info,
                                                      const float4* ln_pts, const int2* ln_meta,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
 
     const int b = blockIdx.x + first;
     const int kind = blockIdx.y + kind0;
+    const int cap = blockIdx.y == 0 ? cap_y0 : cap_y1;  // labelled points this workgroup sorts at most
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* px = ln_pts + (size_t)b * NT;
     const int2* gx = ln_meta + (size_t)b * NT;
@@ -366,16 +367,17 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
         while (npad < cap) npad <<= 1;
         return (size_t)npad * sizeof(unsigned long long);
     };
-    if (cap_corner == cap_surf) {
-        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 2), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
-                           ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+    if (cap_corner == cap_surf || count <= 16) {
+        // (one launch for both kinds: a handful of scans are a chain of launches, not a question of room on the CUs)
+        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 2), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
+                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
                            ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     } else {
         hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), pad(cap_corner), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
-                           ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           cap_corner, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
                            ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
         hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 1, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
-                           ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
                            ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     }
     MML_HIP(hipGetLastError());
