@@ -302,9 +302,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
             if (valid) crop_test(P, p.x, p.y, p.z, keep, near_ok);
         }
     }
-    const unsigned long long eq = match_key(valid, key, nbits);
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (valid && (eq & lt) == 0) atomicAdd(&s_bcnt[key], __popcll(eq));  // first lane of each key group
+    // (one LDS add per valid lane: the adds of a wavefront that meet on a key are serialised by the LDS, a few cycles, where
+    //  grouping the lanes by key first -- match_key, one add per group -- was a quarter of this pass's vector instructions)
+    if (valid) atomicAdd(&s_bcnt[key], 1);
     const unsigned long long vm = __ballot(valid), km = __ballot(keep);
     if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
     if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
@@ -2194,6 +2194,10 @@ __host__ __device__ inline size_t select_lds_bytes(int cap) { return (size_t)(ca
 // list_kind < 0: one workgroup per (line, slot) of the grid.  list_kind 0 / 1: behind k_select_part, the (normally empty) list of the
 // ring / Livox lines that kernel left over, walked by a small grid -- a full grid of workgroups that only find their line done
 // still has to wait for 512 wave slots and 29-53 KB of LDS each, and held its stream for longer than the real work took.
+#ifndef MML_SEL_ROWS_V
+#define MML_SEL_ROWS_V 256
+#define MML_SEL_ROWS_L 128
+#endif
 template <int K>
 __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P, int list_kind) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2991,7 +2995,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
             hipLaunchKernelGGL((k_select_part<u128m, SP_LINES_WIDE, SP_MAXWIN_WIDE>), dim3((ctx->L + SP_LINES_WIDE - 1) / SP_LINES_WIDE, count),
                                dim3(64 * SP_LINES_WIDE), 0, s, P, ctx->L);
             hipLaunchKernelGGL(k_select_list, dim3((count * ctx->L + 255) / 256), dim3(256), 0, s, P, count);
-            const int rows_v = std::min(ctx->cfg.n_rings * count, 256), rows_l = std::min((ctx->L - ctx->cfg.n_rings) * count, 128);
+            const int rows_v = std::min(ctx->cfg.n_rings * count, MML_SEL_ROWS_V), rows_l = std::min((ctx->L - ctx->cfg.n_rings) * count, MML_SEL_ROWS_L);
             hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(rows_v), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap_velo), s, Pv, 0);
             if (rows_l > 0)
                 hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(rows_l), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, Pl, 1);
