@@ -2358,17 +2358,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
             const int w = w4 + u;
             if (w >= nwin) break;
             const int i = 64 * w + lane;
-            const unsigned at = at4[u], key = key4[u];
+            const unsigned key = key4[u];
             const bool inpart = i >= 5 && i <= n - 7;
-            const bool cand = inpart && (at & A_CAND3);
-            const unsigned a = cand ? min((at >> A_A3_SHIFT) & 3u, (unsigned)T) : 0u, bb = cand ? min((at >> A_B3_SHIFT) & 3u, (unsigned)T) : 0u;
-            // "point i - d is visited before point i" inside a partition: key (curvature bits, index) ascending, ties to the lower index
-            const unsigned k1 = __shfl_up(key, 1), k2 = __shfl_up(key, 2), k3 = __shfl_up(key, 3);
-            const unsigned p1 = lane >= 1 ? k1 : tail2, p2 = lane >= 2 ? k2 : (lane == 1 ? tail2 : tail1),
-                           p3 = lane >= 3 ? k3 : (lane == 2 ? tail2 : (lane == 1 ? tail1 : tail0));
-            const u64m m_c = __ballot(cand), m_an = __ballot(inpart && (at & A_ANGLE)), m_fr = __ballot(inpart && (at & A_FAR)),
-                       m_rf = __ballot(inpart && (at & A_REFL)), m_a0 = __ballot(a & 1u), m_a1 = __ballot(a & 2u), m_b0 = __ballot(bb & 1u),
-                       m_b1 = __ballot(bb & 2u), m_g1 = __ballot(p1 <= key), m_g2 = __ballot(p2 <= key), m_g3 = __ballot(p3 <= key);
+            const unsigned at = inpart ? at4[u] : 0u;  // (one select instead of `inpart &&` in front of every ballot)
+            // "point i - d is visited before point i" inside a partition: key (curvature bits, index) ascending, ties to the lower
+            // index.  The keys of the three points before come by whole-wave shifts (DPP wave_shr:1, the lane without a source keeps
+            // `old` = the carried key of the window before): three moves instead of three LDS permutes and six selects.
+            const unsigned p1 = (unsigned)__builtin_amdgcn_update_dpp((int)tail2, (int)key, 0x138, 0xf, 0xf, false);
+            const unsigned p2 = (unsigned)__builtin_amdgcn_update_dpp((int)tail1, (int)p1, 0x138, 0xf, 0xf, false);
+            const unsigned p3 = (unsigned)__builtin_amdgcn_update_dpp((int)tail0, (int)p2, 0x138, 0xf, 0xf, false);
+            // mark ranges as the raw two-bit fields of the stencil: phase B masks them with the candidate plane and applies the
+            // clamp to T there (a >= 3 only exists when T == 3)
+            const u64m m_c = __ballot(at & A_CAND3), m_an = __ballot(at & A_ANGLE), m_fr = __ballot(at & A_FAR), m_rf = __ballot(at & A_REFL),
+                       m_a0 = __ballot(at & (1u << A_A3_SHIFT)), m_a1 = __ballot(at & (2u << A_A3_SHIFT)),
+                       m_b0 = __ballot(at & (1u << A_B3_SHIFT)), m_b1 = __ballot(at & (2u << A_B3_SHIFT)), m_g1 = __ballot(p1 <= key),
+                       m_g2 = __ballot(p2 <= key), m_g3 = __ballot(p3 <= key);
             if (lane == 0) {
                 pl[PL_C][w] = m_c;
                 pl[PL_AN][w] = m_an;
@@ -2406,8 +2410,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
             return act ? (v & maskL) : (M)0;
         };
         const M C = extract(PL_C), AN = extract(PL_AN), FR = extract(PL_FR), RF = extract(PL_RF);
-        const M a0 = extract(PL_A0), a1 = extract(PL_A1), b0 = extract(PL_B0), b1 = extract(PL_B1);
-        const M A1 = a0 | a1, A2 = a1, A3 = a1 & a0, B1 = b0 | b1, B2 = b1, B3 = b1 & b0;
+        const M a0 = extract(PL_A0) & C, a1 = extract(PL_A1) & C, b0 = extract(PL_B0) & C, b1 = extract(PL_B1) & C;
+        const M t3 = T == 3 ? ~(M)0 : (M)0;  // min(mark range, thNumCurvSize): a range of 3 only under T == 3
+        const M A1 = a0 | a1, A2 = a1, A3 = a1 & a0 & t3, B1 = b0 | b1, B2 = b1, B3 = b1 & b0 & t3;
         // order bits: inside the partition from the keys; a point of the partition before is always visited first
         const M G1 = extract(PL_G1) | (M)1, G2 = extract(PL_G2) | (M)3, G3 = extract(PL_G3) | (M)7;
         SP_SYNC();  // every lane has read its planes: three of them now become the (zeroed) result planes
