@@ -2522,10 +2522,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
                 for (int u = 0; u < RK; ++u) {
                     src[u] = owners ? (int)__ffsll((long long)owners) - 1 : -1;
                     owners &= owners - 1;
-                    const int o = src[u] >= 0 ? src[u] : 0;
-                    pk[u] = __shfl(myk, o);
-                    psp[u] = __shfl(sp, o);
-                    pL[u] = __shfl(L, o);
+                    // (the owner's lane number is wave-uniform: its pick, partition start and length come by v_readlane into scalar
+                    //  registers -- three LDS permutes per pick before, each a round trip in front of the loads below)
+                    const int o = __builtin_amdgcn_readfirstlane(src[u] >= 0 ? src[u] : 0);
+                    pk[u] = __builtin_amdgcn_readlane(myk, o);
+                    psp[u] = __builtin_amdgcn_readlane(sp, o);
+                    pL[u] = __builtin_amdgcn_readlane(L, o);
                     mcv[u] = curv[psp[u] + max(pk[u], 0)];
                     mrv[u] = refl[psp[u] + max(pk[u], 0)];
 #pragma unroll
@@ -2545,8 +2547,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
                         const int q = lane + 64 * h;
                         const bool in = q < pL[u];
                         const unsigned kq = __float_as_uint(cv[u][h]), rq = refl_key(rv[u][h]);
-                        rc += __popcll(__ballot(in && ((kq < mk) || (kq == mk && q < pk[u]))));
-                        rr += __popcll(__ballot(in && ((rq < mr) || (rq == mr && q < pk[u]))));
+                        // (key, index) pairs compared as one 64-bit number
+                        const u64m mine_c = ((u64m)mk << 32) | (unsigned)pk[u], mine_r = ((u64m)mr << 32) | (unsigned)pk[u];
+                        rc += __popcll(__ballot(in && ((((u64m)kq << 32) | (unsigned)q) < mine_c)));
+                        rr += __popcll(__ballot(in && ((((u64m)rq << 32) | (unsigned)q) < mine_r)));
                     }
                     if (lane == src[u]) {
                         if (rr < rc) bfirst |= (M)1 << pk[u];
