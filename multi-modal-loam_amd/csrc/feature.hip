@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                 if (bm) {
                     int first = 0;
                     if (lane == (int)__ffsll((long long)bm) - 1) first = atomicAdd(&P.brk_cnt[b], __popcll(bm));
-                    first = __shfl(first, (int)__ffsll((long long)bm) - 1);
+                    first = __builtin_amdgcn_readlane(first, (int)__ffsll((long long)bm) - 1);  // (wave-uniform source lane)
                     if (brk) P.brk_queue[(size_t)b * P.NT + first + lower_count(bm)] = (unsigned)(start + iq);
                 }
                 // ... and to its redo queue
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                 if (rm) {
                     int first = 0;
                     if (lane == (int)__ffsll((long long)rm) - 1) first = atomicAdd(&P.redo_cnt[b], __popcll(rm));
-                    first = __shfl(first, (int)__ffsll((long long)rm) - 1);
+                    first = __builtin_amdgcn_readlane(first, (int)__ffsll((long long)rm) - 1);
                     if (redo) P.redo_queue[(size_t)b * P.NT + first + lower_count(rm)] = (unsigned)(start + iq);
                 }
             }
@@ -2060,8 +2060,8 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             while (bm) {
                 const int src = (int)__ffsll((long long)bm) - 1;
                 bm &= bm - 1;
-                const int pj = __shfl(j, src), pi = __shfl(i, src);
-                const unsigned pk = __shfl(mk, src), pr = __shfl(myr, src);
+                const int pj = __builtin_amdgcn_readlane(j, src), pi = __builtin_amdgcn_readlane(i, src);  // (wave-uniform source lane)
+                const unsigned pk = (unsigned)__builtin_amdgcn_readlane((int)mk, src), pr = (unsigned)__builtin_amdgcn_readlane((int)myr, src);
                 const int sp = s_sp[pj], ep = s_sp[pj + 1] - 1;
                 int rc = 0, rr = 0;
                 for (int q0 = sp; q0 <= ep; q0 += 64) {
@@ -2433,7 +2433,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
         // points of the partition behind cover my last points (b >= d)
         const unsigned tA = (unsigned)((A1 >> (L - 1)) & (M)1) | ((unsigned)((A2 >> (L - 2)) & (M)3) << 1) | ((unsigned)((A3 >> (L - 3)) & (M)7) << 3);
         const unsigned hB = (unsigned)(B1 & (M)1) | ((unsigned)(B2 & (M)3) << 1) | ((unsigned)(B3 & (M)7) << 3);
-        unsigned pA = __shfl_up(tA, 1), nB = __shfl_down(hB, 1);
+        // (neighbour partitions by whole-wave DPP shifts: wave_shr:1 = from the lane below, wave_shl:1 = from the lane above; the lane
+        //  without a source keeps `old` = 0)
+        unsigned pA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)tA, 0x138, 0xf, 0xf, false),
+                 nB = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hB, 0x130, 0xf, 0xf, false);
         if (lane == 0 || !act) pA = 0;
         if (lane >= 49) nB = 0;
         const M inA1 = (M)(pA & 1u), inA2 = (M)((pA >> 1) & 3u), inA3 = (M)((pA >> 3) & 7u);                                 // bits 0 .. d-1
@@ -2449,7 +2452,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
         // dependency steps: a partition's first three points wait for the last three of the partition before
         for (int guard = 0; guard < 4096; ++guard) {
             const unsigned e = (unsigned)((S >> (L - 3)) & (M)7) | ((unsigned)((U >> (L - 3)) & (M)7) << 3);
-            unsigned pe = __shfl_up(e, 1);
+            unsigned pe = (unsigned)__builtin_amdgcn_update_dpp(0, (int)e, 0x138, 0xf, 0xf, false);
             if (lane == 0) pe = 0;
             const M pS = (M)(pe & 7u), pU = (M)((pe >> 3) & 7u);  // bit j <-> point L' - 3 + j of the partition before
             const M S1 = (S << 1) | (pS >> 2), S2 = (S << 2) | (pS >> 1), S3 = (S << 3) | pS;
@@ -2465,7 +2468,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
         // value held when :521-539 runs: 1 when a pick of the same or an earlier partition marks me (it cannot have come before
         // my own pick, or I would not be picked), else 3 for a pick; marks from the partition behind land after :521-539
         const unsigned e2 = (unsigned)((S >> (L - 3)) & (M)7) | ((unsigned)(S & (M)7) << 3);
-        unsigned pe2 = __shfl_up(e2, 1), ne2 = __shfl_down(e2, 1);
+        unsigned pe2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)e2, 0x138, 0xf, 0xf, false),
+                 ne2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)e2, 0x130, 0xf, 0xf, false);
         if (lane == 0) pe2 = 0;
         if (lane >= 49) ne2 = 0;
         const M pS = (M)(pe2 & 7u), nS = (M)((ne2 >> 3) & 7u);  // nS bit j <-> point j of the partition behind
