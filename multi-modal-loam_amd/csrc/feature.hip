@@ -970,14 +970,15 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
     // when the squared form is more than 1e-3 away from the threshold), then the double squared form, then the
     // reference expression.
     bool gl, gn;
+    const float seg_r = q.seg(0), seg_l = q.seg(-1);  // the two segments at the point: read once, used by three sections
     {
         const float lx = PT(-1).x - PT(0).x, ly = PT(-1).y - PT(0).y, lz = PT(-1).z - PT(0).z;
         const float nx = PT(1).x - PT(0).x, ny = PT(1).y - PT(0).y, nz = PT(1).z - PT(0).z;
         // (fused multiply-adds are fine here: this is the banded pre-decision, not the reference arithmetic)
         const float dotl = fmaf(lz, PT(0).z, fmaf(ly, PT(0).y, lx * PT(0).x));
         const float dotn = fmaf(nz, PT(0).z, fmaf(ny, PT(0).y, nx * PT(0).x));
-        const float rl = (0.966f * 0.966f) * (q.seg(-1) * dis2);
-        const float rn = (0.966f * 0.966f) * (q.seg(0) * dis2);
+        const float rl = (0.966f * 0.966f) * (seg_l * dis2);
+        const float rn = (0.966f * 0.966f) * (seg_r * dis2);
         const float el = fmaf(dotl, dotl, -rl), en = fmaf(dotn, dotn, -rn);
         gl = el > 0.f;
         gn = en > 0.f;
@@ -1054,8 +1055,8 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
         // the two loops of :492-517 stop at the first segment longer than the threshold: the six segment lengths are
         // fetched together and the counts formed without branches (a loop that breaks on loaded data is, on a wavefront, a
         // chain of dependent LDS round trips and exec-mask updates)
-        const float sa0 = q.seg(0), sa1 = q.seg(1), sa2 = q.seg(2);     // |PT(l) - PT(l - 1)|^2, l = 1, 2, 3
-        const float sb0 = q.seg(-1), sb1 = q.seg(-2), sb2 = q.seg(-3);  // |PT(l) - PT(l + 1)|^2, l = -1, -2, -3
+        const float sa0 = seg_r, sa1 = q.seg(1), sa2 = q.seg(2);     // |PT(l) - PT(l - 1)|^2, l = 1, 2, 3
+        const float sb0 = seg_l, sb1 = q.seg(-2), sb2 = q.seg(-3);  // |PT(l) - PT(l + 1)|^2, l = -1, -2, -3
         const bool ga0 = !(sa0 > kTh002 || far), ga1 = ga0 && !(sa1 > kTh002), ga2 = ga1 && !(sa2 > kTh002);
         const bool gb0 = !(sb0 > kTh002 || far), gb1 = gb0 && !(sb1 > kTh002), gb2 = gb1 && !(sb2 > kTh002);
         const int a3 = (int)ga0 + (int)ga1 + (int)ga2;
@@ -1088,7 +1089,7 @@ __device__ __forceinline__ bool stencil_point(const WIN q, unsigned& attr, float
     // wavefront pays for it as soon as ONE of its 64 lanes qualifies.  Those points are therefore queued and
     // finished by k_stencil_break with every lane busy.
     {
-        const float sq_right = q.seg(0), sq_left = q.seg(-1);
+        const float sq_right = seg_r, sq_left = seg_l;
         // two distances below 1 m cannot differ by more than thBreakCornerDis = 1 (sqrtf is monotone and
         // sqrtf(x) <= 1 for x < 1)
         brk = !(sq_right < 1.f && sq_left < 1.f);
