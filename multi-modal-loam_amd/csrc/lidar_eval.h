@@ -111,26 +111,31 @@ __device__ __forceinline__ void row_jacobian(const Pose& P, const double* Pw, co
     const double rx = Pw[0] - P.tb[0], ry = Pw[1] - P.tb[1], rz = Pw[2] - P.tb[2];
     // gr^T * (-[Rpb]x) = (Rpb x gr)^T ... (-[a]x)^T g = a x g  => row = (gr x Rpb)?  use explicit form:
     // (-[r]x) = [[0, rz, -ry], [-rz, 0, rx], [ry, -rx, 0]] ; v^T = gr^T (-[r]x)
-    const double v0 = -gr[1] * rz + gr[2] * ry;
-    const double v1 = gr[0] * rz - gr[2] * rx;
-    const double v2 = -gr[0] * ry + gr[1] * rx;
+    // (fused multiply-adds throughout the factor evaluation: the solvers are bound to the oracle by tolerances and to each other
+    //  by sharing this header; a factor is 40 % of k_solve's life and issue-bound on its SIMD)
+    const double v0 = __builtin_fma(gr[2], ry, -(gr[1] * rz));
+    const double v1 = __builtin_fma(gr[0], rz, -(gr[2] * rx));
+    const double v2 = __builtin_fma(gr[1], rx, -(gr[0] * ry));
     J[0] = gr[0];
     J[1] = gr[1];
     J[2] = gr[2];
-    J[3] = (v0 * P.Jl[0] + v1 * P.Jl[3]) + v2 * P.Jl[6];
-    J[4] = (v0 * P.Jl[1] + v1 * P.Jl[4]) + v2 * P.Jl[7];
-    J[5] = (v0 * P.Jl[2] + v1 * P.Jl[5]) + v2 * P.Jl[8];
+    J[3] = __builtin_fma(v2, P.Jl[6], __builtin_fma(v1, P.Jl[3], v0 * P.Jl[0]));
+    J[4] = __builtin_fma(v2, P.Jl[7], __builtin_fma(v1, P.Jl[4], v0 * P.Jl[1]));
+    J[5] = __builtin_fma(v2, P.Jl[8], __builtin_fma(v1, P.Jl[5], v0 * P.Jl[2]));
 }
 
 __device__ __forceinline__ void accum(double* acc, const double* J, double r, double w) {
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
+        const double wj = w * J[a];
 #pragma unroll
-        for (int b = a; b < 6; ++b) acc[k++] += w * J[a] * J[b];
+        for (int b = a; b < 6; ++b) {
+            acc[k] = __builtin_fma(wj, J[b], acc[k]);
+            ++k;
+        }
+        acc[21 + a] = __builtin_fma(wj, r, acc[21 + a]);
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] += w * J[a] * r;
 }
 
 // Evaluate one frame at pose P: thread-strided over the factors; acc[28] per thread.
@@ -144,30 +149,31 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
         const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
         const double ax = f.p1[0], ay = f.p1[1], az = f.p1[2], bx = f.p2[0], by = f.p2[1], bz = f.p2[2];
         double Pw[3];
-        Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
-        Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
-        Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
+        Pw[0] = __builtin_fma(P.R[2], cz, __builtin_fma(P.R[1], cy, __builtin_fma(P.R[0], cx, P.t[0])));
+        Pw[1] = __builtin_fma(P.R[5], cz, __builtin_fma(P.R[4], cy, __builtin_fma(P.R[3], cx, P.t[1])));
+        Pw[2] = __builtin_fma(P.R[8], cz, __builtin_fma(P.R[7], cy, __builtin_fma(P.R[6], cx, P.t[2])));
         double l12, il12, a012, ia012, s12, is12, rs, sm14;
-        sqrt_pair((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz), l12, il12);
-        const double c0 = (Pw[0] - ax) * (Pw[1] - by) - (Pw[0] - bx) * (Pw[1] - ay);
-        const double c1 = (Pw[0] - ax) * (Pw[2] - bz) - (Pw[0] - bx) * (Pw[2] - az);
-        const double c2 = (Pw[1] - ay) * (Pw[2] - bz) - (Pw[1] - by) * (Pw[2] - az);
-        sqrt_pair(c0 * c0 + c1 * c1 + c2 * c2, a012, ia012);
+        const double dx = ax - bx, dy = ay - by, dz = az - bz;
+        sqrt_pair(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), l12, il12);
+        const double pax = Pw[0] - ax, pay = Pw[1] - ay, paz = Pw[2] - az, pbx = Pw[0] - bx, pby = Pw[1] - by, pbz = Pw[2] - bz;
+        const double c0 = __builtin_fma(pax, pby, -(pbx * pay));
+        const double c1 = __builtin_fma(pax, pbz, -(pbx * paz));
+        const double c2 = __builtin_fma(pay, pbz, -(pby * paz));
+        sqrt_pair(__builtin_fma(c2, c2, __builtin_fma(c1, c1, c0 * c0)), a012, ia012);
         const double ld2 = a012 * il12;
-        const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+        const double s = __builtin_fma(Pw[2], Pw[2], __builtin_fma(Pw[1], Pw[1], Pw[0] * Pw[0]));
         sqrt_pair(s, s12, is12);        // s^(1/2), s^(-1/2)
         sqrt_pair(s12, rs, sm14);       // s^(1/4), s^(-1/4)
         const double weight = 1.0 - 0.9 * fabs(ld2) * sm14;
         const double r = ka * weight * ld2;
         // gradient of ld wrt P: ((a-b) x u_hat) / l12, u = (c2, -c1, c0)
         const double ux = c2 * ia012, uy = -c1 * ia012, uz = c0 * ia012;
-        const double dx = ax - bx, dy = ay - by, dz = az - bz;
-        double gl[3] = {(dy * uz - dz * uy) * il12, (dz * ux - dx * uz) * il12, (dx * uy - dy * ux) * il12};
+        double gl[3] = {__builtin_fma(dy, uz, -(dz * uy)) * il12, __builtin_fma(dz, ux, -(dx * uz)) * il12, __builtin_fma(dx, uy, -(dy * ux)) * il12};
         const double sm54 = sm14 * (is12 * is12);
         double gr[3];
         for (int c = 0; c < 3; ++c) {
-            double gw = (-0.9) * (sm14 * gl[c] + (fabs(ld2) * (-0.5) * sm54) * Pw[c]);
-            gr[c] = ka * (weight * gl[c] + ld2 * gw);
+            double gw = (-0.9) * __builtin_fma(fabs(ld2) * (-0.5) * sm54, Pw[c], sm14 * gl[c]);
+            gr[c] = ka * __builtin_fma(ld2, gw, weight * gl[c]);
         }
         double J[6];
         row_jacobian(P, Pw, gr, J);
@@ -187,19 +193,20 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
         if (f.src < 0 || !(fabs(f.error) > 1e-5)) continue;  // Estimator.cpp:1396
         const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
         double Pw[3];
-        Pw[0] = ((P.R[0] * cx + P.R[1] * cy) + P.R[2] * cz) + P.t[0];
-        Pw[1] = ((P.R[3] * cx + P.R[4] * cy) + P.R[5] * cz) + P.t[1];
-        Pw[2] = ((P.R[6] * cx + P.R[7] * cy) + P.R[8] * cz) + P.t[2];
+        Pw[0] = __builtin_fma(P.R[2], cz, __builtin_fma(P.R[1], cy, __builtin_fma(P.R[0], cx, P.t[0])));
+        Pw[1] = __builtin_fma(P.R[5], cz, __builtin_fma(P.R[4], cy, __builtin_fma(P.R[3], cx, P.t[1])));
+        Pw[2] = __builtin_fma(P.R[8], cz, __builtin_fma(P.R[7], cy, __builtin_fma(P.R[6], cx, P.t[2])));
         const double d[3] = {Pw[0] - f.proj[0], Pw[1] - f.proj[1], Pw[2] - f.proj[2]};
         double nd, ind, s12, is12, rs, sm14;
-        sqrt_pair((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], nd, ind);
-        const double s = Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+        sqrt_pair(__builtin_fma(d[2], d[2], __builtin_fma(d[1], d[1], d[0] * d[0])), nd, ind);
+        const double s = __builtin_fma(Pw[2], Pw[2], __builtin_fma(Pw[1], Pw[1], Pw[0] * Pw[0]));
         sqrt_pair(s, s12, is12);   // s^(1/2), s^(-1/2)
         sqrt_pair(s12, rs, sm14);  // s^(1/4), s^(-1/4)
         const double weight = 1.0 - 0.9 * nd * sm14;
         const double sm54 = sm14 * (is12 * is12);
         double gw[3];
-        for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * ((sm14 * ind) * d[c] + (nd * (-0.5) * sm54) * Pw[c]);
+        const double gwa = sm14 * ind, gwb = nd * (-0.5) * sm54;
+        for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * __builtin_fma(gwb, Pw[c], gwa * d[c]);
         // e = weight * d ;  de/dP = weight I + d gw^T ;  row^T de/dP = weight row + (row . d) gw
         const double w[3] = {f.omega[0], f.omega[1], f.omega[2]};
         double rows[3][3];
@@ -232,16 +239,16 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
         }
         double rr[3], sq = 0;
         for (int q = 0; q < nrows; ++q) {
-            rr[q] = weight * ((rows[q][0] * d[0] + rows[q][1] * d[1]) + rows[q][2] * d[2]);
-            sq += rr[q] * rr[q];
+            rr[q] = weight * __builtin_fma(rows[q][2], d[2], __builtin_fma(rows[q][1], d[1], rows[q][0] * d[0]));
+            sq = __builtin_fma(rr[q], rr[q], sq);
         }
         double rho0, rho1;
         huber(sq, huber_delta, rho0, rho1);
         acc[27] += 0.5 * rho0;
         for (int q = 0; q < nrows; ++q) {
-            const double rd = (rows[q][0] * d[0] + rows[q][1] * d[1]) + rows[q][2] * d[2];
-            double gr[3] = {weight * rows[q][0] + rd * gw[0], weight * rows[q][1] + rd * gw[1],
-                            weight * rows[q][2] + rd * gw[2]};
+            const double rd = __builtin_fma(rows[q][2], d[2], __builtin_fma(rows[q][1], d[1], rows[q][0] * d[0]));
+            double gr[3] = {__builtin_fma(rd, gw[0], weight * rows[q][0]), __builtin_fma(rd, gw[1], weight * rows[q][1]),
+                            __builtin_fma(rd, gw[2], weight * rows[q][2])};
             double J[6];
             row_jacobian(P, Pw, gr, J);
             accum(acc, J, rr[q], rho1);

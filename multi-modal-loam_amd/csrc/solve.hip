@@ -203,6 +203,40 @@ __host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
         __builtin_amdgcn_wave_barrier(); \
         asm volatile("" ::: "memory");   \
     } while (0)
+#ifdef MML_SV_TIMING
+// phase clocks of one k_solve workgroup (problem MML_SV_TIMING of every launch): cycles per phase, summed over the iterations and
+// launches; [7] counts the launches
+__device__ unsigned long long g_sv_dbg[16];
+#define SV_MARK(id)                                    \
+    do {                                               \
+        if (sv_dbg) {                                  \
+            const unsigned long long now_ = clock64(); \
+            g_sv_dbg[id] += now_ - sv_prev;            \
+            sv_prev = now_;                            \
+        }                                              \
+    } while (0)
+extern "C" int mml_debug_sv_timing(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_sv_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sv_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#else
+#define SV_MARK(id)
+#endif
+#ifdef MML_SV_TIMING
+#define PV_MARK(id)                                                         \
+    do {                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == MML_SV_TIMING) {              \
+            const unsigned long long now_ = clock64();                      \
+            g_sv_dbg[id] += now_ - pv_prev;                                 \
+            pv_prev = now_;                                                 \
+        }                                                                   \
+    } while (0)
+#else
+#define PV_MARK(id)
+#endif
 __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
     const int lane = threadIdx.x;  // 0..63
     double* T = w;         // 36 terms of a quadratic form
@@ -213,6 +247,9 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
     double* fl = w + 90;   // 2 flags
     const int iter = S.iter, num_invalid = S.num_invalid, reuse = S.reuse;
     const double radius = S.radius;
+#ifdef MML_SV_TIMING
+    unsigned long long pv_prev = clock64();
+#endif
     WSYNC();
     if (lane == 0) S.evaluate = 0;
     if (iter >= max_iters || radius < 1e-32) {
@@ -245,6 +282,7 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
             for (int k = 0; k < 36; ++k) q += T[k];
             S.alpha = gg / q;
         }
+        PV_MARK(8);  // diag / gradient / alpha
         double mu = S.mu;
         solve_ok = false;
         while (mu < 1.0) {
@@ -272,6 +310,7 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
                 }
                 WSYNC();
             }
+            PV_MARK(9);  // Cholesky
             if (ok) {
                 if (lane == 0) {
                     for (int i = 0; i < 6; ++i) {
@@ -302,6 +341,7 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
         if (lane == 0) S.mu = mu;
         if (solve_ok && in6) S.gn[lane] = bv[lane] * -S.diag[lane];
         WSYNC();
+        PV_MARK(10);  // substitutions
     }
     bool step_valid = solve_ok;
     if (solve_ok) {
@@ -342,6 +382,7 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
             }
         }
         WSYNC();
+        PV_MARK(11);  // dogleg
         if (in36) T[lane] = st[a] * mab * st[b];
         WSYNC();
         if (lane == 0) {
@@ -354,6 +395,7 @@ __device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
         }
         WSYNC();
         step_valid = fl[0] != 0.0;
+        PV_MARK(12);  // model change
     }
     if (!step_valid) {
         if (lane == 0) {
@@ -722,6 +764,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     const int W = P.window;
     const int b0 = P.first + prob * W;
     const int tid = threadIdx.x;
+#ifdef MML_SV_TIMING
+    const bool sv_dbg = tid == 0 && prob == MML_SV_TIMING;
+    unsigned long long sv_prev = clock64();
+    if (sv_dbg) g_sv_dbg[7] += 1;
+#endif
     if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x[(size_t)b0 * 6 + tid];
     __syncthreads();
 
@@ -771,6 +818,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
 
     int go = S.go;
     __syncthreads();
+    SV_MARK(0);  // set-up + initial evaluation
     while (go) {
         // lane 0 owns the trust-region state between the barriers; every other lane only reads it after one
         // lane 0 (first wavefront for W = 1) owns the trust-region state between the barriers
@@ -780,6 +828,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
             tr_propose(S, W, P.max_iters);
         }
         __syncthreads();
+        SV_MARK(1);  // trust-region proposal (first wavefront) + barrier
         go = S.go;
         const int ev = S.evaluate;
         if (!go) break;
@@ -790,11 +839,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
                 const int b = b0 + f;
                 eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose,
                            P.w_tan, P.huber, acc);
+                SV_MARK(2);  // factor pass of this thread
                 block_reduce28(acc, s_part, S.recc + 28 * f);
+                SV_MARK(3);  // block reduction (waits for the slowest wavefront's factor pass)
             }
             if (tid < 64) tr_decide_wave(S, s_wd, W, P.fixed);
         }
         __syncthreads();
+        SV_MARK(4);  // accept / reject (first wavefront) + barrier
         go = S.go;
         if (P.trace && tid < 6 * W) P.trace[((size_t)prob * P.max_iters + (S.iter - 1)) * 6 * W + tid] = S.x[tid];
         __syncthreads();
