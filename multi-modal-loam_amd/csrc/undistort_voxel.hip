@@ -171,6 +171,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
     // the labelled points of this (slot, kind): their bucketed positions, listed by the crop pass
     unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * list_stride;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    static_assert(MML_VOXEL_LDS_CAP <= 8192, "the wide key layout carries the place in the label list in 13 bits");
     const bool wide = NT > 65536;
     const int vshift = wide ? 33 : 32;
     auto key_pos = [&](unsigned long long k) -> unsigned { return wide ? seq2idx[(unsigned)k & 0x1fffu] : (unsigned)k & 0xffffu; };
