@@ -278,6 +278,13 @@ int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, d
 /* Factor read-back for parity tests.  line: n x 10 doubles (pointOri, P1, P2, error) plus src feature
  * index; plane: n x 10 doubles (pointOri, pointProj, omega, error). Capacity in factors. */
 int mml_factors_download(mml_ctx* ctx, int slot, int kind, double* out, int* src, int capacity, int* n);
+/* The inverse: n factor records in the layout of mml_factors_download become the slot's vLineFeatures (kind 0) /
+ * vPlanFeatures (kind 1) -- for callers that keep FeatureLine / FeaturePlanVec objects of their own (the outputs of
+ * Estimator::processPointToLine / processPointToPlanVec, Estimator.h:159-186) and only want the solve, and for the
+ * known-answer tests of the residual functors (a factor whose point lies exactly on its line).  Record i gets src = i and
+ * the slot's feature count of that kind becomes n (the down-sampled stack no longer corresponds to the factors);
+ * point / line end points / omega are stored as floats, as the reference's members are (Estimator.cpp:256-271,643-653). */
+int mml_factors_upload(mml_ctx* ctx, int slot, int kind, const double* rec, int n);
 
 /* ---- a17..a20: residual + Jacobian + normal equations ------------------------------------------------
  * Cost_NavState_IMU_Line / Cost_NavState_IMU_Plan_Vec (include/utils/ceresfunc.h:397-458, 517-570) with

@@ -461,6 +461,10 @@ class Context:
                                             C.c_int(max(n.value, 1)), C.byref(n)))
         return out[:n.value], src[:n.value]
 
+    def factors_upload(self, slot, kind, rec):
+        rec = _f64(rec).reshape(-1, 10)
+        self._ck(lib().mml_factors_upload(self._h, C.c_int(slot), C.c_int(kind), _p(rec), C.c_int(len(rec))))
+
     def linearize(self, slot, x, T_bl, w_tan=0.0, huber=0.1 / 1.5e-3):
         H = np.zeros((6, 6))
         g = np.zeros(6)

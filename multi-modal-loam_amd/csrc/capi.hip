@@ -909,6 +909,45 @@ int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, d
     return MML_OK;
 }
 
+int mml_factors_upload(mml_ctx* ctx, int slot, int kind, const double* rec, int n) {
+    CHECK_SLOTS(slot, 1);
+    MML_REQUIRE((kind == 0 || kind == 1) && n >= 0 && (n == 0 || rec), MML_ERR_INVALID, "bad arguments");
+    MML_REQUIRE(n <= ctx->MF, MML_ERR_CAPACITY, "more factors than max_features");
+    if (kind == 0) {
+        std::vector<MmlLineFactor> h(n ? n : 1);
+        for (int i = 0; i < n; ++i) {
+            const double* r = rec + 10 * (size_t)i;
+            for (int c = 0; c < 3; ++c) {
+                h[i].ori[c] = (float)r[c];
+                h[i].p1[c] = (float)r[3 + c];
+                h[i].p2[c] = (float)r[6 + c];
+            }
+            h[i].src = i;
+            h[i].error = r[9];
+        }
+        if (n) MML_HIP(hipMemcpyAsync(ctx->lf + (size_t)slot * ctx->MF, h.data(), sizeof(MmlLineFactor) * n, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+        MML_HIP(hipMemcpyAsync(ctx->ft_n + slot, &n, sizeof(int), hipMemcpyHostToDevice, MML_STREAM(ctx)));
+        MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));  // (the staging vector goes out of scope)
+    } else {
+        std::vector<MmlPlaneFactor> h(n ? n : 1);
+        for (int i = 0; i < n; ++i) {
+            const double* r = rec + 10 * (size_t)i;
+            for (int c = 0; c < 3; ++c) {
+                h[i].ori[c] = (float)r[c];
+                h[i].proj[c] = r[3 + c];
+                h[i].omega[c] = (float)r[6 + c];
+            }
+            h[i].src = i;
+            h[i]._pad = 0;
+            h[i].error = r[9];
+        }
+        if (n) MML_HIP(hipMemcpyAsync(ctx->pf + (size_t)slot * ctx->MF, h.data(), sizeof(MmlPlaneFactor) * n, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+        MML_HIP(hipMemcpyAsync(ctx->ft_n + ctx->B + slot, &n, sizeof(int), hipMemcpyHostToDevice, MML_STREAM(ctx)));
+        MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    }
+    return MML_OK;
+}
+
 int mml_factors_download(mml_ctx* ctx, int slot, int kind, double* out, int* src, int capacity, int* n) {
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE((kind == 0 || kind == 1) && n, MML_ERR_INVALID, "bad arguments");

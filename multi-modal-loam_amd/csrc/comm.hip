@@ -209,11 +209,9 @@ int mml_window_solve_allgather(mml_ctx* ctx, int first_slot, int n_local, const 
 // of the path -- the section offsets of the gather buffers, "linearise only my frames", a broadcast whose root is another
 // rank -- runs on a single-GPU box: the kernels, the buffers and the state machine are the ones mml_window_solve_allgather
 // drives, only the transport differs.  Test / bring-up entry points, not a deployment mode.
-int mml_comm_init_loopback(mml_ctx** ctxs, int n_ranks) {
-    if (!ctxs || n_ranks < 1 || n_ranks > 8) return MML_ERR_INVALID;
+static int comm_init_loopback_ranks(mml_ctx** ctxs, int n_ranks) {
     for (int r = 0; r < n_ranks; ++r) {
         mml_ctx* ctx = ctxs[r];
-        if (!ctx) return MML_ERR_INVALID;
         MML_REQUIRE(ctx->comm == nullptr, MML_ERR_STATE, "the context already has a communicator");
         MML_REQUIRE(ctx->device == ctxs[0]->device, MML_ERR_INVALID, "a loopback group lives on one device");
         MML_HIP(hipSetDevice(ctx->device));
@@ -226,6 +224,23 @@ int mml_comm_init_loopback(mml_ctx** ctxs, int n_ranks) {
         if (rc != MML_OK) return rc;
     }
     return MML_OK;
+}
+
+// all or nothing: a rank that cannot join (it already has a communicator, sits on another device, or runs out of memory) leaves
+// the ranks before it without one as well, so that the call can be retried
+int mml_comm_init_loopback(mml_ctx** ctxs, int n_ranks) {
+    if (!ctxs || n_ranks < 1 || n_ranks > 8) return MML_ERR_INVALID;
+    for (int r = 0; r < n_ranks; ++r)
+        if (!ctxs[r]) return MML_ERR_INVALID;
+    for (int r = 0; r < n_ranks; ++r)
+        if (ctxs[r]->comm != nullptr) {
+            ctxs[r]->err = "the context already has a communicator";
+            return MML_ERR_STATE;
+        }
+    const int rc = comm_init_loopback_ranks(ctxs, n_ranks);
+    if (rc != MML_OK)
+        for (int r = 0; r < n_ranks; ++r) mml_comm_destroy(ctxs[r]);  // (no-op for a rank that never got one)
+    return rc;
 }
 
 // all-gather of `count` doubles per rank at buf(rank) + rank * count, by copies; every stream is drained before and after
@@ -258,8 +273,14 @@ int mml_window_solve_allgather_loopback(mml_ctx** ctxs, int n_ranks, const int* 
         MML_REQUIRE(ctx->comm && ctx->comm->loopback && ctx->comm->n_ranks == n_ranks && ctx->comm->rank == r, MML_ERR_STATE,
                     "not the loopback group these contexts were initialised as (mml_comm_init_loopback)");
     }
+    {   // (before anything is sized by n_local: a negative count must come back as an error, not as a huge memcpy)
+        mml_ctx* ctx = ctxs[0];
+        MML_REQUIRE(n_local >= 1 && n_ranks * n_local <= 8, MML_ERR_INVALID, "window = n_ranks * n_local must be 1 .. 8 frames");
+        MML_REQUIRE(T_bl && opts, MML_ERR_INVALID, "null argument");
+        MML_REQUIRE(opts->max_num_iterations >= 0 && opts->max_num_iterations <= 64, MML_ERR_INVALID, "max_num_iterations must be in [0, 64]");
+    }
     const int W = n_ranks * n_local;
-    std::vector<double> xl(6 * (size_t)(n_local > 0 ? n_local : 1));
+    std::vector<double> xl(6 * (size_t)n_local);
     for (int r = 0; r < n_ranks; ++r) {
         memcpy(xl.data(), x_window_in + 6 * (size_t)r * n_local, sizeof(double) * 6 * n_local);
         int rc = win_begin(ctxs[r], first_slot[r], n_local, T_bl, opts, xl.data());

@@ -1304,7 +1304,11 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
             for (int rep = 0; rep < 4; ++rep) {
                 if (t0 + rep * 64 >= n) break;
                 const int tp = rep * 64 + lane, i = t0 + tp;
-                const unsigned attr = i < n ? (unsigned)P.ln_attr[base + i] : 0u;
+                unsigned attr = i < n ? (unsigned)P.ln_attr[base + i] : 0u;
+                // (launch 1 marked the points it queued for k_stencil_redo in the -- then still unused -- walk bit: they must not
+                //  get the included-angle test here and a second queue entry)
+                if (attr & A_VIS) redo_bits |= 1u << rep;
+                attr &= ~(unsigned)A_VIS;
                 s_attr[tp] = (unsigned short)attr;
                 rmask[rep] = __ballot(attr & A_RFLAT);
             }
@@ -1379,7 +1383,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
 #pragma unroll
             for (int rep = 0; rep < 4; ++rep) {
                 const int tp = rep * 64 + lane, i = t0 + tp;
-                if (i < n) P.ln_attr[base + i] = s_attr[tp];
+                if (i < n) P.ln_attr[base + i] = (unsigned short)(s_attr[tp] | (((redo_bits >> rep) & 1u) ? (unsigned)A_VIS : 0u));
             }
             continue;
         }

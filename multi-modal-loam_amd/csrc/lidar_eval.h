@@ -79,8 +79,13 @@ __device__ void make_pose(const double* x, const double* T_bl, Pose& P) {
 // sqrt() and operator/ of the compiler are 28 and 14 -- a plane factor had three of each, 126 of its ~330 instructions).  The
 // solvers are held to the oracle by tolerances (1e-9 on the iteration trace, 1e-11 on H and g), and to each other bit for bit:
 // every device solver evaluates its factors through this header.
+// x = 0 (a point exactly on its line / plane: ceres::sqrt gives the zero residual there, ceresfunc.h:426-437): the argument of the
+// v_rsq_f64 is clamped at 1e-300, so that root = 0 * 1e150 = 0 and inv_root is a large FINITE number -- every caller multiplies it
+// with a numerator that is exactly zero with x (the cross product, the offset d), and the factor then contributes a zero residual and
+// a zero Jacobian row instead of NaN (the reference's Jet has a NaN derivative at that point; oracle/estimate.cpp takes the same
+// zero-row convention).  One v_max_f64; below 1e-300 the root is only approximate, which no squared length in metres reaches.
 __device__ __forceinline__ void sqrt_pair(double x, double& root, double& inv_root) {
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);

@@ -142,6 +142,112 @@ def livox_scan(k, n=24000, n_lines=6, noise=0.01, motion=False):
     return out
 
 
+# ---- sensor-faithful streams -------------------------------------------------------------------------------------------
+# The scans above are an idealised grid.  The two generators below reproduce what the drivers of the two sensors put on the
+# wire, i.e. the properties of real bags that bit-parity is sensitive to (unionFeatureExtract.cpp:369-388 non-finite points,
+# :453-479 ties in the partition sorts, :985-998 Livox record filter, :1133-1195 start / end azimuth and the half-turn flag):
+#   VLP-16 (velodyne_pointcloud): points in FIRING order (16 lasers per firing in the interleaved elevation order
+#     -15, +1, -13, +3 ... -1, +15 deg, 55.296 us per firing, 2.304 us between lasers), the azimuth of every point interpolated
+#     from encoder readings quantised to 0.01 deg with a slowly wobbling rotor speed; a scan is cut at a packet boundary
+#     (76 packets x 24 firings = 1824 firings: a little MORE than one revolution, so the end azimuth overlaps the start);
+#     ranges in units of 2 mm, calibrated reflectivity as an integer 0..255; no-returns either absent (the driver's default),
+#     NaN (organised clouds) or (0,0,0).
+#   Livox Horizon (livox_ros_driver CustomMsg): 6 lines fired together along a Risley-prism rosette, coordinates in whole
+#     millimetres, integer reflectivity with retro-reflector saturation, `tag` noise / return-number bits (ignored by the
+#     reference -- and so here), no-returns as (0,0,0) records, stray `line` ids above 5, offset_time in whole nanoseconds of
+#     the 240 kHz point clock.
+VLP16_LASER_DEG = np.array([-15, 1, -13, 3, -11, 5, -9, 7, -7, 9, -5, 11, -3, 13, -1, 15], dtype=np.float64)
+
+
+def _reflectivity(rng, world_pts, n):
+    """Integer reflectivity 0..255: a few large-scale surface patches (plateaus -> ties), speckle, retro-reflective stripes."""
+    base = 18.0 + 10.0 * np.sin(0.9 * world_pts[:, 0]) * np.cos(0.7 * world_pts[:, 1]) + 6.0 * np.sin(2.3 * world_pts[:, 2])
+    refl = np.round(base + rng.normal(0.0, 1.2, n))
+    retro = (np.abs(np.mod(world_pts[:, 0] + 0.37 * world_pts[:, 1], 3.1)) < 0.12) | (np.abs(np.mod(world_pts[:, 2], 1.4) - 0.7) < 0.02)
+    refl = np.where(retro, 255.0, refl)
+    return np.clip(refl, 0.0, 255.0)
+
+
+def velo_scan_vlp16(k, n_firings=1824, noise=0.01, motion=False, dropout="skip", drop_rate=0.015, seed=None):
+    """One VLP-16 revolution as velodyne_pointcloud publishes it (see the block comment above): float32 (n, 4) x, y, z,
+    intensity in firing order.  dropout: "skip" (no-returns absent), "nan" or "zero"."""
+    rng = np.random.default_rng((4321 + k) if seed is None else seed)
+    f = np.arange(n_firings)
+    # rotor: 600 rpm nominal with a slow +-0.3 % wobble; encoder readings in 0.01 deg; 0.19906 deg per firing
+    rate = 3600.0 * (1.0 + 0.003 * np.sin(2.0 * np.pi * f / n_firings * 1.7 + 0.4 * k))
+    enc = np.cumsum(np.concatenate([[rng.uniform(0.0, 360.0)], rate[:-1] * 55.296e-6]))
+    enc = np.round(enc * 100.0) / 100.0
+    dstep = np.diff(enc, append=enc[-1] + rate[-1] * 55.296e-6)
+    lasers = np.arange(16)
+    az_deg = enc[:, None] + dstep[:, None] * (lasers[None, :] * 2.304 / 55.296)            # (firings, 16)
+    az = -np.deg2rad(az_deg)                                                                 # clockwise seen from above
+    pitch = np.deg2rad(VLP16_LASER_DEG)[None, :] * np.ones((n_firings, 1))
+    d = np.stack([np.cos(pitch) * np.cos(az), np.cos(pitch) * np.sin(az), np.sin(pitch)], axis=-1).reshape(-1, 3)
+    s = ((f[:, None] * 55.296e-6 + lasers[None, :] * 2.304e-6) / (n_firings * 55.296e-6)).reshape(-1)
+    org, dw = _sweep_rays(k, s, d, motion)
+    r = _raycast(org, dw) + rng.normal(0.0, noise, size=len(d))
+    r = np.round(r / 0.002) * 0.002                                                          # 2 mm range units
+    world = org + dw * r[:, None]
+    inten = _reflectivity(rng, world, len(d))
+    # no-returns: random misses, a glass-like azimuth sector, everything beyond the 130 m / below the 0.4 m driver limits
+    miss = rng.random(len(d)) < drop_rate
+    sector = (np.mod(az_deg.reshape(-1) - 200.0, 360.0) < 6.0) & (pitch.reshape(-1) > np.deg2rad(2.0))
+    miss |= sector | (r > 130.0) | (r < 0.4)
+    pts = (d * r[:, None]).astype(np.float32)
+    out = np.concatenate([pts, inten[:, None].astype(np.float32)], axis=1)
+    if dropout == "skip":
+        return np.ascontiguousarray(out[~miss])
+    out[miss, :3] = np.nan if dropout == "nan" else 0.0
+    if dropout == "zero":
+        out[miss, 3] = 0.0
+    return out
+
+
+def livox_scan_horizon(k, n=24000, noise=0.01, motion=False, drop_rate=0.04, stray_lines=True, seed=None):
+    """One 100 ms Horizon frame as livox_ros_driver publishes it (CustomMsg records, LIVOX_DTYPE)."""
+    rng = np.random.default_rng((94321 + k) if seed is None else seed)
+    n_lines = 6
+    j = np.arange(n)
+    col = j // n_lines                               # the six beams of a column fire together
+    line = (j % n_lines).astype(np.uint8)
+    tt = col / float((n + n_lines - 1) // n_lines)
+    # Risley rosette: two prisms turning at incommensurate rates, stretched to the 81.7 x 25.1 deg field of view
+    w1, w2 = 2.0 * np.pi * 7.0, -2.0 * np.pi * 4.27
+    ph = 0.31 * k
+    half_h = np.deg2rad(81.7 / 2.0) * 0.97
+    half_v = np.deg2rad(25.1 / 2.0) * 0.78
+    az = half_h * 0.5 * (np.cos(w1 * tt + ph) + np.cos(w2 * tt + 1.3 * ph))
+    el = half_v * 0.5 * (np.sin(w1 * tt + ph) + np.sin(w2 * tt + 1.3 * ph)) + np.deg2rad(0.28) * (line.astype(np.float64) - 2.5)
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=-1)
+    off_ns = np.round(j * (1e9 / 240000.0)).astype(np.uint32)   # 240 kHz point clock, whole nanoseconds
+    srel = off_ns.astype(np.float64) / float(off_ns[-1])
+    org, dw = _sweep_rays(k, srel, d, motion)
+    r = _raycast(org, dw) + rng.normal(0.0, noise, size=n)
+    world = org + dw * r[:, None]
+    pts = np.round(d * r[:, None] * 1000.0) / 1000.0                                          # whole millimetres
+    out = np.zeros(n, dtype=LIVOX_DTYPE)
+    out["offset_time"] = off_ns
+    out["x"], out["y"], out["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    out["reflectivity"] = _reflectivity(rng, world, n).astype(np.uint8)
+    out["line"] = line
+    # tag: bits 0-1 spatial-position noise confidence, 2-3 intensity noise confidence, 4-5 return number
+    tag = (rng.random(n) < 0.03) * rng.integers(1, 4, n) + ((rng.random(n) < 0.02) * rng.integers(1, 4, n) << 2) + ((rng.random(n) < 0.1) * 1 << 4)
+    out["tag"] = tag.astype(np.uint8)
+    miss = rng.random(n) < drop_rate
+    # bursts of no-returns (a dark surface): whole stretches of a column sequence
+    for _ in range(6):
+        a = int(rng.integers(0, n - 400))
+        miss[a:a + int(rng.integers(30, 400))] = True
+    out["x"][miss] = 0.0
+    out["y"][miss] = 0.0
+    out["z"][miss] = 0.0
+    out["reflectivity"][miss] = 0
+    if stray_lines:
+        stray = rng.random(n) < 0.002
+        out["line"][stray] = rng.integers(6, 9, int(stray.sum())).astype(np.uint8)
+    return out
+
+
 def transform(T, xyz):
     """Apply a 4x4 to (n,3) float64."""
     return xyz @ T[:3, :3].T + T[:3, 3]

@@ -785,7 +785,9 @@ static void line_eval(const mmlo_line_factor* f, const PoseEval& pe, double* r, 
     if (J) {
         // u = (P-a)x(P-b) = (c2, -c1, c0);  grad_P ld = ((a-b) x u_hat) / l12
         Vec3 u = mk(c2, -c1, c0);
-        Vec3 uh = (1.0 / a012) * u;
+        // a point exactly on the line: the residual is zero and the norm has no derivative there (ceres::sqrt(Jet) at 0 is NaN);
+        // convention shared with the device path (lidar_eval.h sqrt_pair): a zero Jacobian row
+        Vec3 uh = a012 > 0.0 ? (1.0 / a012) * u : mk(0, 0, 0);
         Vec3 gld = (1.0 / l12) * cross(a - b, uh);
         double sgn = ld2 >= 0 ? 1.0 : -1.0;
         // weight = 1 - 0.9 |ld| s^(-1/4);  d s^(-1/4)/dP = -1/2 s^(-5/4) P
@@ -813,7 +815,8 @@ static void plane_core(const mmlo_plane_factor* f, const PoseEval& pe, Vec3* e, 
     if (dedP) {
         double sm14 = 1.0 / rs;
         double sm54 = sm14 / s;
-        Vec3 gw = (-0.9) * ((sm14 / nd) * d + (nd * (-0.5) * sm54) * P);
+        // (nd = 0, a point exactly on its projection: zero rows, as for the line factor)
+        Vec3 gw = (-0.9) * ((nd > 0.0 ? sm14 / nd : 0.0) * d + (nd * (-0.5) * sm54) * P);
         const double dv[3] = {d.x, d.y, d.z};
         const double gv[3] = {gw.x, gw.y, gw.z};
         for (int r = 0; r < 3; ++r)

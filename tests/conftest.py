@@ -148,3 +148,65 @@ def fuzz_line(rng):
         j = int(rng.integers(0, max(1, n - 6)))
         pts[j:j + int(rng.integers(2, 6))] = pts[j]
     return pts
+
+
+# ---- the batch of distinct fused scans the large-batch GPU tests and the batch fuzz share ---------------------------------
+def batch_cases(synth):
+    """12 distinct fused scans of the default 16-ring + 6-line layout, each with the sweep motion and the initial pose it
+    is registered from: clean, intra-sweep motion, dirty (NaN / inf / out-of-range pitch / near / far / bad Livox records),
+    one-sensor, tiny, ragged lines (100-point Livox lines and one 10 k-point line: the lines k_select_part lists for
+    k_select), and two rough scenes (about 2 000 and 3 300 corner-labelled points: at and beyond the 2048-key corner sort)."""
+    def case(v, l, k, motion=False):
+        if motion:
+            dR, dt = synth.sweep_motion(k)
+        else:
+            dR, dt = np.eye(3), np.zeros(3)
+        T0 = perturbed(synth.pose_matrix(k))
+        return dict(velo=v, livox=l, dR=dR, dt=dt, T0=T0, x0=pose_to_x(T0), k=k)
+    out = [case(synth.velo_scan(k), synth.livox_scan(k), k) for k in (10, 11, 12, 13)]
+    out += [case(synth.velo_scan(k, motion=True), synth.livox_scan(k, motion=True), k, motion=True) for k in (30, 31)]
+    v = synth.velo_scan(41).copy()
+    l = synth.livox_scan(41).copy()
+    v[100:130, 0] = np.nan          # removeNaNFromPointCloud
+    v[0, 1] = np.inf                # first point non-finite: startOri comes from the next one
+    v[7::97, 2] = 60.0              # pitch outside the 16 rings
+    v[5000:5200, :3] *= 0.05        # nearer than 2 m: cropped
+    v[9000:9100, :3] *= 30.0        # farther than 50 m (and dropped rings)
+    l["line"][::50] = 7
+    l["x"][1::50] = 0.001
+    out.append(case(v, l, 41))
+    out.append(case(synth.velo_scan(14)[:12345], None, 14))
+    out.append(case(None, synth.livox_scan(15)[:7777], 15))
+    out.append(case(synth.velo_scan(16)[:16 * 3], synth.livox_scan(16)[:600], 16))      # 3-point rings, 100-point Livox lines
+    l = synth.livox_scan(17).copy()
+    l["line"][4000:14000] = 0                                                             # line 0: 11 k points, the others short
+    out.append(case(synth.velo_scan(17, noise=0.03), l, 17))                              # ~2 000 corner labels
+    out.append(case(synth.velo_scan(18, noise=0.05), synth.livox_scan(18, noise=0.05), 18))  # ~3 300 corner labels
+    # order: the two rough scenes last (indices 10, 11)
+    return out
+
+
+def oracle_pipeline(O, cs, tree_corner, tree_surf, thres=25.0, gn_iters=10, **layout):
+    """The whole path for one fused scan on the oracle: extract -> undistort -> label split + voxel filter -> association at
+    the case's initial pose -> gn_iters fixed trust-region iterations (what mml_step does with the same arguments)."""
+    v, l = cs["velo"], cs["livox"]
+    ev = O.extract_velo(v, **layout) if v is not None else None
+    el = O.extract_livox(l) if l is not None else None
+    parts = [e for e in (ev, el) if e is not None]
+    o = {k: np.concatenate([e[k] for e in parts]) for k in ("xyzi", "label", "reltime", "ring")}
+    o["counts"] = ((ev["n_corner"], ev["n_surf"]) if ev else (0, 0)) + ((el["n_corner"], el["n_surf"]) if el else (0, 0))
+    xyz, lab = o["xyzi"][:, :3], o["label"]
+    o["und"] = O.undistort(xyz, o["reltime"], cs["dR"], cs["dt"])
+    o["corner"] = O.voxel_downsample(o["und"][lab == 1], 0.4)
+    o["surf"] = O.voxel_downsample(o["und"][lab == 2], 0.2)
+    if tree_corner is None:
+        return o
+    lf, o["lsrc"] = O.associate_lines(o["corner"], tree_corner, cs["T0"], thres)
+    pf, o["psrc"] = O.associate_planes(o["surf"], tree_surf, cs["T0"], thres)
+    o["lf"], o["pf"] = lf, pf
+    o["lf_arr"] = np.concatenate([lf["point_ori"], lf["p1"], lf["p2"], lf["error"][:, None]], axis=1)
+    o["pf_arr"] = np.concatenate([pf["point_ori"], pf["point_proj"], pf["omega"], pf["error"][:, None]], axis=1)
+    o["min_singular"] = O.check_localizability(pf) if len(pf) else 0.0
+    xo, _, _ = O.solve_window([lf], [pf], cs["x0"][None], np.eye(4), gn_iters, fixed=True)
+    o["x"] = xo[0]
+    return o

@@ -61,4 +61,5 @@ if "--json" in sys.argv:
         stage[st]["salu_wave_instr"] += sa / n
     res = {k: {kk: round(vv) for kk, vv in v.items()} for k, v in stage.items()}
     res["scans_per_launch"] = scans
+    res["lib_sha16"] = os.environ.get("MML_LIB_SHA16")  # the library these counts were taken from (bench.py marks a mismatch as stale)
     json.dump(res, open(out_path, "w"), indent=1)

@@ -34,6 +34,7 @@ def main(fp, wp, scans):
         out[st] = round(2.0 * float(f.get(st, 0.0)) * 1024.0 + float(w.get(st, 0.0)) * 1024.0)
     out["scans_per_launch"] = int(scans)
     out["kernels"] = kf
+    out["lib_sha16"] = os.environ.get("MML_LIB_SHA16")  # the library these bytes were counted on (bench.py marks a mismatch as stale)
     print(json.dumps(out, indent=1))
 
 

@@ -11,6 +11,7 @@ case "$*" in *"--config 3"*) SUF=_config3;; *"--config 4"*) SUF=_config4;; *"--c
 OUT=gpurun_out/prof_$TAG$SUF
 mkdir -p $OUT
 export TMPDIR=/tmp
+export MML_LIB_SHA16=$(sha256sum multi-modal-loam_amd/libmmloam_hip.so | cut -c1-16)
 ARGS="--steps 4 --warmup 1 --cpu-seconds 0 $*"
 python bench.py $* > $OUT/${TAG}_bench$SUF.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
