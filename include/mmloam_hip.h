@@ -478,6 +478,10 @@ int mml_set_lanes(mml_ctx* ctx, int lanes);
 int mml_profile_enable(mml_ctx* ctx, int on);
 int mml_profile_reset(mml_ctx* ctx);
 int mml_profile_get(mml_ctx* ctx, mml_profile* out);
+/* How many points of a slot's last extraction left the fast path: `redo` = points whose float pre-decision of an angle
+ * predicate fell inside its guard band and were recomputed with the full decision chain (k_stencil_redo), `brk` = break-point
+ * candidates finished by k_stencil_break (unionFeatureExtract.cpp:651-806).  Either may be NULL. */
+int mml_extract_queue_counts(mml_ctx* ctx, int slot, int* redo, int* brk);
 /* Device facts for bench.py: name, CU count, total HBM bytes. */
 int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes);
 /* Device-to-device copy bandwidth probe (GB/s) over `bytes` bytes, `reps` repetitions (practical HBM roof). */

@@ -558,6 +558,13 @@ class Context:
         self._ck(lib().mml_profile_get(self._h, C.byref(pr)))
         return {pr.name[i].decode(): (pr.total_ms[i], pr.launches[i]) for i in range(pr.n_stages)}
 
+    def extract_queue_counts(self, slot):
+        """(redo, brk): points of the slot's last extraction recomputed with the full decision chain / finished as break-point
+        candidates."""
+        r, b = C.c_int(0), C.c_int(0)
+        self._ck(lib().mml_extract_queue_counts(self._h, C.c_int(slot), C.byref(r), C.byref(b)))
+        return r.value, b.value
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus = C.c_int(0)

@@ -1502,6 +1502,15 @@ int mml_profile_get(mml_ctx* ctx, mml_profile* out) {
     return MML_OK;
 }
 
+int mml_extract_queue_counts(mml_ctx* ctx, int slot, int* redo, int* brk) {
+    CHECK_SLOTS(slot, 1);
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    if (brk) MML_HIP(hipMemcpy(brk, ctx->brk_cnt + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (redo) MML_HIP(hipMemcpy(redo, ctx->brk_cnt + ctx->B + slot, sizeof(int), hipMemcpyDeviceToHost));  // (redo_cnt = brk_cnt + B)
+    return MML_OK;
+}
+
 int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes) {
     if (!ctx) return MML_ERR_INVALID;
     hipDeviceProp_t prop;

@@ -207,7 +207,11 @@ __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pit
         scanID = (int)t;
     } else {
         const float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;
-        scanID = int((angle - pitch0) / pitch_step + 0.5);
+        // int() of a NaN -- the (0,0,0) no-return records of some drivers: atan(0 / 0) -- or of a value beyond the int range is
+        // "integer indefinite" = INT_MIN on the reference's x86-64 (the point then fails the range test and is dropped), where
+        // v_cvt_i32_f64 returns 0 / saturates: DESIGN.md parity convention 8
+        const double v = (angle - pitch0) / pitch_step + 0.5;
+        scanID = (v != v || v >= 2147483648.0 || v <= -2147483649.0) ? (-2147483647 - 1) : int(v);
     }
     return (scanID > (R - 1) || scanID < 0) ? 255 : scanID;
 }

@@ -168,13 +168,14 @@ def _reflectivity(rng, world_pts, n):
     return np.clip(refl, 0.0, 255.0)
 
 
-def velo_scan_vlp16(k, n_firings=1824, noise=0.01, motion=False, dropout="skip", drop_rate=0.015, seed=None):
+def velo_scan_vlp16(k, n_firings=1824, noise=0.01, motion=False, dropout="skip", drop_rate=0.015, seed=None, firing_step_scale=1.0):
     """One VLP-16 revolution as velodyne_pointcloud publishes it (see the block comment above): float32 (n, 4) x, y, z,
-    intensity in firing order.  dropout: "skip" (no-returns absent), "nan" or "zero"."""
+    intensity in firing order.  dropout: "skip" (no-returns absent), "nan" or "zero".  firing_step_scale > 1 turns the rotor
+    faster (fewer firings per revolution: reduced scans for fixtures)."""
     rng = np.random.default_rng((4321 + k) if seed is None else seed)
     f = np.arange(n_firings)
     # rotor: 600 rpm nominal with a slow +-0.3 % wobble; encoder readings in 0.01 deg; 0.19906 deg per firing
-    rate = 3600.0 * (1.0 + 0.003 * np.sin(2.0 * np.pi * f / n_firings * 1.7 + 0.4 * k))
+    rate = 3600.0 * firing_step_scale * (1.0 + 0.003 * np.sin(2.0 * np.pi * f / n_firings * 1.7 + 0.4 * k))
     enc = np.cumsum(np.concatenate([[rng.uniform(0.0, 360.0)], rate[:-1] * 55.296e-6]))
     enc = np.round(enc * 100.0) / 100.0
     dstep = np.diff(enc, append=enc[-1] + rate[-1] * 55.296e-6)

@@ -432,7 +432,13 @@ extern "C" int mmlo_extract_velo(const float* in_xyzi, int n_in, int n_rings, fl
         float angle = atan(point.z / sqrt(point.x * point.x + point.y * point.y)) * 180 / M_PI;
         int scanID = 0;
         // :1162 scanID = int((angle + 15) / 2 + 0.5), generalised: (angle - pitch0) / step
-        scanID = int((angle - pitch0_deg) / pitch_step_deg + 0.5);
+        // A (0,0,0) record -- a no-return of some drivers -- has angle = atan(0 / 0) = NaN, and int(NaN) is undefined in C++:
+        // the reference binary (x86-64, cvttsd2si) gets INT_MIN, "integer indefinite", so the point fails the range test below
+        // and is dropped.  Written out here so that it does not depend on what this compiler does with the cast.
+        {
+            const double v = (angle - pitch0_deg) / pitch_step_deg + 0.5;
+            scanID = (v != v || v >= 2147483648.0 || v <= -2147483649.0) ? (-2147483647 - 1) : int(v);
+        }
         if (scanID > (n_rings - 1) || scanID < 0) {
             continue;
         }

@@ -115,10 +115,43 @@ def main():
     np.savez_compressed(os.path.join(OUT, "time_offset_small.npz"), velo=tv, livox=tl, tf=ttf, resolution=25, sliced=3000,
                         nn_d2=to["nn_d2"], window_error=to["window_error"], best_window=to["best_window"],
                         lowest_error=to["lowest_error"])
+    sensor_faithful()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def sensor_faithful():
+    """7. a reduced sensor-faithful fused scan (synth.velo_scan_vlp16: firing order, encoder azimuths, 2 mm ranges, integer
+    intensities, NaN and (0,0,0) no-returns, a scan cut past one revolution; synth.livox_scan_horizon: millimetre
+    coordinates, tag bits, (0,0,0) records, stray line ids) through extraction, and two of its lines through
+    detectFeaturePoints.  `python tests/golden/make_golden.py sensor` writes only this fixture."""
+    out = {}
+    # 520 firings at 3.5x the rotor step: a little more than one revolution, like the full-size scan.  No-returns as NaN; the
+    # same records with (0,0,0) in their place must give the same cloud (atan(0 / 0) is NaN, int(NaN) is INT_MIN on x86-64:
+    # scanID < 0, the point is dropped at :1163-1166) -- the tests derive that variant from this one.
+    v = synth.velo_scan_vlp16(23, n_firings=520, dropout="nan", firing_step_scale=3.5)
+    ev = O.extract_velo(v)
+    vz = np.where(np.isnan(v), np.float32(0), v)
+    ez = O.extract_velo(vz)
+    assert all(np.array_equal(ev[key], ez[key]) for key in ("xyzi", "reltime", "ring", "label"))
+    out.update(velo=v, velo_xyzi=ev["xyzi"], velo_rel=ev["reltime"], velo_ring=ev["ring"], velo_label=ev["label"],
+               velo_counts=np.array([ev["n_corner"], ev["n_surf"]]))
+    l = synth.livox_scan_horizon(23, n=7200)
+    el = O.extract_livox(l)
+    out.update(livox=l, livox_xyzi=el["xyzi"], livox_rel=el["reltime"], livox_ring=el["ring"], livox_label=el["label"],
+               livox_counts=np.array([el["n_corner"], el["n_surf"]]))
+    vf = synth.velo_scan_vlp16(24)                         # (no-returns absent: every record is a point of some ring)
+    full = O.extract_velo(vf, near=0.0, far=1e9)
+    assert len(full["xyzi"]) == len(vf)
+    ring = vf[full["ring"] == 9].copy()                    # the raw records: extraction zeroes the intensity (:1254-1256)
+    s, f, fl = O.detect_feature_points(ring)
+    out.update(ring=ring, ring_sharp=s, ring_flat=f, ring_flags=fl)
+    np.savez_compressed(os.path.join(OUT, "extract_sensor.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sensor":
+        sensor_faithful()
+    else:
+        main()

@@ -756,3 +756,118 @@ def test_gicp_alignment_properties(O, synth):
     assert not ok and np.array_equal(T, T0)
     ok, T, _, _, _ = O.gicp_align(ls, vs[:19], T0)
     assert not ok and np.array_equal(T, T0)
+
+
+# ---- sensor-faithful inputs (synth.velo_scan_vlp16 / livox_scan_horizon) ----------------------------------------------
+def test_sensor_faithful_generators_have_the_driver_properties(synth):
+    """What makes a real bag different from the ideal grid (unionFeatureExtract.cpp:369-388,453-479,985-998,1133-1195): firing
+    order, encoder azimuths, a scan cut past one revolution, quantised ranges / coordinates, integer intensities, no-returns."""
+    v = synth.velo_scan_vlp16(7, dropout="nan")
+    assert v.shape == (1824 * 16, 4)
+    fin = np.isfinite(v[:, 0])
+    assert 0.005 < 1.0 - fin.mean() < 0.06
+    pitch = np.rad2deg(np.arctan2(v[:, 2], np.hypot(v[:, 0], v[:, 1]))).reshape(-1, 16)
+    ok = fin.reshape(-1, 16)
+    assert np.all(np.abs(pitch - synth.VLP16_LASER_DEG[None, :])[ok] < 1e-3)              # interleaved elevation order
+    r = np.linalg.norm(v[fin, :3].astype(np.float64), axis=1)
+    assert np.abs(r / 0.002 - np.round(r / 0.002)).max() < 2e-3                             # 2 mm range units (float32 xyz)
+    assert np.array_equal(v[fin, 3], np.round(v[fin, 3])) and len(np.unique(v[fin, 3])) < 80    # integer intensities: mass ties
+    az = np.unwrap(-np.arctan2(v[:, 1], v[:, 0])[fin])
+    assert 2 * np.pi + 0.02 < az[-1] - az[0] < 2 * np.pi + 0.1                              # the scan overlaps its own start
+    z = synth.velo_scan_vlp16(7, dropout="zero")
+    assert np.all(z[~fin] == 0) and np.array_equal(z[fin], v[fin])
+    assert np.array_equal(synth.velo_scan_vlp16(7, dropout="skip"), v[fin])
+    l = synth.livox_scan_horizon(7)
+    xyz = np.stack([l["x"], l["y"], l["z"]], 1).astype(np.float64)
+    assert np.abs(xyz * 1000 - np.round(xyz * 1000)).max() < 1e-2                           # whole millimetres
+    miss = (l["x"] == 0) & (l["y"] == 0) & (l["z"] == 0)
+    assert 0.03 < miss.mean() < 0.2 and (l["tag"] != 0).mean() > 0.05 and (l["line"] > 5).sum() > 10
+    assert np.all(np.diff(l["offset_time"].astype(np.int64)) >= 4166) and l["offset_time"][0] == 0
+
+
+def test_sensor_faithful_golden_and_no_return_conventions(O, synth):
+    g = load("extract_sensor.npz")
+    ev = O.extract_velo(g["velo"])
+    assert np.isnan(g["velo"][:, 0]).sum() > 50
+    vz = np.where(np.isnan(g["velo"]), np.float32(0), g["velo"])     # (0,0,0) no-returns: dropped like the NaN ones (int(NaN) < 0)
+    for e in (ev, O.extract_velo(vz)):
+        assert np.array_equal(e["xyzi"], g["velo_xyzi"]) and np.array_equal(e["reltime"], g["velo_rel"])
+        assert np.array_equal(e["ring"], g["velo_ring"]) and np.array_equal(e["label"], g["velo_label"])
+        assert [e["n_corner"], e["n_surf"]] == list(g["velo_counts"])
+    el = O.extract_livox(g["livox"])
+    assert np.array_equal(el["xyzi"], g["livox_xyzi"]) and np.array_equal(el["reltime"], g["livox_rel"])
+    assert np.array_equal(el["ring"], g["livox_ring"]) and np.array_equal(el["label"], g["livox_label"])
+    assert [el["n_corner"], el["n_surf"]] == list(g["livox_counts"])
+    s, f, fl = O.detect_feature_points(g["ring"])
+    assert np.array_equal(s, g["ring_sharp"]) and np.array_equal(f, g["ring_flat"]) and np.array_equal(fl, g["ring_flags"])
+    # the tag byte plays no part (the reference never reads it): clearing it changes nothing
+    l2 = g["livox"].copy()
+    l2["tag"] = 0
+    e2 = O.extract_livox(l2)
+    assert np.array_equal(e2["label"], el["label"]) and np.array_equal(e2["xyzi"], el["xyzi"])
+
+
+def test_velo_time_assignment_against_a_serial_loop(O, synth):
+    """getVeloFeature's per-point loop (unionFeatureExtract.cpp:1133-1195: start / end azimuth with the 3 pi / pi corrections,
+    the serial halfPassed flag, relTime) written out in Python with numpy float32 scalars, on scans that overlap their own
+    start (the real driver's cut) -- the oracle's ring ids and times equal it bit for bit."""
+    for k, mode in ((8, "skip"), (9, "nan")):
+        v = synth.velo_scan_vlp16(k, dropout=mode)
+        e = O.extract_velo(v, near=0.0, far=1e9)
+        p = v[np.isfinite(v[:, 0]) & np.isfinite(v[:, 1]) & np.isfinite(v[:, 2])]
+        f32, pi = np.float32, np.pi
+        start = f32(-np.arctan2(np.float64(p[0, 1]), np.float64(p[0, 0])))
+        end = f32(-np.arctan2(np.float64(p[-1, 1]), np.float64(p[-1, 0])) + 2 * pi)
+        if np.float64(end) - np.float64(start) > 3 * pi:
+            end = f32(np.float64(end) - 2 * pi)
+        elif np.float64(end) - np.float64(start) < pi:
+            end = f32(np.float64(end) + 2 * pi)
+        half = False
+        rel, ring = [], []
+        ang = np.arctan(p[:, 2].astype(np.float64) / np.sqrt((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]).astype(np.float64)))
+        ang = (ang * 180 / pi).astype(np.float32)
+        oris = (-np.arctan2(p[:, 1].astype(np.float64), p[:, 0].astype(np.float64))).astype(np.float32)
+        for i in range(len(p)):
+            sid = int((np.float64(ang[i]) + 15) / 2 + 0.5)
+            if sid > 15 or sid < 0:
+                continue
+            ori = oris[i]
+            if not half:
+                if ori < np.float64(start) - pi / 2:
+                    ori = f32(np.float64(ori) + 2 * pi)
+                elif ori > np.float64(start) + pi * 3 / 2:
+                    ori = f32(np.float64(ori) - 2 * pi)
+                if np.float64(ori) - np.float64(start) > pi:   # float - float promoted against the double constant
+                    half = True
+            else:
+                ori = f32(np.float64(ori) + 2 * pi)
+                if ori < np.float64(end) - pi * 3 / 2:
+                    ori = f32(np.float64(ori) + 2 * pi)
+                elif ori > np.float64(end) + pi / 2:
+                    ori = f32(np.float64(ori) - 2 * pi)
+            rel.append(f32(f32(ori - start) / f32(end - start)))
+            ring.append(sid)
+        assert np.array_equal(e["ring"], np.array(ring, np.int32))
+        assert np.array_equal(e["reltime"], np.array(rel, np.float32))
+        assert e["reltime"][-1] == 1.0 and np.float64(end) - np.float64(start) > 2 * pi + 0.02   # the sweep overlaps its own start
+
+
+def test_sensor_faithful_lines_against_numpy_restatement(O, synth):
+    """Quantised ranges and integer intensities give mass ties in both partition sorts (:453-479) and runs of equal points:
+    the second, independently written detectFeaturePoints agrees with the oracle on such rings / Livox lines."""
+    from second_opinion import detect_feature_points_py
+    v = synth.velo_scan_vlp16(11)
+    e = O.extract_velo(v, near=0.0, far=1e9)
+    lines = [v[e["ring"] == r].copy() for r in (2, 13)]
+    l = synth.livox_scan_horizon(11)
+    keep = (l["line"] <= 5) & ~(l["x"] < 0.01)
+    for ln in (1,):
+        m = keep & (l["line"] == ln)
+        lines.append(np.stack([l["x"][m], l["y"][m], l["z"][m], l["reflectivity"][m].astype(np.float32)], 1))
+    ties = 0
+    for pts in lines:
+        so, fo, flo = O.detect_feature_points(pts)
+        sp, fp, flp = detect_feature_points_py(pts)
+        assert np.array_equal(flp, flo) and np.array_equal(sp, so) and np.array_equal(fp, fo)
+        ties += len(pts) - len(np.unique(pts[:, 3]))
+    assert ties > 3000
