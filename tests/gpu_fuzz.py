@@ -6,7 +6,7 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations; `cubes` = random trajectories through the global cube store; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+pose perturbations; `cubes` = random trajectories through the global cube store; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `batch` (--batch N) = N rounds of 96 slots of fresh random scans -- ideal grid with dirt and sensor-faithful streams -- through the large-batch kernels and mml_step; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
 loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
@@ -24,6 +24,125 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+def random_dirt(rng, v, l):
+    """The dirt of the `scans` section: NaN runs, rings out of range, near / far crops, repeated points, bad Livox records."""
+    for _ in range(int(rng.integers(0, 6))):
+        kind = int(rng.integers(0, 8))
+        a = int(rng.integers(0, max(1, len(v) - 400)))
+        n = int(rng.integers(1, 400))
+        if kind == 0:
+            v[a:a + n, int(rng.integers(0, 3))] = np.nan
+        elif kind == 1:
+            v[a::int(rng.integers(50, 200)), 2] = rng.uniform(20, 80)
+        elif kind == 2:
+            v[a:a + n, :3] *= rng.uniform(0.01, 0.2)
+        elif kind == 3:
+            v[a:a + n, :3] *= rng.uniform(5, 40)
+        elif kind == 4:
+            l["line"][int(rng.integers(0, 50))::int(rng.integers(20, 90))] = int(rng.integers(6, 9))
+        elif kind == 5:
+            l["x"][int(rng.integers(0, 50))::int(rng.integers(20, 90))] = rng.uniform(-1, 0.01)
+        elif kind == 6:
+            v[a:a + n, :3] = 0.0                        # (0,0,0) no-return records
+        else:
+            v[a:a + n] = v[a]
+    return v, l
+
+
+def batch_section(args, M, O, synth, rng):
+    """Large batches -- the kernels bench.py runs: k_stencil<0>, batch k_select_part + k_select_list, k_voxel<256> / <1024>, the
+    lane-per-feature search, mml_step on 4 stream lanes -- on 96 slots of 24 fresh random scans per round: ideal-grid scans with
+    dirt and truncations, sensor-faithful scans (firing order, quantised ranges, NaN / (0,0,0) / absent no-returns, rosette,
+    tag bits, stray lines), with and without intra-sweep motion, lines made ragged by hand.  Everything mml_step leaves behind
+    against the oracle pipeline of every slot."""
+    from conftest import oracle_pipeline, perturbed, pose_to_x
+    B, ND = 96, 24
+    NVM = 1824 * 16
+    t0 = time.time()
+    # the map: sensor-faithful and ideal scans of the room, merged
+    maps = [[], []]
+    for k in range(8):
+        mk = (synth.velo_scan_vlp16(k), synth.livox_scan_horizon(k)) if k % 2 else (synth.velo_scan(k), synth.livox_scan(k))
+        o = oracle_pipeline(O, dict(velo=mk[0], livox=mk[1], dR=np.eye(3), dt=np.zeros(3)), None, None)
+        T = synth.pose_matrix(k)
+        maps[0].append(synth.transform(T, o["corner"].astype(np.float64)).astype(np.float32))
+        maps[1].append(synth.transform(T, o["surf"].astype(np.float64)).astype(np.float32))
+    cm, sm = O.voxel_downsample(np.concatenate(maps[0]), 0.4), O.voxel_downsample(np.concatenate(maps[1]), 0.2)
+    tc, ts = O.KdTree(cm), O.KdTree(sm)
+    c = M.Context(max_scans=B, max_velo_points=NVM, max_livox_points=24000)
+    c.map_set_local(0, cm)
+    c.map_set_local(1, sm)
+    n_pts = n_fac = redo = 0
+    worst_pose = 0.0
+    for rnd in range(args.batch):
+        cases = []
+        for j in range(ND):
+            k = int(rng.integers(0, 5000))
+            motion = bool(rng.integers(0, 2))
+            if rng.integers(0, 2):
+                v = synth.velo_scan_vlp16(k, dropout=("skip", "nan", "zero")[int(rng.integers(0, 3))], motion=motion,
+                                          drop_rate=float(rng.choice([0.0, 0.015, 0.1])), seed=int(rng.integers(0, 1 << 30)))
+                l = synth.livox_scan_horizon(k, motion=motion, drop_rate=float(rng.choice([0.0, 0.04, 0.2])), seed=int(rng.integers(0, 1 << 30)))
+            else:
+                v, l = synth.velo_scan(k, motion=motion, noise=float(rng.choice([0.01, 0.003, 0.03]))).copy(), synth.livox_scan(k, motion=motion).copy()
+            v, l = random_dirt(rng, v.copy(), l.copy())
+            r = int(rng.integers(0, 8))
+            if r == 0:
+                v = v[:int(rng.integers(16, len(v)))]
+            elif r == 1:
+                l = l[:int(rng.integers(3, len(l)))]
+            elif r == 2:                                    # ragged lines: one very long Livox line, the others short
+                a = int(rng.integers(0, len(l) // 2))
+                l["line"][a:a + int(rng.integers(2000, 12000))] = int(rng.integers(0, 6))
+            elif r == 3:
+                v, l = (None, l) if rng.integers(0, 2) else (v, None)
+            dR, dt = synth.sweep_motion(k) if motion else (np.eye(3), np.zeros(3))
+            T0 = perturbed(synth.pose_matrix(k), dt=rng.normal(0, 0.03, 3), rotvec=rng.normal(0, 0.004, 3))
+            cases.append(dict(velo=v, livox=l, dR=dR, dt=dt, T0=T0, x0=pose_to_x(T0), k=k))
+        ora = [oracle_pipeline(O, cs, tc, ts) for cs in cases]
+        perm = rng.permutation(B) % ND                      # which scan a slot holds
+        for s in range(B):
+            c.scan_upload(s, cases[perm[s]]["velo"], cases[perm[s]]["livox"])
+        dR = np.stack([cases[perm[s]]["dR"].reshape(9) for s in range(B)])
+        dt = np.stack([cases[perm[s]]["dt"] for s in range(B)])
+        x0 = np.stack([cases[perm[s]]["x0"] for s in range(B)])
+        if rnd % 2:
+            c.set_lanes(1)
+        c.extract(0, B)
+        for s in range(B):
+            d, o = c.scan_download(s), ora[perm[s]]
+            i = d["info"]
+            ok = i.n_points == len(o["xyzi"]) and all(np.array_equal(d[key], o[key]) for key in ("xyzi", "label", "ring", "reltime"))
+            ok = ok and (i.velo_corner_num, i.velo_surf_num, i.livox_corner_num, i.livox_surf_num) == o["counts"]
+            if not ok:
+                print("BATCH EXTRACT MISMATCH seed %d round %d slot %d (scan %d of the round)" % (args.seed, rnd, s, perm[s]))
+                np.save("gpurun_out/fuzz_batch_seed%d_round%d_v.npy" % (args.seed, rnd), cases[perm[s]]["velo"] if cases[perm[s]]["velo"] is not None else np.zeros(0))
+                np.save("gpurun_out/fuzz_batch_seed%d_round%d_l.npy" % (args.seed, rnd), cases[perm[s]]["livox"] if cases[perm[s]]["livox"] is not None else np.zeros(0))
+                return 1
+            redo += c.extract_queue_counts(s)[0]
+        x = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
+        c.set_lanes(4)
+        for s in range(B):
+            d, o = c.scan_download(s), ora[perm[s]]
+            gl, glsrc = c.factors_download(s, 0)
+            gp, gpsrc = c.factors_download(s, 1)
+            ok = (np.array_equal(d["label"], o["label"]) and np.array_equal(d["xyzi"][:, :3], o["und"]) and np.all(d["reltime"] == 1.0)
+                  and c.features_download(s, 0).tobytes() == o["corner"].tobytes() and c.features_download(s, 1).tobytes() == o["surf"].tobytes()
+                  and np.array_equal(glsrc, o["lsrc"]) and np.array_equal(gpsrc, o["psrc"])
+                  and np.allclose(gl, o["lf_arr"], rtol=0, atol=1e-9) and np.allclose(gp, o["pf_arr"], rtol=0, atol=1e-9))
+            dd = float(np.abs(x[s] - o["x"]).max())
+            worst_pose = max(worst_pose, dd)
+            if not ok or not dd < 1e-6:
+                print("BATCH STEP MISMATCH seed %d round %d slot %d (scan %d): records ok %s, pose diff %.3g" % (args.seed, rnd, s, perm[s], ok, dd))
+                return 1
+            n_pts += len(o["xyzi"])
+            n_fac += len(glsrc) + len(gpsrc)
+    print("batch: %d rounds x %d slots ok (%d points, %d factor records, redo-queue share %.3f %%, worst pose difference %.2e) %.0f s"
+          % (args.batch, B, n_pts, n_fac, 100.0 * redo / max(n_pts, 1), worst_pose, time.time() - t0), flush=True)
+    c.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
@@ -35,6 +154,8 @@ def main():
     ap.add_argument("--maps", type=int, default=2)
     ap.add_argument("--dense", type=int, default=2)
     ap.add_argument("--cubes", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="rounds of the large-batch section (96 slots each)")
+    ap.add_argument("--only-batch", action="store_true", help="run the batch section alone")
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -44,6 +165,10 @@ def main():
     from conftest import fuzz_line, perturbed
 
     rng = np.random.default_rng(args.seed)
+    if args.batch > 0:
+        rc = batch_section(args, M, O, synth, rng)
+        if rc or args.only_batch:
+            return rc
     ctx = M.Context(max_scans=4)
     t0 = time.time()
 
@@ -71,24 +196,7 @@ def main():
         k = int(rng.integers(0, 5000))
         v = synth.velo_scan(k).copy()
         l = synth.livox_scan(k, motion=bool(rng.integers(0, 2))).copy()
-        for _ in range(int(rng.integers(0, 6))):           # dirt
-            kind = int(rng.integers(0, 7))
-            a = int(rng.integers(0, len(v) - 400))
-            n = int(rng.integers(1, 400))
-            if kind == 0:
-                v[a:a + n, int(rng.integers(0, 3))] = np.nan
-            elif kind == 1:
-                v[a::int(rng.integers(50, 200)), 2] = rng.uniform(20, 80)
-            elif kind == 2:
-                v[a:a + n, :3] *= rng.uniform(0.01, 0.2)
-            elif kind == 3:
-                v[a:a + n, :3] *= rng.uniform(5, 40)
-            elif kind == 4:
-                l["line"][int(rng.integers(0, 50))::int(rng.integers(20, 90))] = int(rng.integers(6, 9))
-            elif kind == 5:
-                l["x"][int(rng.integers(0, 50))::int(rng.integers(20, 90))] = rng.uniform(-1, 0.01)
-            else:
-                v[a:a + n] = v[a]
+        v, l = random_dirt(rng, v, l)
         if rng.integers(0, 4) == 0:
             v = v[:int(rng.integers(16, len(v)))]
         if rng.integers(0, 4) == 0:
