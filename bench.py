@@ -182,6 +182,24 @@ def lib_sha16(M):
         return None
 
 
+def rccl_report(M):
+    """Which RCCL the process runs on: every librccl mapped (there must be ONE: the package maps PyTorch's copy before its own
+    library asks for `librccl.so.1`, see multi-modal-loam_amd/__init__.py), the version behind the C-ABI's collectives and the
+    version torch.distributed's "nccl" backend reports."""
+    try:
+        r = M.rccl_libraries()
+        try:
+            import torch
+            tv = torch.cuda.nccl.version()
+            r["torch_version"] = int(tv[0]) * 10000 + int(tv[1]) * 100 + int(tv[2]) if isinstance(tv, tuple) else int(tv)
+        except Exception:
+            r["torch_version"] = None
+        r["single_copy"] = len(r["loaded"]) == 1
+        return r
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def make_scan(synth, cfg, k, motion=True):
     v = synth.velo_scan(k, n_rings=cfg["n_rings"], n_az=cfg["n_az"], pitch0=cfg["pitch0"], pitch_step=cfg["pitch_step"], motion=motion)
     l = synth.livox_scan(k, n=cfg["livox"], motion=motion) if cfg["livox"] else np.zeros(0, synth.LIVOX_DTYPE)
@@ -609,6 +627,7 @@ def run_throughput(args, rank, local_rank, world, dist):
                          "stage_ms_per_launch": stage_ms},
             "cpu_baseline": cpu,
             "window_solve": window,
+            "rccl": rccl_report(M),
         }
         return json.dumps(out), window_timed_out
     return None, window_timed_out

@@ -367,6 +367,8 @@ int mml_comm_unique_id(uint8_t* id /* MML_COMM_ID_BYTES, filled by the calling r
 int mml_comm_init(mml_ctx* ctx, int n_ranks, int rank, const uint8_t* id);
 int mml_comm_destroy(mml_ctx* ctx);   /* also done by mml_destroy */
 int mml_comm_info(mml_ctx* ctx, int* n_ranks, int* rank);
+/* ncclGetVersion of the RCCL copy the entry points of this section are bound to (MAJOR * 10000 + MINOR * 100 + PATCH). */
+int mml_rccl_version(int* version);
 typedef struct {
     int evaluations;     /* linearisations of the own frames that did work */
     int rounds;          /* kernels enqueued (max_num_iterations + 2) */

@@ -141,6 +141,28 @@ def build(force=False):
 _lib = None
 
 
+def rccl_libraries():
+    """ONE RCCL per process is what a multi-rank run wants.  libmmloam_hip.so needs `librccl.so.1` / `libamdhip64.so.7` (the
+    ROCm copies, by its RUNPATH); a PyTorch wheel ships its own `torch/lib/librccl.so` and `libamdhip64.so` with the same
+    SONAMEs.  The dynamic loader identifies a library by SONAME and by file: when torch is imported FIRST, our NEEDED entries
+    resolve to its copies and the process holds one HIP runtime and one RCCL; the other way round torch's `librccl.so` request
+    matches neither the name nor the file of the ROCm copy and a second runtime and a second RCCL are mapped (harmless for a
+    single rank -- the two never exchange a pointer -- but two communicator registries on one device are not something to
+    bring to an 8-GPU run).  bench.py imports torch first; Context.comm_init refuses to build a communicator when two copies
+    are mapped.  Returns the paths of every librccl in /proc/self/maps and the version behind the C-ABI's collectives."""
+    v = C.c_int(0)
+    lib().mml_rccl_version(C.byref(v))
+    paths = []
+    try:
+        for line in open("/proc/self/maps"):
+            f = line.split()
+            if len(f) >= 6 and "librccl" in f[5] and f[5] not in paths:
+                paths.append(f[5])
+    except OSError:
+        pass
+    return dict(loaded=paths, version=v.value)
+
+
 def lib():
     """Load libmmloam_hip.so; fails loudly when the HIP extension has not been built."""
     global _lib
@@ -513,6 +535,10 @@ class Context:
 
     # ---- multi-GPU (RCCL inside the C-ABI) ----
     def comm_init(self, n_ranks, rank, comm_id):
+        r = rccl_libraries()
+        if n_ranks > 1 and len(r["loaded"]) > 1:
+            raise MmlError(MML_ERR_STATE, "two RCCL copies are mapped into this process (%s): import torch BEFORE the package so "
+                                          "that both use the same one" % ", ".join(r["loaded"]))
         if len(comm_id) != COMM_ID_BYTES:
             raise ValueError("the communicator id is %d bytes" % COMM_ID_BYTES)
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))

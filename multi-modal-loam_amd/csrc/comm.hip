@@ -133,6 +133,11 @@ int mml_comm_unique_id(uint8_t* id) {
     return MML_OK;
 }
 
+int mml_rccl_version(int* version) {
+    if (!version) return MML_ERR_INVALID;
+    return ncclGetVersion(version) == ncclSuccess ? MML_OK : MML_ERR_HIP;
+}
+
 int mml_comm_destroy(mml_ctx* ctx) {
     if (!ctx) return MML_ERR_INVALID;
     MmlComm* c = ctx->comm;
