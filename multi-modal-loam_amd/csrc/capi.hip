@@ -75,7 +75,7 @@ void mml_destroy(mml_ctx* ctx) {
     mml_comm_destroy(ctx);
     mml_fullwindow_dev_release(ctx);
     void* ptrs[] = {ctx->wstate, ctx->wrec, ctx->waux, ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
-                    ctx->ln_meta,  ctx->line_start, ctx->line_len, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
+                    ctx->ln_meta,  ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
                     ctx->cb_n,     ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
@@ -171,6 +171,15 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->slot_flags, B * 2);
     ALLOC(ctx->line_start, B * L);
     ALLOC(ctx->line_len, B * L);
+    ALLOC(ctx->seg_cum, B * L * (MML_SEG_MAX + 1));
+    ALLOC(ctx->seg_pos, B * L * MML_SEG_MAX);
+    ALLOC(ctx->seg_n, B * L);
+    ALLOC(ctx->seg_flat, B * 2 * MML_SEG_FLAT);
+    ALLOC(ctx->seg_flat_n, B * 4);
+    ALLOC(ctx->op_agg, B * 2 * MML_SEG_MAX);
+    ctx->seg_rstride = (int)((NT >> 6) + 6 * L + 8);
+    ALLOC(ctx->seg_rs, B * (size_t)ctx->seg_rstride);
+    ALLOC(ctx->seg_rw, B * (size_t)ctx->seg_rstride);
     ALLOC(ctx->ln_curv, B * NT);
     ALLOC(ctx->ln_refl, B * NT);
     ALLOC(ctx->ln_attr, B * NT);
@@ -382,7 +391,8 @@ struct FusedView {
     const uint8_t* line;      // uploaded clouds
     const uint8_t* label;
     const int* cb_n;          // this slot's two valid counts
-    const int* line_start;    // extracted clouds: the slot's line table (L entries; rings, then Livox lines)
+    const int* seg_flat;      // extracted clouds: per sensor the starts of the storage segments in storage order (block-major,
+    const int* seg_flat_n;    //   line inside a block) -- 2 x MML_SEG_FLAT ints -- and (entries, lines per block) per sensor
     int NV, NT, L, n_rings, flags;
 };
 __device__ __forceinline__ bool fused_at(const FusedView& V, int pos, int& g, float4& p, float& rel, int& line) {
@@ -397,17 +407,19 @@ __device__ __forceinline__ bool fused_at(const FusedView& V, int pos, int& g, fl
         line = V.line[pos];
     } else {
         if (pos < V.NV) p.w = 0.f;  // intensity of the Velodyne part is zeroed (unionFeatureExtract.cpp:1254-1256)
-        // last line of the region whose start is <= pos (starts are non-decreasing inside a region)
-        const int r0 = pos < V.NV ? 0 : V.n_rings, r1 = pos < V.NV ? V.n_rings : V.L;
-        int lo = r0, hi = r1 - 1;
+        // last storage segment of the region whose start is <= pos (starts are non-decreasing; an empty segment shares its start
+        // with the next one); segment f belongs to line f mod (lines per block)
+        const int sensor = pos < V.NV ? 0 : 1;
+        const int* flat = V.seg_flat + sensor * MML_SEG_FLAT;
+        int lo = 0, hi = V.seg_flat_n[2 * sensor] - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (V.line_start[mid] <= pos)
+            if (flat[mid] <= pos)
                 lo = mid;
             else
                 hi = mid - 1;
         }
-        line = lo - r0;
+        line = lo % V.seg_flat_n[2 * sensor + 1];
     }
     return true;
 }
@@ -530,7 +542,8 @@ int fused_view(mml_ctx* ctx, int slot, FusedView& V) {
     V.line = ctx->ln_line + off;
     V.label = ctx->ln_label + off;
     V.cb_n = ctx->cb_n + 2 * (size_t)slot;
-    V.line_start = ctx->line_start + (size_t)slot * ctx->L;
+    V.seg_flat = ctx->seg_flat + (size_t)slot * 2 * MML_SEG_FLAT;
+    V.seg_flat_n = ctx->seg_flat_n + (size_t)slot * 4;
     V.NV = ctx->NV;
     V.NT = ctx->NT;
     V.L = ctx->L;

@@ -87,7 +87,105 @@ struct FeatParams {
     int* sel_list_cnt;       // [B][2] list lengths of the launch that starts at slot `first`
     unsigned char* st_exit;  // [B][st_stride] k_stencil, segment mode: the stride walk's exit offsets of every tile, for the four entries
     int st_stride;
+    // storage segments of the lines (mml_internal.h): line index -> storage position
+    int* seg_cum;
+    int* seg_pos;
+    int* seg_n;
+    int* seg_flat;
+    int* seg_flat_n;
+    unsigned long long* op_agg;
+    unsigned op_epoch;
+    int4* seg_rs;   // per 64 line indices: (boundary, offset below it, offset from it on, 1 = no second boundary): rounds of k_stencil
+    int4* seg_rw;   //   the same for aligned windows (k_select_part)
+    int seg_rstride;
 };
+
+// ---- line index -> storage position ---------------------------------------------------------------------------------------
+// ln_curv / ln_refl / ln_attr are indexed in LINE ORDER (line_start[line] + i); the points themselves (ln_pts, ln_meta,
+// ln_label) sit where the bucketing put them: with the three-pass bucketing a line is one contiguous run, with the one-pass
+// bucketing it is a run per 4096-point block of the raw scan.  Segment s of a line holds its indices [cum[s], cum[s + 1]).
+struct SegTab {
+    const int* cum;
+    const int* pos;
+    int nseg;
+};
+__device__ __forceinline__ SegTab seg_tab(const FeatParams& P, int b, int line) {
+    const size_t o = (size_t)b * P.L + line;
+    return SegTab{P.seg_cum + o * (MML_SEG_MAX + 1), P.seg_pos + o * MML_SEG_MAX, P.seg_n[o]};
+}
+// storage position (inside the slot) of line index i, 0 <= i < line length; `s` is a hint and is left at i's segment
+__device__ __forceinline__ int seg_xlate(const SegTab& S, int i, int& s) {
+    while (s + 1 < S.nseg && S.cum[s + 1] <= i) ++s;
+    return S.pos[s] + (i - S.cum[s]);
+}
+__device__ __forceinline__ int seg_xlate(const SegTab& S, int i) {
+    int s = 0;
+    return seg_xlate(S, i, s);
+}
+// The same for a wavefront that walks ONE line front to back (k_stencil, k_select_part): the line's table sits in two vector
+// registers -- lane l holds cum[l] and pos[l] -- and is read with v_readlane at wave-uniform indices, so a look-up touches no
+// memory.  For a window [first, last] of line indices the (at most four) segments it crosses become seven scalars, and a lane's
+// translation is three compares, three selects and an add.  `ok` is false when the window crosses more than four segments (lines
+// with tiny or empty segments): the caller then translates through the table in memory (seg_xlate).
+struct SegLanes {
+    int cum, pos, nseg;
+};
+__device__ __forceinline__ SegLanes seg_lanes(const SegTab& g) {
+    const int l = threadIdx.x & 63;
+    SegLanes T;
+    T.cum = l <= g.nseg ? g.cum[l] : 0x7fffffff;
+    T.pos = l < g.nseg ? g.pos[l] : 0;
+    T.nseg = g.nseg;
+    return T;
+}
+struct SegWin {
+    int c1, c2, c3, d0, e1, e2, e3;  // boundaries; offset of the first segment; offset steps at the boundaries
+    bool ok;
+    // (sums of selected steps, not a selection among four offsets: the latter is turned into an indexed load from a copy of the
+    //  struct in scratch memory)
+    __device__ __forceinline__ int at(int i) const { return i + d0 + (i >= c1 ? e1 : 0) + (i >= c2 ? e2 : 0) + (i >= c3 ? e3 : 0); }
+};
+// A translation record through the SCALAR data path (s_load_dwordx4 into four scalar registers).  The compiler only uses scalar
+// loads for addresses it can prove uniform and memory it can prove unwritten; a record address derived from the wavefront's number
+// (threadIdx.x >> 6) and read between the kernel's own stores is neither to it, and as a vector load the five records of a tile
+// held twenty vector registers.  The wait is a separate statement that names the registers, so that no use can be moved above it.
+typedef int seg_v4i __attribute__((ext_vector_type(4)));
+// (a pointer the compiler takes for divergent -- it depends on the wavefront's number -- as the scalar it is)
+__device__ __forceinline__ const int4* seg_uniform_ptr(const int4* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const int4*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ seg_v4i seg_sload(const int4* base /* from seg_uniform_ptr */, int index) {
+    seg_v4i r;
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long q = ((unsigned long long)hi << 32) | lo;
+    const int off = __builtin_amdgcn_readfirstlane(index * 16);
+    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(q), "s"(off) : "memory");
+    return r;
+}
+#define SEG_SWAIT5(a, b, c, d, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e)::"memory")
+#define SEG_SWAIT8(a, b, c, d, e, f, g, h) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g), "+s"(h)::"memory")
+// s: wave-uniform hint (segment of an earlier window of the same walk), left at the segment of `first`
+__device__ __forceinline__ SegWin seg_window(const SegLanes& T, int first, int last, int& s) {
+    s = __builtin_amdgcn_readfirstlane(s);
+    while (s + 1 < T.nseg && __builtin_amdgcn_readlane(T.cum, s + 1) <= first) ++s;
+    SegWin W;
+    W.c1 = __builtin_amdgcn_readlane(T.cum, s + 1);
+    W.c2 = __builtin_amdgcn_readlane(T.cum, s + 2);      // (lanes beyond nseg hold INT_MAX; nseg <= MML_SEG_MAX keeps s + 4 < 64)
+    W.c3 = __builtin_amdgcn_readlane(T.cum, s + 3);
+    const int c4 = __builtin_amdgcn_readlane(T.cum, s + 4);
+    W.d0 = __builtin_amdgcn_readlane(T.pos, s) - __builtin_amdgcn_readlane(T.cum, s);
+    const int d1 = __builtin_amdgcn_readlane(T.pos, s + 1) - W.c1, d2 = __builtin_amdgcn_readlane(T.pos, s + 2) - W.c2,
+              d3 = __builtin_amdgcn_readlane(T.pos, s + 3) - W.c3;
+    W.e1 = d1 - W.d0;
+    W.e2 = d2 - d1;
+    W.e3 = d3 - d2;
+    W.ok = last < c4;
+    return W;
+}
 
 struct D3 {
     double x, y, z;
@@ -463,11 +561,21 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
         int acc = sensor == 0 ? 0 : P.NV;  // livox lines live behind the velodyne region
         int* ls = P.line_start + (size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings);
         int* ll = P.line_len + (size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings);
+        const size_t lo = (size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings);
+        int* flat = P.seg_flat + ((size_t)b * 2 + sensor) * MML_SEG_FLAT;
         for (int r = 0; r < nkeys; ++r) {
             ls[r] = acc;
             ll[r] = s_tot[r];
+            // one storage segment per line: the line is contiguous, stored where its line-order index says
+            P.seg_n[lo + r] = 1;
+            P.seg_cum[(lo + r) * (MML_SEG_MAX + 1)] = 0;
+            P.seg_cum[(lo + r) * (MML_SEG_MAX + 1) + 1] = s_tot[r];
+            P.seg_pos[(lo + r) * MML_SEG_MAX] = acc;
+            if (r < MML_SEG_FLAT) flat[r] = acc;
             acc += s_tot[r];
         }
+        P.seg_flat_n[((size_t)b * 2 + sensor) * 2] = nkeys < MML_SEG_FLAT ? nkeys : MML_SEG_FLAT;
+        P.seg_flat_n[((size_t)b * 2 + sensor) * 2 + 1] = nkeys;
         P.cb_n[2 * b + sensor] = s_tot[nkeys];
         if (sensor == 0)
             a->kept_velo = s_tot[nkeys + 1];
@@ -731,6 +839,435 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
         const size_t g = (size_t)b * P.NT + s_dst[tid];
         P.ln_pts[g] = s_pt[tid];
         P.ln_meta[g] = s_meta[tid];
+    }
+}
+
+// ---- a1 / a2 in ONE pass over the raw scan (ring layouts up to 32 rings, scans up to MML_SEG_MAX x 4096 points per sensor) -----
+// The three passes above read every raw record twice and carry ring id and azimuth from pass A to pass C through memory: 66 bytes
+// of traffic per point for the 40 the job needs, both passes at the HBM roof.  Here a 512-thread workgroup owns a block of
+// MML_OP_BLK = 4096 consecutive raw points, eight per thread, which stay IN REGISTERS between being counted and being stored
+// (sixteen per thread: 207 registers, two wavefronts per SIMD):
+//   1. load; ring / line id, azimuth, crop test, the half-turn condition of :1169-1177 per point; the rank of a point among the
+//      points of its line inside its wavefront round (ballots), per (round, wavefront) group counts in LDS
+//   2. exclusive scan of the 64 group counts per line -> the block's line histogram and the offset of every group
+//   3. the block publishes (valid points, kept points, first half-turn index) as ONE 64-bit word tagged with the launch's epoch and
+//      reads the words of the blocks in front of it (decoupled look-back: a scan has at most 16 blocks, one lane per
+//      predecessor, nobody waits for a successor) -> where the block's points start in the slot, where its kept points start
+//      in the fused cloud, whether the half turn was passed before it
+//   4. the points leave for  region + (valid points of the blocks before) + (offset of the line inside the block) + rank.
+// The storage order is therefore BLOCK-major, line-bucketed inside a block: a line is a sequence of segments, one per block
+// (k_assign_tables lists them: seg_cum / seg_pos), in raw order -- which is all the per-line kernels need (seg_xlate).  Nothing
+// is written but the 16-byte point, the 8-byte (fused index, time) record and 2 x 32 ints per block: 42 bytes per point.
+constexpr int OP_THREADS = 512, OP_PPT = MML_OP_BLK / OP_THREADS, OP_WAVES = OP_THREADS / 64, OP_GROUPS = OP_PPT * OP_WAVES;
+constexpr int OP_MAXKEYS = 32, OP_CSTRIDE = OP_MAXKEYS + 1, OP_REC_POS = 80;
+static_assert(OP_PPT * OP_THREADS == MML_OP_BLK, "block size");
+static_assert(OP_GROUPS <= 64, "one lane per (round, wavefront) group in the scans");
+static_assert(OP_REC_POS + OP_MAXKEYS <= MAX_LINES, "the block record holds histogram and positions in front of the two counts");
+constexpr unsigned OP_NONE = 0x1fffu;
+enum : unsigned { OPI_VALID = 1u << 8, OPI_KEEP = 1u << 9, OPI_NEAR = 1u << 10, OPI_RANK_SHIFT = 12, OPI_KRANK_SHIFT = 20 };
+
+// start / end azimuth of the sweep (:1136-1146) and the per-slot resets, one wavefront per slot
+__global__ __launch_bounds__(64) void k_assign_ends(FeatParams P, int count) {
+    const int t = blockIdx.x;
+    if (t >= count) return;
+    const int b = P.first + t, lane = threadIdx.x;
+    const int n = P.n_in[2 * b];
+    const float4* in = P.velo_in + (size_t)b * P.NV;
+    int ff = -1, lf = -1;
+    for (int i0 = 0; i0 < n && ff < 0; i0 += 64) {
+        const int i = i0 + lane;
+        bool fin = false;
+        if (i < n) {
+            const float4 p = in[i];
+            fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+        }
+        const unsigned long long m = __ballot(fin);
+        if (m) ff = i0 + (int)__ffsll((long long)m) - 1;
+    }
+    for (int i0 = n > 0 ? ((n - 1) / 64) * 64 : -1; i0 >= 0 && lf < 0; i0 -= 64) {
+        const int i = i0 + lane;
+        bool fin = false;
+        if (i < n) {
+            const float4 p = in[i];
+            fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+        }
+        const unsigned long long m = __ballot(fin);
+        if (m) lf = i0 + 63 - __clzll((long long)m);
+    }
+    if (lane == 0) {
+        AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
+        float startOri = 0.f, endOri = 0.f;
+        if (lf >= 0) {
+            const float4 p0 = in[ff], p1 = in[lf];
+            startOri = -atan2((double)p0.y, (double)p0.x);   // :1136
+            endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
+            if (endOri - startOri > 3 * M_PI)
+                endOri -= 2 * M_PI;
+            else if (endOri - startOri < M_PI)
+                endOri += 2 * M_PI;
+        }
+        a->first_finite = ff < 0 ? 0x7fffffff : ff;
+        a->last_finite = lf;
+        a->trig = 0x7fffffff;
+        a->startOri = startOri;
+        a->endOri = endOri;
+        P.slot_flags[2 * b] = 0;  // an extracted cloud, not undistorted yet
+        P.brk_cnt[b] = 0;         // the stencil's two queues start empty
+        P.redo_cnt[b] = 0;
+    }
+}
+
+// inclusive scan over the 64 lanes of a wavefront
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(v, o);
+        if (lane >= o) v += y;
+    }
+    return v;
+}
+
+template <int SENSOR>
+__global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
+    __shared__ int s_cnt[OP_GROUPS][OP_CSTRIDE];  // points per (group, line); after the scan: points of the line in the groups before
+    __shared__ int s_gv[OP_GROUPS], s_gk[OP_GROUPS];  // valid / kept points per group -> exclusive over the groups
+    __shared__ int s_hist[OP_MAXKEYS + 2], s_koff[OP_MAXKEYS];
+    __shared__ int s_cond[OP_WAVES];
+    __shared__ int s_base[3];
+    const int b = blockIdx.y + P.first, blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n_in[2 * b + SENSOR];
+    const int i0 = blk * MML_OP_BLK;
+    if (i0 >= n) return;
+    const int nkeys = SENSOR == 0 ? P.n_rings : P.n_lines;
+    const int nbits = SENSOR == 0 ? P.ring_bits : P.line_bits;
+    const int region = SENSOR == 0 ? 0 : P.NV;
+    for (int k = tid; k < OP_GROUPS * OP_CSTRIDE; k += OP_THREADS) (&s_cnt[0][0])[k] = 0;
+    const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);
+    // ---- 1. the block's records, all loads in flight together ----
+    float4 pt[OP_PPT];
+    unsigned xw[OP_PPT];    // velodyne: the raw azimuth (float bits), Livox: offset_time
+    unsigned info[OP_PPT];  // [0:7] line id, OPI_* flags, rank among the points of the line / among the kept points in the wavefront round
+    if constexpr (SENSOR == 0) {
+        const float4* in = P.velo_in + (size_t)b * P.NV;
+#pragma unroll
+        for (int r = 0; r < OP_PPT; ++r) {
+            const int i = i0 + r * OP_THREADS + tid;
+            pt[r] = i < n ? nt_load4(in + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
+#pragma unroll
+        for (int r = 0; r < OP_PPT; ++r) {
+            const int i = i0 + r * OP_THREADS + tid;
+            pt[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xw[r] = 0;
+            info[r] = 255;
+            if (i < n) {
+                const mml_livox_point q = in[i];
+                pt[r] = make_float4(q.x, q.y, q.z, (float)q.reflectivity);  // (the float it becomes at :994)
+                xw[r] = q.offset_time;
+                info[r] = q.line;
+            }
+        }
+    }
+    __syncthreads();  // (the counters are zero)
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int cond_min = 0x7fffffff;  // (wave-uniform) first index of this wavefront's points that sets halfPassed
+#pragma unroll
+    for (int r = 0; r < OP_PPT; ++r) {
+        const int i = i0 + r * OP_THREADS + tid;
+        bool valid = false, keep = false, near_ok = false, cond = false;
+        int key = 0;
+        if (i < n) {
+            if constexpr (SENSOR == 0) {
+                const float4 p = pt[r];
+                float ori = 0.f;
+                if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {  // (non-finite records are removed at :1133)
+                    const int ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
+                    valid = ring != 255;                                  // outside the ring table: dropped at :1163-1166
+                    key = valid ? ring : 0;
+                    ori = neg_atan2_f(p.y, p.x);
+                }
+                xw[r] = __float_as_uint(ori);
+                if (valid) {
+                    // would this point set halfPassed (:1169-1177)?  Evaluated as if the flag were still clear: only the FIRST
+                    // such point matters, and for it the flag is clear
+                    float o = ori;
+                    if (o < aux.startOri - M_PI / 2)
+                        o += 2 * M_PI;
+                    else if (o > aux.startOri + M_PI * 3 / 2)
+                        o -= 2 * M_PI;
+                    cond = o - aux.startOri > M_PI;
+                }
+            } else {
+                const int line_num = (int)(info[r] & 255u);
+                valid = !(line_num > nkeys - 1) && !(pt[r].x < 0.01);     // :989-990
+                key = valid ? line_num : 0;
+            }
+            if (valid) crop_test(P, pt[r].x, pt[r].y, pt[r].z, keep, near_ok);
+        }
+        const unsigned long long eq = match_key(valid, key, nbits);
+        const unsigned long long km = __ballot(keep), vm = __ballot(valid);
+        const int g = r * OP_WAVES + wave;
+        if (valid && (eq & lt) == 0) s_cnt[g][key] = __popcll(eq);
+        if (lane == 0) {
+            s_gv[g] = __popcll(vm);
+            s_gk[g] = __popcll(km);
+        }
+        if constexpr (SENSOR == 0) {
+            const unsigned long long cm = __ballot(cond);
+            if (cm && cond_min == 0x7fffffff) cond_min = i0 + r * OP_THREADS + wave * 64 + (int)__ffsll((long long)cm) - 1;
+        }
+        info[r] = (unsigned)key | (valid ? OPI_VALID : 0u) | (keep ? OPI_KEEP : 0u) | (near_ok ? OPI_NEAR : 0u) |
+                  ((unsigned)__popcll(eq & lt) << OPI_RANK_SHIFT) | ((unsigned)__popcll(km & lt) << OPI_KRANK_SHIFT);
+        // (one point at a time: interleaving the sixteen evaluations keeps all their temporaries alive at once -- 207 registers, two
+        //  wavefronts per SIMD)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane == 0) s_cond[wave] = cond_min;
+    __syncthreads();
+    // ---- 2. per line: exclusive scan over the 64 groups (lane = group) ----
+    const bool gl = lane < OP_GROUPS;
+    for (int k = wave; k < nkeys; k += OP_WAVES) {
+        const int v = gl ? s_cnt[lane][k] : 0;
+        const int x = wave_incl_scan(v);
+        if (gl) s_cnt[lane][k] = x - v;
+        if (lane == 63) s_hist[k] = x;
+    }
+    if (wave == 0) {
+        const int v = gl ? s_gv[lane] : 0, x = wave_incl_scan(v);
+        if (gl) s_gv[lane] = x - v;
+        if (lane == 63) s_hist[nkeys] = x;
+    } else if (wave == 1) {
+        const int v = gl ? s_gk[lane] : 0, x = wave_incl_scan(v);
+        if (gl) s_gk[lane] = x - v;
+        if (lane == 63) s_hist[nkeys + 1] = x;
+    }
+    __syncthreads();
+    // ---- 3. offsets of the lines inside the block; publish; look back ----
+    if (wave == 0) {
+        const int h = lane < nkeys ? s_hist[lane] : 0;
+        const int koff = wave_incl_scan(h) - h;
+        if (lane < nkeys) s_koff[lane] = koff;
+        const int tv = s_hist[nkeys], tk = s_hist[nkeys + 1];
+        int cmin = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < OP_WAVES; ++q) cmin = min(cmin, s_cond[q]);
+        const unsigned coff = cmin == 0x7fffffff ? OP_NONE : (unsigned)(cmin - i0);
+        unsigned long long* agg = P.op_agg + ((size_t)b * 2 + SENSOR) * MML_SEG_MAX;
+        const unsigned epoch = P.op_epoch;
+        if (lane == 0) {
+            const unsigned long long word = ((unsigned long long)epoch << 39) | ((unsigned long long)coff << 26) | ((unsigned long long)tk << 13) | (unsigned)tv;
+            __hip_atomic_store(agg + blk, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // lanes 0 .. blk-1: the blocks in front of this one (they were dispatched before it: they are running or done).  Livox:
+        // lanes 32 ..: every Velodyne block of the slot -- its kernel has completed on this stream -- for the number of Velodyne
+        // points in front of the Livox part of the fused cloud.
+        unsigned long long w = 0;
+        bool need = lane < blk;
+        while (__any(need)) {
+            if (need) {
+                w = __hip_atomic_load(agg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                need = (unsigned)(w >> 39) != epoch;
+            }
+            if (__any(need)) __builtin_amdgcn_s_sleep(1);
+        }
+        int pv = lane < blk ? (int)(w & 0x1fffu) : 0;
+        int pk = lane < blk ? (int)((w >> 13) & 0x1fffu) : 0;
+        int pc = 0x7fffffff;
+        if (lane < blk && (unsigned)((w >> 26) & 0x1fffu) != OP_NONE) pc = lane * MML_OP_BLK + (int)((w >> 26) & 0x1fffu);
+        if constexpr (SENSOR == 1) {
+            const int nbv = (P.n_in[2 * b] + MML_OP_BLK - 1) / MML_OP_BLK;
+            if (lane >= 32 && lane - 32 < nbv) {
+                const unsigned long long wv = __hip_atomic_load(P.op_agg + (size_t)b * 2 * MML_SEG_MAX + (lane - 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pk = (int)((wv >> 13) & 0x1fffu);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pv += __shfl_xor(pv, o);
+            pk += __shfl_xor(pk, o);
+            pc = min(pc, __shfl_xor(pc, o));
+        }
+        if (lane == 0) {
+            s_base[0] = pv;
+            s_base[1] = pk;
+            s_base[2] = min(pc, cmin);
+        }
+        // the block's record for k_assign_tables: line histogram, where each line's segment starts, the two counts
+        int* rec = P.blk_cnt + ((size_t)(b * 2 + SENSOR) * P.nblk_max + blk) * BLK_STRIDE;
+        if (lane < nkeys) {
+            rec[lane] = h;
+            rec[OP_REC_POS + lane] = region + pv + koff;
+        }
+        if (lane == 0) {
+            rec[MAX_LINES] = tv;
+            rec[MAX_LINES + 1] = tk;
+        }
+    }
+    __syncthreads();
+    // ---- 4. the points leave ----
+    const int base_valid = region + s_base[0], base_keep = s_base[1], trig = s_base[2];
+    double timeSpan = 1.0;
+    if constexpr (SENSOR == 1) timeSpan = livox_to_sec(P.livox_in[(size_t)b * P.NL + n - 1].offset_time);  // :985
+#pragma unroll
+    for (int r = 0; r < OP_PPT; ++r) {
+        const unsigned f = info[r];
+        if (!(f & OPI_VALID)) continue;
+        const int i = i0 + r * OP_THREADS + tid;
+        const int key = (int)(f & 255u), g = r * OP_WAVES + wave;
+        const int dst = base_valid + s_koff[key] + s_cnt[g][key] + (int)((f >> OPI_RANK_SHIFT) & 63u);
+        const int fdst = base_keep + s_gk[g] + (int)((f >> OPI_KRANK_SHIFT) & 63u);
+        float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
+        if constexpr (SENSOR == 0) {
+            const float startOri = aux.startOri, endOri = aux.endOri;
+            float ori = __uint_as_float(xw[r]);
+            if (i <= trig) {  // :1169-1177
+                if (ori < startOri - M_PI / 2)
+                    ori += 2 * M_PI;
+                else if (ori > startOri + M_PI * 3 / 2)
+                    ori -= 2 * M_PI;
+            } else {  // :1178-1184
+                ori += 2 * M_PI;
+                if (ori < endOri - M_PI * 3 / 2)
+                    ori += 2 * M_PI;
+                else if (ori > endOri + M_PI / 2)
+                    ori -= 2 * M_PI;
+            }
+            rel = (ori - startOri) / (endOri - startOri);  // :1186
+        } else {
+            rel = livox_to_sec(xw[r]) / timeSpan;           // :995
+        }
+        const size_t gpos = (size_t)b * P.NT + dst;
+        P.ln_pts[gpos] = pt[r];
+        const bool keep = (f & OPI_KEEP) != 0;
+        P.ln_meta[gpos] = make_int2(keep ? fdst : ((SENSOR == 1 && (f & OPI_NEAR)) ? -2 : -1), __float_as_int(rel));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the line tables of a slot from its block records, one wavefront per slot (lane = line): line lengths, line-order starts,
+// storage segments (seg_cum / seg_pos / seg_flat), the valid and kept counts of both sensors
+__global__ __launch_bounds__(64) void k_assign_tables(FeatParams P, int count) {
+    const int t = blockIdx.x;
+    if (t >= count) return;
+    const int b = P.first + t, lane = threadIdx.x;
+    const bool in = lane < P.L;
+    const int sensor = lane < P.n_rings ? 0 : 1;
+    const int key = lane - (sensor == 0 ? 0 : P.n_rings);
+    const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
+    const int n = P.n_in[2 * b + sensor];
+    const int nblk = (n + MML_OP_BLK - 1) / MML_OP_BLK;
+    const int* rec0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * BLK_STRIDE;
+    const size_t lo = (size_t)b * P.L + lane;
+    int acc = 0;
+    if (in) {
+        int* cum = P.seg_cum + lo * (MML_SEG_MAX + 1);
+        int* pos = P.seg_pos + lo * MML_SEG_MAX;
+        int* flat = P.seg_flat + ((size_t)b * 2 + sensor) * MML_SEG_FLAT;
+        for (int k = 0; k < nblk; ++k) {
+            const int* rec = rec0 + (size_t)k * BLK_STRIDE;
+            const int p = rec[OP_REC_POS + key];
+            cum[k] = acc;
+            pos[k] = p;
+            flat[k * nkeys + key] = p;
+            acc += rec[key];
+        }
+        cum[nblk] = acc;
+        if (nblk == 0) {
+            cum[1] = 0;
+            pos[0] = sensor == 0 ? 0 : P.NV;
+        }
+        P.seg_n[lo] = nblk > 0 ? nblk : 1;
+        P.line_len[lo] = acc;
+    }
+    // line-order starts: rings from 0, Livox lines from NV
+    const int x = wave_incl_scan(in ? acc : 0);
+    const int velo_total = __shfl(x, P.n_rings - 1);
+    if (in) P.line_start[lo] = sensor == 0 ? x - acc : P.NV + (x - acc - velo_total);
+    if (lane < 2) {  // lane = sensor
+        const int ns = P.n_in[2 * b + lane];
+        const int nb = (ns + MML_OP_BLK - 1) / MML_OP_BLK;
+        const int* r0 = P.blk_cnt + ((size_t)(b * 2 + lane) * P.nblk_max) * BLK_STRIDE;
+        int tv = 0, tk = 0;
+        for (int k = 0; k < nb; ++k) {
+            tv += r0[(size_t)k * BLK_STRIDE + MAX_LINES];
+            tk += r0[(size_t)k * BLK_STRIDE + MAX_LINES + 1];
+        }
+        P.cb_n[2 * b + lane] = tv;
+        AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
+        if (lane == 0)
+            a->kept_velo = tk;
+        else
+            a->kept_livox = tk;
+        const int nk = lane == 0 ? P.n_rings : P.n_lines;
+        P.seg_flat_n[((size_t)b * 2 + lane) * 2] = nb * nk;
+        P.seg_flat_n[((size_t)b * 2 + lane) * 2 + 1] = nk;
+    }
+}
+
+// The translation records of a slot (see SegTab): for every run of 64 consecutive line indices of every line the ONE segment
+// boundary the run may cross and the storage offset on either side of it, so that the per-line kernels translate an index with a
+// compare, a select and an add on scalars they load with one scalar request -- no search, no table in LDS.  .w = 0: the run
+// crosses a second boundary (a sparse line: segments shorter than 64 points), the caller then walks the segment table itself.
+// `shift` = 5: the rounds of k_stencil's tiles (run r = indices 64 r - 5 .. 64 r + 58), 0: aligned windows.
+__device__ __forceinline__ int seg_rec_base(const FeatParams& P, int b, int line) {
+    return (P.line_start[(size_t)b * P.L + line] >> 6) + 6 * line;  // (a tile of k_stencil reads up to 5 runs past the line's last full one)
+}
+__global__ __launch_bounds__(256) void k_seg_records(FeatParams P, int count) {
+    const int b = P.first + blockIdx.y;
+    const int rho = blockIdx.x * 256 + threadIdx.x;
+    if (rho >= P.seg_rstride) return;
+    // the line whose records cover rho: the last line whose base is <= rho (bases grow with the line number)
+    int lo = 0, hi = P.L - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_rec_base(P, b, mid) <= rho)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int line = lo, r = rho - seg_rec_base(P, b, line);
+    const int n = P.line_len[(size_t)b * P.L + line];
+    if (r < 0 || n <= 0) return;  // (every run the line's range holds, also those behind its end: a tile reads them, clamped)
+    const SegTab S = seg_tab(P, b, line);
+#pragma unroll
+    for (int form = 0; form < 2; ++form) {
+        const int a0 = 64 * r - (form == 0 ? 5 : 0);
+        const int first = min(max(a0, 0), n - 1), last = min(a0 + 63, n - 1);
+        int sg = 0;
+        while (sg + 1 < S.nseg && S.cum[sg + 1] <= first) ++sg;
+        int4 rec;
+        rec.x = S.cum[sg + 1];
+        rec.y = S.pos[sg] - S.cum[sg];
+        rec.z = sg + 1 < S.nseg ? S.pos[sg + 1] - S.cum[sg + 1] : 0;
+        rec.w = (sg + 2 > S.nseg || last < S.cum[sg + 2]) ? 1 : 0;
+        (form == 0 ? P.seg_rs : P.seg_rw)[(size_t)b * P.seg_rstride + rho] = rec;
+    }
+}
+
+// storage positions of the line indices i - H .. i + H of one line (H <= 5) for a single lane (k_stencil_redo / k_stencil_break): the
+// window lies inside the two rounds i / 64 and i / 64 + 1 of the stencil records; a sparse line goes through the segment table
+template <int H>
+__device__ __forceinline__ void seg_point_window(const FeatParams& P, int b, int line, int i, int (&pos)[2 * H + 1]) {
+    const int4* rec = P.seg_rs + (size_t)b * P.seg_rstride + seg_rec_base(P, b, line);
+    const int r = i >> 6;
+    const int4 r0 = rec[r], r1 = rec[r + 1];
+    if (r0.w && r1.w) {
+#pragma unroll
+        for (int k = 0; k < 2 * H + 1; ++k) {
+            const int j = i + k - H;
+            const bool lo = j <= 64 * r + 58;
+            const int cb = lo ? r0.x : r1.x, dl = lo ? r0.y : r1.y, dh = lo ? r0.z : r1.z;
+            pos[k] = j + (j < cb ? dl : dh);
+        }
+    } else {
+        const SegTab seg = seg_tab(P, b, line);
+        int sh = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * H + 1; ++k) pos[k] = seg_xlate(seg, i + k - H, sh);
     }
 }
 
@@ -1194,12 +1731,23 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
 #endif
     const int b = (MODE == 0 ? blockIdx.y : blockIdx.z) + P.first;
     const int wave_id = threadIdx.x >> 6;
-    const int line = (MODE == 0 ? blockIdx.x : blockIdx.y) * ST_LINES + wave_id;
+    // (the wavefront's number is a scalar: said so, everything derived from the line -- its table entries, base addresses -- stays
+    //  in scalar registers)
+    const int line = __builtin_amdgcn_readfirstlane((int)((MODE == 0 ? blockIdx.x : blockIdx.y) * ST_LINES + wave_id));
     if (line >= P.L) return;
     const int n = P.line_len[(size_t)b * P.L + line];
     if (n <= 0) return;
     const int start = P.line_start[(size_t)b * P.L + line];
-    const size_t base = (size_t)b * P.NT + start;
+    const size_t base = (size_t)b * P.NT + start;  // line order: ln_curv / ln_refl / ln_attr
+    const float4* slot_pts = P.ln_pts + (size_t)b * P.NT;
+    // where the line's points are stored: the translation records of its rounds (k_seg_records), the segment table for sparse lines
+    // (its three words as the scalars they are: as values derived from the wavefront's number they sat in five vector registers
+    //  across the whole tile loop, one wavefront per SIMD less)
+    SegTab seg = seg_tab(P, b, line);
+    seg.cum = reinterpret_cast<const int*>(seg_uniform_ptr(reinterpret_cast<const int4*>(seg.cum)));
+    seg.pos = reinterpret_cast<const int*>(seg_uniform_ptr(reinterpret_cast<const int4*>(seg.pos)));
+    seg.nseg = __builtin_amdgcn_readfirstlane(seg.nseg);
+    const int4* seg_rec = seg_uniform_ptr(P.seg_rs + (size_t)b * P.seg_rstride + seg_rec_base(P, b, line));
     __shared__ float4 s_pt_all[ST_LINES][ST_TILE + 10];
     __shared__ float s_sq_all[ST_LINES][ST_TILE + 10];
     __shared__ unsigned short s_attr_all[ST_LINES][ST_TILE];
@@ -1238,19 +1786,60 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
             // consecutive points (each is tested by six windows).  Every lane requests its point AND the successor (the second
             // request is served from the lines the first one brings in), all requests of the phase in flight together.
             constexpr int NLD = (ST_TILE + 10 + 63) / 64;
-            float4 pa[NLD], pb[NLD];
+            float4 pa[NLD];
+            // Per round of 64 consecutive line indices: the one segment boundary the round may cross and the storage offset on either
+            // side of it come as a precomputed record (k_seg_records) with one scalar request per round: a lane's translation is a
+            // compare, a select and an add.  A round that crosses two boundaries (segments shorter than 64 points: a sparse line)
+            // sends the tile through the general path below.
+            static_assert(NLD == 5, "five records per tile");
+            seg_v4i rr[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int gp = t0 - 5 + lane + 64 * u;
-                const bool in_tile = lane + 64 * u < ST_TILE + 10;
-                pa[u] = (in_tile && gp >= 0 && gp < n) ? P.ln_pts[base + gp] : make_float4(0.f, 0.f, 0.f, 0.f);
-                pb[u] = (in_tile && gp + 1 >= 0 && gp + 1 < n) ? P.ln_pts[base + gp + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int u = 0; u < NLD; ++u) rr[u] = seg_sload(seg_rec, (t0 >> 6) + u);
+            SEG_SWAIT5(rr[0], rr[1], rr[2], rr[3], rr[4]);
+            const bool ok = (rr[0].w & rr[1].w & rr[2].w & rr[3].w & rr[4].w) != 0;
+            if (ok) {
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int k = lane + 64 * u;
-                if (k < ST_TILE + 10) s_pt[k] = pa[u];
-                if (k < ST_TILE + 9) s_sq[k] = seg_sq(pa[u], pb[u]);
+                for (int u = 0; u < NLD; ++u) {  // every request of the phase in flight together
+                    const int gp = t0 - 5 + lane + 64 * u;
+                    const bool in_tile = lane + 64 * u < ST_TILE + 10;
+                    const bool ha = in_tile && gp >= 0 && gp < n;
+                    pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ha) pa[u] = slot_pts[(unsigned)(gp + (gp < rr[u].x ? rr[u].y : rr[u].z))];
+                }
+                // the successor of a point is the next lane's point (whole-wave DPP shift; lane 63 takes lane 0 of the next round):
+                // one request per point, and no second set of addresses and values in registers
+#pragma unroll
+                for (int u = 0; u < NLD; ++u) {
+                    const int k = lane + 64 * u;
+                    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (u + 1 < NLD) {  // (bit patterns: the builtin takes an int)
+                        nx.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pa[u + 1 < NLD ? u + 1 : u].x)));
+                        nx.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pa[u + 1 < NLD ? u + 1 : u].y)));
+                        nx.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pa[u + 1 < NLD ? u + 1 : u].z)));
+                    }
+                    nx.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nx.x), __float_as_int(pa[u].x), 0x130, 0xf, 0xf, false));
+                    nx.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nx.y), __float_as_int(pa[u].y), 0x130, 0xf, 0xf, false));
+                    nx.z = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nx.z), __float_as_int(pa[u].z), 0x130, 0xf, 0xf, false));
+                    if (k < ST_TILE + 10) s_pt[k] = pa[u];
+                    if (k < ST_TILE + 9) s_sq[k] = seg_sq(pa[u], nx);
+                }
+            } else {
+                // (wave-uniform, rare) a sparse line -- a round crosses two segment boundaries: point and successor through the
+                // segment table, one index at a time, straight into the tile (a rolled loop: the common path must not pay registers
+                // for it)
+                int sh = 0;
+#pragma unroll 1
+                for (int k = lane; k < ST_TILE + 10; k += 64) {
+                    const int gp = t0 - 5 + k;
+                    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+                    if (gp >= 0 && gp < n) va = slot_pts[seg_xlate(seg, gp, sh)];
+                    if (gp + 1 >= 0 && gp + 1 < n) {
+                        int s2 = sh;
+                        vb = slot_pts[seg_xlate(seg, gp + 1, s2)];
+                    }
+                    s_pt[k] = va;
+                    if (k < ST_TILE + 9) s_sq[k] = seg_sq(va, vb);
+                }
             }
         }
         WAVE_SYNC();
@@ -1291,7 +1880,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                     int first = 0;
                     if (lane == (int)__ffsll((long long)bm) - 1) first = atomicAdd(&P.brk_cnt[b], __popcll(bm));
                     first = __builtin_amdgcn_readlane(first, (int)__ffsll((long long)bm) - 1);  // (wave-uniform source lane)
-                    if (brk) P.brk_queue[(size_t)b * P.NT + first + lower_count(bm)] = (unsigned)(start + iq);
+                    if (brk) P.brk_queue[(size_t)b * P.NT + first + lower_count(bm)] = ((unsigned)line << 24) | (unsigned)iq;
                 }
                 // ... and to its redo queue
                 const unsigned long long rm = __ballot(redo);
@@ -1299,7 +1888,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                     int first = 0;
                     if (lane == (int)__ffsll((long long)rm) - 1) first = atomicAdd(&P.redo_cnt[b], __popcll(rm));
                     first = __builtin_amdgcn_readlane(first, (int)__ffsll((long long)rm) - 1);
-                    if (redo) P.redo_queue[(size_t)b * P.NT + first + lower_count(rm)] = (unsigned)(start + iq);
+                    if (redo) P.redo_queue[(size_t)b * P.NT + first + lower_count(rm)] = ((unsigned)line << 24) | (unsigned)iq;
                 }
             }
         } else {  // the rounds ran in launch 1: the flatness bits come back with the attribute words
@@ -1416,7 +2005,7 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
                 bool decided;
                 const bool c150 = c150_point<true>(WinTile{s_pt + tp, s_sq + tp}, decided);
                 if (!decided)  // (about one point in a thousand) the whole point again, with the full decision chain
-                    P.redo_queue[(size_t)b * P.NT + atomicAdd(&P.redo_cnt[b], 1)] = (unsigned)(start + t0 + tp);
+                    P.redo_queue[(size_t)b * P.NT + atomicAdd(&P.redo_cnt[b], 1)] = ((unsigned)line << 24) | (unsigned)(t0 + tp);
                 else if (c150)
                     s_attr[tp] = (unsigned short)(s_attr[tp] | A_C150);
             }
@@ -1439,11 +2028,15 @@ __global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {
     const int b = blockIdx.y + P.first;
     const int cnt = P.redo_cnt[b];
     for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
-        const unsigned pos_in_slot = P.redo_queue[(size_t)b * P.NT + e];
-        const size_t pos = (size_t)b * P.NT + pos_in_slot;
+        const unsigned entry = P.redo_queue[(size_t)b * P.NT + e];  // (line, index inside the line): an inner point, 5 <= i < n - 5
+        const int line = (int)(entry >> 24), i = (int)(entry & 0xffffffu);
+        const size_t pos = (size_t)b * P.NT + P.line_start[(size_t)b * P.L + line] + i;  // line order
+        const float4* slot_pts = P.ln_pts + (size_t)b * P.NT;
         float4 q[11];
+        int qp[11];
+        seg_point_window<5>(P, b, line, i, qp);
 #pragma unroll
-        for (int k = 0; k < 11; ++k) q[k] = P.ln_pts[pos + k - 5];
+        for (int k = 0; k < 11; ++k) q[k] = slot_pts[qp[k]];
         unsigned attr = 0;
         float curv = 0.f, refl = 0.f;
         bool brk = false;
@@ -1451,7 +2044,7 @@ __global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {
         P.ln_curv[pos] = curv;
         P.ln_refl[pos] = refl;
         P.ln_attr[pos] = (uint16_t)(attr | (P.ln_attr[pos] & A_VIS));  // (the walk's bit is k_stencil's)
-        if (brk) P.brk_queue[(size_t)b * P.NT + atomicAdd(&P.brk_cnt[b], 1)] = pos_in_slot;
+        if (brk) P.brk_queue[(size_t)b * P.NT + atomicAdd(&P.brk_cnt[b], 1)] = entry;
     }
 }
 
@@ -1462,11 +2055,15 @@ __global__ __launch_bounds__(256) void k_stencil_break(FeatParams P) {
     const int cnt = P.brk_cnt[b];
     const float thBreakCornerDis = 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
-        const size_t pos = (size_t)b * P.NT + P.brk_queue[(size_t)b * P.NT + e];
-        const float4* pt = P.ln_pts + pos;
+        const unsigned entry = P.brk_queue[(size_t)b * P.NT + e];
+        const int line = (int)(entry >> 24), i = (int)(entry & 0xffffffu);
+        const size_t pos = (size_t)b * P.NT + P.line_start[(size_t)b * P.L + line] + i;  // line order
+        const float4* slot_pts = P.ln_pts + (size_t)b * P.NT;
         float4 q[7];
+        int qp[7];
+        seg_point_window<3>(P, b, line, i, qp);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) q[k] = pt[k - 3];
+        for (int k = 0; k < 7; ++k) q[k] = slot_pts[qp[k]];
 #define PT(o) q[3 + (o)]
         unsigned f5 = 0;
         {
@@ -1672,7 +2269,7 @@ __device__ __forceinline__ void p2_acc(const uint2 o, unsigned me, unsigned mk, 
 // global load removed from a phase removes a full HBM round trip from the critical path of the workgroup.
 // K == 0: any length, per-point state in a global scratch, attributes re-read where needed.
 template <int K, typename WP>
-__device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, size_t base, WP W, WP R, int* s_sp,
+__device__ __forceinline__ void select_body(const FeatParams& P, int b, int line, int n, size_t base, WP W, WP R, int* s_sp,
                                             unsigned long long (*s_pm)[3], unsigned long long* s_minE,
                                             unsigned long long* s_minG, unsigned char* s_bfirst,
                                             unsigned char* s_list, int* s_cnt, int* s_flag, unsigned short* s_walk) {
@@ -1682,7 +2279,9 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     const uint16_t* attr = P.ln_attr + base;
     const float* curv = P.ln_curv + base;
     const float* refl = P.ln_refl + base;
-    const int2* gidx = P.ln_meta + base;
+    // (fused indices and labels live at the points' STORAGE positions: translated through the line's segment table)
+    const int2* gidx = P.ln_meta + (size_t)b * P.NT;
+    const SegTab seg = seg_tab(P, b, line);
     unsigned r_attr[KK];
     int r_gidx[KK];
     (void)r_attr;
@@ -1719,7 +2318,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
             r_attr[k] = attr[i];
             r_curv[k] = curv[i];
             r_refl[k] = refl[i];
-            r_gidx[k] = gidx[i].x;
+            r_gidx[k] = gidx[seg_xlate(seg, i)].x;
         }
     }
     if (n >= 11) T = (at_last & A_W2) ? 2 : 3;
@@ -2161,7 +2760,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
     // (phase 4, the stride walk of :543-650, is resolved by k_stencil: attribute bit A_VIS)
     SEL_MARK(10);
     // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
-    uint8_t* lnlab = P.ln_label + base;
+    uint8_t* lnlab = P.ln_label + (size_t)b * P.NT;
     FOR_POINTS(
         const unsigned me = W[2 * i + 1];
         const unsigned at = ATTR(i, k);
@@ -2194,14 +2793,14 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int n, s
         if (inner && !(at & A_NEAR)) {
             const int lab = (f == 2) ? 2 : ((f == 100 || f == 150) ? 1 : 0);
             if (lab) {
-                const int gi = CACHED ? r_gidx[k] : gidx[i].x;
+                const int gi = CACHED ? r_gidx[k] : gidx[seg_xlate(seg, i)].x;
                 if (gi >= 0)
                     labv = lab;
                 else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940 and part of the
                     labv = lab | 0x80;  // surf cloud the GICP refresh aligns (:296-312); k_crop counts these, nobody lists them
             }
         }
-        lnlab[i] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
+        lnlab[seg_xlate(seg, i)] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
     )
     SEL_MARK(11);
 #undef FOR_POINTS
@@ -2246,12 +2845,12 @@ __global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P, int list_
         if (n <= cap) {
             unsigned* W = reinterpret_cast<unsigned*>(smem) + 8;  // 4 pad records in front, 4 behind
             unsigned* R = reinterpret_cast<unsigned*>(smem) + 2 * (size_t)(cap + 8);
-            select_body<K>(P, b, n, base, W, R, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+            select_body<K>(P, b, line, n, base, W, R, s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
         } else {
             // global scratch: four 4-byte slots per bucketed point (W pairs | window tables)
             // (+8 * line + 8 words: room for the pad records of every line in front of this one)
             unsigned* W = P.sel_scratch + 2 * base + 16 * ((size_t)b * (P.L + 2) + line + 1);
-            select_body<0>(P, b, n, base, W, static_cast<unsigned*>(nullptr), s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
+            select_body<0>(P, b, line, n, base, W, static_cast<unsigned*>(nullptr), s_sp, s_pm, s_minE, s_minG, s_bfirst, s_list, &s_cnt, s_flag, s_walk);
         }
         if (list_kind < 0) break;
     }
@@ -2320,14 +2919,15 @@ __device__ __forceinline__ M m_bits(int nbits) {
 }
 // M = 64-bit masks: partitions of up to 64 points (lines of 161 .. 3211 points: the rings); M = 128-bit masks: up to 128 points
 // (.. 6411: the Livox lines).  WAVES = lines (wavefronts) per workgroup, MAXWIN = 64-point windows of the longest line + 2.
+// (the narrow form needs 81 vector registers left alone -- one more than six wavefronts per SIMD allow: it is asked to fit them)
 template <typename M, int WAVES, int MAXWIN>
-__global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_lines_launch) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(M) > 8 ? 3 : 6))) void k_select_part(FeatParams P, int n_lines_launch) {
     constexpr int MBITS = (int)(8 * sizeof(M));
     constexpr bool WIDE = MBITS > 64;
     __shared__ u64m s_plane_all[WAVES][PL_COUNT][MAXWIN];
     const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y + P.first;
-    const int line = P.line0 + blockIdx.x * WAVES + wave_id;
+    const int line = __builtin_amdgcn_readfirstlane((int)(P.line0 + blockIdx.x * WAVES + wave_id));  // (a scalar: see k_stencil)
     if ((int)(blockIdx.x * WAVES + wave_id) >= n_lines_launch) return;
     const int n = P.line_len[(size_t)b * P.L + line];
     const int range = n - 11;
@@ -2655,17 +3255,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
     SP_SYNC();
     SP_MARK(6);
     // ---- phase C: flags and labels, one point per lane -----------------------------------------------------------------
-    uint8_t* lnlab = P.ln_label + base;
-    const int2* gidx = P.ln_meta + base;
+    // (labels and fused indices live at the points' STORAGE positions: translated through the line's segment table)
+    uint8_t* lnlab = P.ln_label + (size_t)b * P.NT;
+    const int2* gidx = P.ln_meta + (size_t)b * P.NT;
+    const SegTab seg = seg_tab(P, b, line);
+    const int4* seg_rec = seg_uniform_ptr(P.seg_rw + (size_t)b * P.seg_rstride + seg_rec_base(P, b, line));  // aligned windows (k_seg_records)
+    int sh = 0;
     for (int w4 = 0; w4 < nwin; w4 += 8) {
         unsigned at4[8];
-        int gi4[8];
+        int gi4[8], ps4[8];
+        seg_v4i rr[8];  // (one scalar request per window: boundary, offsets on either side, regular?)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rr[u] = seg_sload(seg_rec, min(w4 + u, nwin - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) at4[u] = attr[min(64 * (w4 + u) + lane, n - 1)];
+        SEG_SWAIT8(rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], rr[6], rr[7]);
+        bool all_ok = true;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = min(64 * (w4 + u) + lane, n - 1);
-            at4[u] = attr[i];
-            gi4[u] = gidx[i].x;
+            ps4[u] = i + (i < rr[u].x ? rr[u].y : rr[u].z);
+            all_ok = all_ok && rr[u].w != 0;
         }
+        if (!all_ok) {  // (wave-uniform) a sparse line: through the segment table
+#pragma unroll 1
+            for (int u = 0; u < 8; ++u) {
+                const int p = seg_xlate(seg, min(64 * (w4 + u) + lane, n - 1), sh);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q == u) ps4[q] = p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gi4[u] = gidx[ps4[u]].x;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int w = w4 + u, i = 64 * w + lane;
@@ -2693,7 +3315,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_select_part(FeatParams P, int n_
                         labv = lab | 0x80;
                 }
             }
-            lnlab[i] = (uint8_t)labv;
+            lnlab[ps4[u]] = (uint8_t)labv;
         }
     }
     SP_MARK(7);
@@ -2890,6 +3512,11 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
     if (t < P.L) {
         P.line_start[t] = (t < P.n_rings) ? (t == 0 ? 0 : n) : P.NV;
         P.line_len[t] = (t == 0) ? n : 0;
+        // one storage segment: the line is stored where its line-order index says
+        P.seg_n[t] = 1;
+        P.seg_cum[(size_t)t * (MML_SEG_MAX + 1)] = 0;
+        P.seg_cum[(size_t)t * (MML_SEG_MAX + 1) + 1] = (t == 0) ? n : 0;
+        P.seg_pos[(size_t)t * MML_SEG_MAX] = P.line_start[t];
     }
     if (t < n) {
         P.ln_meta[t] = make_int2(t, 0);
@@ -2960,6 +3587,16 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.sel_list_cnt = ctx->sel_list_cnt;
     P.st_exit = ctx->st_exit;
     P.st_stride = ctx->NT / 256 + ctx->L + 8;
+    P.seg_cum = ctx->seg_cum;
+    P.seg_pos = ctx->seg_pos;
+    P.seg_n = ctx->seg_n;
+    P.seg_flat = ctx->seg_flat;
+    P.seg_flat_n = ctx->seg_flat_n;
+    P.op_agg = ctx->op_agg;
+    P.op_epoch = 0;
+    P.seg_rs = ctx->seg_rs;
+    P.seg_rw = ctx->seg_rw;
+    P.seg_rstride = ctx->seg_rstride;
     return P;
 }
 
@@ -2969,6 +3606,27 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     FeatParams P = make_params(ctx, first);
     P.extr = have_extrinsic ? ctx->d_extr : nullptr;
     hipStream_t s = MML_STREAM(ctx);
+    if (ctx->onepass) {
+        // one pass over the raw scan: 4096-point blocks that keep their points in registers between counting and storing
+        ctx->op_epoch = (ctx->op_epoch + 1) & 0x1ffffffu;
+        if (ctx->op_epoch == 0) ctx->op_epoch = 1;  // (0 is what freshly allocated aggregate words hold)
+        P.op_epoch = ctx->op_epoch;
+        const int nbv = (ctx->NV + MML_OP_BLK - 1) / MML_OP_BLK, nbl = (ctx->NL + MML_OP_BLK - 1) / MML_OP_BLK;
+        {
+            MmlStageScope t(ctx, "assign_ends");
+            hipLaunchKernelGGL(k_assign_ends, dim3(count), dim3(64), 0, s, P, count);
+        }
+        {
+            MmlStageScope t(ctx, "assign_onepass");
+            if (nbv > 0) hipLaunchKernelGGL(k_assign_onepass<0>, dim3(nbv, count), dim3(OP_THREADS), 0, s, P);
+            if (nbl > 0) hipLaunchKernelGGL(k_assign_onepass<1>, dim3(nbl, count), dim3(OP_THREADS), 0, s, P);
+        }
+        {
+            MmlStageScope t(ctx, "assign_tables");
+            hipLaunchKernelGGL(k_assign_tables, dim3(count), dim3(64), 0, s, P, count);
+            hipLaunchKernelGGL(k_seg_records, dim3((ctx->seg_rstride + 255) / 256, count), dim3(256), 0, s, P, count);
+        }
+    } else {
     {
         MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
@@ -2977,6 +3635,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     {
         MmlStageScope t(ctx, "assign_scan");
         hipLaunchKernelGGL(k_assign_b, dim3(count, 2), dim3(ASB_THREADS), sizeof(int) * 64 * (size_t)P.asb_stride, s, P);
+        hipLaunchKernelGGL(k_seg_records, dim3((ctx->seg_rstride + 255) / 256, count), dim3(256), 0, s, P, count);
     }
     {
         MmlStageScope t(ctx, "assign_scatter");
@@ -2991,6 +3650,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         } else {
             hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
         }
+    }
     }
     {
         MmlStageScope t(ctx, "stencil");
@@ -3096,6 +3756,15 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
     return MML_OK;
 }
 
+// ring / line id of every raw point of one slot into raw_line[] (pass A of the three-pass bucketing on that slot; its block
+// histograms land in blk_cnt, which nobody reads afterwards)
+int mml_launch_raw_lines(mml_ctx* ctx, int slot) {
+    FeatParams P = make_params(ctx, slot);
+    hipLaunchKernelGGL(k_assign_a, dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+    MML_HIP(hipGetLastError());
+    return MML_OK;
+}
+
 // mml_detect_line back end: pts already copied to ln_pts[0..n) of slot 0; results in ln_label[0..n) and ln_final.
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     FeatParams P = make_params(ctx, 0);
@@ -3103,6 +3772,7 @@ int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final) {
     hipStream_t s = MML_STREAM(ctx);
     const int t = (n > ctx->L ? n : ctx->L);
     hipLaunchKernelGGL(k_setup_single_line, dim3((t + 255) / 256), dim3(256), 0, s, P, n);
+    hipLaunchKernelGGL(k_seg_records, dim3((ctx->seg_rstride + 255) / 256, 1), dim3(256), 0, s, P, 1);
     MML_HIP(hipMemsetAsync(ctx->brk_cnt, 0, sizeof(int), s));
     MML_HIP(hipMemsetAsync(ctx->brk_cnt + ctx->B, 0, sizeof(int), s));
     if (n > 0) {
@@ -3128,6 +3798,15 @@ int mml_feature_init(mml_ctx* ctx) {
     {
         const char* e = getenv("MML_SELECT_PART");  // measurement switch: 0 = every line through k_select
         ctx->select_part = !(e && atoi(e) == 0);
+    }
+    {
+        // one-pass bucketing: ring layouts whose block tables fit (lines as lanes of one wavefront, <= 16 blocks per sensor);
+        // dense layouts (128 rings, 262 k points) keep the three staged passes.  MML_ASSIGN_ONEPASS=0: measurement switch
+        const char* e = getenv("MML_ASSIGN_ONEPASS");
+        const int nbv = (ctx->NV + MML_OP_BLK - 1) / MML_OP_BLK, nbl = (ctx->NL + MML_OP_BLK - 1) / MML_OP_BLK;
+        ctx->onepass = !(e && atoi(e) == 0) && ctx->cfg.n_rings >= 1 && ctx->cfg.n_rings <= OP_MAXKEYS && ctx->cfg.n_livox_lines <= OP_MAXKEYS &&
+                       ctx->L <= 64 && nbv <= MML_SEG_MAX && nbl <= MML_SEG_MAX && nbv * ctx->cfg.n_rings <= MML_SEG_FLAT &&
+                       nbl * ctx->cfg.n_livox_lines <= MML_SEG_FLAT;
     }
     // LDS budget of k_select: twice the nominal ring length / the nominal Livox line length + 2 %, rounded up to a
     // whole number of points per thread (the default 16 x 1800 + 6 x 4000 layout gets 4096 points = 51.6 KB, three

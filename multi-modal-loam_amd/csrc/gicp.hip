@@ -655,8 +655,8 @@ __global__ void k_gicp_init(GicpState* st) {
 // its labelled points beyond far_th carry bit 7 in their label byte.  One wavefront per sensor walks the raw line ids in
 // order and rebuilds every point's bucketed position (line start + rank among the earlier points of its line), which is
 // where its label and its coordinates live.  Not a hot path: one slot, once per refresh.
-__global__ __launch_bounds__(64) void k_gicp_gather_raw(const uint8_t* raw_line, const int* n_in, const int* line_start, const uint8_t* label,
-                                                       const float4* ln_pts, int NV, int n_rings, float4* velo, float4* livox, int* counts) {
+__global__ __launch_bounds__(64) void k_gicp_gather_raw(const uint8_t* raw_line, const int* n_in, const int* seg_flat, const int* seg_flat_n, int blk_points,
+                                                       const uint8_t* label, const float4* ln_pts, int NV, float4* velo, float4* livox, int* counts) {
     __shared__ int s_run[256];
     const int sensor = blockIdx.x, lane = threadIdx.x;
     const int n = n_in[sensor], region = sensor == 0 ? 0 : NV;
@@ -665,7 +665,17 @@ __global__ __launch_bounds__(64) void k_gicp_gather_raw(const uint8_t* raw_line,
     float4* out = sensor == 0 ? velo : livox;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     int n_out = 0;
+    // storage: block-major (blocks of blk_points raw points; one block = the whole scan after the three-pass bucketing), line-bucketed
+    // inside a block, raw order inside a (block, line) segment -- segment (blk, key) starts at flat[blk * nkeys + key]
+    const int* flat = seg_flat + sensor * MML_SEG_FLAT;
+    const int nkeys = seg_flat_n[2 * sensor + 1];
     for (int i0 = 0; i0 < n; i0 += 64) {
+        if (i0 % blk_points == 0 && i0 > 0) {  // (blk_points is a multiple of 64: a wavefront round never straddles blocks)
+            __syncthreads();
+            for (int k = lane; k < 256; k += 64) s_run[k] = 0;
+            __syncthreads();
+        }
+        const int blk = i0 / blk_points;
         const int i = i0 + lane;
         const int key = i < n ? (int)raw_line[region + i] : 255;
         const bool valid = key < 254;
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(64) void k_gicp_gather_raw(const uint8_t* raw_line,
         bool take = false;
         int p = 0;
         if (valid) {
-            p = line_start[(sensor == 0 ? 0 : n_rings) + key] + pos;
+            p = flat[blk * nkeys + key] + pos;
             const unsigned l = label[p];
             take = (l & 3u) == 2u && l < (sensor == 0 ? 0x80u : 0x100u);
         }
@@ -812,9 +822,14 @@ extern "C" int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, 
     int cnt[2] = {0, 0};
     {
         const size_t o = (size_t)slot * ctx->NT;
+        // (the one-pass bucketing keeps no per-point line ids: they are recomputed for this one slot)
+        if (ctx->onepass) {
+            rc = mml_launch_raw_lines(ctx, slot);
+            if (rc != MML_OK) return rc;
+        }
         hipLaunchKernelGGL(k_gicp_gather_raw, dim3(2), dim3(64), 0, s, ctx->raw_line + o, ctx->d_n_in + 2 * (size_t)slot,
-                           ctx->line_start + (size_t)slot * ctx->L, ctx->ln_label + o, ctx->ln_pts + o, ctx->NV, ctx->cfg.n_rings, S.tgt, S.src,
-                           S.counts);
+                           ctx->seg_flat + (size_t)slot * 2 * MML_SEG_FLAT, ctx->seg_flat_n + (size_t)slot * 4,
+                           ctx->onepass ? MML_OP_BLK : (1 << 30), ctx->ln_label + o, ctx->ln_pts + o, ctx->NV, S.tgt, S.src, S.counts);
         MML_HIP(hipMemcpyAsync(cnt, S.counts, sizeof(cnt), hipMemcpyDeviceToHost, s));
         MML_HIP(hipStreamSynchronize(s));
     }

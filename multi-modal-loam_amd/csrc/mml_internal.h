@@ -23,6 +23,11 @@ __device__ __forceinline__ double sconst(double v) {
     return v;
 }
 }  // namespace mml_und
+// One-pass bucketing (feature.hip k_assign_onepass): a scan line is stored as up to MML_SEG_MAX segments, one per MML_OP_BLK-point
+// block of the raw scan; MML_SEG_FLAT bounds (blocks x lines) of one sensor.
+#define MML_SEG_MAX 16
+#define MML_OP_BLK 4096
+#define MML_SEG_FLAT 512
 #define MML_VOXEL_LDS_CAP 8192  // labelled points per (slot, kind) that k_voxel sorts in LDS; more go the global-sort way
 
 // ---- factor records kept on the device (SoA would save little: every field is read once per GN pass) ----
@@ -118,8 +123,24 @@ struct mml_ctx {
     float4* ln_pts = nullptr;   // B * NT
     int2* ln_meta = nullptr;    // B * NT  (.x fused index of the point: >= 0 kept, -1 dropped, -2 Livox beyond far_th;
                                 //           .y bits of its in-sweep time, normal_x) -- one 8-byte record, one scattered store
-    int* line_start = nullptr;  // B * L
+    int* line_start = nullptr;  // B * L   start of the line in LINE ORDER (the index space of ln_curv / ln_refl / ln_attr)
     int* line_len = nullptr;    // B * L
+    // where the points of a line are STORED (ln_pts / ln_meta / ln_label): segment s of a line covers its line indices
+    // [seg_cum[s], seg_cum[s + 1]) at storage positions seg_pos[s] ...  (three-pass bucketing: one segment, = line_start)
+    int* seg_cum = nullptr;     // B * L * (MML_SEG_MAX + 1)
+    int* seg_pos = nullptr;     // B * L * MML_SEG_MAX
+    int* seg_n = nullptr;       // B * L
+    int* seg_flat = nullptr;    // B * 2 * MML_SEG_FLAT: the segment starts of a sensor's region in storage order (block-major)
+    int* seg_flat_n = nullptr;  // B * 2 * 2: entries | lines per block
+    // per 64 line indices the one segment boundary they may cross and the storage offsets on either side (k_seg_records):
+    // seg_rs for the rounds of k_stencil's tiles (indices 64 r - 5 ...), seg_rw for aligned windows (64 w ...); record
+    // (line, r) sits at  slot * seg_rstride + (line_start[line] >> 6) + 6 * line + r
+    int4* seg_rs = nullptr;
+    int4* seg_rw = nullptr;
+    int seg_rstride = 0;
+    unsigned long long* op_agg = nullptr;  // B * 2 * MML_SEG_MAX: block aggregates of the one-pass bucketing (epoch-tagged)
+    unsigned op_epoch = 0;
+    bool onepass = false;       // the ring layout takes the one-pass bucketing
     float* ln_curv = nullptr;
     float* ln_refl = nullptr;
     uint16_t* ln_attr = nullptr;
@@ -303,6 +324,7 @@ int mml_window_solve_continue(mml_ctx* ctx, int first, int count, int window, co
 int mml_feature_init(mml_ctx* ctx);
 void mml_fullwindow_dev_release(mml_ctx* ctx);
 int mml_launch_detect_line(mml_ctx* ctx, int n, uint16_t* d_final);
+int mml_launch_raw_lines(mml_ctx* ctx, int slot);  // raw_line[] of one slot (ring / line id per raw point), for the GICP refresh
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan,
                          double huber, double* d_record, int frames = 1);
 
