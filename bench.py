@@ -54,6 +54,11 @@ STAGE_BYTES = {
     "assign_count":     lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l,  # k_assign_a: read the raw records, ring id / crop test
     "assign_scan":      lambda n_v, n_l, nf, it: 0,                    # k_assign_b: block records only
     "assign_scatter":   lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l + 20 * (n_v + n_l),  # k_assign_c: read again, write xyzi + label slot
+    # one-pass bucketing (ring layouts up to 32 rings): every raw record read once, the bucketed point (16 B) and its (fused index,
+    # in-sweep time) record (8 B) written once
+    "assign_ends":      lambda n_v, n_l, nf, it: 0,
+    "assign_onepass":   lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l + 24 * (n_v + n_l),
+    "assign_tables":    lambda n_v, n_l, nf, it: 0,
     "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),     # read xyzi of every bucketed point
     "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),     # attr 2 B + 2 order keys 8 B + label 1 B
     "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),      # write the 4 B label/line/time record

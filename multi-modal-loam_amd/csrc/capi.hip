@@ -75,7 +75,7 @@ void mml_destroy(mml_ctx* ctx) {
     mml_comm_destroy(ctx);
     mml_fullwindow_dev_release(ctx);
     void* ptrs[] = {ctx->wstate, ctx->wrec, ctx->waux, ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
-                    ctx->ln_meta,  ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
+                    ctx->ln_gidx, ctx->ln_rel, ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
                     ctx->cb_n,     ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
@@ -167,7 +167,8 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->raw_line, B * NT);
     ALLOC(ctx->raw_ori, B * NV);
     ALLOC(ctx->ln_pts, B * NT);
-    ALLOC(ctx->ln_meta, B * NT);
+    ALLOC(ctx->ln_gidx, B * NT);
+    ALLOC(ctx->ln_rel, B * NT);
     ALLOC(ctx->slot_flags, B * 2);
     ALLOC(ctx->line_start, B * L);
     ALLOC(ctx->line_len, B * L);
@@ -387,7 +388,8 @@ __global__ void k_decode_custompoints(const uint8_t* raw, int n, mml_livox_point
 // part of an extracted cloud carries intensity 0 (unionFeatureExtract.cpp:1254-1256); an uploaded cloud keeps its own.
 struct FusedView {
     const float4* pts;
-    const int2* meta;
+    const int* gidx;
+    const int* rel;
     const uint8_t* line;      // uploaded clouds
     const uint8_t* label;
     const int* cb_n;          // this slot's two valid counts
@@ -398,11 +400,10 @@ struct FusedView {
 __device__ __forceinline__ bool fused_at(const FusedView& V, int pos, int& g, float4& p, float& rel, int& line) {
     if (pos >= V.NT) return false;
     if (pos < V.NV ? pos >= V.cb_n[0] : pos - V.NV >= V.cb_n[1]) return false;
-    const int2 m = V.meta[pos];
-    g = m.x;
+    g = V.gidx[pos];
     if (g < 0) return false;
     p = V.pts[pos];
-    rel = (V.flags & 2) ? 1.0f : __int_as_float(m.y);  // RemoveLidarDistortion leaves normal_x = 1 (unionPoseEstimation.cpp:419)
+    rel = (V.flags & 2) ? 1.0f : __int_as_float(V.rel[pos]);  // RemoveLidarDistortion leaves normal_x = 1 (unionPoseEstimation.cpp:419)
     if (V.flags & 1) {
         line = V.line[pos];
     } else {
@@ -538,7 +539,8 @@ int fused_view(mml_ctx* ctx, int slot, FusedView& V) {
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
     const size_t off = (size_t)slot * ctx->NT;
     V.pts = ctx->ln_pts + off;
-    V.meta = ctx->ln_meta + off;
+    V.gidx = ctx->ln_gidx + off;
+    V.rel = ctx->ln_rel + off;
     V.line = ctx->ln_line + off;
     V.label = ctx->ln_label + off;
     V.cb_n = ctx->cb_n + 2 * (size_t)slot;

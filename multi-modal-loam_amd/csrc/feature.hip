@@ -54,7 +54,8 @@ struct FeatParams {
     float* raw_ori;
     int sensor_base;     // pass C launched per sensor: blockIdx.z + sensor_base
     float4* ln_pts;
-    int2* ln_meta;       // (fused index, bits of the in-sweep time) of the bucketed point
+    int* ln_gidx;        // fused index of the bucketed point (>= 0 kept, -1 dropped, -2 Livox beyond far_th)
+    int* ln_rel;         // bits of its in-sweep time
     int* line_start;
     int* line_len;
     float* ln_curv;
@@ -101,7 +102,7 @@ struct FeatParams {
 };
 
 // ---- line index -> storage position ---------------------------------------------------------------------------------------
-// ln_curv / ln_refl / ln_attr are indexed in LINE ORDER (line_start[line] + i); the points themselves (ln_pts, ln_meta,
+// ln_curv / ln_refl / ln_attr are indexed in LINE ORDER (line_start[line] + i); the points themselves (ln_pts, ln_gidx, ln_rel,
 // ln_label) sit where the bucketing put them: with the three-pass bucketing a line is one contiguous run, with the one-pass
 // bucketing it is a run per 4096-point block of the raw scan.  Segment s of a line holds its indices [cum[s], cum[s + 1]).
 struct SegTab {
@@ -693,7 +694,8 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c_direct(FeatParams P) {
     // its label still counts towards livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The
     // label byte is written by k_select for every point of a line, the line id follows from the line table: two
     // scattered stores per point in all (the pass is bound by their number, not by their bytes).
-    P.ln_meta[g] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
+    P.ln_gidx[g] = keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1);
+    P.ln_rel[g] = __float_as_int(rel);
 }
 
 // Pass C for sensors with many lines (> 32): CB_SUB pass-A blocks per workgroup, the records staged in LDS in (line, rank)
@@ -838,7 +840,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
     if (tid < s_kstart[nkeys]) {
         const size_t g = (size_t)b * P.NT + s_dst[tid];
         P.ln_pts[g] = s_pt[tid];
-        P.ln_meta[g] = s_meta[tid];
+        P.ln_gidx[g] = s_meta[tid].x;
+        P.ln_rel[g] = s_meta[tid].y;
     }
 }
 
@@ -935,6 +938,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
     __shared__ int s_hist[OP_MAXKEYS + 2], s_koff[OP_MAXKEYS];
     __shared__ int s_cond[OP_WAVES];
     __shared__ int s_base[3];
+    __shared__ int s_out[2][MML_OP_BLK];  // fused index | in-sweep time of the block's points in storage order
     const int b = blockIdx.y + P.first, blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n_in[2 * b + SENSOR];
@@ -1143,8 +1147,23 @@ __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
         const size_t gpos = (size_t)b * P.NT + dst;
         P.ln_pts[gpos] = pt[r];
         const bool keep = (f & OPI_KEEP) != 0;
-        P.ln_meta[gpos] = make_int2(keep ? fdst : ((SENSOR == 1 && (f & OPI_NEAR)) ? -2 : -1), __float_as_int(rel));
+        // the two 4-byte records of the point go through LDS, in the order the block's region is laid out, and leave it as whole
+        // rows below: as scattered 4-byte stores they were what the pass waited for (0.61 -> 0.71 ms when the 8-byte record of
+        // round 3 became two arrays)
+        const int q = dst - base_valid;
+        s_out[0][q] = keep ? fdst : ((SENSOR == 1 && (f & OPI_NEAR)) ? -2 : -1);
+        s_out[1][q] = __float_as_int(rel);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    {
+        const int tv = s_hist[nkeys];
+        int* og = P.ln_gidx + (size_t)b * P.NT + base_valid;
+        int* orl = P.ln_rel + (size_t)b * P.NT + base_valid;
+        for (int k = tid; k < tv; k += OP_THREADS) {
+            og[k] = s_out[0][k];
+            orl[k] = s_out[1][k];
+        }
     }
 }
 
@@ -2280,7 +2299,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
     const float* curv = P.ln_curv + base;
     const float* refl = P.ln_refl + base;
     // (fused indices and labels live at the points' STORAGE positions: translated through the line's segment table)
-    const int2* gidx = P.ln_meta + (size_t)b * P.NT;
+    const int* gidx = P.ln_gidx + (size_t)b * P.NT;
     const SegTab seg = seg_tab(P, b, line);
     unsigned r_attr[KK];
     int r_gidx[KK];
@@ -2318,7 +2337,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
             r_attr[k] = attr[i];
             r_curv[k] = curv[i];
             r_refl[k] = refl[i];
-            r_gidx[k] = gidx[seg_xlate(seg, i)].x;
+            r_gidx[k] = gidx[seg_xlate(seg, i)];
         }
     }
     if (n >= 11) T = (at_last & A_W2) ? 2 : 3;
@@ -2793,7 +2812,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
         if (inner && !(at & A_NEAR)) {
             const int lab = (f == 2) ? 2 : ((f == 100 || f == 150) ? 1 : 0);
             if (lab) {
-                const int gi = CACHED ? r_gidx[k] : gidx[seg_xlate(seg, i)].x;
+                const int gi = CACHED ? r_gidx[k] : gidx[seg_xlate(seg, i)];
                 if (gi >= 0)
                     labv = lab;
                 else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940 and part of the
@@ -3257,7 +3276,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     // ---- phase C: flags and labels, one point per lane -----------------------------------------------------------------
     // (labels and fused indices live at the points' STORAGE positions: translated through the line's segment table)
     uint8_t* lnlab = P.ln_label + (size_t)b * P.NT;
-    const int2* gidx = P.ln_meta + (size_t)b * P.NT;
+    const int* gidx = P.ln_gidx + (size_t)b * P.NT;
     const SegTab seg = seg_tab(P, b, line);
     const int4* seg_rec = seg_uniform_ptr(P.seg_rw + (size_t)b * P.seg_rstride + seg_rec_base(P, b, line));  // aligned windows (k_seg_records)
     int sh = 0;
@@ -3287,7 +3306,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gi4[u] = gidx[ps4[u]].x;
+        for (int u = 0; u < 8; ++u) gi4[u] = gidx[ps4[u]];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int w = w4 + u, i = 64 * w + lane;
@@ -3519,7 +3538,8 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
         P.seg_pos[(size_t)t * MML_SEG_MAX] = P.line_start[t];
     }
     if (t < n) {
-        P.ln_meta[t] = make_int2(t, 0);
+        P.ln_gidx[t] = t;
+        P.ln_rel[t] = 0;
     }
     if (t == 0) {
         P.cb_n[0] = n;
@@ -3547,7 +3567,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.raw_line = ctx->raw_line;
     P.raw_ori = ctx->raw_ori;
     P.ln_pts = ctx->ln_pts;
-    P.ln_meta = ctx->ln_meta;
+    P.ln_gidx = ctx->ln_gidx;
+    P.ln_rel = ctx->ln_rel;
     P.line_start = ctx->line_start;
     P.line_len = ctx->line_len;
     P.ln_curv = ctx->ln_curv;
@@ -3735,7 +3756,8 @@ __global__ void k_decode_xyzinormal(const float* raw, int n, int n_velo, int slo
     // fused index i -> storage position: the Velodyne part from 0, the Livox part from NV
     const size_t o = (size_t)slot * P.NT + (i < n_velo ? i : P.NV + (i - n_velo));
     P.ln_pts[o] = make_float4(r[0], r[1], r[2], r[8]);
-    P.ln_meta[o] = make_int2(i, __float_as_int(r[4]));
+    P.ln_gidx[o] = i;
+    P.ln_rel[o] = __float_as_int(r[4]);
     const float ln = r[5], nz = r[6];
     P.ln_line[o] = (uint8_t)(ln >= 0.f && ln < 255.f ? (int)ln : 255);
     // std::abs(normal_z - 1.0) < 1e-5 etc. are evaluated in double on the float field

@@ -227,7 +227,7 @@ struct SegParams {
     float leaf_corner, leaf_surf;
     const int* fu_info;
     const float4* ln_pts;
-    const int2* ln_meta;
+    const int* ln_gidx;
     const unsigned* lists;
     int* seg_off;     // 2 * count + 1
     int* seg_bbox;    // 2 * count x 6 order-preserving int keys
@@ -266,11 +266,11 @@ __global__ void k_seg_gather_bbox(SegParams P) {
     const int n = P.fu_info[8 * b + 6 + kind], off = P.seg_off[g];
     const unsigned* list = P.lists + ((size_t)b * 2 + kind) * P.list_stride;
     const float4* px = P.ln_pts + (size_t)b * P.NT;
-    const int2* gx = P.ln_meta + (size_t)b * P.NT;
+    const int* gx = P.ln_gidx + (size_t)b * P.NT;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 p = px[list[i]];
-        p.w = __int_as_float(gx[list[i]].x);  // the fused index rides along: it orders the points of a voxel
+        p.w = __int_as_float(gx[list[i]]);  // the fused index rides along: it orders the points of a voxel
         P.cat[off + i] = p;
         mn[0] = fminf(mn[0], p.x);
         mn[1] = fminf(mn[1], p.y);
@@ -408,7 +408,7 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
     P.leaf_surf = ctx->cfg.leaf_surf;
     P.fu_info = ctx->fu_info;
     P.ln_pts = ctx->ln_pts;
-    P.ln_meta = ctx->ln_meta;
+    P.ln_gidx = ctx->ln_gidx;
     P.lists = reinterpret_cast<const unsigned*>(ctx->vx_keys);
     int* meta = ctx->seg_meta + (size_t)ctx->cur * (8 * (size_t)ctx->B * 2 + 16);
     P.seg_off = meta + 8;

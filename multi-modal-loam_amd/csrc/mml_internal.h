@@ -121,11 +121,12 @@ struct mml_ctx {
 
     // line-bucketed points
     float4* ln_pts = nullptr;   // B * NT
-    int2* ln_meta = nullptr;    // B * NT  (.x fused index of the point: >= 0 kept, -1 dropped, -2 Livox beyond far_th;
-                                //           .y bits of its in-sweep time, normal_x) -- one 8-byte record, one scattered store
+    int* ln_gidx = nullptr;     // B * NT  fused index of the point: >= 0 kept, -1 dropped, -2 Livox beyond far_th
+    int* ln_rel = nullptr;      // B * NT  bits of its in-sweep time, normal_x (two 4-byte arrays: the undistortion reads the time only, the
+                                //         label pass the index only; as one 8-byte record each of them fetched both)
     int* line_start = nullptr;  // B * L   start of the line in LINE ORDER (the index space of ln_curv / ln_refl / ln_attr)
     int* line_len = nullptr;    // B * L
-    // where the points of a line are STORED (ln_pts / ln_meta / ln_label): segment s of a line covers its line indices
+    // where the points of a line are STORED (ln_pts / ln_gidx / ln_rel / ln_label): segment s of a line covers its line indices
     // [seg_cum[s], seg_cum[s + 1]) at storage positions seg_pos[s] ...  (three-pass bucketing: one segment, = line_start)
     int* seg_cum = nullptr;     // B * L * (MML_SEG_MAX + 1)
     int* seg_pos = nullptr;     // B * L * MML_SEG_MAX

@@ -51,7 +51,7 @@ __global__ void k_undistort_prep(int count, const double* params, double* derive
 // "point.normal_x = 1" (:419) is a per-slot flag, not a store per point: k_undistort_prep raises bit 1 of slot_flags[2 b]
 // after saving its previous value in slot_flags[2 b + 1]; a slot that is undistorted again reads its time as 1.
 __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, const int* cb_n, float4* ln_pts,
-                                                  const int2* ln_meta, const int* slot_flags, const double* params,
+                                                  const int* ln_rel, const int* slot_flags, const double* params,
                                                   const double* derived) {
     const int b = blockIdx.y + first;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, co
     v4f* pp = reinterpret_cast<v4f*>(ln_pts + (size_t)b * NT + i);
     const v4f raw = __builtin_nontemporal_load(pp);
     float4 p = make_float4(raw.x, raw.y, raw.z, raw.w);
-    const float s = (slot_flags[2 * b + 1] & 2) ? 1.0f : __int_as_float(__builtin_nontemporal_load(&ln_meta[(size_t)b * NT + i].y));
+    const float s = (slot_flags[2 * b + 1] & 2) ? 1.0f : __int_as_float(__builtin_nontemporal_load(&ln_rel[(size_t)b * NT + i]));
     mml_und::undistort_point(dR, dR + 9, derived + 8 * blockIdx.y, s, p);
     v4f outv = {p.x, p.y, p.z, p.w};
     __builtin_nontemporal_store(outv, pp);
@@ -148,7 +148,7 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 // list -- their labelled clouds are no larger than a small scan's, only their indices are wider.
 template <int VX_THREADS>
 __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int NT, int MF, int B, int cap_y0, int cap_y1, int list_stride, const int* fu_info,
-                                                     const float4* ln_pts, const int2* ln_meta,
+                                                     const float4* ln_pts, const int* ln_gidx,
                                                      float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
                                                      int* ft_n, unsigned* seq_scratch) {
     constexpr int VX_WAVES = VX_THREADS / 64;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
     const int cap = blockIdx.y == 0 ? cap_y0 : cap_y1;  // labelled points this workgroup sorts at most
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* px = ln_pts + (size_t)b * NT;
-    const int2* gx = ln_meta + (size_t)b * NT;
+    const int* gx = ln_gidx + (size_t)b * NT;
     const float leaf = kind == 0 ? leaf_corner : leaf_surf;
     float4* out = (kind == 0 ? ft0 : ft1) + (size_t)b * MF;
     // the labelled points of this (slot, kind): their bucketed positions, listed by the crop pass
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
         const int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
-        if (wide) return ((unsigned long long)(unsigned)idx << 33) | ((unsigned long long)(unsigned)gx[pos].x << 13) | (unsigned)sidx;
-        return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos].x << 16) | pos;
+        if (wide) return ((unsigned long long)(unsigned)idx << 33) | ((unsigned long long)(unsigned)gx[pos] << 13) | (unsigned)sidx;
+        return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos] << 16) | pos;
     };
     // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
     if (cnt <= VX_THREADS) {
@@ -348,7 +348,7 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
     hipLaunchKernelGGL(k_undistort_prep, dim3((count + 63) / 64), dim3(64), 0, MML_STREAM(ctx), count, d_params, ctx->d_und + 8 * (size_t)first,
                        ctx->slot_flags + 2 * (size_t)first);
     hipLaunchKernelGGL(k_undistort, grid, dim3(256), 0, MML_STREAM(ctx), first, ctx->NT, ctx->NV, ctx->cb_n, ctx->ln_pts,
-                       ctx->ln_meta, ctx->slot_flags, d_params, ctx->d_und + 8 * (size_t)first);
+                       ctx->ln_rel, ctx->slot_flags, d_params, ctx->d_und + 8 * (size_t)first);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
@@ -371,14 +371,14 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     if (cap_corner == cap_surf || count <= 16) {
         // (one launch for both kinds: a handful of scans are a chain of launches, not a question of room on the CUs)
         hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 2), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
-                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
                            ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     } else {
         hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), pad(cap_corner), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
-                           cap_corner, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           cap_corner, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
                            ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
         hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 1, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
-                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_meta, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
+                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
                            ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
     }
     MML_HIP(hipGetLastError());
