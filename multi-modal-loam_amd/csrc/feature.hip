@@ -99,6 +99,8 @@ struct FeatParams {
     int4* seg_rs;   // per 64 line indices: (boundary, offset below it, offset from it on, 1 = no second boundary): rounds of k_stencil
     int4* seg_rw;   //   the same for aligned windows (k_select_part)
     int seg_rstride;
+    int xcd_remap;  // k_assign_c_staged: slots dealt to the XCDs (measurement switch MML_XCD_REMAP=0)
+    int ab_ppt;     // points per thread of pass A on the Velodyne part (dense layouts: 4, i.e. 1024-point count blocks)
 };
 
 // ---- line index -> storage position ---------------------------------------------------------------------------------------
@@ -366,7 +368,6 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     const int sensor = blockIdx.z;  // 0 velodyne, 1 livox
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = P.n_in[2 * b + sensor];
-    const int i = blockIdx.x * AB_THREADS + tid;
     const int nblk = sensor == 0 ? P.nblk_v : P.nblk_l;
     if ((int)blockIdx.x >= nblk) return;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
@@ -378,6 +379,11 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
         s_keep = 0;
     }
     __syncthreads();
+    // (dense layouts: four points per thread -- a 130-entry histogram record per 1024 points instead of per 256: the records were a
+    //  quarter of this pass's written bytes and all of pass B's work)
+    const int ppt = sensor == 0 ? P.ab_ppt : 1;
+    for (int r = 0; r < ppt; ++r) {
+    const int i = (blockIdx.x * ppt + r) * AB_THREADS + tid;
     bool valid = false, keep = false, near_ok = false;
     int key = 0;
     if (i < n) {
@@ -411,6 +417,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     const unsigned long long vm = __ballot(valid), km = __ballot(keep);
     if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
     if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
+    }
     __syncthreads();
     int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
     if (tid < nkeys) cnt[tid] = s_bcnt[tid];
@@ -432,7 +439,8 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
     const int sensor = blockIdx.y;
     const int tid = threadIdx.x;
     const int n = P.n_in[2 * b + sensor];
-    const int nblk = (n + AB_THREADS - 1) / AB_THREADS;
+    const int ab_pts = AB_THREADS * (sensor == 0 ? P.ab_ppt : 1);
+    const int nblk = (n + ab_pts - 1) / ab_pts;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
     int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * BLK_STRIDE;
@@ -702,84 +710,109 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c_direct(FeatParams P) {
 // order before they leave:
 // a dense scan has 128 rings and consecutive raw points belong to different rings, so a lane-by-lane scatter writes 16 isolated
 // bytes per lane (1.6 TB/s at BASELINE configs[3]); out of the staged order consecutive lanes write consecutive records of a
-// line -- runs of (points per line per workgroup) x 16 bytes.
-constexpr int CB_SUB = 4;
-constexpr int CB_THREADS = AB_THREADS * CB_SUB;
+// line -- runs of (points per line per workgroup) x 16 bytes.  A workgroup stages 2048 points, two per thread (round 3: 1024 --
+// 8-point runs of 128 / 32 / 32 bytes per line and array; now 16-point runs), and the workgroups of one scan run on ONE XCD.
+constexpr int CB_TP = 2;                        // points per thread
+constexpr int CB_THREADS = 1024;
+constexpr int CB_TILE = CB_THREADS * CB_TP;     // points per workgroup
+constexpr int CB_SUB = CB_TILE / AB_THREADS;    // pass-A blocks per workgroup at most (256-point blocks)
 constexpr int CB_WAVES = CB_THREADS / 64;
+constexpr int CB_GROUPS = CB_WAVES * CB_TP;     // (round, wavefront) groups in raw order
 __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
-    __shared__ int s_wcnt[CB_WAVES][MAX_LINES];
-    __shared__ int s_wvalid[CB_WAVES];
+    __shared__ unsigned char s_wcnt[CB_GROUPS][MAX_LINES];  // points per (group, line): at most 64
+    __shared__ unsigned char s_wvalid[CB_GROUPS];
     __shared__ int s_cnt[CB_SUB][MAX_LINES + 2];
     __shared__ int s_ls[MAX_LINES];
     __shared__ int s_kstart[MAX_LINES + 1];  // where the run of each line starts in the staged order; [nkeys] = valid points
-    __shared__ float4 s_pt[CB_THREADS];
-    __shared__ int2 s_meta[CB_THREADS];
-    __shared__ int s_dst[CB_THREADS];
-    const int b = blockIdx.y + P.first;
+    __shared__ float4 s_pt[CB_TILE];
+    __shared__ int2 s_meta[CB_TILE];
+    __shared__ int s_dst[CB_TILE];
+    // Workgroups are dealt to the eight XCDs round-robin in dispatch order, and every XCD has its own L2: with the plain
+    // (tile, slot) = blockIdx mapping the tiles of one scan -- whose runs of a line are neighbours in memory, a run of 16 points
+    // ends in the middle of a 128-byte line of the 4-byte arrays -- land on eight different L2s, none of which ever sees a whole
+    // line.  Remapped: XCD x owns the slots x, x + 8, ... of the launch and walks their tiles in order, so the pieces of a line meet
+    // in ONE L2 and leave it merged (configs[3]: 4.42 -> 4.01 ms per 1024 scans with the 1024-point tiles).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (P.xcd_remap && (gridDim.y & 7) == 0) {
+        const int g = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = g & 7, idx = g >> 3;
+        by = (idx / (int)gridDim.x) * 8 + xcd;
+        bx = idx % (int)gridDim.x;
+    }
+    const int b = by + P.first;
     const int sensor = blockIdx.z + P.sensor_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = wave / AB_WAVES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n_in[2 * b + sensor];
-    const int i = blockIdx.x * CB_THREADS + tid;
-    if ((int)(blockIdx.x * CB_THREADS) >= n) return;
+    if ((int)(bx * CB_TILE) >= n) return;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
-    const int nblk = (n + AB_THREADS - 1) / AB_THREADS;
-    for (int k = tid; k < CB_WAVES * MAX_LINES; k += CB_THREADS) (&s_wcnt[0][0])[k] = 0;
+    const int ab_ppt = sensor == 0 ? P.ab_ppt : 1;
+    const int ab_pts = AB_THREADS * ab_ppt;          // points per pass-A block
+    const int sub_n = CB_TILE / ab_pts;              // pass-A blocks per workgroup
+    const int gpb = AB_WAVES * ab_ppt;               // (round, wavefront) groups per pass-A block
+    const int nblk = (n + ab_pts - 1) / ab_pts;
+    for (int k = tid; k < CB_GROUPS * MAX_LINES / 4; k += CB_THREADS) reinterpret_cast<unsigned*>(&s_wcnt[0][0])[k] = 0;
+    static_assert((CB_GROUPS * MAX_LINES) % 4 == 0, "cleared as words");
     // the blocks' offsets, the line starts and the per-slot constants are requested here, next to the points themselves: a
     // lane's destination is then two LDS look-ups behind its key instead of two more dependent trips to memory (key ->
     // block offset -> line start) -- the lanes of this pass live as long as their longest load chain
-    const int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + (size_t)blockIdx.x * CB_SUB) * BLK_STRIDE;
-    for (int k = tid; k < CB_SUB * nkeys; k += CB_THREADS) {
+    const int* cnt0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + (size_t)bx * sub_n) * BLK_STRIDE;
+    for (int k = tid; k < sub_n * nkeys; k += CB_THREADS) {
         const int u = k / nkeys, kk = k - u * nkeys;
-        s_cnt[u][kk] = ((int)blockIdx.x * CB_SUB + u < nblk) ? cnt0[(size_t)u * BLK_STRIDE + kk] : 0;
+        s_cnt[u][kk] = (bx * sub_n + u < nblk) ? cnt0[(size_t)u * BLK_STRIDE + kk] : 0;
     }
     for (int k = tid; k < nkeys; k += CB_THREADS) s_ls[k] = P.line_start[(size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings) + k];
-    if (tid < CB_SUB) s_cnt[tid][MAX_LINES + 1] = ((int)blockIdx.x * CB_SUB + tid < nblk) ? cnt0[(size_t)tid * BLK_STRIDE + MAX_LINES + 1] : 0;
+    if (tid < sub_n) s_cnt[tid][MAX_LINES + 1] = (bx * sub_n + tid < nblk) ? cnt0[(size_t)tid * BLK_STRIDE + MAX_LINES + 1] : 0;
     const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);
-    // ... and so are the key and the record of the lane's own point (the record whether or not the key will call it valid:
+    // ... and so are the keys and the records of the lane's own points (the record whether or not the key will call it valid:
     // the few invalid ones cost nothing, and the load no longer waits for the key)
     const int region = sensor == 0 ? 0 : P.NV;
-    int key = 255;
-    float4 praw = make_float4(0.f, 0.f, 0.f, 0.f);
-    float ori = 0.f;
-    mml_livox_point q;
-    q.x = q.y = q.z = 0.f;
-    q.reflectivity = 0;
-    q.offset_time = 0;
+    int key[CB_TP];
+    float4 praw[CB_TP];
+    float ori[CB_TP];
+    uint32_t off_time[CB_TP];
     double timeSpan = 1.0;
-    if (i < n) {
-        key = P.raw_line[(size_t)b * P.NT + region + i];
-        if (sensor == 0) {
-            praw = nt_load4(P.velo_in + (size_t)b * P.NV + i);
-            ori = P.raw_ori[(size_t)b * P.NV + i];
-        } else {
-            q = P.livox_in[(size_t)b * P.NL + i];
+#pragma unroll
+    for (int r = 0; r < CB_TP; ++r) {
+        const int i = bx * CB_TILE + r * CB_THREADS + tid;
+        key[r] = 255;
+        praw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ori[r] = 0.f;
+        off_time[r] = 0;
+        if (i < n) {
+            key[r] = P.raw_line[(size_t)b * P.NT + region + i];
+            if (sensor == 0) {
+                praw[r] = nt_load4(P.velo_in + (size_t)b * P.NV + i);
+                ori[r] = P.raw_ori[(size_t)b * P.NV + i];
+            } else {
+                const mml_livox_point q = P.livox_in[(size_t)b * P.NL + i];
+                praw[r] = make_float4(q.x, q.y, q.z, (float)q.reflectivity);
+                off_time[r] = q.offset_time;
+            }
         }
     }
     if (sensor == 1) timeSpan = livox_to_sec(P.livox_in[(size_t)b * P.NL + n - 1].offset_time);  // :985
     __syncthreads();
-    const bool valid = key < 254;
-    if (!valid) key = 0;
-    // the crop decision is geometric (lidars_extrinsic_cali.h:424-477), so the position of a point in the fused cloud
-    // [velo kept ; livox kept] is known before any label is: the point goes straight there
-    bool keep = false, near_ok = false;
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t off_time = 0;
-    if (valid) {
-        if (sensor == 0) {
-            out = make_float4(praw.x, praw.y, praw.z, 0.f);  // intensity zeroed, :1254-1256
-        } else {
-            out = make_float4(q.x, q.y, q.z, (float)q.reflectivity);
-            praw = out;
-            off_time = q.offset_time;
-        }
-        crop_test(P, out.x, out.y, out.z, keep, near_ok);
-    }
-    const unsigned long long eq = match_key(valid, key, nbits);
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long km = __ballot(keep);
-    if (valid && (eq & lt) == 0) s_wcnt[wave][key] = __popcll(eq);
-    if (lane == 0) s_wvalid[wave] = __popcll(km);
+    bool valid[CB_TP], keep[CB_TP], near_ok[CB_TP];
+    int rank[CB_TP], krank[CB_TP];
+#pragma unroll
+    for (int r = 0; r < CB_TP; ++r) {
+        valid[r] = key[r] < 254;
+        if (!valid[r]) key[r] = 0;
+        // the crop decision is geometric (lidars_extrinsic_cali.h:424-477), so the position of a point in the fused cloud
+        // [velo kept ; livox kept] is known before any label is: the point goes straight there
+        keep[r] = false;
+        near_ok[r] = false;
+        if (valid[r]) crop_test(P, praw[r].x, praw[r].y, praw[r].z, keep[r], near_ok[r]);
+        const unsigned long long eq = match_key(valid[r], key[r], nbits);
+        const unsigned long long km = __ballot(keep[r]);
+        const int g = r * CB_WAVES + wave;
+        if (valid[r] && (eq & lt) == 0) s_wcnt[g][key[r]] = (unsigned char)__popcll(eq);
+        if (lane == 0) s_wvalid[g] = (unsigned char)__popcll(km);
+        rank[r] = __popcll(eq & lt);
+        krank[r] = __popcll(km & lt);
+    }
     __syncthreads();
     // staged order: lines ascending, inside a line the raw order.  The first wavefront scans the workgroup's line counts.
     if (wave == 0) {
@@ -788,7 +821,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
             const int k = k0 + lane;
             int c = 0;
             if (k < nkeys)
-                for (int w = 0; w < CB_WAVES; ++w) c += s_wcnt[w][k];
+                for (int w = 0; w < CB_GROUPS; ++w) c += s_wcnt[w][k];
             int x = c;
             for (int o = 1; o < 64; o <<= 1) {
                 const int y = __shfl_up(x, o);
@@ -800,48 +833,55 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
         if (lane == 0) s_kstart[nkeys] = carry;
     }
     __syncthreads();
-    if (valid) {
+#pragma unroll
+    for (int r = 0; r < CB_TP; ++r) {
+        if (!valid[r]) continue;
+        const int i = bx * CB_TILE + r * CB_THREADS + tid;
         const AssignAux* a = &aux;
-        int pos = s_cnt[sub][key] + __popcll(eq & lt);
-        int fdst = (sensor == 0 ? 0 : a->kept_velo) + s_cnt[sub][MAX_LINES + 1] + __popcll(km & lt);
-        for (int w = sub * AB_WAVES; w < wave; ++w) {
-            pos += s_wcnt[w][key];
+        const int g = r * CB_WAVES + wave;       // my (round, wavefront) group; its pass-A block holds gpb groups
+        const int sub = g / gpb;
+        int pos = s_cnt[sub][key[r]] + rank[r];
+        int fdst = (sensor == 0 ? 0 : a->kept_velo) + s_cnt[sub][MAX_LINES + 1] + krank[r];
+        for (int w = sub * gpb; w < g; ++w) {
+            pos += s_wcnt[w][key[r]];
             fdst += s_wvalid[w];
         }
         float rel;  // (also for the few points the crop drops: the undistortion runs over the whole region)
         if (sensor == 0) {
             const float startOri = a->startOri, endOri = a->endOri;
+            float o = ori[r];
             if (i <= a->trig) {  // :1169-1177
-                if (ori < startOri - M_PI / 2)
-                    ori += 2 * M_PI;
-                else if (ori > startOri + M_PI * 3 / 2)
-                    ori -= 2 * M_PI;
+                if (o < startOri - M_PI / 2)
+                    o += 2 * M_PI;
+                else if (o > startOri + M_PI * 3 / 2)
+                    o -= 2 * M_PI;
             } else {  // :1178-1184
-                ori += 2 * M_PI;
-                if (ori < endOri - M_PI * 3 / 2)
-                    ori += 2 * M_PI;
-                else if (ori > endOri + M_PI / 2)
-                    ori -= 2 * M_PI;
+                o += 2 * M_PI;
+                if (o < endOri - M_PI * 3 / 2)
+                    o += 2 * M_PI;
+                else if (o > endOri + M_PI / 2)
+                    o -= 2 * M_PI;
             }
-            rel = (ori - startOri) / (endOri - startOri);  // :1186
+            rel = (o - startOri) / (endOri - startOri);  // :1186
         } else {
-            rel = livox_to_sec(off_time) / timeSpan;       // :995
+            rel = livox_to_sec(off_time[r]) / timeSpan;   // :995
         }
         // the point's rank inside its line, counted from the first of this workgroup's pass-A blocks
-        const int e = s_kstart[key] + (pos - s_cnt[0][key]);
-        s_pt[e] = praw;
-        // one 8-byte record per point: its index in the fused cloud (or -2 for a Livox point that only fails the far test --
-        // its label still counts towards livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The
-        // label byte is written by k_select for every point of a line, the line id follows from the line table.
-        s_meta[e] = make_int2(keep ? fdst : ((sensor == 1 && near_ok) ? -2 : -1), __float_as_int(rel));
-        s_dst[e] = s_ls[key] + pos;
+        const int e = s_kstart[key[r]] + (pos - s_cnt[0][key[r]]);
+        s_pt[e] = praw[r];
+        // its index in the fused cloud (or -2 for a Livox point that only fails the far test -- its label still counts towards
+        // livox_corner_num / livox_surf_num, :925-940 -- or -1) and its in-sweep time.  The label byte is written by k_select for
+        // every point of a line, the line id follows from the line table.
+        s_meta[e] = make_int2(keep[r] ? fdst : ((sensor == 1 && near_ok[r]) ? -2 : -1), __float_as_int(rel));
+        s_dst[e] = s_ls[key[r]] + pos;
     }
     __syncthreads();
-    if (tid < s_kstart[nkeys]) {
-        const size_t g = (size_t)b * P.NT + s_dst[tid];
-        P.ln_pts[g] = s_pt[tid];
-        P.ln_gidx[g] = s_meta[tid].x;
-        P.ln_rel[g] = s_meta[tid].y;
+    const int nstaged = s_kstart[nkeys];
+    for (int e = tid; e < nstaged; e += CB_THREADS) {
+        const size_t g = (size_t)b * P.NT + s_dst[e];
+        P.ln_pts[g] = s_pt[e];
+        P.ln_gidx[g] = s_meta[e].x;
+        P.ln_rel[g] = s_meta[e].y;
     }
 }
 
@@ -3576,7 +3616,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.ln_attr = ctx->ln_attr;
     P.blk_cnt = ctx->blk_cnt;
     P.assign_aux = ctx->assign_aux;
-    P.nblk_v = (ctx->NV + AB_THREADS - 1) / AB_THREADS;
+    P.ab_ppt = ctx->cfg.n_rings > 32 ? 4 : 1;  // (dense layouts: 1024-point count blocks; CB_TILE is a multiple of either size)
+    P.nblk_v = (ctx->NV + AB_THREADS * P.ab_ppt - 1) / (AB_THREADS * P.ab_ppt);
     P.nblk_l = (ctx->NL + AB_THREADS - 1) / AB_THREADS;
     P.nblk_max = P.nblk_v > P.nblk_l ? P.nblk_v : P.nblk_l;
     P.ring_bits = 1;
@@ -3618,6 +3659,11 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.seg_rs = ctx->seg_rs;
     P.seg_rw = ctx->seg_rw;
     P.seg_rstride = ctx->seg_rstride;
+    {
+        static int remap = -1;
+        if (remap < 0) remap = getenv("MML_XCD_REMAP") ? atoi(getenv("MML_XCD_REMAP")) : 1;
+        P.xcd_remap = remap;
+    }
     return P;
 }
 
@@ -3662,7 +3708,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         MmlStageScope t(ctx, "assign_scatter");
         if (P.n_rings > 32) {  // dense scans: consecutive raw points belong to different rings
             P.sensor_base = 0;
-            hipLaunchKernelGGL(k_assign_c_staged, dim3((P.nblk_v + CB_SUB - 1) / CB_SUB, count, 1), dim3(CB_THREADS), 0, s, P);
+            hipLaunchKernelGGL(k_assign_c_staged, dim3((ctx->NV + CB_TILE - 1) / CB_TILE, count, 1), dim3(CB_THREADS), 0, s, P);
             if (P.nblk_l > 0) {  // (a context without a Livox region, max_livox_points = 0: a zero-sized grid is not a launch)
                 P.sensor_base = 1;
                 hipLaunchKernelGGL(k_assign_c_direct, dim3(P.nblk_l, count, 1), dim3(AB_THREADS), 0, s, P);

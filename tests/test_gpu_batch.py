@@ -195,3 +195,51 @@ def test_full_size_step_properties(M, O, scene, synth):
             assert np.abs(x1[s][:3] - frames[s]["T_gt"][:3, 3]).max() < 0.02
     finally:
         c.close()
+
+
+def test_sparse_lines_take_the_general_translation_path(M, O, synth):
+    """The one-pass bucketing stores a line as one segment per 4096-point block of the raw scan; k_stencil, k_select_part,
+    k_stencil_redo / _break translate line indices through per-64-index records that allow ONE segment boundary per run.  A ring
+    that keeps only a few points per block -- sky above the upper rings of an outdoor scan -- has segments shorter than that:
+    those runs take the general path through the segment table (stencil tile load, label pass, point windows).  Here: rings
+    thinned to 1 point in 8 / 1 in 40 over parts of the sweep (NaN, (0,0,0) and absent records), a ring that survives in two
+    blocks only, Livox lines thinned the same way; 24 slots (batch kernels) and 2 slots (segment-mode kernels), every field
+    against the oracle."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for k, mode in ((50, "nan"), (51, "zero"), (52, "skip")):
+        v = synth.velo_scan(k).reshape(1800, 16, 4).copy()
+        thin = rng.random((1800, 16)) < 0.875
+        thin[:, :11] = False                                   # rings 11..15: 1 point in 8 ...
+        thin[600:1300, 13] = rng.random(700) < 0.975           # ... ring 13: 1 in 40 over a third of the sweep
+        thin[:, 15] = True
+        thin[100:140, 15] = False                              # ring 15: two short stretches only
+        thin[1500:1530, 15] = False
+        if mode == "nan":
+            v[thin, 0] = np.nan
+        elif mode == "zero":
+            v[thin, :3] = 0.0
+        v = v.reshape(-1, 4)
+        if mode == "skip":
+            v = v[~thin.reshape(-1)]
+        l = synth.livox_scan(k).copy()
+        drop = (rng.random(len(l)) < 0.93) & np.isin(l["line"], (1, 4))
+        l["x"][drop] = 0.0                                      # (x < 0.01: the record is skipped, :990)
+        cases.append(dict(velo=v, livox=l, dR=np.eye(3), dt=np.zeros(3)))
+    ora = [oracle_pipeline(O, cs, None, None) for cs in cases]
+    for B in (24, 2):
+        c = M.Context(max_scans=B)
+        try:
+            for s in range(B):
+                c.scan_upload(s, cases[s % 3]["velo"], cases[s % 3]["livox"])
+            c.extract(0, B)
+            for s in range(B):
+                _check_extraction(c.scan_download(s), ora[s % 3])
+            c.undistort(0, B, np.tile(np.eye(3).reshape(1, 9), (B, 1)), np.zeros((B, 3)))
+            c.downsample(0, B)
+            for s in range(B):
+                assert c.features_download(s, 0).tobytes() == ora[s % 3]["corner"].tobytes()
+                assert c.features_download(s, 1).tobytes() == ora[s % 3]["surf"].tobytes()
+        finally:
+            c.close()
+    assert sum(int((o["label"] > 0).sum()) for o in ora) > 2000

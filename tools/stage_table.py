@@ -5,7 +5,8 @@ import sys
 
 PEAK = 256 * 4 * 2.4e9 / 4  # VALU wave-instructions / s
 
-GROUPS = [("assign (3 kernels)", ["assign_count", "assign_scan", "assign_scatter"]), ("stencil (3 kernels)", ["stencil"]),
+GROUPS = [("assign", ["assign_count", "assign_scan", "assign_scatter", "assign_ends", "assign_onepass", "assign_tables"]),
+          ("stencil (3 kernels)", ["stencil"]),
           ("select", ["select"]), ("undistort", ["undistort"]), ("solve", ["solve"]),
           ("associate + fit + far", ["associate", "associate_fit", "associate_far"]), ("voxel", ["voxel_downsample"]),
           ("crop, stats", ["crop_compact", "assoc_stats"])]
@@ -20,9 +21,10 @@ def main(bench, sq, traffic):
     print("|---|---|---|---|")
     tv = tb = tm = 0.0
     for name, keys in GROUPS:
+        keys = [k for k in keys if k in st]   # (three-pass or one-pass bucketing: whichever stages the run had)
         ms = sum(st[k] for k in keys)
-        v = sum(sq[k]["valu_wave_instr"] for k in keys)
-        by = sum(tr[k] for k in keys)
+        v = sum(sq[k]["valu_wave_instr"] for k in keys if k in sq)
+        by = sum(tr[k] for k in keys if k in tr)
         tv += v
         tb += by
         tm += ms
