@@ -101,6 +101,7 @@ struct FeatParams {
     int seg_rstride;
     int xcd_remap;  // k_assign_c_staged: slots dealt to the XCDs (measurement switch MML_XCD_REMAP=0)
     int ab_ppt;     // points per thread of pass A on the Velodyne part (dense layouts: 4, i.e. 1024-point count blocks)
+    int ends_inline;  // k_assign_onepass computes the sweep's start / end azimuth itself (a handful of scans: one launch less)
 };
 
 // ---- line index -> storage position ---------------------------------------------------------------------------------------
@@ -909,11 +910,11 @@ static_assert(OP_REC_POS + OP_MAXKEYS <= MAX_LINES, "the block record holds hist
 constexpr unsigned OP_NONE = 0x1fffu;
 enum : unsigned { OPI_VALID = 1u << 8, OPI_KEEP = 1u << 9, OPI_NEAR = 1u << 10, OPI_RANK_SHIFT = 12, OPI_KRANK_SHIFT = 20 };
 
-// start / end azimuth of the sweep (:1136-1146) and the per-slot resets, one wavefront per slot
-__global__ __launch_bounds__(64) void k_assign_ends(FeatParams P, int count) {
-    const int t = blockIdx.x;
-    if (t >= count) return;
-    const int b = P.first + t, lane = threadIdx.x;
+// start / end azimuth of the sweep (:1136-1146), by one wavefront: first and last finite record of the Velodyne part (normally
+// the first and the last one: two requests), then the two arctangents on one lane.  Every block of the one-pass kernel does this
+// for itself -- eight times the same few hundred instructions per scan cost less than a kernel of their own in front of it.
+__device__ __forceinline__ void sweep_ends(const FeatParams& P, int b, float& startOri, float& endOri) {
+    const int lane = threadIdx.x & 63;
     const int n = P.n_in[2 * b];
     const float4* in = P.velo_in + (size_t)b * P.NV;
     int ff = -1, lf = -1;
@@ -937,26 +938,31 @@ __global__ __launch_bounds__(64) void k_assign_ends(FeatParams P, int count) {
         const unsigned long long m = __ballot(fin);
         if (m) lf = i0 + 63 - __clzll((long long)m);
     }
-    if (lane == 0) {
+    startOri = 0.f;
+    endOri = 0.f;
+    if (lf >= 0) {
+        const float4 p0 = in[ff], p1 = in[lf];
+        startOri = -atan2((double)p0.y, (double)p0.x);   // :1136
+        endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
+        if (endOri - startOri > 3 * M_PI)
+            endOri -= 2 * M_PI;
+        else if (endOri - startOri < M_PI)
+            endOri += 2 * M_PI;
+    }
+}
+
+// ... as a kernel of its own for batches, one wavefront per slot (the blocks then read the two floats instead of computing them:
+// the two arctangents on one lane sit in front of every block's first barrier, +12 % on the pass at 1024 scans)
+__global__ __launch_bounds__(64) void k_assign_ends(FeatParams P, int count) {
+    const int t = blockIdx.x;
+    if (t >= count) return;
+    const int b = P.first + t;
+    float so, eo;
+    sweep_ends(P, b, so, eo);
+    if (threadIdx.x == 0) {
         AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
-        float startOri = 0.f, endOri = 0.f;
-        if (lf >= 0) {
-            const float4 p0 = in[ff], p1 = in[lf];
-            startOri = -atan2((double)p0.y, (double)p0.x);   // :1136
-            endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
-            if (endOri - startOri > 3 * M_PI)
-                endOri -= 2 * M_PI;
-            else if (endOri - startOri < M_PI)
-                endOri += 2 * M_PI;
-        }
-        a->first_finite = ff < 0 ? 0x7fffffff : ff;
-        a->last_finite = lf;
-        a->trig = 0x7fffffff;
-        a->startOri = startOri;
-        a->endOri = endOri;
-        P.slot_flags[2 * b] = 0;  // an extracted cloud, not undistorted yet
-        P.brk_cnt[b] = 0;         // the stencil's two queues start empty
-        P.redo_cnt[b] = 0;
+        a->startOri = so;
+        a->endOri = eo;
     }
 }
 
@@ -971,24 +977,57 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+struct OnepassLds {
+    int cnt[OP_GROUPS][OP_CSTRIDE];  // points per (group, line); after the scan: points of the line in the groups before
+    int gv[OP_GROUPS], gk[OP_GROUPS];  // valid / kept points per group -> exclusive over the groups
+    int hist[OP_MAXKEYS + 2], koff[OP_MAXKEYS];
+    int cond[OP_WAVES];
+    int base[3];
+    float ori[2];
+    int out[2][MML_OP_BLK];  // fused index | in-sweep time of the block's points in storage order
+};
 template <int SENSOR>
-__global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
-    __shared__ int s_cnt[OP_GROUPS][OP_CSTRIDE];  // points per (group, line); after the scan: points of the line in the groups before
-    __shared__ int s_gv[OP_GROUPS], s_gk[OP_GROUPS];  // valid / kept points per group -> exclusive over the groups
-    __shared__ int s_hist[OP_MAXKEYS + 2], s_koff[OP_MAXKEYS];
-    __shared__ int s_cond[OP_WAVES];
-    __shared__ int s_base[3];
-    __shared__ int s_out[2][MML_OP_BLK];  // fused index | in-sweep time of the block's points in storage order
+__device__ __forceinline__ void assign_onepass_body(const FeatParams& P, OnepassLds& S) {
+    auto& s_cnt = S.cnt;
+    auto& s_gv = S.gv;
+    auto& s_gk = S.gk;
+    auto& s_hist = S.hist;
+    auto& s_koff = S.koff;
+    auto& s_cond = S.cond;
+    auto& s_base = S.base;
+    auto& s_out = S.out;
     const int b = blockIdx.y + P.first, blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n_in[2 * b + SENSOR];
     const int i0 = blk * MML_OP_BLK;
+    // the per-slot resets (one block of the slot: the first Velodyne block, or the first Livox block of a scan without a Velodyne part)
+    if (blk == 0 && tid == 0 && (SENSOR == 0 || P.n_in[2 * b] <= 0)) {
+        P.slot_flags[2 * b] = 0;  // an extracted cloud, not undistorted yet
+        P.brk_cnt[b] = 0;         // the stencil's two queues start empty
+        P.redo_cnt[b] = 0;
+    }
     if (i0 >= n) return;
     const int nkeys = SENSOR == 0 ? P.n_rings : P.n_lines;
     const int nbits = SENSOR == 0 ? P.ring_bits : P.line_bits;
     const int region = SENSOR == 0 ? 0 : P.NV;
     for (int k = tid; k < OP_GROUPS * OP_CSTRIDE; k += OP_THREADS) (&s_cnt[0][0])[k] = 0;
-    const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);
+    if (SENSOR == 0 && wave == 0) {
+        float so, eo;
+        if (P.ends_inline) {
+            sweep_ends(P, b, so, eo);
+        } else {
+            const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
+            so = a->startOri;
+            eo = a->endOri;
+        }
+        if (lane == 0) {
+            S.ori[0] = so;
+            S.ori[1] = eo;
+        }
+    }
+    struct {
+        float startOri, endOri;
+    } aux;
     // ---- 1. the block's records, all loads in flight together ----
     float4 pt[OP_PPT];
     unsigned xw[OP_PPT];    // velodyne: the raw azimuth (float bits), Livox: offset_time
@@ -1016,7 +1055,9 @@ __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
             }
         }
     }
-    __syncthreads();  // (the counters are zero)
+    __syncthreads();  // (the counters are zero, the sweep's ends are known)
+    aux.startOri = S.ori[0];
+    aux.endOri = S.ori[1];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int cond_min = 0x7fffffff;  // (wave-uniform) first index of this wavefront's points that sets halfPassed
 #pragma unroll
@@ -1123,11 +1164,19 @@ __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
         int pc = 0x7fffffff;
         if (lane < blk && (unsigned)((w >> 26) & 0x1fffu) != OP_NONE) pc = lane * MML_OP_BLK + (int)((w >> 26) & 0x1fffu);
         if constexpr (SENSOR == 1) {
+            // (the Velodyne blocks of the slot are part of the same launch, z = 0: dispatched before every Livox block)
             const int nbv = (P.n_in[2 * b] + MML_OP_BLK - 1) / MML_OP_BLK;
-            if (lane >= 32 && lane - 32 < nbv) {
-                const unsigned long long wv = __hip_atomic_load(P.op_agg + (size_t)b * 2 * MML_SEG_MAX + (lane - 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pk = (int)((wv >> 13) & 0x1fffu);
+            unsigned long long wv = 0;
+            bool needv = lane >= 32 && lane - 32 < nbv;
+            const bool minev = needv;
+            while (__any(needv)) {
+                if (needv) {
+                    wv = __hip_atomic_load(P.op_agg + (size_t)b * 2 * MML_SEG_MAX + (lane - 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    needv = (unsigned)(wv >> 39) != epoch;
+                }
+                if (__any(needv)) __builtin_amdgcn_s_sleep(1);
             }
+            if (minev) pk = (int)((wv >> 13) & 0x1fffu);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1207,63 +1256,127 @@ __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
     }
 }
 
+// one launch for both sensors (a handful of scans: one launch less in the chain): z = 0 the Velodyne blocks, z = 1 the Livox blocks,
+// which wait for the Velodyne blocks' words ...
+__global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
+    __shared__ OnepassLds S;
+    if (blockIdx.z == 0)
+        assign_onepass_body<0>(P, S);
+    else
+        assign_onepass_body<1>(P, S);
+}
+// ... and one per sensor for batches (the combined kernel is 14 % slower at 1024 scans: 0.64 against 0.56 ms)
+template <int SENSOR>
+__global__ __launch_bounds__(OP_THREADS) void k_assign_onepass_s(FeatParams P) {
+    __shared__ OnepassLds S;
+    assign_onepass_body<SENSOR>(P, S);
+}
+
 // the line tables of a slot from its block records, one wavefront per slot (lane = line): line lengths, line-order starts,
 // storage segments (seg_cum / seg_pos / seg_flat), the valid and kept counts of both sensors
-__global__ __launch_bounds__(64) void k_assign_tables(FeatParams P, int count) {
+// (... and, second half, the translation records of the slot's lines from the tables still in LDS: k_seg_records without a launch of
+//  its own and without reading the tables back)
+constexpr int TB_THREADS = 256;
+__global__ __launch_bounds__(TB_THREADS) void k_assign_tables(FeatParams P, int count) {
+    __shared__ int s_cum[64][MML_SEG_MAX + 1], s_pos[64][MML_SEG_MAX];
+    __shared__ int s_nseg[64], s_len[64], s_rb[64];
     const int t = blockIdx.x;
     if (t >= count) return;
-    const int b = P.first + t, lane = threadIdx.x;
-    const bool in = lane < P.L;
-    const int sensor = lane < P.n_rings ? 0 : 1;
-    const int key = lane - (sensor == 0 ? 0 : P.n_rings);
-    const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
-    const int n = P.n_in[2 * b + sensor];
-    const int nblk = (n + MML_OP_BLK - 1) / MML_OP_BLK;
-    const int* rec0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * BLK_STRIDE;
-    const size_t lo = (size_t)b * P.L + lane;
-    int acc = 0;
-    if (in) {
-        int* cum = P.seg_cum + lo * (MML_SEG_MAX + 1);
-        int* pos = P.seg_pos + lo * MML_SEG_MAX;
-        int* flat = P.seg_flat + ((size_t)b * 2 + sensor) * MML_SEG_FLAT;
-        for (int k = 0; k < nblk; ++k) {
-            const int* rec = rec0 + (size_t)k * BLK_STRIDE;
-            const int p = rec[OP_REC_POS + key];
-            cum[k] = acc;
-            pos[k] = p;
-            flat[k * nkeys + key] = p;
-            acc += rec[key];
+    const int b = P.first + t, tid = threadIdx.x;
+    if (tid < 64) {
+        const int lane = tid;
+        const bool in = lane < P.L;
+        const int sensor = lane < P.n_rings ? 0 : 1;
+        const int key = lane - (sensor == 0 ? 0 : P.n_rings);
+        const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
+        const int n = P.n_in[2 * b + sensor];
+        const int nblk = (n + MML_OP_BLK - 1) / MML_OP_BLK;
+        const int* rec0 = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max) * BLK_STRIDE;
+        const size_t lo = (size_t)b * P.L + lane;
+        int acc = 0;
+        if (in) {
+            int* cum = P.seg_cum + lo * (MML_SEG_MAX + 1);
+            int* pos = P.seg_pos + lo * MML_SEG_MAX;
+            int* flat = P.seg_flat + ((size_t)b * 2 + sensor) * MML_SEG_FLAT;
+            for (int k = 0; k < nblk; ++k) {
+                const int* rec = rec0 + (size_t)k * BLK_STRIDE;
+                const int p = rec[OP_REC_POS + key];
+                cum[k] = acc;
+                pos[k] = p;
+                s_cum[lane][k] = acc;
+                s_pos[lane][k] = p;
+                flat[k * nkeys + key] = p;
+                acc += rec[key];
+            }
+            cum[nblk] = acc;
+            s_cum[lane][nblk] = acc;
+            if (nblk == 0) {
+                cum[1] = 0;
+                pos[0] = sensor == 0 ? 0 : P.NV;
+                s_cum[lane][1] = 0;
+                s_pos[lane][0] = pos[0];
+            }
+            P.seg_n[lo] = nblk > 0 ? nblk : 1;
+            s_nseg[lane] = nblk > 0 ? nblk : 1;
+            P.line_len[lo] = acc;
+            s_len[lane] = acc;
         }
-        cum[nblk] = acc;
-        if (nblk == 0) {
-            cum[1] = 0;
-            pos[0] = sensor == 0 ? 0 : P.NV;
+        // line-order starts: rings from 0, Livox lines from NV
+        const int x = wave_incl_scan(in ? acc : 0);
+        const int velo_total = __shfl(x, P.n_rings - 1);
+        if (in) {
+            const int ls = sensor == 0 ? x - acc : P.NV + (x - acc - velo_total);
+            P.line_start[lo] = ls;
+            s_rb[lane] = (ls >> 6) + 6 * lane;  // = seg_rec_base
         }
-        P.seg_n[lo] = nblk > 0 ? nblk : 1;
-        P.line_len[lo] = acc;
+        if (lane < 2) {  // lane = sensor
+            const int ns = P.n_in[2 * b + lane];
+            const int nb = (ns + MML_OP_BLK - 1) / MML_OP_BLK;
+            const int* r0 = P.blk_cnt + ((size_t)(b * 2 + lane) * P.nblk_max) * BLK_STRIDE;
+            int tv = 0, tk = 0;
+            for (int k = 0; k < nb; ++k) {
+                tv += r0[(size_t)k * BLK_STRIDE + MAX_LINES];
+                tk += r0[(size_t)k * BLK_STRIDE + MAX_LINES + 1];
+            }
+            P.cb_n[2 * b + lane] = tv;
+            AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
+            if (lane == 0)
+                a->kept_velo = tk;
+            else
+                a->kept_livox = tk;
+            const int nk = lane == 0 ? P.n_rings : P.n_lines;
+            P.seg_flat_n[((size_t)b * 2 + lane) * 2] = nb * nk;
+            P.seg_flat_n[((size_t)b * 2 + lane) * 2 + 1] = nk;
+        }
     }
-    // line-order starts: rings from 0, Livox lines from NV
-    const int x = wave_incl_scan(in ? acc : 0);
-    const int velo_total = __shfl(x, P.n_rings - 1);
-    if (in) P.line_start[lo] = sensor == 0 ? x - acc : P.NV + (x - acc - velo_total);
-    if (lane < 2) {  // lane = sensor
-        const int ns = P.n_in[2 * b + lane];
-        const int nb = (ns + MML_OP_BLK - 1) / MML_OP_BLK;
-        const int* r0 = P.blk_cnt + ((size_t)(b * 2 + lane) * P.nblk_max) * BLK_STRIDE;
-        int tv = 0, tk = 0;
-        for (int k = 0; k < nb; ++k) {
-            tv += r0[(size_t)k * BLK_STRIDE + MAX_LINES];
-            tk += r0[(size_t)k * BLK_STRIDE + MAX_LINES + 1];
+    __syncthreads();
+    // ---- the translation records (see k_seg_records) ----
+    for (int rho = tid; rho < P.seg_rstride; rho += TB_THREADS) {
+        int lo = 0, hi = P.L - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_rb[mid] <= rho)
+                lo = mid;
+            else
+                hi = mid - 1;
         }
-        P.cb_n[2 * b + lane] = tv;
-        AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
-        if (lane == 0)
-            a->kept_velo = tk;
-        else
-            a->kept_livox = tk;
-        const int nk = lane == 0 ? P.n_rings : P.n_lines;
-        P.seg_flat_n[((size_t)b * 2 + lane) * 2] = nb * nk;
-        P.seg_flat_n[((size_t)b * 2 + lane) * 2 + 1] = nk;
+        const int line = lo, r = rho - s_rb[line], n = s_len[line], nseg = s_nseg[line];
+        if (r < 0 || n <= 0) continue;
+        const int* cum = s_cum[line];
+        const int* pos = s_pos[line];
+#pragma unroll
+        for (int form = 0; form < 2; ++form) {
+            const int a0 = 64 * r - (form == 0 ? 5 : 0);
+            const int first = min(max(a0, 0), n - 1), last = min(a0 + 63, n - 1);
+            int sg = 0;
+            while (sg + 1 < nseg && cum[sg + 1] <= first) ++sg;
+            int4 rec;
+            rec.x = cum[sg + 1];
+            rec.y = pos[sg] - cum[sg];
+            rec.z = sg + 1 < nseg ? pos[sg + 1] - cum[sg + 1] : 0;
+            rec.w = (sg + 2 > nseg || last < cum[sg + 2]) ? 1 : 0;
+            (form == 0 ? P.seg_rs : P.seg_rw)[(size_t)b * P.seg_rstride + rho] = rec;
+        }
     }
 }
 
@@ -2341,6 +2454,13 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
     // (fused indices and labels live at the points' STORAGE positions: translated through the line's segment table)
     const int* gidx = P.ln_gidx + (size_t)b * P.NT;
     const SegTab seg = seg_tab(P, b, line);
+    const int4* seg_rec = P.seg_rw + (size_t)b * P.seg_rstride + seg_rec_base(P, b, line);  // aligned windows (k_seg_records)
+    // storage position of line index i: one record per 64 indices (the lanes of a wavefront share it), the segment table for the
+    // runs of a sparse line
+    auto xlate = [&](int i) -> int {
+        const int4 rr = seg_rec[i >> 6];
+        return rr.w ? i + (i < rr.x ? rr.y : rr.z) : seg_xlate(seg, i);
+    };
     unsigned r_attr[KK];
     int r_gidx[KK];
     (void)r_attr;
@@ -2377,7 +2497,7 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
             r_attr[k] = attr[i];
             r_curv[k] = curv[i];
             r_refl[k] = refl[i];
-            r_gidx[k] = gidx[seg_xlate(seg, i)];
+            r_gidx[k] = gidx[xlate(i)];
         }
     }
     if (n >= 11) T = (at_last & A_W2) ? 2 : 3;
@@ -2852,14 +2972,14 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
         if (inner && !(at & A_NEAR)) {
             const int lab = (f == 2) ? 2 : ((f == 100 || f == 150) ? 1 : 0);
             if (lab) {
-                const int gi = CACHED ? r_gidx[k] : gidx[seg_xlate(seg, i)];
+                const int gi = CACHED ? r_gidx[k] : gidx[xlate(i)];
                 if (gi >= 0)
                     labv = lab;
                 else if (gi == -2)  // Livox point beyond far_th: not in the fused cloud, but counted at :925-940 and part of the
                     labv = lab | 0x80;  // surf cloud the GICP refresh aligns (:296-312); k_crop counts these, nobody lists them
             }
         }
-        lnlab[seg_xlate(seg, i)] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
+        lnlab[xlate(i)] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
     )
     SEL_MARK(11);
 #undef FOR_POINTS
@@ -3656,6 +3776,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.seg_flat_n = ctx->seg_flat_n;
     P.op_agg = ctx->op_agg;
     P.op_epoch = 0;
+    P.ends_inline = 0;
     P.seg_rs = ctx->seg_rs;
     P.seg_rw = ctx->seg_rw;
     P.seg_rstride = ctx->seg_rstride;
@@ -3679,19 +3800,24 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         if (ctx->op_epoch == 0) ctx->op_epoch = 1;  // (0 is what freshly allocated aggregate words hold)
         P.op_epoch = ctx->op_epoch;
         const int nbv = (ctx->NV + MML_OP_BLK - 1) / MML_OP_BLK, nbl = (ctx->NL + MML_OP_BLK - 1) / MML_OP_BLK;
-        {
+        P.ends_inline = count <= ST_SEGMENT_MAX_SLOTS ? 1 : 0;
+        if (!P.ends_inline) {
             MmlStageScope t(ctx, "assign_ends");
             hipLaunchKernelGGL(k_assign_ends, dim3(count), dim3(64), 0, s, P, count);
         }
         {
             MmlStageScope t(ctx, "assign_onepass");
-            if (nbv > 0) hipLaunchKernelGGL(k_assign_onepass<0>, dim3(nbv, count), dim3(OP_THREADS), 0, s, P);
-            if (nbl > 0) hipLaunchKernelGGL(k_assign_onepass<1>, dim3(nbl, count), dim3(OP_THREADS), 0, s, P);
+            const int nb = nbv > nbl ? nbv : nbl;
+            if (P.ends_inline) {
+                if (nb > 0) hipLaunchKernelGGL(k_assign_onepass, dim3(nb, count, nbl > 0 ? 2 : 1), dim3(OP_THREADS), 0, s, P);
+            } else {
+                if (nbv > 0) hipLaunchKernelGGL(k_assign_onepass_s<0>, dim3(nbv, count), dim3(OP_THREADS), 0, s, P);
+                if (nbl > 0) hipLaunchKernelGGL(k_assign_onepass_s<1>, dim3(nbl, count), dim3(OP_THREADS), 0, s, P);
+            }
         }
         {
             MmlStageScope t(ctx, "assign_tables");
-            hipLaunchKernelGGL(k_assign_tables, dim3(count), dim3(64), 0, s, P, count);
-            hipLaunchKernelGGL(k_seg_records, dim3((ctx->seg_rstride + 255) / 256, count), dim3(256), 0, s, P, count);
+            hipLaunchKernelGGL(k_assign_tables, dim3(count), dim3(TB_THREADS), 0, s, P, count);
         }
     } else {
     {
