@@ -3098,9 +3098,11 @@ __device__ __forceinline__ M m_bits(int nbits) {
 }
 // M = 64-bit masks: partitions of up to 64 points (lines of 161 .. 3211 points: the rings); M = 128-bit masks: up to 128 points
 // (.. 6411: the Livox lines).  WAVES = lines (wavefronts) per workgroup, MAXWIN = 64-point windows of the longest line + 2.
-// (the narrow form needs 81 vector registers left alone -- one more than six wavefronts per SIMD allow: it is asked to fit them)
+// (the narrow form needs 81 vector registers left alone -- one more than six wavefronts per SIMD allow: it is asked to fit them; the
+//  wide form 144: asked for four wavefronts per SIMD it spills 18 registers and is still 4 % faster, 0.497 -> 0.476 ms for the stage --
+//  this kernel waits for its own memory round trips, a fourth wavefront covers more of them than the spills cost)
 template <typename M, int WAVES, int MAXWIN>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(M) > 8 ? 3 : 6))) void k_select_part(FeatParams P, int n_lines_launch) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(M) > 8 ? 4 : 6))) void k_select_part(FeatParams P, int n_lines_launch) {
     constexpr int MBITS = (int)(8 * sizeof(M));
     constexpr bool WIDE = MBITS > 64;
     __shared__ u64m s_plane_all[WAVES][PL_COUNT][MAXWIN];
