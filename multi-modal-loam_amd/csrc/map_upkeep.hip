@@ -106,7 +106,10 @@ __global__ void k_vox_keys(const float4* pts, int m, const int* bbox_keys, float
     const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
     const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
     const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
-    keys[i] = (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
+    const float bmn[3] = {unkey(bbox_keys[0]), unkey(bbox_keys[1]), unkey(bbox_keys[2])};
+    const float bmx[3] = {unkey(bbox_keys[3]), unkey(bbox_keys[4]), unkey(bbox_keys[5])};
+    // (more than INT_MAX voxels in the box: PCL returns the cloud unfiltered = every point its own voxel, in input order)
+    keys[i] = mml_voxel_grid_overflows(bmn, bmx, inv) ? (unsigned)i : (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
     vals[i] = (unsigned)i;
 }
 
@@ -316,12 +319,16 @@ __global__ void k_seg_keys(SegParams P) {
         const int max_b = static_cast<int>(floor(unkey(P.seg_bbox[6 * g + 3 + c]) * inv));
         div_b[c] = max_b - min_b[c] + 1;
     }
+    const float bmn[3] = {unkey(P.seg_bbox[6 * g]), unkey(P.seg_bbox[6 * g + 1]), unkey(P.seg_bbox[6 * g + 2])};
+    const float bmx[3] = {unkey(P.seg_bbox[6 * g + 3]), unkey(P.seg_bbox[6 * g + 4]), unkey(P.seg_bbox[6 * g + 5])};
+    const bool unfiltered = n > 0 && mml_voxel_grid_overflows(bmn, bmx, inv);  // (PCL returns the cloud as it came)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = P.cat[off + i];
         const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
-        const unsigned vox = (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
+        // (unfiltered: every point its own voxel, in the order of the fused cloud -- the gathered list is in storage order)
+        const unsigned vox = unfiltered ? (unsigned)__float_as_int(p.w) : (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * (div_b[0] * div_b[1]));
         // (segment 12 bits | voxel 32 bits | fused index 20 bits): one sort gives segment, voxel, reference order
         P.keys[off + i] = ((unsigned long long)g << 52) | ((unsigned long long)vox << 20) | (unsigned)__float_as_int(p.w);
         P.vals[off + i] = (unsigned)(off + i);

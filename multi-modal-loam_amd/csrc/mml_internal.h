@@ -264,6 +264,14 @@ struct mml_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 
+// pcl::VoxelGrid::applyFilter (PCL 1.8.1 voxel_grid.hpp): a bounding box of more than INT_MAX voxels ("Leaf size is too small for the
+// input dataset. Integer indices would overflow.") returns the cloud UNFILTERED.  The device filters then key every point by its
+// own ordinal, which is the same thing: every voxel holds one point, in input order.
+__host__ __device__ inline bool mml_voxel_grid_overflows(const float* mn, const float* mx, float inv) {
+    const long long dx = static_cast<long long>((mx[0] - mn[0]) * inv) + 1, dy = static_cast<long long>((mx[1] - mn[1]) * inv) + 1,
+                    dz = static_cast<long long>((mx[2] - mn[2]) * inv) + 1;
+    return dx * dy * dz > 2147483647LL;
+}
 #define MML_STREAM(ctx) ((ctx)->streams[(ctx)->cur])
 int mml_sync_all(mml_ctx* ctx);
 double* mml_stage_alloc(mml_ctx* ctx, size_t doubles);  // pinned staging ring (capi.hip): small read-backs land here

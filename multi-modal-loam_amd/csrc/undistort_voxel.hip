@@ -239,6 +239,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         div_b[c] = max_b - min_b[c] + 1;
     }
     const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+    const bool unfiltered = mml_voxel_grid_overflows(gmn, gmx, inv);  // (Estimator.cpp:1015-1024 then gets its input back)
     // keys (voxel idx, fused index, position) of my elements e = tid + VX_THREADS * k; padding sorts to the end.  The
     // fused index (the point's place in [velo_combine ; livox_combine]) orders the points of a voxel as the reference
     // sums them; position and fused index both fit 16 bits on this path (NT <= 65536).
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
         const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
         const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
-        const int idx = ijk0 + ijk1 * mul1 + ijk2 * mul2;
+        // (unfiltered: every point its own voxel, in the order of the fused cloud -- the label list is in storage order)
+        const int idx = unfiltered ? gx[pos] : ijk0 + ijk1 * mul1 + ijk2 * mul2;
         if (wide) return ((unsigned long long)(unsigned)idx << 33) | ((unsigned long long)(unsigned)gx[pos] << 13) | (unsigned)sidx;
         return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos] << 16) | pos;
     };

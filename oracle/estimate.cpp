@@ -82,6 +82,16 @@ extern "C" int mmlo_voxel_downsample(const float* xyz, int n, float leaf, float*
         max_b[c] = static_cast<int>(floor(mx[c] * inv));
         div_b[c] = max_b[c] - min_b[c] + 1;
     }
+    // "Leaf size is too small for the input dataset. Integer indices would overflow." (voxel_grid.hpp applyFilter): when the bounding
+    // box holds more than INT_MAX voxels PCL warns and returns the input cloud unfiltered
+    {
+        const int64_t dx = static_cast<int64_t>((mx[0] - mn[0]) * inv) + 1, dy = static_cast<int64_t>((mx[1] - mn[1]) * inv) + 1,
+                      dz = static_cast<int64_t>((mx[2] - mn[2]) * inv) + 1;
+        if ((dx * dy * dz) > static_cast<int64_t>(2147483647)) {
+            memcpy(out_xyz, xyz, sizeof(float) * 3 * (size_t)n);
+            return n;
+        }
+    }
     int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
     std::vector<std::pair<unsigned int, int>> iv(n);
     for (int i = 0; i < n; ++i) {

@@ -283,3 +283,34 @@ def test_bucketing_block_boundaries_and_both_forms(M, O, synth):
         finally:
             c.close()
     assert downloads["1"] == downloads["0"]
+
+
+def test_voxel_grid_index_overflow_returns_the_labelled_cloud_unfiltered(M, O, synth):
+    """pcl::VoxelGrid with more than INT_MAX voxels in its bounding box returns its input (Estimator.cpp:1015-1024 then hands the
+    labelled points on unfiltered): a scene of 1.2 km extent at far_th = 100 km.  Slot 0 (25 k surf-labelled points) takes the
+    global-sort filter, slot 1 (a shorter scan: 3.3 k surf points, corner box NOT overflowing) the LDS sort; both against the oracle."""
+    cfg = M.default_config(2, far_th=100000.0, max_livox_points=64, max_features=32768)
+    c = M.Context(cfg)
+    try:
+        scans = []
+        for nkeep in (28800, 6000):
+            v = synth.velo_scan(3, noise=0.002).copy()
+            v[:, :3] *= 60.0
+            scans.append(v[:nkeep])
+        ev = [O.extract_velo(v, far=100000.0) for v in scans]
+        for s, v in enumerate(scans):
+            c.scan_upload(s, v, None)
+        c.extract(0, 2)
+        c.undistort(0, 2, np.tile(np.eye(3).reshape(1, 9), (2, 1)), np.zeros((2, 3)))
+        c.downsample(0, 2)
+        unfiltered = 0
+        for s in range(2):
+            xyz, lab = ev[s]["xyzi"][:, :3], ev[s]["label"]
+            assert np.array_equal(c.scan_download(s)["label"], lab)
+            for kind, leaf in ((0, 0.4), (1, 0.2)):
+                want = O.voxel_downsample(xyz[lab == kind + 1], leaf)
+                assert c.features_download(s, kind).tobytes() == want.tobytes()
+                unfiltered += int(np.array_equal(want, xyz[lab == kind + 1]))
+        assert unfiltered >= 3
+    finally:
+        c.close()

@@ -871,3 +871,19 @@ def test_sensor_faithful_lines_against_numpy_restatement(O, synth):
         assert np.array_equal(flp, flo) and np.array_equal(sp, so) and np.array_equal(fp, fo)
         ties += len(pts) - len(np.unique(pts[:, 3]))
     assert ties > 3000
+
+
+def test_voxel_grid_returns_the_input_when_its_indices_would_overflow(O):
+    """pcl::VoxelGrid::applyFilter (PCL 1.8.1): a bounding box of more than INT_MAX voxels -- "Leaf size is too small for the input
+    dataset. Integer indices would overflow." -- returns the cloud unfiltered (call site Estimator.cpp:1015-1024)."""
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-300, 300, (500, 3)).astype(np.float32)            # 3000^3 voxels of 0.2 m: beyond INT_MAX
+    assert np.array_equal(O.voxel_downsample(p, 0.2), p)
+    q = (p * 0.1).astype(np.float32)                                    # 300^3: filtered as usual
+    out = O.voxel_downsample(q, 0.2)
+    assert len(out) <= len(q) and not np.array_equal(out, q[:len(out)])
+    # the boundary itself: dx * dy * dz against INT_MAX, the three factors as PCL forms them (float difference times float inverse)
+    box = np.array([[0, 0, 0], [258.0, 258.0, 258.0], [1.05, 1.0, 1.0], [1.0, 1.05, 1.0]], np.float32)   # 1291^3 = 2.15e9 > 2^31 - 1
+    assert np.array_equal(O.voxel_downsample(box, 0.2), box)
+    box[1] = [257.0, 257.0, 257.0]                                      # 1286^3 = 2.127e9 < 2^31 - 1: the two near points merge
+    assert len(O.voxel_downsample(box, 0.2)) == 3
