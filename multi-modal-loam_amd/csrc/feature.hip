@@ -4,14 +4,15 @@
 // detectFeaturePoints :341-844) and include/lidars_extrinsic_cali.h:424-477 (crop filters).
 //
 // Kernel chain for a batch of scan slots (one launch each, all slots at once):
-//   k_assign_velo / k_assign_livox : ring / line id, in-scan time, order-preserving bucketing by line
-//   k_stencil                      : one point per lane: curvature / depth / reflect stencil + every
-//                                    per-point predicate of the flag state machine packed in 16 bits
-//   k_select                       : one workgroup per scan line: the order-dependent part of the state machine
-//                                    (flags 3/1/2/300 by dependency rounds on order keys -- the partition sorts
-//                                    are never materialised -- stride walk for 150) + label scatter
+//   k_assign_onepass (+ _ends, _tables) : ring / line id, in-scan time, crop, order-preserving bucketing by line in ONE pass over the
+//                                    raw scan (ring layouts up to 32 rings; storage block-major, a line = segments: SegTab);
+//                                    dense layouts: k_assign_a / _b / _c_staged (three passes, lines contiguous)
+//   k_stencil (+ _redo, _break)    : one wavefront per scan line: curvature / depth / reflect stencil + every per-point predicate
+//                                    of the flag state machine packed in 16 bits, the stride walk for 150
+//   k_select_part / k_select       : the order-dependent part of the state machine (flags 3/1/2/300 by dependency steps on order
+//                                    keys -- the partition sorts are never materialised) + label scatter
 //   k_crop                         : label counts, corner / surf index lists, Livox extrinsic (the crop itself is
-//                                    geometric and happens in k_assign_c)
+//                                    geometric and happens in the bucketing)
 // Everything that is order-independent was hoisted into per-point predicates (k_stencil).
 //
 // Floating point: compiled with -ffp-contract=off; float expressions are written exactly as in the reference
@@ -126,29 +127,6 @@ __device__ __forceinline__ int seg_xlate(const SegTab& S, int i) {
     int s = 0;
     return seg_xlate(S, i, s);
 }
-// The same for a wavefront that walks ONE line front to back (k_stencil, k_select_part): the line's table sits in two vector
-// registers -- lane l holds cum[l] and pos[l] -- and is read with v_readlane at wave-uniform indices, so a look-up touches no
-// memory.  For a window [first, last] of line indices the (at most four) segments it crosses become seven scalars, and a lane's
-// translation is three compares, three selects and an add.  `ok` is false when the window crosses more than four segments (lines
-// with tiny or empty segments): the caller then translates through the table in memory (seg_xlate).
-struct SegLanes {
-    int cum, pos, nseg;
-};
-__device__ __forceinline__ SegLanes seg_lanes(const SegTab& g) {
-    const int l = threadIdx.x & 63;
-    SegLanes T;
-    T.cum = l <= g.nseg ? g.cum[l] : 0x7fffffff;
-    T.pos = l < g.nseg ? g.pos[l] : 0;
-    T.nseg = g.nseg;
-    return T;
-}
-struct SegWin {
-    int c1, c2, c3, d0, e1, e2, e3;  // boundaries; offset of the first segment; offset steps at the boundaries
-    bool ok;
-    // (sums of selected steps, not a selection among four offsets: the latter is turned into an indexed load from a copy of the
-    //  struct in scratch memory)
-    __device__ __forceinline__ int at(int i) const { return i + d0 + (i >= c1 ? e1 : 0) + (i >= c2 ? e2 : 0) + (i >= c3 ? e3 : 0); }
-};
 // A translation record through the SCALAR data path (s_load_dwordx4 into four scalar registers).  The compiler only uses scalar
 // loads for addresses it can prove uniform and memory it can prove unwritten; a record address derived from the wavefront's number
 // (threadIdx.x >> 6) and read between the kernel's own stores is neither to it, and as a vector load the five records of a tile
@@ -172,24 +150,6 @@ __device__ __forceinline__ seg_v4i seg_sload(const int4* base /* from seg_unifor
 #define SEG_SWAIT5(a, b, c, d, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e)::"memory")
 #define SEG_SWAIT8(a, b, c, d, e, f, g, h) \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g), "+s"(h)::"memory")
-// s: wave-uniform hint (segment of an earlier window of the same walk), left at the segment of `first`
-__device__ __forceinline__ SegWin seg_window(const SegLanes& T, int first, int last, int& s) {
-    s = __builtin_amdgcn_readfirstlane(s);
-    while (s + 1 < T.nseg && __builtin_amdgcn_readlane(T.cum, s + 1) <= first) ++s;
-    SegWin W;
-    W.c1 = __builtin_amdgcn_readlane(T.cum, s + 1);
-    W.c2 = __builtin_amdgcn_readlane(T.cum, s + 2);      // (lanes beyond nseg hold INT_MAX; nseg <= MML_SEG_MAX keeps s + 4 < 64)
-    W.c3 = __builtin_amdgcn_readlane(T.cum, s + 3);
-    const int c4 = __builtin_amdgcn_readlane(T.cum, s + 4);
-    W.d0 = __builtin_amdgcn_readlane(T.pos, s) - __builtin_amdgcn_readlane(T.cum, s);
-    const int d1 = __builtin_amdgcn_readlane(T.pos, s + 1) - W.c1, d2 = __builtin_amdgcn_readlane(T.pos, s + 2) - W.c2,
-              d3 = __builtin_amdgcn_readlane(T.pos, s + 3) - W.c3;
-    W.e1 = d1 - W.d0;
-    W.e2 = d2 - d1;
-    W.e3 = d3 - d2;
-    W.ok = last < c4;
-    return W;
-}
 
 struct D3 {
     double x, y, z;
@@ -207,8 +167,6 @@ __device__ __forceinline__ void dnormalize(D3& a) {
     }
 }
 
-constexpr int ASSIGN_THREADS = 1024;
-constexpr int ASSIGN_WAVES = ASSIGN_THREADS / MML_WAVE;
 constexpr int MAX_LINES = 160;  // n_rings + n_livox_lines upper bound
 constexpr int BLK_STRIDE = MAX_LINES + 2;  // per-block record: key histogram | valid points | points kept by the crop
 
@@ -1441,68 +1399,6 @@ __device__ __forceinline__ void seg_point_window(const FeatParams& P, int b, int
 #pragma unroll
         for (int k = 0; k < 2 * H + 1; ++k) pos[k] = seg_xlate(seg, i + k - H, sh);
     }
-}
-
-// locate the scan line that owns bucketed position p of slot b.  Must be called by every lane of the wavefront.
-// The line table of the slot (<= MAX_LINES starts and lengths) is read ONCE into the lanes of the wavefront - lane j
-// holds lines j, j + 64, j + 128 - and searched there with ballots and lane shuffles: one memory round trip instead of
-// a chain of dependent scalar loads in front of every wavefront's real work.
-__device__ __forceinline__ int line_tab_get(const int (&tab)[3], int idx, int L) {
-    int v = __shfl(tab[0], idx & 63);
-    if (L > 64) {
-        const int v1 = __shfl(tab[1], idx & 63);
-        v = idx >= 64 ? v1 : v;
-        if (L > 128) {
-            const int v2 = __shfl(tab[2], idx & 63);
-            v = idx >= 128 ? v2 : v;
-        }
-    }
-    return v;
-}
-struct LineTab {
-    int ls[3], ll[3];
-};
-__device__ __forceinline__ void load_line_tab(const FeatParams& P, int b, LineTab& t) {
-    static_assert(MAX_LINES <= 192, "three table registers per lane");
-    const int* ls = P.line_start + (size_t)b * P.L;
-    const int* ll = P.line_len + (size_t)b * P.L;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int j = lane + 64 * r;
-        const bool in = j < P.L;
-        t.ls[r] = in ? ls[j] : 0x7fffffff;
-        t.ll[r] = in ? ll[j] : 0;
-    }
-}
-__device__ __forceinline__ bool find_line(const FeatParams& P, const LineTab& t, int p, int& line, int& i, int& n, int& start) {
-    const int lane = threadIdx.x & 63;
-    // line_start is non-decreasing inside each region (rings | Livox lines): last line of the region with start <= p.
-    // The lanes hold consecutive p: one ballot search for the first lane, then every lane steps forward from there
-    // (0 or 1 steps unless a line is very short).
-    const int p0 = __builtin_amdgcn_readfirstlane(p);
-    const bool velo0 = p0 < P.NV;
-    const int r0 = velo0 ? 0 : P.n_rings, r1 = velo0 ? P.n_rings : P.L;
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int j = lane + 64 * r;
-        cnt += __popcll(__ballot(j >= r0 && j < r1 && t.ls[r] <= p0));
-    }
-    const bool velo = p < P.NV;
-    const int end = velo ? P.n_rings : P.L;
-    line = (velo == velo0) ? r0 + cnt - 1 : P.n_rings;  // a wavefront that straddles NV: its Livox lanes start at their region
-    for (;;) {
-        const int nx = line + 1;
-        const int nxs = line_tab_get(t.ls, nx < P.L ? nx : 0, P.L);
-        const bool adv = nx < end && nxs <= p;
-        if (!__any(adv)) break;
-        if (adv) line = nx;
-    }
-    start = line_tab_get(t.ls, line, P.L);
-    n = line_tab_get(t.ll, line, P.L);
-    i = p - start;
-    return i >= 0 && i < n;
 }
 
 // ---- a3 + every order-independent predicate of a5..a7: one point per lane -----------------------------------
