@@ -6,7 +6,7 @@ against the CPU oracle), over many fresh seeds instead of the few the suite pins
 Sections: `lines` = detectFeaturePoints on randomised scan lines (flags and both index lists bit for bit);
 `scans` = whole fused scans with dirt (NaN, rings out of range, near / far crops, truncation) through mml_extract,
 then undistort with a random sweep motion and the voxel down-sample; `poses` = association + Estimate from random
-pose perturbations; `cubes` = random trajectories through the global cube store; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `batch` (--batch N) = N rounds of 96 slots of fresh random scans -- ideal grid with dirt and sensor-faithful streams -- through the large-batch kernels and mml_step; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
+pose perturbations; `cubes` = random trajectories through the global cube store; `dense` = other ring layouts / scans beyond 64 k points / labelled clouds beyond the LDS sort; `solves` = factor records of random associations and the lidar-only window solve; `maps` = random walks of key scans through the local-map upkeep; `batch` (--batch N) = N rounds of 96 slots of fresh random scans -- ideal grid with dirt and sensor-faithful streams -- through the large-batch kernels and mml_step; `dense-batch` (--dense-batch N) = N rounds of 24 slots of random 64 / 128-ring scans through the dense layout's batch kernels; `windows` = the full-window (IMU factors, prior) trust-region loop on the device against the host
 loop on random window sizes, missing factors, iteration limits.  Prints one line per section and exits non-zero at the first mismatch (the offending seed / trial
 is printed so that it can be replayed)."""
 import argparse
@@ -143,6 +143,82 @@ def batch_section(args, M, O, synth, rng):
     return 0
 
 
+def dense_batch_section(args, M, O, synth, rng):
+    """Dense ring layouts in batches of 24 slots -- the dense layout's batch kernels: pass A on 1024-point blocks, k_assign_b,
+    k_assign_c_staged (2048-point tiles dealt to the XCDs slot by slot), k_stencil<0> / batch k_select_part over 70 / 134 lines,
+    the chunked label pass, the batch undistortion and both down-sampler forms -- on 6 fresh random scans per round (64 or 128
+    rings, 512 .. 2048 azimuths, noise levels, NaN / (0,0,0) runs, near / far crops, truncations, with and without a Livox part),
+    every slot against the oracle: extraction fields bit for bit, undistorted points within 1 ulp, both stacks byte for byte."""
+    from scipy.spatial.transform import Rotation as Rsc
+    B, ND = 24, 6
+    t0 = time.time()
+    npts = 0
+    for rnd in range(args.dense_batch):
+        n_rings = int(rng.choice([64, 128]))
+        n_az = int(rng.choice([512, 1024, 1536, 2048] if n_rings == 64 else [512, 1024, 2048]))
+        pitch0 = float(rng.choice([-15.5, -25.0, -16.0]))
+        step = np.float32((abs(pitch0) * 2 + rng.uniform(-1, 3)) / (n_rings - 1))
+        far = float(rng.choice([50.0, 1000.0]))
+        kw = dict(n_rings=n_rings, pitch0=pitch0, pitch_step=step)
+        cases = []
+        for j in range(ND):
+            v = synth.velo_scan(int(rng.integers(0, 3000)), n_rings=n_rings, n_az=n_az, pitch0=pitch0, pitch_step=step,
+                                noise=float(rng.choice([0.0, 0.002, 0.01]))).copy()
+            l = synth.livox_scan(int(rng.integers(0, 3000))).copy() if rng.integers(0, 2) else None
+            if l is None:
+                v, _ = random_dirt(rng, v, synth.livox_scan(0).copy())
+            else:
+                v, l = random_dirt(rng, v, l)
+            r = int(rng.integers(0, 6))
+            if r == 0:
+                v = v[:int(rng.integers(n_rings, len(v)))]          # a sweep cut short (the last blocks / tiles are partial)
+            elif r == 1:
+                v = v[::int(rng.integers(2, 5))]                    # every 2nd .. 4th record: firings with missing rings
+            elif r == 2:
+                v[:, :3] *= float(rng.choice([0.3, 6.0]))           # mostly inside the near crop / beyond 50 m
+            cases.append((v, l))
+        cfgd = M.default_config(B, n_rings=n_rings, pitch0_deg=pitch0, pitch_step_deg=step, far_th=far, max_velo_points=n_rings * n_az,
+                                max_livox_points=24000, max_features=1 << 18)
+        cd = M.Context(cfgd)
+        ora = []
+        for v, l in cases:
+            parts = [O.extract_velo(v, far=far, **kw)] + ([O.extract_livox(l, far=far)] if l is not None else [])
+            ora.append({key: np.concatenate([e[key] for e in parts]) for key in ("xyzi", "label", "reltime", "ring")})
+        perm = rng.permutation(B) % ND
+        for s in range(B):
+            cd.scan_upload(s, cases[perm[s]][0], cases[perm[s]][1])
+        cd.extract(0, B)
+        for s in range(B):
+            d, o = cd.scan_download(s), ora[perm[s]]
+            if not (d["info"].n_points == len(o["xyzi"]) and all(np.array_equal(d[key], o[key]) for key in o)):
+                print("DENSE BATCH EXTRACT MISMATCH seed %d round %d slot %d (scan %d) rings %d az %d pitch0 %g step %g far %g"
+                      % (args.seed, rnd, s, perm[s], n_rings, n_az, pitch0, step, far))
+                np.save("gpurun_out/fuzz_dense_batch_seed%d_round%d_v.npy" % (args.seed, rnd), cases[perm[s]][0])
+                return 1
+        dR = [Rsc.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix() for _ in range(ND)]
+        dt = [rng.normal(0, 0.05, 3) for _ in range(ND)]
+        cd.undistort(0, B, np.stack([dR[perm[s]].reshape(9) for s in range(B)]), np.stack([dt[perm[s]] for s in range(B)]))
+        cd.downsample(0, B)
+        exp = []
+        for j in range(ND):
+            ou = O.undistort(ora[j]["xyzi"][:, :3], ora[j]["reltime"], dR[j], dt[j])
+            exp.append(ou)
+        for s in range(B):
+            j = perm[s]
+            und = cd.scan_download(s)["xyzi"][:, :3]
+            ulp = np.abs(und.view(np.int32).astype(np.int64) - exp[j].view(np.int32).astype(np.int64))
+            ok = (ulp.max(initial=0) <= 1 and np.array_equal(cd.features_download(s, 0), O.voxel_downsample(und[ora[j]["label"] == 1], 0.4))
+                  and np.array_equal(cd.features_download(s, 1), O.voxel_downsample(und[ora[j]["label"] == 2], 0.2)))
+            if not ok:
+                print("DENSE BATCH UNDISTORT / VOXEL MISMATCH seed %d round %d slot %d rings %d az %d far %g ulp %d"
+                      % (args.seed, rnd, s, n_rings, n_az, far, ulp.max(initial=0)))
+                return 1
+            npts += len(und)
+        cd.close()
+    print("dense-batch: %d rounds x %d slots ok (%d points) %.0f s" % (args.dense_batch, B, npts, time.time() - t0), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
@@ -155,7 +231,8 @@ def main():
     ap.add_argument("--dense", type=int, default=2)
     ap.add_argument("--cubes", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="rounds of the large-batch section (96 slots each)")
-    ap.add_argument("--only-batch", action="store_true", help="run the batch section alone")
+    ap.add_argument("--only-batch", action="store_true", help="run the batch section(s) alone")
+    ap.add_argument("--dense-batch", type=int, default=0, help="rounds of the dense-layout batch section (24 slots of 64 / 128-ring scans each)")
     args = ap.parse_args()
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
@@ -167,8 +244,14 @@ def main():
     rng = np.random.default_rng(args.seed)
     if args.batch > 0:
         rc = batch_section(args, M, O, synth, rng)
-        if rc or args.only_batch:
+        if rc:
             return rc
+    if args.dense_batch > 0:
+        rc = dense_batch_section(args, M, O, synth, rng)
+        if rc:
+            return rc
+    if args.only_batch:
+        return 0
     ctx = M.Context(max_scans=4)
     t0 = time.time()
 
