@@ -73,15 +73,18 @@ STAGE_BYTES = {
 
 # BASELINE.json configs[i] -> shapes.  slots = resident scan slots per GPU; scans_per_step = the batch one step processes
 # (the resident slots are passed over scans_per_step / slots times: every pass recomputes everything from the raw points).
+# The slots are sized for the 288 GB of the device (61 GB at configs[1], ~180 GB at the dense layouts): one mml_step call per pass,
+# i.e. one host synchronisation and one ramp-up / drain of the four stream lanes per 8192 (4096) scans -- 2048 / 1024 / 512 slots
+# measured 345 k / 71.0 k / 66.7 k scans/s where these sizes give 353 k / 75.6 k / 76.7 k on the same boxes.
 CONFIGS = {
     1: dict(name="BASELINE configs[1]: fused VLP-16 16x1800 + Livox Horizon 24000 scan (52800 pts)", n_rings=16, n_az=1800,
-            pitch0=-15.0, pitch_step=2.0, livox=24000, map_points=200000, gn_iters=10, slots=2048, scans_per_step=32768,
+            pitch0=-15.0, pitch_step=2.0, livox=24000, map_points=200000, gn_iters=10, slots=8192, scans_per_step=32768,
             max_features=0, distinct=64),
     3: dict(name="BASELINE configs[3]: 128-ring x 2048 dense scan (262144 pts)", n_rings=128, n_az=2048, pitch0=-25.0,
-            pitch_step=40.0 / 127.0, livox=0, map_points=2000000, gn_iters=10, slots=1024, scans_per_step=5120,
+            pitch_step=40.0 / 127.0, livox=0, map_points=2000000, gn_iters=10, slots=4096, scans_per_step=8192,
             max_features=1 << 16, distinct=8),
     4: dict(name="BASELINE configs[4]: 240k-pt fused scan (128 x 1687 + Livox 24000)", n_rings=128, n_az=1687, pitch0=-25.0,
-            pitch_step=40.0 / 127.0, livox=24000, map_points=10000000, gn_iters=20, slots=512, scans_per_step=5120,
+            pitch_step=40.0 / 127.0, livox=24000, map_points=10000000, gn_iters=20, slots=4096, scans_per_step=8192,
             max_features=1 << 16, distinct=8),
 }
 
@@ -106,6 +109,7 @@ def parse():
     ap.add_argument("--cell-surf", type=float, default=0.0, help="kNN grid cell edge for the surf map (0: library default)")
     ap.add_argument("--replay-scans", type=int, default=240, help="--config 2: scans replayed through the odometry loop")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: CPU plumbing test only)")
+    ap.add_argument("--skip-upload", action="store_true", help="skip the PCIe-inclusive section (counter passes: only launches of one size)")
     ap.add_argument("--stub-step", action="store_true", help="CPU plumbing test: no device, a step is a short sleep")
     return ap.parse_args()
 
@@ -328,6 +332,11 @@ def run_throughput(args, rank, local_rank, world, dist):
     gn_iters = args.gn_iters or cfg["gn_iters"]
     ctx = make_context(M, cfg, B, local_rank, args, map_points)
     dev_name, cus, hbm = ctx.device_info()
+    # stream lanes of mml_step: with passes of 8192 (4096) scans two lanes of 4096 (2048) give the best rate -- 2 / 3 / 4 / 6 lanes:
+    # 360 / 360 / 351 / 340 k scans/s at configs[1], 76.4 / 75.7 k at configs[3] -- (the library's default of 4 is for calls of
+    # ~2000 scans, where 2 .. 4 lanes are equal); $MML_LANES overrides
+    n_lanes = int(os.environ.get("MML_LANES", "0")) or 2
+    ctx.set_lanes(n_lanes)
 
     # ---- synthetic inputs (same on every rank except the seed offset) ---------------------------------------
     base = 100 + 1000 * rank
@@ -392,7 +401,7 @@ def run_throughput(args, rank, local_rank, world, dist):
         ctx.step(0, KB, dR[:KB], dt[:KB], exTlb, 25.0, gn_iters, x0[:KB])
     prof = ctx.profile_get()
     ctx.profile_enable(False)
-    ctx.set_lanes(4)
+    ctx.set_lanes(n_lanes)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -467,7 +476,11 @@ def run_throughput(args, rank, local_rank, world, dist):
     # one pass with every scan of the batch copied in from pinned host memory in front of the step (serial: upload, then
     # compute); never `value`
     with_upload = None
+    B_all = B
     try:
+        if args.skip_upload:
+            raise RuntimeError("skipped (--skip-upload)")
+        B = min(B_all, 2048)  # (this section on at most 2048 slots: its pinned staging arrays are slots x scan size)
         ps = [(pinned(v), pinned(l)) for v, l in scans]
         ctx.synchronize()
         t1 = time.perf_counter()
@@ -476,10 +489,10 @@ def run_throughput(args, rank, local_rank, world, dist):
         ctx.synchronize()
         t_up = time.perf_counter() - t1
         t1 = time.perf_counter()
-        ctx.step(0, B, dR, dt, exTlb, 25.0, gn_iters, x0)
+        ctx.step(0, B, dR[:B], dt[:B], exTlb, 25.0, gn_iters, x0[:B])
         t_st = time.perf_counter() - t1
         up_bytes = sum(scans[s % nd][0].nbytes + scans[s % nd][1].nbytes for s in range(B))
-        with_upload = {"scans_per_s": B / (t_up + t_st) * world, "upload_GBps": up_bytes / t_up / 1e9,
+        with_upload = {"slots": B, "scans_per_s": B / (t_up + t_st) * world, "upload_GBps": up_bytes / t_up / 1e9,
                        "upload_ms_per_scan": t_up / B * 1e3, "note": "uploads (pinned host memory, one hipMemcpyAsync per "
                        "sensor per scan) serialised in front of the step; with uploads overlapped the bound is min(upload, compute)"}
         # the same batch staged in two slot-strided pinned arrays and copied with mml_scan_upload_batch (two copies in all)
@@ -520,6 +533,7 @@ def run_throughput(args, rank, local_rank, world, dist):
                                                  "under mml_step of the other; every scan crosses PCIe once per step"}
     except Exception as e:
         with_upload = {"error": repr(e)[:200]}
+    B = B_all
 
     # ---- joint window solve across ranks through the C-ABI: one frame per GPU, ncclAllGather of the
     # 32-double normal-equation record per evaluation, the dogleg state machine resident on every device.  Outside the
@@ -615,7 +629,7 @@ def run_throughput(args, rank, local_rank, world, dist):
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
             "config": {"workload": "%s, local map %d pts, 1 association pass (thres_dist 25), %d GN iterations, W=1"
                                    % (cfg["name"], map_points, gn_iters),
-                       "scans_per_step_per_gpu": batch, "resident_slots": B, "passes_per_step": passes, "distinct_scans": nd,
+                       "scans_per_step_per_gpu": batch, "resident_slots": B, "passes_per_step": passes, "stream_lanes": n_lanes, "distinct_scans": nd,
                        "map_tiles_touched": len(tiles), "parallelism": "scan-sharded x%d" % world,
                        "device": dev_name, "cus": cus, "features_per_scan": nf / KB, "points_per_scan": (n_v + n_l) / KB,
                        "algorithmic_bytes_per_scan": bytes_per_scan, "max_pose_err_vs_gt_m_tile0": gt_err,

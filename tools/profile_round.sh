@@ -13,18 +13,23 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 export MML_LIB_SHA16=$(sha256sum multi-modal-loam_amd/libmmloam_hip.so | cut -c1-16)
 ARGS="--steps 4 --warmup 1 --cpu-seconds 0 $*"
+# The counter passes run ONLY launches of 1024 scans on one stream (the launches bench.py times for its roofline object): the
+# summarisers average a kernel's launches of the largest grid, and the kernels with a fixed grid (k_associate, the k_select rows) look
+# the same at every batch size -- mixed with the timed region's per-lane launches their counters would describe no launch at all.
+PMCARGS="--steps 1 --warmup 0 --cpu-seconds 0 --slots 1024 --batch 1024 --skip-upload $*"
+export PMC_LANES=1
 python bench.py $* > $OUT/${TAG}_bench$SUF.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(ls $OUT/trace/*/*.db 2>/dev/null | head -1); [ -z "$DB" ] && DB=$(ls $OUT/trace/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/${TAG}_kernel_stats$SUF.md
 if [ "$SUF" != "_config2" ]; then
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -o s -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- env MML_LANES=$PMC_LANES python bench.py $PMCARGS > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- env MML_LANES=$PMC_LANES python bench.py $PMCARGS > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -o s -- env MML_LANES=$PMC_LANES python bench.py $PMCARGS > /dev/null 2> $OUT/pmc_sq.err
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 S=$(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1)
-KB=$(python -c "import json,sys; print(json.load(open('$OUT/${TAG}_bench$SUF.json'))['roofline']['scans_per_launch'])" 2>/dev/null || echo 1024)
+KB=1024
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W $KB > $OUT/traffic_${TAG%%[a-z]}$SUF.json
 [ -n "$S" ] && python tools/pmc_sq.py $S --json $OUT/sq_${TAG%%[a-z]}$SUF.json $KB > $OUT/${TAG}_sq_counters$SUF.md
 fi
