@@ -669,15 +669,95 @@ def run_replay(args, rank, local_rank, world, dist):
     motions = [synth.sweep_motion(k0 + i) for i in range(n)]
     T_bl = np.eye(4)
 
-    def perturbed(T, dt_=(0.02, -0.015, 0.01), rv=(0.002, -0.001, 0.003)):
+    # Pose conversions of the replay loop, plain numpy on 3 x 3 arrays.  scipy's Rotation.from_matrix costs ~50 us a call (it
+    # orthogonalises through an SVD); the loop converts ten poses per scan, which was a fifth of the per-scan time this harness
+    # reported for the device path it is there to measure.  (Checked against scipy below, once, outside the timed region.)
+    def quat_from_matrix(R):   # (x, y, z, w), Shepperd's method
+        m00, m01, m02, m10, m11, m12, m20, m21, m22 = R[0, 0], R[0, 1], R[0, 2], R[1, 0], R[1, 1], R[1, 2], R[2, 0], R[2, 1], R[2, 2]
+        tr = m00 + m11 + m22
+        if tr > 0.0:
+            r = np.sqrt(1.0 + tr)
+            q = np.array([(m21 - m12) / (2 * r), (m02 - m20) / (2 * r), (m10 - m01) / (2 * r), 0.5 * r])
+        elif m00 >= m11 and m00 >= m22:
+            r = np.sqrt(1.0 + m00 - m11 - m22)
+            q = np.array([0.5 * r, (m01 + m10) / (2 * r), (m02 + m20) / (2 * r), (m21 - m12) / (2 * r)])
+        elif m11 >= m22:
+            r = np.sqrt(1.0 - m00 + m11 - m22)
+            q = np.array([(m01 + m10) / (2 * r), 0.5 * r, (m12 + m21) / (2 * r), (m02 - m20) / (2 * r)])
+        else:
+            r = np.sqrt(1.0 - m00 - m11 + m22)
+            q = np.array([(m02 + m20) / (2 * r), (m12 + m21) / (2 * r), 0.5 * r, (m10 - m01) / (2 * r)])
+        q /= np.sqrt(q @ q)
+        return q if q[3] >= 0 else -q
+
+    def matrix_from_quat(q):
+        x, y, z, w = q / np.sqrt(q @ q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def rotvec_from_matrix(R):
+        q = quat_from_matrix(R)
+        nv = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
+        k = 2.0 if nv < 1e-12 else 2.0 * np.arctan2(nv, q[3]) / nv
+        return k * q[:3]
+
+    def matrix_from_rotvec(v):
+        th = np.sqrt(v @ v)
+        im, re = (0.5, 1.0) if th < 1e-12 else (np.sin(0.5 * th) / th, np.cos(0.5 * th))
+        return matrix_from_quat(np.array([im * v[0], im * v[1], im * v[2], re]))
+
+    def rotvec_from_quat(q):
+        nv = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
+        w = q[3] if q[3] >= 0 else -q[3]
+        sg = 1.0 if q[3] >= 0 else -1.0
+        k = 2.0 if nv < 1e-12 else 2.0 * np.arctan2(nv, w) / nv
+        return (sg * k) * np.asarray(q[:3], dtype=np.float64)
+
+    def matrices_from_x(x):    # (W, 6) poses (translation | rotation vector) -> (W, 4, 4), Rodrigues, all frames at once
+        v = x[:, 3:]
+        th = np.sqrt((v * v).sum(1))
+        k = v / np.maximum(th, 1e-300)[:, None]
+        c, sn = np.cos(th), np.sin(th)
+        T = np.zeros((len(x), 4, 4))
+        T[:, :3, :3] = (1 - c)[:, None, None] * k[:, :, None] * k[:, None, :]
+        T[:, 0, 0] += c
+        T[:, 1, 1] += c
+        T[:, 2, 2] += c
+        T[:, 0, 1] -= sn * k[:, 2]
+        T[:, 1, 0] += sn * k[:, 2]
+        T[:, 0, 2] += sn * k[:, 1]
+        T[:, 2, 0] -= sn * k[:, 1]
+        T[:, 1, 2] -= sn * k[:, 0]
+        T[:, 2, 1] += sn * k[:, 0]
+        T[:, :3, 3] = x[:, :3]
+        T[:, 3, 3] = 1.0
+        return T
+
+    _rng = np.random.default_rng(5)
+    _xs = np.concatenate([_rng.normal(0, 3, (16, 3)), _rng.normal(0, 1.2, (16, 3))], axis=1)
+    _xs[0, 3:] = 0.0
+    assert np.abs(matrices_from_x(_xs)[:, :3, :3] - Rsc.from_rotvec(_xs[:, 3:]).as_matrix()).max() < 1e-12
+    for _ in range(64):
+        _R = Rsc.from_rotvec(_rng.normal(0, 1.5, 3)).as_matrix()
+        assert np.abs(rotvec_from_matrix(_R) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
+        assert np.abs(matrix_from_rotvec(rotvec_from_matrix(_R)) - _R).max() < 1e-12
+        _q = Rsc.from_matrix(_R).as_quat()
+        assert min(np.abs(quat_from_matrix(_R) - _q).max(), np.abs(quat_from_matrix(_R) + _q).max()) < 1e-12
+        assert np.abs(matrix_from_quat(_q) - _R).max() < 1e-12
+        assert np.abs(rotvec_from_quat(_q) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
+        assert np.abs(rotvec_from_quat(-_q) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
+    R_PERT = Rsc.from_rotvec((0.002, -0.001, 0.003)).as_matrix()
+
+    def perturbed(T, dt_=(0.02, -0.015, 0.01)):
         T2 = T.copy()
-        T2[:3, :3] = T[:3, :3] @ Rsc.from_rotvec(rv).as_matrix()
+        T2[:3, :3] = T[:3, :3] @ R_PERT
         T2[:3, 3] = T[:3, 3] + np.asarray(dt_)
         return T2
 
     def replay(timed):
         odo = odometry.LidarOdometry(ctx, lidar_mode=2)
-        poses = {}
+        poses_x = np.zeros((W, 6))   # the window's poses as (translation | rotation vector), the form the solver takes and returns
         lat, lat_win = [], []
         T_prev = T_prev_gt = None
         worst_gt = 0.0
@@ -692,23 +772,17 @@ def run_replay(args, rank, local_rank, world, dist):
             ctx.scan_upload(slot, scans[i][0], scans[i][1])
             ctx.extract(slot, 1)
             ctx.undistort(slot, 1, motions[i][0].reshape(1, 9), motions[i][1].reshape(1, 3))
-            P, Q, grew = odo.estimate_lidar_pose(slot, Tp[:3, 3], Rsc.from_matrix(Tp[:3, :3]).as_quat())
-            T = np.eye(4)
-            T[:3, :3] = Rsc.from_quat(Q).as_matrix()
-            T[:3, 3] = P
-            poses[slot] = T
+            P, Q, grew = odo.estimate_lidar_pose(slot, Tp[:3, 3], quat_from_matrix(Tp[:3, :3]))
+            poses_x[slot, :3] = P
+            poses_x[slot, 3:] = rotvec_from_quat(np.asarray(Q, dtype=np.float64))
             t2 = time.perf_counter()
             if i + 1 >= W and odo.n_surf_local > 100:
                 # the 8-scan sliding window: every frame re-associated at its current pose (thres_dist 1, full-window
                 # weights, Estimator.cpp:1203-1204) and solved jointly on the device
-                Tw = np.stack([poses[s] for s in range(W)])
-                ctx.associate(0, W, Tw, 1.0, stats=False)      # enqueue only: the joint solve follows on the same stream
-                xw = np.stack([np.concatenate([Tw[s][:3, 3], Rsc.from_matrix(Tw[s][:3, :3]).as_rotvec()]) for s in range(W)])
-                xs, _, _ = ctx.solve(0, W, xw, T_bl, window=W, max_iters=10, huber=0.0, w_tan=3e-4)
-                for s in range(W):
-                    poses[s][:3, :3] = Rsc.from_rotvec(xs[s][3:]).as_matrix()
-                    poses[s][:3, 3] = xs[s][:3]
-                T = poses[slot]
+                ctx.associate(0, W, matrices_from_x(poses_x), 1.0, stats=False)  # enqueue only: the joint solve follows on the same stream
+                xs, _, _ = ctx.solve(0, W, poses_x, T_bl, window=W, max_iters=10, huber=0.0, w_tan=3e-4)
+                poses_x[:] = xs
+            T = matrices_from_x(poses_x[slot:slot + 1])[0]
             t3 = time.perf_counter()
             lat.append((t3 - t1) * 1e3)
             lat_win.append((t3 - t2) * 1e3)

@@ -474,7 +474,7 @@ int mml_fullwindow_marginalize(const mml_fullwindow*, const double* lidar_record
 int mml_fullwindow_solve(mml_ctx* ctx, mml_fullwindow* fw, int first_slot, const double* T_bl, double* x,
                          mml_solve_summary* summary, int* evaluations);
 
-/* Number of HIP streams mml_step pipelines its sub-batches over (1..4, default 4 or $MML_LANES).  With 1 every
+/* Number of HIP streams mml_step pipelines its sub-batches over (1..8, default 2 or $MML_LANES).  With 1 every
  * kernel covers the whole batch and runs alone on the device, which is what per-kernel timing wants. */
 int mml_set_lanes(mml_ctx* ctx, int lanes);
 int mml_profile_enable(mml_ctx* ctx, int on);

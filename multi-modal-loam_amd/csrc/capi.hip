@@ -145,7 +145,9 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-    ctx->n_lanes = 4;
+    // (two lanes: with calls of ~2000 scans two to four lanes give the same rate, with 8192 two give 360 k scans/s against 351 k for
+    //  four, and a call of a few hundred scans splits into launches that still fill the device)
+    ctx->n_lanes = 2;
     if (const char* e_l = getenv("MML_LANES")) {  // tuning knob: number of stream lanes mml_step pipelines over
         int v = atoi(e_l);
         if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;

@@ -996,10 +996,13 @@ __global__ __launch_bounds__(128) void k_associate_fit_all(AssocParams P) {
 // one LANE per feature -- inside this kernel it would run on one lane in sixteen.
 // round 0: every queued feature, continuing after ring 1 of the stage it was queued in.
 // round 1: the features whose cube-stage fit failed (HARD_REDO), local map from ring 0 (:283 / :702).
+// SPAN = lanes that share one query (they split the rows of every shell): 16 for batches -- many queries, throughput --, 64 for
+// the live path's handful of scans, where the kernel lasts as long as its slowest query and a far query walks up to 169 rows a shell.
+template <int SPAN>
 __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round) {
-    const int gl = threadIdx.x & 15;
-    const int group = (blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int ngroups = (gridDim.x * 256) >> 4;
+    const int gl = threadIdx.x & (SPAN - 1);
+    const int group = (blockIdx.x * 256 + threadIdx.x) / SPAN;
+    const int ngroups = (gridDim.x * 256) / SPAN;
     const int total = *P.hard_count;
     for (int w0 = 0; w0 < total; w0 += ngroups) {
         const int w = w0 + group;
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
             }
         }
         const int r0 = (round == 0 && !fresh) ? 2 : 0;
-        const float start_d5 = __shfl(knn_d(loc, 4), (threadIdx.x & 63) & ~15);  // the group's lane 0 (INFINITY unless round 0)
+        const float start_d5 = __shfl(knn_d(loc, 4), (threadIdx.x & 63) & ~(SPAN - 1));  // the group's lane 0 (INFINITY unless round 0)
         // the entry's grid descriptor, selected field by field into registers once (a reference to one of four kernel
         // argument structs picked per lane is re-read from memory at every use)
         MmlGrid g = P.g[0];
@@ -1064,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
         bool sdone = !live;
         if (!sdone && r0 > rmax) {
             sdone = true;
-            lanes_merge5<16>(loc, best);
+            lanes_merge5<SPAN>(loc, best);
         }
         for (int r = r0;; ++r) {
             if (!sdone && r > rmax) sdone = true;
@@ -1076,10 +1079,10 @@ __global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round
                 const int ylo = max(q.hy - r, 0), yhi = min(q.hy + r, g.dim[1] - 1), zlo = max(q.hz - r, 0), zhi = min(q.hz + r, g.dim[2] - 1);
                 const int wy = yhi - ylo + 1, wz = zhi - zlo + 1;
                 if (wy > 0 && wz > 0)
-                    for (int t = gl; t < wy * wz; t += 16)
+                    for (int t = gl; t < wy * wz; t += SPAN)
                         scan_shell_row(g, q, r, ylo + (t % wy), zlo + (t / wy), loc, mytag, fminf(fminf(knn_d(best, 4), knn_d(loc, 4)), start_d5));
             }
-            lanes_merge5<16>(loc, best);
+            lanes_merge5<SPAN>(loc, best);
             if (!sdone && knn_done(g, q.inset, r, knn_d(best, 4), P.thres)) sdone = true;
         }
         if (live && gl == 0) {
@@ -1451,10 +1454,21 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     }
     {
         MmlStageScope t(ctx, "associate_far");
-        hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, 0);
+        // (a whole / half a wavefront per query while all queries of the call -- every feature of up to 4 / 8 scans -- are resident
+        //  at once: 2048 workgroups hold 8192 / 16384 of them)
+        const int span = !P.fresh_all ? 16 : (count <= 4 ? 64 : 32);
+        auto launch_hard = [&](int round) {
+            if (span == 64)
+                hipLaunchKernelGGL(k_associate_hard<64>, dim3(2048), dim3(256), 0, MML_STREAM(ctx), P, round);
+            else if (span == 32)
+                hipLaunchKernelGGL(k_associate_hard<32>, dim3(2048), dim3(256), 0, MML_STREAM(ctx), P, round);
+            else
+                hipLaunchKernelGGL(k_associate_hard<16>, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, round);
+        };
+        launch_hard(0);
         hipLaunchKernelGGL(k_associate_fit, dim3(512), dim3(128), 0, MML_STREAM(ctx), P, 0);
         if (ctx->have_gmap[0] || ctx->have_gmap[1]) {  // features whose cube neighbourhood did not yield a model
-            hipLaunchKernelGGL(k_associate_hard, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, 1);
+            launch_hard(1);
             hipLaunchKernelGGL(k_associate_fit, dim3(512), dim3(128), 0, MML_STREAM(ctx), P, 1);
         }
     }

@@ -51,7 +51,7 @@ def random_dirt(rng, v, l):
 
 def batch_section(args, M, O, synth, rng):
     """Large batches -- the kernels bench.py runs: k_stencil<0>, batch k_select_part + k_select_list, k_voxel<256> / <1024>, the
-    lane-per-feature search, mml_step on 4 stream lanes -- on 96 slots of 24 fresh random scans per round: ideal-grid scans with
+    lane-per-feature search, mml_step on 4 / 1 / 2 stream lanes by turns -- on 96 slots of 24 fresh random scans per round: ideal-grid scans with
     dirt and truncations, sensor-faithful scans (firing order, quantised ranges, NaN / (0,0,0) / absent no-returns, rosette,
     tag bits, stray lines), with and without intra-sweep motion, lines made ragged by hand.  Everything mml_step leaves behind
     against the oracle pipeline of every slot."""
@@ -106,8 +106,7 @@ def batch_section(args, M, O, synth, rng):
         dR = np.stack([cases[perm[s]]["dR"].reshape(9) for s in range(B)])
         dt = np.stack([cases[perm[s]]["dt"] for s in range(B)])
         x0 = np.stack([cases[perm[s]]["x0"] for s in range(B)])
-        if rnd % 2:
-            c.set_lanes(1)
+        c.set_lanes((4, 1, 2)[rnd % 3])                     # mml_step on four, one, two (the default) stream lanes by turns
         c.extract(0, B)
         for s in range(B):
             d, o = c.scan_download(s), ora[perm[s]]
@@ -121,7 +120,6 @@ def batch_section(args, M, O, synth, rng):
                 return 1
             redo += c.extract_queue_counts(s)[0]
         x = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
-        c.set_lanes(4)
         for s in range(B):
             d, o = c.scan_download(s), ora[perm[s]]
             gl, glsrc = c.factors_download(s, 0)

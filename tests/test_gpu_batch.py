@@ -5,7 +5,7 @@ Batch size routes the path to different kernels in five places (DESIGN.md sectio
   * count > 16  -> batch k_select_part<u64/u128> grid + k_select_list + list-mode k_select   instead of direct k_select
   * count > 16  -> k_voxel<256> for the corner lists + k_voxel<1024> for the surf lists      instead of one k_voxel<1024>
   * count > 8   -> lane-per-feature k_associate search                   instead of the <= 8-slot group search
-  * count >= 64 -> mml_step pipelines 4 sub-batches over 4 stream lanes  instead of one stream
+  * count >= 64 -> mml_step pipelines sub-batches over stream lanes (set to 4 here; the library's default is 2) instead of one stream
 Every test below is sized so that EACH lane's sub-batch is still > 16 slots, and compares what those kernels leave
 behind with the oracle's restatement of unionFeatureExtract.cpp:341-844,952-1035,1113-1317, unionPoseEstimation.cpp:402-421,
 Estimator.cpp:148-365,573-777,992-1026 and the solver restatement: labels / rings / times / coordinates / stacks bit for
@@ -73,6 +73,7 @@ def test_batch96_default_layout_matches_oracle(M, O, synth, scene):
         for s in range(B):
             _check_extraction(c.scan_download(s), ora[s % 12])
         # (2) the fused step, 4 lanes and 1 lane
+        c.set_lanes(4)
         dR = np.stack([cases[s % 12]["dR"].reshape(9) for s in range(B)])
         dt = np.stack([cases[s % 12]["dt"] for s in range(B)])
         x0 = np.stack([cases[s % 12]["x0"] for s in range(B)])
@@ -179,6 +180,7 @@ def test_full_size_step_properties(M, O, scene, synth):
     ora = [oracle_pipeline(O, cs, tc, ts) for cs in cases]
     c = M.Context(max_scans=B, max_map_points=200000)
     try:
+        c.set_lanes(4)
         c.map_set_local(0, cm)
         c.map_set_local(1, sm)
         for s in range(B):

@@ -65,6 +65,7 @@ def test_batch72_sensor_faithful_scans_match_oracle(M, O, synth):
     assert sum(len(o["xyzi"]) for o in ora) > 1_000_000
     c = M.Context(max_scans=B, max_velo_points=NV, max_livox_points=24000)
     try:
+        c.set_lanes(4)
         c.map_set_local(0, cm)
         c.map_set_local(1, sm)
         for s in range(B):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One measurement round on the GPU box: bench line, kernel trace and the three PMC passes of the same bench command,
+# One measurement round on the GPU box: kernel trace of the bench command, three PMC passes over its 1024-scan launches, then the bench line itself,
 # summarised into gpurun_out/prof_<tag>/ (copy what is to be judged into profiles/).
 #   bash tools/profile_round.sh r03a             -> configs[1] (the driver's line)
 #   bash tools/profile_round.sh r03a --config 3  -> files carry the suffix _config3
@@ -18,7 +18,6 @@ ARGS="--steps 4 --warmup 1 --cpu-seconds 0 $*"
 # the same at every batch size -- mixed with the timed region's per-lane launches their counters would describe no launch at all.
 PMCARGS="--steps 1 --warmup 0 --cpu-seconds 0 --slots 1024 --batch 1024 --skip-upload $*"
 export PMC_LANES=1
-python bench.py $* > $OUT/${TAG}_bench$SUF.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(ls $OUT/trace/*/*.db 2>/dev/null | head -1); [ -z "$DB" ] && DB=$(ls $OUT/trace/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/${TAG}_kernel_stats$SUF.md
@@ -34,4 +33,8 @@ KB=1024
 [ -n "$S" ] && python tools/pmc_sq.py $S --json $OUT/sq_${TAG%%[a-z]}$SUF.json $KB > $OUT/${TAG}_sq_counters$SUF.md
 fi
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+# the bench line last, against the counter files just taken (copied into profiles/ of this checkout: the line then carries their
+# traffic and instruction counts as current, not stale)
+for f in $OUT/traffic_*.json $OUT/sq_*.json; do [ -s "$f" ] && cp $f profiles/; done
+python bench.py $* > $OUT/${TAG}_bench$SUF.json 2> $OUT/bench.err
 ls -la $OUT; tail -c 400 $OUT/${TAG}_bench$SUF.json; echo; head -30 $OUT/${TAG}_kernel_stats$SUF.md | cut -c1-150
