@@ -74,7 +74,7 @@ STAGE_BYTES = {
 # BASELINE.json configs[i] -> shapes.  slots = resident scan slots per GPU; scans_per_step = the batch one step processes
 # (the resident slots are passed over scans_per_step / slots times: every pass recomputes everything from the raw points).
 # The slots are sized for the 288 GB of the device (61 GB at configs[1], ~180 GB at the dense layouts): one mml_step call per pass,
-# i.e. one host synchronisation and one ramp-up / drain of the four stream lanes per 8192 (4096) scans -- 2048 / 1024 / 512 slots
+# i.e. one host synchronisation and one ramp-up / drain of the two stream lanes per 8192 (4096) scans -- 2048 / 1024 / 512 slots
 # measured 345 k / 71.0 k / 66.7 k scans/s where these sizes give 353 k / 75.6 k / 76.7 k on the same boxes.
 CONFIGS = {
     1: dict(name="BASELINE configs[1]: fused VLP-16 16x1800 + Livox Horizon 24000 scan (52800 pts)", n_rings=16, n_az=1800,
@@ -111,6 +111,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: CPU plumbing test only)")
     ap.add_argument("--skip-upload", action="store_true", help="skip the PCIe-inclusive section (counter passes: only launches of one size)")
     ap.add_argument("--stub-step", action="store_true", help="CPU plumbing test: no device, a step is a short sleep")
+    ap.add_argument("--strict", action="store_true", help="exit non-zero when any section of the run reported an error (the JSON line's "
+                    "\"errors\" list is not empty); tools/profile_round.sh passes it")
     return ap.parse_args()
 
 
@@ -207,6 +209,29 @@ def rccl_report(M):
         return r
     except Exception as e:
         return {"error": repr(e)[:200]}
+
+
+def replica_check(digests, x, keys):
+    """Groups of slots with equal `keys` (same scan, same map tile, same initial pose) must have equal digest rows and equal
+    poses.  Returns the JSON object of the bench line."""
+    groups = {}
+    for s, k in enumerate(keys):
+        groups.setdefault(k, []).append(s)
+    mism, examples, replicated = 0, [], 0
+    for k, slots in groups.items():
+        f = slots[0]
+        replicated += len(slots) - 1
+        for s in slots[1:]:
+            bad = [int(w) for w in np.nonzero(digests[s] != digests[f])[0]]
+            if bad or not np.array_equal(x[s], x[f]):
+                mism += 1
+                if len(examples) < 8:
+                    examples.append({"slot": int(s), "first_slot_of_group": int(f), "digest_words": bad})
+    out = {"slots": int(len(keys)), "groups": len(groups), "replica_slots_compared": int(replicated), "digest_words": int(digests.shape[1]),
+           "mismatches": int(mism)}
+    if examples:
+        out["examples"] = examples
+    return out
 
 
 def make_scan(synth, cfg, k, motion=True):
@@ -333,10 +358,11 @@ def run_throughput(args, rank, local_rank, world, dist):
     ctx = make_context(M, cfg, B, local_rank, args, map_points)
     dev_name, cus, hbm = ctx.device_info()
     # stream lanes of mml_step: with passes of 8192 (4096) scans two lanes of 4096 (2048) give the best rate -- 2 / 3 / 4 / 6 lanes:
-    # 360 / 360 / 351 / 340 k scans/s at configs[1], 76.4 / 75.7 k at configs[3] -- (the library's default of 4 is for calls of
-    # ~2000 scans, where 2 .. 4 lanes are equal); $MML_LANES overrides
+    # 360 / 360 / 351 / 340 k scans/s at configs[1], 76.4 / 75.7 k at configs[3] -- which is the library's default (capi.hip:
+    # n_lanes = 2), so without $MML_LANES the bench runs the library as it comes and never calls mml_set_lanes before the timed region
     n_lanes = int(os.environ.get("MML_LANES", "0")) or 2
-    ctx.set_lanes(n_lanes)
+    if "MML_LANES" in os.environ:
+        ctx.set_lanes(n_lanes)
 
     # ---- synthetic inputs (same on every rank except the seed offset) ---------------------------------------
     base = 100 + 1000 * rank
@@ -388,11 +414,20 @@ def run_throughput(args, rank, local_rank, world, dist):
         x = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # Per-kernel durations for the roofline object: the timed region overlaps sub-batches on 4 streams, so kernel
+    errors = []
+    # ---- replica check (outside the timed region): slots that were given the same scan on the same map tile with the same initial
+    # pose must hold bit-identical results -- labels, rings, undistorted cloud, times, both stacks, both factor lists, pose
+    # (mml_slot_digest, ten words per slot) -- at the launch shapes of the timed region.  tests/test_gpu_shapes.py ties the
+    # first slot of such a group to the oracle; here the equality is checked on the run that is being reported.
+    dg_timed = ctx.slot_digest(0, B)
+    replica = replica_check(dg_timed, x, [(s % nd, (s // nd) % len(tiles)) for s in range(B)])
+    if replica["mismatches"]:
+        raise RuntimeError("bench: replica check failed: %s" % json.dumps(replica))
+    # Per-kernel durations for the roofline object: the timed region overlaps sub-batches on the stream lanes, so kernel
     # time there is shared between concurrent kernels.  The same step is therefore repeated on ONE stream (every
     # kernel covers the whole batch and owns the device) with HIP events around each stage on that stream; these
     # are the launches of grid size `KB scans` in the rocprofv3 summary under profiles/ (KB = min(B, 1024): distinct,
-    # in that summary, from the timed region's per-lane launches of B / 4 scans).
+    # in that summary, from the timed region's per-lane launches of B / lanes scans).
     KB = min(B, 1024)
     ctx.set_lanes(1)
     ctx.profile_enable(True)
@@ -401,6 +436,12 @@ def run_throughput(args, rank, local_rank, world, dist):
         ctx.step(0, KB, dR[:KB], dt[:KB], exTlb, 25.0, gn_iters, x0[:KB])
     prof = ctx.profile_get()
     ctx.profile_enable(False)
+    # ... and the one-lane pass over the first KB slots must leave exactly what the timed region's lanes left there
+    dg_one = ctx.slot_digest(0, KB)
+    replica["one_lane_vs_timed_region_slots"] = KB
+    replica["one_lane_vs_timed_region_mismatches"] = int(np.any(dg_one != dg_timed[:KB], axis=1).sum())
+    if replica["one_lane_vs_timed_region_mismatches"]:
+        raise RuntimeError("bench: the single-lane pass differs from the timed region: %s" % json.dumps(replica))
     ctx.set_lanes(n_lanes)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -431,7 +472,7 @@ def run_throughput(args, rank, local_rank, world, dist):
     # (both files carry the hash of the library they were measured on; numbers from another build are reported as stale)
     lib_sha = lib_sha16(M)
     traffic, traffic_file, traffic_stale = None, None, None
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         tr_file = os.path.join(ROOT, "profiles", "traffic_%s%s.json" % (tag, suffix))
         if os.path.exists(tr_file):
             try:
@@ -447,7 +488,7 @@ def run_throughput(args, rank, local_rank, world, dist):
     # CUs x 4 SIMDs x clock / 4 wave-instructions per second (6.14e11 at 256 CUs, 2.4 GHz); the fraction of that peak the
     # dominant stage reaches says how much of its time is instruction issue -- for such a kernel THIS is the roof, not HBM.
     issue = None
-    sq_file = next((f for f in (os.path.join(ROOT, "profiles", "sq_%s%s.json" % (tag, suffix)) for tag in ("r04", "r03"))
+    sq_file = next((f for f in (os.path.join(ROOT, "profiles", "sq_%s%s.json" % (tag, suffix)) for tag in ("r05", "r04", "r03"))
                     if os.path.exists(f)), None)
     if sq_file is not None:
         try:
@@ -460,14 +501,34 @@ def run_throughput(args, rank, local_rank, world, dist):
                          "source": os.path.relpath(sq_file, ROOT), "stale": sq.get("lib_sha16") != lib_sha}
         except Exception:
             issue = None
+    # counter traffic / algorithmic bytes for every stage the counter file has (the file is per KB scans): wasted re-reads show here
+    traffic_ratio = None
+    if traffic_file is not None:
+        try:
+            tr = json.load(open(os.path.join(ROOT, traffic_file)))
+            scale = KB / float(tr.get("scans_per_launch", KB))
+            traffic_ratio = {"stale": traffic_stale}
+            tot_t = tot_a = 0.0
+            for st in stage_ms:
+                ab = STAGE_BYTES.get(st, lambda *a: 0)(n_v, n_l, nf, gn_iters)
+                if tr.get(st) is not None:
+                    tot_t += tr[st] * scale
+                    tot_a += ab
+                    if ab > 0:
+                        traffic_ratio[st] = tr[st] * scale / ab
+            traffic_ratio["step"] = tot_t / tot_a if tot_a > 0 else None
+            traffic_ratio["step_traffic_bytes_per_launch"] = tot_t
+        except Exception as e:
+            errors.append("traffic_ratio: " + repr(e)[:200])
     hbm_frac = achieved / HBM_PEAK_GBPS
     # (a stale instruction count -- taken on another build of the library -- does not decide the bound)
     bound = "valu-issue" if issue is not None and not issue["stale"] and issue["frac"] > max(hbm_frac, 0.5) else "hbm"
     # the practical HBM roof of THIS box: a device-to-device copy (read + write counted), next to the 8 TB/s of the data sheet
     try:
         copy_gbps = float(ctx.copy_bandwidth(1 << 30, 10))
-    except Exception:
+    except Exception as e:
         copy_gbps = None
+        errors.append("copy_bandwidth: " + repr(e)[:200])
     bytes_per_scan = 48 * (n_v + n_l) / KB + 112 * nf / KB + 72 * nf / KB * gn_iters
     total_scans = world * batch * args.steps
     value = total_scans / elapsed
@@ -533,6 +594,8 @@ def run_throughput(args, rank, local_rank, world, dist):
                                                  "under mml_step of the other; every scan crosses PCIe once per step"}
     except Exception as e:
         with_upload = {"error": repr(e)[:200]}
+        if not args.skip_upload:
+            errors.append("value_with_upload: " + repr(e)[:200])
     B = B_all
 
     # ---- joint window solve across ranks through the C-ABI: one frame per GPU, ncclAllGather of the
@@ -569,9 +632,9 @@ def run_throughput(args, rank, local_rank, world, dist):
                 res = ctx.window_solve_allgather(0, 1, xm[None], np.eye(4), max_iters=gn_iters, fixed=False, huber=0.0, w_tan=3e-4)
                 lat.append(res[3].device_ms)
             xl, xw, sm, tim = res
-            chk = torch.from_numpy(xw.reshape(-1).copy()).to("cuda")
             agree = True
             if dist is not None:
+                chk = torch.from_numpy(xw.reshape(-1).copy()).to("cuda")
                 ref = chk.clone()
                 dist.broadcast(ref, src=0)
                 ag = torch.tensor([1.0 if torch.equal(ref, chk) else 0.0], device="cuda")
@@ -608,6 +671,8 @@ def run_throughput(args, rank, local_rank, world, dist):
             window, window_timed_out = {"error": "window section timed out after 180 s"}, True
         else:
             window = box.get("window")
+        if isinstance(window, dict) and "error" in window:
+            errors.append("window_solve: " + str(window["error"])[:200])
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) ----------------------------------
     cpu = None
@@ -620,6 +685,8 @@ def run_throughput(args, rank, local_rank, world, dist):
             cpu = cpu_baseline_cpp(ctx, cfg, scans, dR, dt, xs, corner_map, surf_map, gn_iters, 25.0, args.cpu_seconds, xg)
         except Exception as e:
             cpu = {"error": repr(e)[:300]}
+        if isinstance(cpu, dict) and "error" in cpu:
+            errors.append("cpu_baseline: " + str(cpu["error"])[:200])
 
     if rank == 0:
         out = {
@@ -643,13 +710,116 @@ def run_throughput(args, rank, local_rank, world, dist):
                          "avg_launch_ms": stage_ms[dom], "algorithmic_bytes_per_launch": alg_bytes,
                          "scans_per_launch": KB, "timing": "HIP events, %d single-stream steps after the timed region" % args.kernel_steps,
                          "whole_path_frac": bytes_per_scan * value / world / 1e9 / HBM_PEAK_GBPS,
-                         "stage_ms_per_launch": stage_ms},
+                         "stage_ms_per_launch": stage_ms, "traffic_ratio": traffic_ratio},
             "cpu_baseline": cpu,
             "window_solve": window,
             "rccl": rccl_report(M),
+            "replica_check": replica,
+            "errors": errors,
         }
-        return json.dumps(out), window_timed_out
-    return None, window_timed_out
+        return json.dumps(out), window_timed_out, errors
+    return None, window_timed_out, errors
+
+
+# ---- pose conversions of the replay loop (module level: tests/test_host.py exercises them without a device) -------------
+# Plain numpy on 3 x 3 arrays.  scipy's Rotation.from_matrix costs ~50 us a call (it
+# orthogonalises through an SVD); the loop converts ten poses per scan, which was a fifth of the per-scan time this harness
+# reported for the device path it is there to measure.  (Checked against scipy below, once, outside the timed region.)
+def quat_from_matrix(R):   # (x, y, z, w), Shepperd's method
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = R[0, 0], R[0, 1], R[0, 2], R[1, 0], R[1, 1], R[1, 2], R[2, 0], R[2, 1], R[2, 2]
+    tr = m00 + m11 + m22
+    if tr > 0.0:
+        r = np.sqrt(1.0 + tr)
+        q = np.array([(m21 - m12) / (2 * r), (m02 - m20) / (2 * r), (m10 - m01) / (2 * r), 0.5 * r])
+    elif m00 >= m11 and m00 >= m22:
+        r = np.sqrt(1.0 + m00 - m11 - m22)
+        q = np.array([0.5 * r, (m01 + m10) / (2 * r), (m02 + m20) / (2 * r), (m21 - m12) / (2 * r)])
+    elif m11 >= m22:
+        r = np.sqrt(1.0 - m00 + m11 - m22)
+        q = np.array([(m01 + m10) / (2 * r), 0.5 * r, (m12 + m21) / (2 * r), (m02 - m20) / (2 * r)])
+    else:
+        r = np.sqrt(1.0 - m00 - m11 + m22)
+        q = np.array([(m02 + m20) / (2 * r), (m12 + m21) / (2 * r), 0.5 * r, (m10 - m01) / (2 * r)])
+    q /= np.sqrt(q @ q)
+    return q if q[3] >= 0 else -q
+
+
+def matrix_from_quat(q):
+    x, y, z, w = q / np.sqrt(q @ q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def rotvec_from_matrix(R):
+    q = quat_from_matrix(R)
+    nv = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
+    k = 2.0 if nv < 1e-12 else 2.0 * np.arctan2(nv, q[3]) / nv
+    return k * q[:3]
+
+
+def matrix_from_rotvec(v):
+    th = np.sqrt(v @ v)
+    im, re = (0.5, 1.0) if th < 1e-12 else (np.sin(0.5 * th) / th, np.cos(0.5 * th))
+    return matrix_from_quat(np.array([im * v[0], im * v[1], im * v[2], re]))
+
+
+def rotvec_from_quat(q):
+    nv = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
+    w = q[3] if q[3] >= 0 else -q[3]
+    sg = 1.0 if q[3] >= 0 else -1.0
+    k = 2.0 if nv < 1e-12 else 2.0 * np.arctan2(nv, w) / nv
+    return (sg * k) * np.asarray(q[:3], dtype=np.float64)
+
+
+def matrices_from_x(x):    # (W, 6) poses (translation | rotation vector) -> (W, 4, 4), Rodrigues, all frames at once
+    v = x[:, 3:]
+    th = np.sqrt((v * v).sum(1))
+    k = v / np.maximum(th, 1e-300)[:, None]
+    c, sn = np.cos(th), np.sin(th)
+    T = np.zeros((len(x), 4, 4))
+    T[:, :3, :3] = (1 - c)[:, None, None] * k[:, :, None] * k[:, None, :]
+    T[:, 0, 0] += c
+    T[:, 1, 1] += c
+    T[:, 2, 2] += c
+    T[:, 0, 1] -= sn * k[:, 2]
+    T[:, 1, 0] += sn * k[:, 2]
+    T[:, 0, 2] += sn * k[:, 1]
+    T[:, 2, 0] -= sn * k[:, 1]
+    T[:, 1, 2] -= sn * k[:, 0]
+    T[:, 2, 1] += sn * k[:, 0]
+    T[:, :3, 3] = x[:, :3]
+    T[:, 3, 3] = 1.0
+    return T
+
+
+def pose_helpers_selfcheck():
+    """The plain-numpy conversions against scipy (run once per replay, outside the timed region; also tests/test_host.py)."""
+    from scipy.spatial.transform import Rotation as Rsc
+    _rng = np.random.default_rng(5)
+    _xs = np.concatenate([_rng.normal(0, 3, (16, 3)), _rng.normal(0, 1.2, (16, 3))], axis=1)
+    _xs[0, 3:] = 0.0
+    assert np.abs(matrices_from_x(_xs)[:, :3, :3] - Rsc.from_rotvec(_xs[:, 3:]).as_matrix()).max() < 1e-12
+    for _ in range(64):
+        _R = Rsc.from_rotvec(_rng.normal(0, 1.5, 3)).as_matrix()
+        assert np.abs(rotvec_from_matrix(_R) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
+        assert np.abs(matrix_from_rotvec(rotvec_from_matrix(_R)) - _R).max() < 1e-12
+        _q = Rsc.from_matrix(_R).as_quat()
+        assert min(np.abs(quat_from_matrix(_R) - _q).max(), np.abs(quat_from_matrix(_R) + _q).max()) < 1e-12
+        assert np.abs(matrix_from_quat(_q) - _R).max() < 1e-12
+        assert np.abs(rotvec_from_quat(_q) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
+        assert np.abs(rotvec_from_quat(-_q) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
+
+
+R_PERT = matrix_from_rotvec(np.array((0.002, -0.001, 0.003)))   # the IMU-sized rotation error of the replay's predictions
+
+
+def perturbed(T, dt_=(0.02, -0.015, 0.01), rv=None):
+    """T with a translation error dt_ added and a rotation error exp(rv) (default: R_PERT) multiplied on the right."""
+    T2 = T.copy()
+    T2[:3, :3] = T[:3, :3] @ (R_PERT if rv is None else matrix_from_rotvec(np.asarray(rv, dtype=np.float64)))
+    T2[:3, 3] = T[:3, 3] + np.asarray(dt_)
+    return T2
 
 
 # ---- configs[2]: replay through the whole odometry loop ----------------------------------------------------------------
@@ -669,91 +839,7 @@ def run_replay(args, rank, local_rank, world, dist):
     motions = [synth.sweep_motion(k0 + i) for i in range(n)]
     T_bl = np.eye(4)
 
-    # Pose conversions of the replay loop, plain numpy on 3 x 3 arrays.  scipy's Rotation.from_matrix costs ~50 us a call (it
-    # orthogonalises through an SVD); the loop converts ten poses per scan, which was a fifth of the per-scan time this harness
-    # reported for the device path it is there to measure.  (Checked against scipy below, once, outside the timed region.)
-    def quat_from_matrix(R):   # (x, y, z, w), Shepperd's method
-        m00, m01, m02, m10, m11, m12, m20, m21, m22 = R[0, 0], R[0, 1], R[0, 2], R[1, 0], R[1, 1], R[1, 2], R[2, 0], R[2, 1], R[2, 2]
-        tr = m00 + m11 + m22
-        if tr > 0.0:
-            r = np.sqrt(1.0 + tr)
-            q = np.array([(m21 - m12) / (2 * r), (m02 - m20) / (2 * r), (m10 - m01) / (2 * r), 0.5 * r])
-        elif m00 >= m11 and m00 >= m22:
-            r = np.sqrt(1.0 + m00 - m11 - m22)
-            q = np.array([0.5 * r, (m01 + m10) / (2 * r), (m02 + m20) / (2 * r), (m21 - m12) / (2 * r)])
-        elif m11 >= m22:
-            r = np.sqrt(1.0 - m00 + m11 - m22)
-            q = np.array([(m01 + m10) / (2 * r), 0.5 * r, (m12 + m21) / (2 * r), (m02 - m20) / (2 * r)])
-        else:
-            r = np.sqrt(1.0 - m00 - m11 + m22)
-            q = np.array([(m02 + m20) / (2 * r), (m12 + m21) / (2 * r), 0.5 * r, (m10 - m01) / (2 * r)])
-        q /= np.sqrt(q @ q)
-        return q if q[3] >= 0 else -q
-
-    def matrix_from_quat(q):
-        x, y, z, w = q / np.sqrt(q @ q)
-        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
-
-    def rotvec_from_matrix(R):
-        q = quat_from_matrix(R)
-        nv = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
-        k = 2.0 if nv < 1e-12 else 2.0 * np.arctan2(nv, q[3]) / nv
-        return k * q[:3]
-
-    def matrix_from_rotvec(v):
-        th = np.sqrt(v @ v)
-        im, re = (0.5, 1.0) if th < 1e-12 else (np.sin(0.5 * th) / th, np.cos(0.5 * th))
-        return matrix_from_quat(np.array([im * v[0], im * v[1], im * v[2], re]))
-
-    def rotvec_from_quat(q):
-        nv = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
-        w = q[3] if q[3] >= 0 else -q[3]
-        sg = 1.0 if q[3] >= 0 else -1.0
-        k = 2.0 if nv < 1e-12 else 2.0 * np.arctan2(nv, w) / nv
-        return (sg * k) * np.asarray(q[:3], dtype=np.float64)
-
-    def matrices_from_x(x):    # (W, 6) poses (translation | rotation vector) -> (W, 4, 4), Rodrigues, all frames at once
-        v = x[:, 3:]
-        th = np.sqrt((v * v).sum(1))
-        k = v / np.maximum(th, 1e-300)[:, None]
-        c, sn = np.cos(th), np.sin(th)
-        T = np.zeros((len(x), 4, 4))
-        T[:, :3, :3] = (1 - c)[:, None, None] * k[:, :, None] * k[:, None, :]
-        T[:, 0, 0] += c
-        T[:, 1, 1] += c
-        T[:, 2, 2] += c
-        T[:, 0, 1] -= sn * k[:, 2]
-        T[:, 1, 0] += sn * k[:, 2]
-        T[:, 0, 2] += sn * k[:, 1]
-        T[:, 2, 0] -= sn * k[:, 1]
-        T[:, 1, 2] -= sn * k[:, 0]
-        T[:, 2, 1] += sn * k[:, 0]
-        T[:, :3, 3] = x[:, :3]
-        T[:, 3, 3] = 1.0
-        return T
-
-    _rng = np.random.default_rng(5)
-    _xs = np.concatenate([_rng.normal(0, 3, (16, 3)), _rng.normal(0, 1.2, (16, 3))], axis=1)
-    _xs[0, 3:] = 0.0
-    assert np.abs(matrices_from_x(_xs)[:, :3, :3] - Rsc.from_rotvec(_xs[:, 3:]).as_matrix()).max() < 1e-12
-    for _ in range(64):
-        _R = Rsc.from_rotvec(_rng.normal(0, 1.5, 3)).as_matrix()
-        assert np.abs(rotvec_from_matrix(_R) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
-        assert np.abs(matrix_from_rotvec(rotvec_from_matrix(_R)) - _R).max() < 1e-12
-        _q = Rsc.from_matrix(_R).as_quat()
-        assert min(np.abs(quat_from_matrix(_R) - _q).max(), np.abs(quat_from_matrix(_R) + _q).max()) < 1e-12
-        assert np.abs(matrix_from_quat(_q) - _R).max() < 1e-12
-        assert np.abs(rotvec_from_quat(_q) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
-        assert np.abs(rotvec_from_quat(-_q) - Rsc.from_matrix(_R).as_rotvec()).max() < 1e-12
-    R_PERT = Rsc.from_rotvec((0.002, -0.001, 0.003)).as_matrix()
-
-    def perturbed(T, dt_=(0.02, -0.015, 0.01)):
-        T2 = T.copy()
-        T2[:3, :3] = T[:3, :3] @ R_PERT
-        T2[:3, 3] = T[:3, 3] + np.asarray(dt_)
-        return T2
+    pose_helpers_selfcheck()
 
     def replay(timed):
         odo = odometry.LidarOdometry(ctx, lidar_mode=2)
@@ -830,6 +916,7 @@ def run_replay(args, rank, local_rank, world, dist):
     # are linearised on the device in one launch per trust-region evaluation and the dense iteration runs on the host
     # (mml_fullwindow_step); "device": the whole iteration is one kernel launch per ceres::Solve (mml_fullwindow_solve)
     fullwin = {}
+    errors = []
     for solver, Wf in (("host", 5), ("device", 5), ("host", 8), ("device", 8)):
         try:
             west = odometry.WindowEstimator(ctx, gravity=synth.GRAVITY, solver=solver)
@@ -874,6 +961,7 @@ def run_replay(args, rank, local_rank, world, dist):
                                                         solve_device_ms_per_evaluation=float(k_ms[0]) / max(evals, 1))
         except Exception as e:
             fullwin["%s_w%d" % (solver, Wf)] = {"error": repr(e)[:200]}
+            errors.append("full_window_imu %s_w%d: %s" % (solver, Wf, repr(e)[:200]))
 
     # stage times of the same B = 1 step (HIP events)
     ctx.profile_enable(True)
@@ -935,6 +1023,7 @@ def run_replay(args, rank, local_rank, world, dist):
                              % (done, os.cpu_count())}
         except Exception as e:
             cpu = {"error": repr(e)[:300]}
+            errors.append("cpu_baseline: " + repr(e)[:200])
     # <<< cpu_baseline leg
 
     if rank == 0:
@@ -960,9 +1049,10 @@ def run_replay(args, rank, local_rank, world, dist):
                          "note": "one scan per launch cannot fill 256 CUs: this mode is bound by launch latency and the serial "
                                  "dependency chain, not by HBM"},
             "cpu_baseline": cpu,
+            "errors": errors,
         }
-        return json.dumps(out)
-    return None
+        return json.dumps(out), errors
+    return None, errors
 
 
 def main():
@@ -984,7 +1074,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    line, stuck = None, False
+    line, stuck, errors = None, False, []
     try:
         if args.stub_step:
             run_stub(args, rank, world, dist)
@@ -992,9 +1082,9 @@ def main():
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
             if args.config == 2:
-                line = run_replay(args, rank, local_rank, world, dist)
+                line, errors = run_replay(args, rank, local_rank, world, dist)
             else:
-                line, stuck = run_throughput(args, rank, local_rank, world, dist)
+                line, stuck, errors = run_throughput(args, rank, local_rank, world, dist)
     finally:
         if dist is not None and not stuck:   # (a rank stuck in a collective cannot be torn down cleanly: just leave)
             dist.destroy_process_group()
@@ -1008,8 +1098,12 @@ def main():
         except Exception:
             pass
         print(line, flush=True)
+    if errors and rank == 0:
+        print("bench.py: %d section(s) reported an error: %s" % (len(errors), "; ".join(errors)), file=sys.stderr, flush=True)
     if stuck:
-        os._exit(0)
+        os._exit(3 if (args.strict and errors) else 0)
+    if args.strict and errors:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

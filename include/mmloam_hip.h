@@ -410,6 +410,26 @@ int mml_window_solve_allgather_loopback(mml_ctx** ctxs, int n_ranks, const int* 
 int mml_comm_broadcast_features_loopback(mml_ctx** ctxs, int n_ranks, int slot, int root);
 int mml_comm_broadcast_local_map_loopback(mml_ctx** ctxs, int n_ranks, int root);
 
+/* ---- verification hook: digests of the per-slot state -------------------------------------------------------------------
+ * One 64-bit digest per slot for each piece of state the path leaves behind, computed on the device from what the download
+ * entry points would hand out (so a digest can be recomputed on the host from mml_scan_download / mml_features_download /
+ * mml_factors_download output: tests/conftest.py host_digest), for checks over batches too large to download slot by slot --
+ * e.g. "every slot that was given the same scan holds the same result" at the benchmark's launch shapes.  Every word is a
+ * sum over the elements e of the piece of  mix(mix(index(e)) ^ field bits ...)  (splitmix64 finaliser), i.e. independent of
+ * the order the elements are stored or visited in.  out: count x MML_DIGEST_WORDS.  Pieces (what they are in the reference):
+ *   0 counts       n_points, n_velo, the four union_cloud.msg *_num (union_cloud.msg:4-19), both stack sizes
+ *   1 label        normal_z of every fused point, keyed by its index in [velo_combine ; livox_combine]
+ *                  (unionFeatureExtract.cpp:1016-1032,1233-1252)
+ *   2 line         normal_y (ring / Livox line, :1186, :997)
+ *   3 xyzi         x, y, z, intensity -- after mml_undistort the output of RemoveLidarDistortion (unionPoseEstimation.cpp:402-421)
+ *   4 reltime      normal_x
+ *   5 / 6          corner / surf stack after pcl::VoxelGrid (Estimator.cpp:1015-1024), keyed by position in the stack
+ *   7 / 8          line / plane factor records as mml_factors_download returns them (Estimator.h:59-122), keyed by src
+ *   9 pose         the 6 doubles of the slot's pose after the last solve (Estimator.cpp:937-964 para_PR)
+ * Synchronous. */
+#define MML_DIGEST_WORDS 10
+int mml_slot_digest(mml_ctx* ctx, int first_slot, int count, uint64_t* out);
+
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the ctx stream. */
 #define MML_MAX_STAGES 32

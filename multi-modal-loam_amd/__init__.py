@@ -11,6 +11,7 @@ Import with importlib.import_module("multi-modal-loam_amd") (the directory name 
 """
 import ctypes as C
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -22,6 +23,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmloam_hip.h")
 MML_OK, MML_ERR_INVALID, MML_ERR_NO_DEVICE, MML_ERR_HIP, MML_ERR_CAPACITY, MML_ERR_STATE = 0, -1, -2, -3, -4, -5
 NEQ_RECORD_DOUBLES = 32
 MAX_STAGES = 32
+DIGEST_WORDS = 10
 
 LIVOX_DTYPE = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
                         ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1"), ("_pad", "u1")])
@@ -156,7 +158,8 @@ def rccl_libraries():
     try:
         for line in open("/proc/self/maps"):
             f = line.split()
-            if len(f) >= 6 and "librccl" in f[5] and f[5] not in paths:
+            # the library itself, not what it loads: RCCL dlopens net plugins (librccl-net.so, librccl-net-ofi.so ...) during init
+            if len(f) >= 6 and f[5] not in paths and re.fullmatch(r"librccl\.so(\.\d+)*", os.path.basename(f[5])):
                 paths.append(f[5])
     except OSError:
         pass
@@ -597,6 +600,13 @@ class Context:
         mem = C.c_size_t(0)
         self._ck(lib().mml_device_info(self._h, name, C.c_int(256), C.byref(cus), C.byref(mem)))
         return name.value.decode(), cus.value, mem.value
+
+    def slot_digest(self, first, count):
+        """(count, DIGEST_WORDS) uint64: one digest per slot and piece of state (mml_slot_digest; recomputable on the host from
+        the download entry points, see `host_digest`)."""
+        out = np.zeros((count, DIGEST_WORDS), np.uint64)
+        self._ck(lib().mml_slot_digest(self._h, C.c_int(first), C.c_int(count), _p(out)))
+        return out
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         g = C.c_double(0)

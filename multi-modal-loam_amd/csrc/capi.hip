@@ -459,6 +459,132 @@ __global__ void k_fused_arrays(FusedView V, int n, float4* xyzi, float* rel, uin
     line[g] = (uint8_t)ln;
     label[g] = V.label[pos];
 }
+// ---- mml_slot_digest: order-independent 64-bit digests of what the download entry points would hand out -----------------------
+__host__ __device__ __forceinline__ unsigned long long dg_mix(unsigned long long z) {  // splitmix64 finaliser
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ULL;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return z;
+}
+__host__ __device__ __forceinline__ unsigned long long dg_key(unsigned long long i, unsigned tag) {
+    return dg_mix(i * 0x9E3779B97F4A7C15ULL + tag);
+}
+__device__ __forceinline__ unsigned long long dg_pair(float a, float b) {
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+}
+__device__ __forceinline__ unsigned long long dg_dbits(double d) { return (unsigned long long)__double_as_longlong(d); }
+// sum over the workgroup, one atomic per wavefront
+__device__ __forceinline__ void dg_commit(unsigned long long v, unsigned long long* dst) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = (unsigned long long)__shfl_down(lo, o) | ((unsigned long long)__shfl_down(hi, o) << 32);
+        v += t;
+        lo = (unsigned)v;
+        hi = (unsigned)(v >> 32);
+    }
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+struct DigestArgs {
+    const float4* pts;
+    const int* gidx;
+    const int* rel;
+    const uint8_t* line;
+    const uint8_t* label;
+    const int* cb_n;
+    const int* seg_flat;
+    const int* seg_flat_n;
+    const int* slot_flags;
+    const int* fu_info;
+    const int* ft_n;
+    const float4* ft[2];
+    const MmlLineFactor* lf;
+    const MmlPlaneFactor* pf;
+    const double* x;
+    int B, NV, NT, L, MF, n_rings, first;
+};
+// pieces 1-4: the fused cloud, one storage position per thread (blockIdx.y = slot of the call)
+__global__ void __launch_bounds__(256) k_digest_cloud(DigestArgs A, unsigned long long* out) {
+    const int slot = A.first + blockIdx.y;
+    FusedView V;
+    const size_t off = (size_t)slot * A.NT;
+    V.pts = A.pts + off;
+    V.gidx = A.gidx + off;
+    V.rel = A.rel + off;
+    V.line = A.line + off;
+    V.label = A.label + off;
+    V.cb_n = A.cb_n + 2 * (size_t)slot;
+    V.seg_flat = A.seg_flat + (size_t)slot * 2 * MML_SEG_FLAT;
+    V.seg_flat_n = A.seg_flat_n + (size_t)slot * 4;
+    V.NV = A.NV;
+    V.NT = A.NT;
+    V.L = A.L;
+    V.n_rings = A.n_rings;
+    V.flags = A.slot_flags[2 * (size_t)slot];
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = 0, ln = 0;
+    float4 p;
+    float r;
+    unsigned long long h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+    if (fused_at(V, pos, g, p, r, ln)) {
+        h1 = dg_mix(dg_key(g, 1) ^ (unsigned long long)V.label[pos]);
+        h2 = dg_mix(dg_key(g, 2) ^ (unsigned long long)(ln & 255));
+        h3 = dg_mix(dg_key(g, 3) ^ dg_pair(p.x, p.y)) + dg_mix(dg_key(g, 4) ^ dg_pair(p.z, p.w));
+        h4 = dg_mix(dg_key(g, 5) ^ (unsigned long long)__float_as_uint(r));
+    }
+    unsigned long long* o = out + (size_t)blockIdx.y * MML_DIGEST_WORDS;
+    dg_commit(h1, o + 1);
+    dg_commit(h2, o + 2);
+    dg_commit(h3, o + 3);
+    dg_commit(h4, o + 4);
+}
+// pieces 0, 5-9: counts, stacks, factor records, pose (one stack entry per thread)
+__global__ void __launch_bounds__(256) k_digest_stacks(DigestArgs A, unsigned long long* out) {
+    const int slot = A.first + blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n0 = A.ft_n[slot], n1 = A.ft_n[A.B + slot];
+    unsigned long long h5 = 0, h6 = 0, h7 = 0, h8 = 0;
+    if (i < n0) {
+        const float4 q = A.ft[0][(size_t)slot * A.MF + i];
+        h5 = dg_mix(dg_key(i, 6) ^ dg_pair(q.x, q.y)) + dg_mix(dg_key(i, 8) ^ (unsigned long long)__float_as_uint(q.z));
+        const MmlLineFactor f = A.lf[(size_t)slot * A.MF + i];
+        if (f.src >= 0) {
+            unsigned long long h = dg_key((unsigned)f.src, 10);
+            for (int c = 0; c < 3; ++c) h = dg_mix(h ^ dg_dbits((double)f.ori[c]));
+            for (int c = 0; c < 3; ++c) h = dg_mix(h ^ dg_dbits((double)f.p1[c]));
+            for (int c = 0; c < 3; ++c) h = dg_mix(h ^ dg_dbits((double)f.p2[c]));
+            h7 = dg_mix(h ^ dg_dbits(f.error));
+        }
+    }
+    if (i < n1) {
+        const float4 q = A.ft[1][(size_t)slot * A.MF + i];
+        h6 = dg_mix(dg_key(i, 7) ^ dg_pair(q.x, q.y)) + dg_mix(dg_key(i, 9) ^ (unsigned long long)__float_as_uint(q.z));
+        const MmlPlaneFactor f = A.pf[(size_t)slot * A.MF + i];
+        if (f.src >= 0) {
+            unsigned long long h = dg_key((unsigned)f.src, 11);
+            for (int c = 0; c < 3; ++c) h = dg_mix(h ^ dg_dbits((double)f.ori[c]));
+            for (int c = 0; c < 3; ++c) h = dg_mix(h ^ dg_dbits(f.proj[c]));
+            for (int c = 0; c < 3; ++c) h = dg_mix(h ^ dg_dbits((double)f.omega[c]));
+            h8 = dg_mix(h ^ dg_dbits(f.error));
+        }
+    }
+    unsigned long long* o = out + (size_t)blockIdx.y * MML_DIGEST_WORDS;
+    dg_commit(h5, o + 5);
+    dg_commit(h6, o + 6);
+    dg_commit(h7, o + 7);
+    dg_commit(h8, o + 8);
+    if (i == 0) {
+        unsigned long long h = dg_key(0, 13);
+        for (int c = 0; c < 6; ++c) h = dg_mix(h ^ (unsigned long long)(unsigned)A.fu_info[8 * (size_t)slot + c]);
+        h = dg_mix(h ^ (unsigned long long)(unsigned)n0);
+        h = dg_mix(h ^ (unsigned long long)(unsigned)n1);
+        o[0] = h;
+        unsigned long long hp = dg_key(0, 12);
+        for (int c = 0; c < 6; ++c) hp = dg_mix(hp ^ dg_dbits(A.x[6 * (size_t)slot + c]));
+        o[9] = hp;
+    }
+}
 int ensure_wire_stage(mml_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->wire_stage_bytes) return MML_OK;
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
@@ -657,6 +783,57 @@ int mml_scan_download(mml_ctx* ctx, int slot, float* xyzi, float* reltime, uint8
     if (line) MML_HIP(hipMemcpyAsync(line, s_line, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     if (label) MML_HIP(hipMemcpyAsync(label, s_label, n, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
     MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+    return MML_OK;
+}
+
+int mml_slot_digest(mml_ctx* ctx, int first_slot, int count, uint64_t* out) {
+    CHECK_SLOTS(first_slot, count);
+    MML_REQUIRE(out != nullptr, MML_ERR_INVALID, "null out");
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    unsigned long long* d = nullptr;
+    const size_t bytes = sizeof(unsigned long long) * MML_DIGEST_WORDS * (size_t)count;
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    hipError_t e = hipMemsetAsync(d, 0, bytes, MML_STREAM(ctx));
+    DigestArgs A;
+    A.pts = ctx->ln_pts;
+    A.gidx = ctx->ln_gidx;
+    A.rel = ctx->ln_rel;
+    A.line = ctx->ln_line;
+    A.label = ctx->ln_label;
+    A.cb_n = ctx->cb_n;
+    A.seg_flat = ctx->seg_flat;
+    A.seg_flat_n = ctx->seg_flat_n;
+    A.slot_flags = ctx->slot_flags;
+    A.fu_info = ctx->fu_info;
+    A.ft_n = ctx->ft_n;
+    A.ft[0] = ctx->ft_xyz[0];
+    A.ft[1] = ctx->ft_xyz[1];
+    A.lf = ctx->lf;
+    A.pf = ctx->pf;
+    A.x = ctx->d_x;
+    A.B = ctx->B;
+    A.NV = ctx->NV;
+    A.NT = ctx->NT;
+    A.L = ctx->L;
+    A.MF = ctx->MF;
+    A.n_rings = ctx->cfg.n_rings;
+    // (gridDim.y is limited to 65535: calls of more slots go in pieces)
+    for (int done = 0; done < count && e == hipSuccess; done += 32768) {
+        const int c = std::min(32768, count - done);
+        A.first = first_slot + done;
+        unsigned long long* o = d + (size_t)done * MML_DIGEST_WORDS;
+        hipLaunchKernelGGL(k_digest_cloud, dim3((ctx->NT + 255) / 256, c), dim3(256), 0, MML_STREAM(ctx), A, o);
+        hipLaunchKernelGGL(k_digest_stacks, dim3((ctx->MF + 255) / 256, c), dim3(256), 0, MML_STREAM(ctx), A, o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, MML_STREAM(ctx));
+    if (e == hipSuccess) e = hipStreamSynchronize(MML_STREAM(ctx));
+    hipFree(d);
+    if (e != hipSuccess) {
+        ctx->err = std::string("mml_slot_digest: ") + hipGetErrorString(e);
+        return MML_ERR_HIP;
+    }
     return MML_OK;
 }
 
@@ -1289,6 +1466,14 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     // The stages are enqueued stage by stage across the lanes (each lane's stream keeps its own order): every lane has
     // its first kernels in its queue within a few tens of microseconds, instead of lane 3 waiting for the host to finish
     // enqueueing the whole chains of lanes 0..2.
+    // Entry points outside mml_step enqueue on stream 0 (mml_scan_upload's copies, a staged mml_extract ...): the other lanes
+    // start behind whatever stream 0 holds at this point.  (Found by running 80 slots on the default two lanes straight
+    // after their uploads: the last slot's copy was still in flight when lane 1 began to bucket it.)
+    if (lanes > 1) {
+        if (hipEventRecord(ctx->lane_mark[0], ctx->streams[0]) != hipSuccess) return MML_ERR_HIP;
+        for (int l = 1; l < lanes; ++l)
+            if (hipStreamWaitEvent(ctx->streams[l], ctx->lane_mark[0], 0) != hipSuccess) return MML_ERR_HIP;
+    }
     auto lane_span = [&](int l, int& f, int& c) {
         f = first_slot + l * chunk;
         c = std::min(chunk, first_slot + count - f);

@@ -417,14 +417,18 @@ class Estimator {
             T[7] = front.P.v[1];
         }
         if (!is_degenerate) {  // :1070-1136
-            const double dx = last_update_pose_[0] - T[3], dy = last_update_pose_[1] - T[7], dz = last_update_pose_[2] - T[11];
+            // Both modes COMPARE with last_velo_update_pose (:1082, :1119); mode 1 WRITES last_hori_update_pose (:1115), which
+            // nothing ever reads: a Horizon-mode estimator that never sees a mode-2 call keeps comparing with (-1, -1, -1) and
+            // grows its map on every scan farther than sqrt(0.5) m from there.  Preserved as it is.
+            const double dx = last_velo_update_pose_[0] - T[3], dy = last_velo_update_pose_[1] - T[7], dz = last_velo_update_pose_[2] - T[11];
             const double d2 = lidarMode == 2 ? (double)(float)(dx * dx + dy * dy + dz * dz) : (dx * dx + dy * dy + dz * dz);
-            if (d2 >= 0.5) {
+            if (d2 >= 0.5 && (lidarMode == 1 || lidarMode == 2)) {
                 check(ctx_.get(), mml_map_increment_local(ctx_.get(), front.slot, T, &n_corner_map_, &n_surf_map_),
                       "MapIncrementLocal");
-                last_update_pose_[0] = T[3];
-                last_update_pose_[1] = T[7];
-                last_update_pose_[2] = T[11];
+                double* last = lidarMode == 2 ? last_velo_update_pose_ : last_hori_update_pose_;
+                last[0] = T[3];
+                last[1] = T[7];
+                last[2] = T[11];
             }
         }
         _fail_detected = is_degenerate;  // :1139
@@ -632,7 +636,8 @@ class Estimator {
     mml_prior prior_;
     bool have_prior_ = false;
     int n_corner_map_ = 0, n_surf_map_ = 0;
-    double last_update_pose_[3] = {-1.0, -1.0, -1.0};  // Estimator.h:339-340
+    double last_velo_update_pose_[3] = {-1.0, -1.0, -1.0};  // Estimator.h:339-340
+    double last_hori_update_pose_[3] = {-1.0, -1.0, -1.0};
     bool _fail_detected = false;
 };
 

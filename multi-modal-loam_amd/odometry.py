@@ -24,7 +24,8 @@ class LidarOdometry:
         self.exPbl = -1.0 * self.exRbl @ self.exTlb[:3, 3]            # :974
         self.lidar_mode = lidar_mode
         self.max_outer, self.inner_iters = max_outer, inner_iters
-        self.last_update_pose = np.array([-1.0, -1.0, -1.0])          # Estimator.h:339-340
+        self.last_velo_update_pose = np.array([-1.0, -1.0, -1.0])     # Estimator.h:339-340
+        self.last_hori_update_pose = np.array([-1.0, -1.0, -1.0])
         self.n_corner_local = 0
         self.n_surf_local = 0
         self.fail_detected = False
@@ -59,11 +60,16 @@ class LidarOdometry:
         grew = False
         if not is_degenerate:                                          # :1070-1136
             cur = T[:3, 3].copy()
-            d = self.last_update_pose - cur
+            # both modes compare with last_velo_update_pose (:1082, :1119); mode 1 writes last_hori_update_pose (:1115), which
+            # nothing reads -- the reference's bookkeeping as it is
+            d = self.last_velo_update_pose - cur
             dis = float(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) if self.lidar_mode == 2 else float(d @ d)
-            if dis >= 0.5:
-                self.n_corner_local, self.n_surf_local = ctx.map_increment_local(slot, T)   # :1125-1130
-                self.last_update_pose = cur
+            if dis >= 0.5 and self.lidar_mode in (1, 2):
+                self.n_corner_local, self.n_surf_local = ctx.map_increment_local(slot, T)   # :1112, :1125-1130
+                if self.lidar_mode == 2:
+                    self.last_velo_update_pose = cur
+                else:
+                    self.last_hori_update_pose = cur
                 self.key_scans += 1
                 grew = True
         self.fail_detected = is_degenerate                              # :1139

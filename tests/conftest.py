@@ -210,3 +210,69 @@ def oracle_pipeline(O, cs, tree_corner, tree_surf, thres=25.0, gn_iters=10, **la
     xo, _, _ = O.solve_window([lf], [pf], cs["x0"][None], np.eye(4), gn_iters, fixed=True)
     o["x"] = xo[0]
     return o
+
+
+# ---- mml_slot_digest recomputed on the host from what the download entry points return (include/mmloam_hip.h) -------------
+_U = np.uint64
+
+
+def _dg_mix(z):
+    z = np.asarray(z, dtype=np.uint64).copy()
+    with np.errstate(over="ignore"):
+        z ^= z >> _U(30)
+        z *= _U(0xbf58476d1ce4e5b9)
+        z ^= z >> _U(27)
+        z *= _U(0x94d049bb133111eb)
+        z ^= z >> _U(31)
+    return z
+
+
+def _dg_key(i, tag):
+    with np.errstate(over="ignore"):
+        return _dg_mix(np.asarray(i, dtype=np.uint64) * _U(0x9E3779B97F4A7C15) + _U(tag))
+
+
+def _dg_pair(a, b):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64) | \
+        (np.ascontiguousarray(b, np.float32).view(np.uint32).astype(np.uint64) << _U(32))
+
+
+def _dg_sum(h):
+    with np.errstate(over="ignore"):
+        return np.uint64(np.sum(np.asarray(h, dtype=np.uint64), dtype=np.uint64))
+
+
+def host_digest(c, slot, x_slot):
+    """The ten words mml_slot_digest computes for `slot`, from mml_scan_download / mml_features_download /
+    mml_factors_download output and the pose mml_step returned for the slot."""
+    d = c.scan_download(slot)
+    i = d["info"]
+    n = len(d["label"])
+    g = np.arange(n, dtype=np.uint64)
+    out = np.zeros(10, np.uint64)
+    cf, sf = c.features_download(slot, 0), c.features_download(slot, 1)
+    h = _dg_key(0, 13)
+    for v in (i.n_points, i.n_velo, i.velo_corner_num, i.velo_surf_num, i.livox_corner_num, i.livox_surf_num, len(cf), len(sf)):
+        h = _dg_mix(h ^ _U(v & 0xffffffff))
+    out[0] = h
+    out[1] = _dg_sum(_dg_mix(_dg_key(g, 1) ^ d["label"].astype(np.uint64)))
+    out[2] = _dg_sum(_dg_mix(_dg_key(g, 2) ^ (d["ring"].astype(np.uint64) & _U(255))))
+    xyzi = d["xyzi"]
+    with np.errstate(over="ignore"):
+        out[3] = _dg_sum(_dg_mix(_dg_key(g, 3) ^ _dg_pair(xyzi[:, 0], xyzi[:, 1])) + _dg_mix(_dg_key(g, 4) ^ _dg_pair(xyzi[:, 2], xyzi[:, 3])))
+        out[4] = _dg_sum(_dg_mix(_dg_key(g, 5) ^ np.ascontiguousarray(d["reltime"], np.float32).view(np.uint32).astype(np.uint64)))
+        for kind, f in ((0, cf), (1, sf)):
+            k = np.arange(len(f), dtype=np.uint64)
+            out[5 + kind] = _dg_sum(_dg_mix(_dg_key(k, 6 + kind) ^ _dg_pair(f[:, 0], f[:, 1])) +
+                                    _dg_mix(_dg_key(k, 8 + kind) ^ np.ascontiguousarray(f[:, 2], np.float32).view(np.uint32).astype(np.uint64)))
+            rec, src = c.factors_download(slot, kind)
+            hh = _dg_key(src.astype(np.uint64), 10 + kind)
+            rec = np.ascontiguousarray(rec, np.float64).reshape(-1, 10)
+            for col in range(10):
+                hh = _dg_mix(hh ^ np.ascontiguousarray(rec[:, col]).view(np.uint64))
+            out[7 + kind] = _dg_sum(hh)
+    hp = _dg_key(0, 12)
+    for v in np.ascontiguousarray(x_slot, np.float64).view(np.uint64):
+        hp = _dg_mix(hp ^ v)
+    out[9] = hp
+    return out

@@ -5,7 +5,8 @@ Batch size routes the path to different kernels in five places (DESIGN.md sectio
   * count > 16  -> batch k_select_part<u64/u128> grid + k_select_list + list-mode k_select   instead of direct k_select
   * count > 16  -> k_voxel<256> for the corner lists + k_voxel<1024> for the surf lists      instead of one k_voxel<1024>
   * count > 8   -> lane-per-feature k_associate search                   instead of the <= 8-slot group search
-  * count >= 64 -> mml_step pipelines sub-batches over stream lanes (set to 4 here; the library's default is 2) instead of one stream
+  * count >= 64 -> mml_step pipelines sub-batches over stream lanes (set to 4 in some tests; test_full_size_step_properties and
+    test_gpu_shapes.py run the library's default of 2) instead of one stream
 Every test below is sized so that EACH lane's sub-batch is still > 16 slots, and compares what those kernels leave
 behind with the oracle's restatement of unionFeatureExtract.cpp:341-844,952-1035,1113-1317, unionPoseEstimation.cpp:402-421,
 Estimator.cpp:148-365,573-777,992-1026 and the solver restatement: labels / rings / times / coordinates / stacks bit for
@@ -164,10 +165,11 @@ def test_batch24_dense_128_ring_layout_matches_oracle(M, O, synth):
 
 
 def test_full_size_step_properties(M, O, scene, synth):
-    """BASELINE configs[1] shape (fused 52.8 k-point scans, 200 k-point map, 10 GN iterations) at batch size 80 -- 4 stream
-    lanes of 20 slots, i.e. the kernels of the bench line (k_stencil<0>, batch k_select_part, k_voxel<256>/<1024>, lane
-    search): deterministic, slot-independent, every slot's labels, stacks, factor records and pose equal to the oracle
-    pipeline, on the 200 k-point tiled map bench.py registers against."""
+    """BASELINE configs[1] shape (fused 52.8 k-point scans, 200 k-point map, 10 GN iterations) at batch size 80 on the
+    library's DEFAULT stream lanes (no set_lanes call: two lanes of 40 slots), i.e. the kernels of the bench line
+    (k_stencil<0>, batch k_select_part, k_voxel<256>/<1024>, lane search): deterministic, slot-independent, every slot's
+    labels, stacks, factor records and pose equal to the oracle pipeline, on the 200 k-point tiled map bench.py registers
+    against."""
     B = 80
     frames = scene["frames"]
     cm = synth.grow_map(scene["corner_map"], 40000, seed=7)
@@ -180,7 +182,6 @@ def test_full_size_step_properties(M, O, scene, synth):
     ora = [oracle_pipeline(O, cs, tc, ts) for cs in cases]
     c = M.Context(max_scans=B, max_map_points=200000)
     try:
-        c.set_lanes(4)
         c.map_set_local(0, cm)
         c.map_set_local(1, sm)
         for s in range(B):

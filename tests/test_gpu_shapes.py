@@ -1,0 +1,85 @@
+"""GPU parity at the LAUNCH SHAPES of the benchmark: thousands of slots per mml_step call on the library's default stream lanes.
+
+The other batch tests (test_gpu_batch.py, test_gpu_sensor.py) put the large-batch kernel variants under the oracle at 72-96 slots;
+bench.py runs 4096 slots per lane.  Code that first executes more than once -- or at all -- beyond a few hundred slots per call:
+  * k_assoc_prefix: the loop over tiles of 1024 (kind, slot) items (map_assoc.hip, 2 * count > 1024)
+  * the fixed-grid work lists of k_associate / k_associate_fit_all (4096 x 128 threads walking > 1 M features), the far-query
+    list k_associate_hard / k_associate_fit walk at that fill
+  * list-mode k_select beyond its 256 / 128 row caps (feature.hip MML_SEL_ROWS_V / _L): thousands of listed lines per launch
+  * gridDim.y = 2048 (two lanes) and 4096 (one lane) in every per-slot grid
+Here: 4096 resident slots of the configs[1] layout (fused 52.8 k-point scans, 200 k-point map), 20 DISTINCT scans -- the twelve of
+batch_cases (clean, motion, dirty, one-sensor, tiny, ragged lines, rough scenes) and eight sensor-faithful ones -- dealt to the
+slots at random.  The oracle runs 20 times, not 4096: every distinct scan's first slot is compared with oracle_pipeline as
+_check_after_step does (labels, undistorted cloud, stacks, factor records, pose), a sample of far slots likewise, and EVERY
+replica must be bit-identical to that first slot in all ten pieces of mml_slot_digest (counts, labels, rings, cloud, times, both
+stacks, both factor lists, pose) -- the digest itself being recomputed on the host from the download entry points for the
+compared slots.  Reference functions at stake: unionFeatureExtract.cpp:453-541 (selection), Estimator.cpp:148-365,573-777
+(association + model fit), :992-1026 (stacks)."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import batch_cases, host_digest, oracle_pipeline
+from test_gpu_batch import _check_after_step
+from test_gpu_sensor import NV, sensor_case
+
+pytestmark = pytest.mark.gpu
+
+PIECES = ("counts", "label", "line", "xyzi", "reltime", "corner stack", "surf stack", "line factors", "plane factors", "pose")
+
+
+def test_bench_launch_shapes_replicas_match_oracle(M, O, synth, scene):
+    B = 4096
+    t0 = time.time()
+    cases = batch_cases(synth)
+    modes = ("skip", "nan", "zero")
+    cases += [sensor_case(synth, 60 + j, modes[j % 3], motion=(j % 4 == 1)) for j in range(8)]
+    ND = len(cases)
+    assert ND == 20
+    cm = synth.grow_map(scene["corner_map"], 40000, seed=7)
+    sm = synth.grow_map(scene["surf_map"], 160000, seed=8)
+    tc, ts = O.KdTree(cm), O.KdTree(sm)
+    ora = [oracle_pipeline(O, cs, tc, ts) for cs in cases]
+    rng = np.random.default_rng(2024)
+    assign = rng.integers(0, ND, B)
+    assign[:ND] = np.arange(ND)              # every scan occurs; its first slot is in [0, ND)
+    assign[B - ND:] = np.arange(ND)[::-1]    # ... and every scan also sits in the last wavefronts' worth of slots
+    c = M.Context(max_scans=B, max_velo_points=NV, max_livox_points=24000, max_map_points=200000)
+    try:
+        c.map_set_local(0, cm)
+        c.map_set_local(1, sm)
+        for s in range(B):
+            cs = cases[assign[s]]
+            c.scan_upload(s, cs["velo"], cs["livox"])
+        dR = np.stack([cases[k]["dR"].reshape(9) for k in assign])
+        dt = np.stack([cases[k]["dt"] for k in assign])
+        x0 = np.stack([cases[k]["x0"] for k in assign])
+        # (1) the library's DEFAULT lanes (no set_lanes call): two lanes of 2048 slots
+        x = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
+        dg = c.slot_digest(0, B)
+        first = np.array([int(np.argmax(assign == k)) for k in range(ND)])
+        mism = []
+        for s in range(B):
+            f = first[assign[s]]
+            if not np.array_equal(dg[s], dg[f]) or not np.array_equal(x[s], x[f]):
+                mism.append((s, int(assign[s]), [PIECES[w] for w in range(10) if dg[s][w] != dg[f][w]]))
+        assert not mism, "replicas differ from the first slot of their scan: %d slots, e.g. %s" % (len(mism), mism[:5])
+        # the first slot of every distinct scan, and 12 replicas spread over the call (incl. the last slot), against the oracle;
+        # the digest of each of them recomputed on the host from the downloads
+        far = sorted(set([B - 1, B // 2 - 1, B // 2, 1023, 1024, 2049] + list(rng.integers(ND, B, 6))))
+        for s in list(first) + far:
+            _check_after_step(c, s, ora[assign[s]], x[s])
+            hd = host_digest(c, s, x[s])
+            assert np.array_equal(hd, dg[s]), (s, [PIECES[w] for w in range(10) if hd[w] != dg[s][w]])
+        # distinct scans have distinct digests (the digest is not blind)
+        for w in (1, 3, 5, 6, 9):
+            assert len(set(int(v) for v in dg[first, w])) >= ND - 2, PIECES[w]
+        # (2) one lane: every per-slot grid at gridDim.y = 4096; same results, slot for slot
+        c.set_lanes(1)
+        x1 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
+        dg1 = c.slot_digest(0, B)
+        assert np.array_equal(x1, x) and np.array_equal(dg1, dg)
+        print("launch shapes: %d slots, %d distinct scans, 0 mismatching replicas, %.1f s" % (B, ND, time.time() - t0))
+    finally:
+        c.close()
