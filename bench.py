@@ -607,6 +607,12 @@ def run_throughput(args, rank, local_rank, world, dist):
         def window_section():
             W = world
             if dist is not None:
+                # every rank takes the same decision before any of them enters ncclCommInitRank: a rank that refused alone
+                # (two RCCL copies mapped, Context.comm_init) would leave the others waiting in the rendezvous
+                two = torch.tensor([1.0 if len(M.rccl_libraries()["loaded"]) > 1 else 0.0], device="cuda")
+                dist.all_reduce(two, op=dist.ReduceOp.MAX)
+                if two.item() > 0:
+                    raise RuntimeError("two RCCL copies are mapped on at least one rank: window section skipped on all ranks")
                 idt = torch.zeros(M.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
                 if rank == 0:
                     idt = torch.frombuffer(bytearray(M.comm_unique_id()), dtype=torch.uint8).to("cuda")

@@ -164,7 +164,8 @@ int mml_gicp_align(mml_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * clouds are the reference's: label-2 points in the order of each sensor's raw cloud (:1024-1031, :1242-1252), the
  * Velodyne one cropped near + far (:1287-1293), the Livox one near only (removeNearPointCloud, :925 -- its labelled points
  * beyond far_th are part of the source although they are not part of the fused cloud).  MML_ERR_STATE when the slot holds
- * an uploaded or already undistorted cloud: the refresh belongs between mml_extract and mml_undistort.  Synchronous. */
+ * an uploaded or already undistorted cloud -- the refresh belongs between mml_extract and mml_undistort -- or when the slot's
+ * raw scan was uploaded again after the extraction (the line ids of the raw records are re-derived from them).  Synchronous. */
 int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, int apply, int* refreshed, mml_gicp_info* info);
 
 /* ---- a1..a8: feature extraction -----------------------------------------------------------------
@@ -506,7 +507,8 @@ int mml_profile_get(mml_ctx* ctx, mml_profile* out);
 int mml_extract_queue_counts(mml_ctx* ctx, int slot, int* redo, int* brk);
 /* Device facts for bench.py: name, CU count, total HBM bytes. */
 int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes);
-/* Device-to-device copy bandwidth probe (GB/s) over `bytes` bytes, `reps` repetitions (practical HBM roof). */
+/* Device-to-device copy bandwidth probe (GB/s, read + write counted) over `bytes` bytes, `reps` repetitions: the better of a
+ * grid-stride 16-byte copy and a non-temporal one with four loads in flight per lane (the practical HBM roof). */
 int mml_copy_bandwidth(mml_ctx* ctx, size_t bytes, int reps, double* gbps);
 
 #ifdef __cplusplus

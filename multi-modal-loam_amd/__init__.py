@@ -148,10 +148,10 @@ def rccl_libraries():
     ROCm copies, by its RUNPATH); a PyTorch wheel ships its own `torch/lib/librccl.so` and `libamdhip64.so` with the same
     SONAMEs.  The dynamic loader identifies a library by SONAME and by file: when torch is imported FIRST, our NEEDED entries
     resolve to its copies and the process holds one HIP runtime and one RCCL; the other way round torch's `librccl.so` request
-    matches neither the name nor the file of the ROCm copy and a second runtime and a second RCCL are mapped (harmless for a
-    single rank -- the two never exchange a pointer -- but two communicator registries on one device are not something to
-    bring to an 8-GPU run).  bench.py imports torch first; Context.comm_init refuses to build a communicator when two copies
-    are mapped.  Returns the paths of every librccl in /proc/self/maps and the version behind the C-ABI's collectives."""
+    matches neither the name nor the file of the ROCm copy and a second runtime and a second RCCL would be mapped.  lib()
+    therefore maps torch's copies itself before loading the library (_share_torch_runtime), so the order of the imports no
+    longer matters; Context.comm_init still refuses to build a communicator of more than one rank when two copies are mapped.
+    Returns the paths of every librccl in /proc/self/maps and the version behind the C-ABI's collectives."""
     v = C.c_int(0)
     lib().mml_rccl_version(C.byref(v))
     paths = []
@@ -166,6 +166,34 @@ def rccl_libraries():
     return dict(loaded=paths, version=v.value)
 
 
+def _share_torch_runtime():
+    """Import-order independence of "one HIP runtime, one RCCL per process" (see rccl_libraries): when a PyTorch wheel with its
+    own `libamdhip64.so` / `librccl.so` is installed, map THOSE files (by path, without importing torch) before
+    libmmloam_hip.so is loaded.  Their SONAMEs are `libamdhip64.so.7` / `librccl.so.1`, so our NEEDED entries then bind to them,
+    and a later `import torch` finds its own files already mapped -- the state "torch imported first" used to give, whichever
+    comes first.  Without torch (a C++ host, a torch-free Python) nothing is preloaded and the ROCm copies are used.
+    $MML_NO_TORCH_RUNTIME=1 switches the preload off."""
+    if os.environ.get("MML_NO_TORCH_RUNTIME") == "1":
+        return []
+    done = []
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return done
+        tl = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libamdhip64.so", "librccl.so"):
+            path = os.path.join(tl, name)
+            if os.path.exists(path):
+                # RTLD_LOCAL: the loader's SONAME / file matching does not depend on symbol visibility, and RCCL's symbols put
+                # into the global scope ahead of torch's own libraries end in a double free at process exit (measured)
+                C.CDLL(path, mode=C.RTLD_LOCAL)
+                done.append(path)
+    except OSError:
+        pass   # an unloadable wheel copy: fall back to the ROCm copies (rccl_libraries() still reports what is mapped)
+    return done
+
+
 def lib():
     """Load libmmloam_hip.so; fails loudly when the HIP extension has not been built."""
     global _lib
@@ -173,6 +201,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MmlError(MML_ERR_STATE, "libmmloam_hip.so is missing: run __graft_entry__.build() "
                                           "(or make -C multi-modal-loam_amd/csrc); there is no CPU fallback")
+        _share_torch_runtime()
         L = C.CDLL(LIB_PATH)
         L.mml_last_error.restype = C.c_char_p
         L.mml_last_error.argtypes = [C.c_void_p]
@@ -540,8 +569,8 @@ class Context:
     def comm_init(self, n_ranks, rank, comm_id):
         r = rccl_libraries()
         if n_ranks > 1 and len(r["loaded"]) > 1:
-            raise MmlError(MML_ERR_STATE, "two RCCL copies are mapped into this process (%s): import torch BEFORE the package so "
-                                          "that both use the same one" % ", ".join(r["loaded"]))
+            raise MmlError(MML_ERR_STATE, "two RCCL copies are mapped into this process (%s): the library and torch.distributed "
+                                          "would each drive their own" % ", ".join(r["loaded"]))
         if len(comm_id) != COMM_ID_BYTES:
             raise ValueError("the communicator id is %d bytes" % COMM_ID_BYTES)
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))

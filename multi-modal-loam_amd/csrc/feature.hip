@@ -1108,14 +1108,22 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
         // lanes 0 .. blk-1: the blocks in front of this one (they were dispatched before it: they are running or done).  Livox:
         // lanes 32 ..: every Velodyne block of the slot -- its kernel has completed on this stream -- for the number of Velodyne
         // points in front of the Livox part of the fused cloud.
+        // The wait is bounded: a producer is a block dispatched BEFORE this one (smaller blockIdx.x of the same (y, z); for the Livox
+        // blocks also every z = 0 block -- grid order is x fastest, then y, then z) that never waits for a later block, so a word
+        // arrives within microseconds.  2^22 polls (seconds) without it mean a garbled n_in / epoch or a dispatcher that does not
+        // keep that order: the kernel then traps -- an error at the next synchronisation -- instead of hanging the device.
         unsigned long long w = 0;
         bool need = lane < blk;
+        unsigned polls = 0;
         while (__any(need)) {
             if (need) {
                 w = __hip_atomic_load(agg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 need = (unsigned)(w >> 39) != epoch;
             }
-            if (__any(need)) __builtin_amdgcn_s_sleep(1);
+            if (__any(need)) {
+                if (++polls > (1u << 22)) __builtin_trap();
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
         int pv = lane < blk ? (int)(w & 0x1fffu) : 0;
         int pk = lane < blk ? (int)((w >> 13) & 0x1fffu) : 0;
@@ -1132,7 +1140,10 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
                     wv = __hip_atomic_load(P.op_agg + (size_t)b * 2 * MML_SEG_MAX + (lane - 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     needv = (unsigned)(wv >> 39) != epoch;
                 }
-                if (__any(needv)) __builtin_amdgcn_s_sleep(1);
+                if (__any(needv)) {
+                    if (++polls > (1u << 22)) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
             if (minev) pk = (int)((wv >> 13) & 0x1fffu);
         }
@@ -3689,6 +3700,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
 }  // namespace
 
 int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) {
+    for (int i = 0; i < count; ++i) ctx->raw_extracted[first + i] = 1;  // (mml_gicp_refresh re-derives line ids from the raw buffers)
     FeatParams P = make_params(ctx, first);
     P.extr = have_extrinsic ? ctx->d_extr : nullptr;
     hipStream_t s = MML_STREAM(ctx);

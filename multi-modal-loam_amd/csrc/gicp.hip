@@ -814,6 +814,10 @@ extern "C" int mml_gicp_refresh(mml_ctx* ctx, int slot, float* extrinsic_inout, 
     // the refresh belongs to the feature node: it aligns the surf clouds of the EXTRACTED scan (raw coordinates, raw order)
     MML_REQUIRE((fl[0] & 3) == 0, MML_ERR_STATE,
                 "mml_gicp_refresh: the slot holds an uploaded or undistorted cloud (call it after mml_extract, before mml_undistort)");
+    // (the one-pass bucketing keeps no per-point line ids; they are re-derived below from the slot's RAW buffers, which must
+    //  therefore still be the ones the extraction read -- not a scan staged early for the next call)
+    MML_REQUIRE(ctx->raw_extracted[slot], MML_ERR_STATE,
+                "mml_gicp_refresh: the slot's raw scan was re-uploaded after mml_extract (or never extracted)");
     if (!(fi[4] > 100)) return MML_OK;  // union_msg.livox_corner_num > 100 (unionFeatureExtract.cpp:302)
     Scratch S;
     bool ok = S.take((void**)&S.src, sizeof(float4) * (size_t)(cb[1] + 1)) && S.take((void**)&S.tgt, sizeof(float4) * (size_t)(cb[0] + 1)) &&

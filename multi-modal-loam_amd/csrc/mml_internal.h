@@ -114,6 +114,7 @@ struct mml_ctx {
     mml_livox_point* livox_in = nullptr;  // B * NL
     int* d_n_in = nullptr;                // B * 2 (velo, livox)
     std::vector<int> h_n_in;
+    std::vector<char> raw_extracted;      // B: 1 while the slot's raw buffers are the ones its extracted state was made from
 
     // per raw point scratch
     uint8_t* raw_line = nullptr;  // B * NT   line id or 255

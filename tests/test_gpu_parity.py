@@ -1340,6 +1340,15 @@ def test_gicp_refresh_on_a_slot(M, O, synth):
             c.undistort(1, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
             with pytest.raises(Exception):
                 c.gicp_refresh(1, T1, apply=True)
+            # ... and so is a slot whose raw scan was uploaded again after the extraction (the next scan staged early): the line
+            # ids of the raw records are re-derived from the raw buffers, which no longer are the extracted ones
+            c.extract(0, 1)
+            c.scan_upload(0, synth.velo_scan(77), synth.livox_scan(77))
+            with pytest.raises(M.MmlError) as ei:
+                c.gicp_refresh(0, np.eye(4), apply=False)
+            assert ei.value.code == M.MML_ERR_STATE
+            c.extract(0, 1)
+            c.gicp_refresh(0, np.eye(4), apply=False)
         finally:
             c.close()
 

@@ -280,3 +280,32 @@ def test_window_solve_two_ranks_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "GLOO_WINDOW_OK" in out.stdout
+
+
+_ORDER_PROBE = r'''
+import importlib, sys
+sys.path.insert(0, sys.argv[1])
+if sys.argv[2] == "torch_first":
+    import torch
+M = importlib.import_module("multi-modal-loam_amd")
+M.lib()
+if sys.argv[2] == "package_first":
+    import torch
+r = M.rccl_libraries()
+hip = sorted(set(l.split()[5] for l in open("/proc/self/maps") if len(l.split()) >= 6 and "libamdhip64" in l.split()[5]))
+print("PROBE", len(r["loaded"]), len(hip), r["version"])
+'''
+
+
+@pytest.mark.parametrize("order", ["torch_first", "package_first"])
+def test_one_hip_runtime_and_one_rccl_whatever_the_import_order(tmp_path, order):
+    """libmmloam_hip.so (RCCL inside the C-ABI) and torch.distributed must drive the SAME RCCL on the SAME HIP runtime; the
+    package maps the PyTorch wheel's copies before its own library whichever is imported first (and the process must still exit
+    cleanly: RCCL's symbols in the global scope ahead of torch's libraries end in a double free at exit)."""
+    script = tmp_path / "probe.py"
+    script.write_text(_ORDER_PROBE)
+    out = subprocess.run([sys.executable, str(script), ROOT, order], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    probe = [ln for ln in out.stdout.splitlines() if ln.startswith("PROBE")][0].split()
+    assert probe[1] == "1" and probe[2] == "1", out.stdout
+    assert int(probe[3]) >= 20000

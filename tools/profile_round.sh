@@ -12,11 +12,11 @@ OUT=gpurun_out/prof_$TAG$SUF
 mkdir -p $OUT
 export TMPDIR=/tmp
 export MML_LIB_SHA16=$(sha256sum multi-modal-loam_amd/libmmloam_hip.so | cut -c1-16)
-ARGS="--steps 4 --warmup 1 --cpu-seconds 0 $*"
+ARGS="--steps 4 --warmup 1 --cpu-seconds 0 --strict $*"
 # The counter passes run ONLY launches of 1024 scans on one stream (the launches bench.py times for its roofline object): the
 # summarisers average a kernel's launches of the largest grid, and the kernels with a fixed grid (k_associate, the k_select rows) look
 # the same at every batch size -- mixed with the timed region's per-lane launches their counters would describe no launch at all.
-PMCARGS="--steps 1 --warmup 0 --cpu-seconds 0 --slots 1024 --batch 1024 --skip-upload $*"
+PMCARGS="--steps 1 --warmup 0 --cpu-seconds 0 --slots ${KB:-1024} --batch ${KB:-1024} --skip-upload $*"
 export PMC_LANES=1
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(ls $OUT/trace/*/*.db 2>/dev/null | head -1); [ -z "$DB" ] && DB=$(ls $OUT/trace/*.db 2>/dev/null | head -1)
@@ -28,13 +28,15 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCL
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 S=$(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1)
-KB=1024
+KB=${KB:-1024}   # scans per launch of the counter passes (= --slots / --batch of PMCARGS)
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W $KB > $OUT/traffic_${TAG%%[a-z]}$SUF.json
 [ -n "$S" ] && python tools/pmc_sq.py $S --json $OUT/sq_${TAG%%[a-z]}$SUF.json $KB > $OUT/${TAG}_sq_counters$SUF.md
 fi
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
-# the bench line last, against the counter files just taken (copied into profiles/ of this checkout: the line then carries their
-# traffic and instruction counts as current, not stale)
+# the bench line last, against the counter files just taken.  SIDE EFFECT, on purpose: they are copied into profiles/ of THIS
+# checkout (on the GPU box: the scratch copy) so that the line carries their traffic and instruction counts as current, not
+# stale; what is to be committed still has to be copied from gpurun_out/prof_<tag>/ into profiles/ by hand.
 for f in $OUT/traffic_*.json $OUT/sq_*.json; do [ -s "$f" ] && cp $f profiles/; done
-python bench.py $* > $OUT/${TAG}_bench$SUF.json 2> $OUT/bench.err
+python bench.py --strict $* > $OUT/${TAG}_bench$SUF.json 2> $OUT/bench.err
+echo "bench rc=$?" >> $OUT/bench.err
 ls -la $OUT; tail -c 400 $OUT/${TAG}_bench$SUF.json; echo; head -30 $OUT/${TAG}_kernel_stats$SUF.md | cut -c1-150
