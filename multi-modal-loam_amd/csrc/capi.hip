@@ -101,6 +101,7 @@ void mml_destroy(mml_ctx* ctx) {
     for (auto& g : ctx->win_graphs) hipGraphExecDestroy(g.exec);
     for (auto& u : ctx->uploads) hipEventDestroy(u.done);
     for (auto e : ctx->upload_event_pool) hipEventDestroy(e);
+    for (auto e : ctx->pipe_events) hipEventDestroy(e);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
         if (ctx->lane_mark[l]) hipEventDestroy(ctx->lane_mark[l]);
         if (ctx->streams[l]) hipStreamDestroy(ctx->streams[l]);
@@ -1459,58 +1460,127 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     so.fixed_iterations = 1;
     so.huber_delta = 0.1 / 1.5e-3;
     so.plan_weight_tan = 0.0;
-    // Sub-batches on independent streams: the latency-bound stages of one sub-batch (per-slot scans, the 10 serial
-    // solver iterations) overlap the issue-bound stages of the others.  Scans are independent, results identical.
+    // How the five stages of the batch are spread over the context's streams (`lanes`, mml_set_lanes):
+    //   pipeline (default): the batch is cut into pieces of ~1024 scans; stream 0 runs the extraction of piece after piece, the
+    //     other streams the later stages of the pieces behind it, each piece's stages chained by events.  At any moment the
+    //     device holds an extraction kernel (instruction-issue or HBM bound: bucketing, stencil, selection) next to kernels of
+    //     the back end of an EARLIER piece (latency bound: down-sampling sort, 5-NN search, the ten serial solver iterations)
+    //     -- work that is limited by different things shares the CUs.
+    //   lanes ($MML_STEP_PIPE=0, the form of rounds 2-4): `lanes` contiguous sub-batches, each the whole chain on its own
+    //     stream.  All lanes start together and run the same kernels of the same length: assign next to assign, solve next
+    //     to solve -- like against like, which is why 2 lanes gained 14 % where the stage times promised far more.
+    // Scans are independent; the results do not depend on the schedule (tests/test_gpu_shapes.py, bench.py replica_check).
     const int lanes = (count >= 64 && ctx->lanes_enabled) ? ctx->n_lanes : 1;
-    const int chunk = (count + lanes - 1) / lanes;
+    static const bool pipe_env = !(getenv("MML_STEP_PIPE") && atoi(getenv("MML_STEP_PIPE")) == 0);
+    const bool pipe = lanes > 1 && pipe_env;
+    // stage -> stream
+    int smap[5] = {0, 0, 0, 0, 0};
+    int n_pieces = 1;
+    if (pipe) {
+        static const char* map_env = getenv("MML_PIPE_MAP");  // e.g. "01122" (measurements)
+        if (map_env && strlen(map_env) == 5) {
+            for (int k = 0; k < 5; ++k) smap[k] = std::min(std::max(map_env[k] - '0', 0), mml_ctx::MAX_LANES - 1);
+        } else {
+            static const int maps[4][5] = {{0, 1, 1, 1, 1}, {0, 1, 1, 2, 2}, {0, 1, 1, 2, 3}, {0, 1, 2, 3, 4}};
+            const int* m = maps[std::min(lanes, 5) - 2];
+            for (int k = 0; k < 5; ++k) smap[k] = m[k];
+        }
+        static const int sub_env = getenv("MML_PIPE_SUB") ? atoi(getenv("MML_PIPE_SUB")) : 0;
+        const int sub = sub_env > 0 ? sub_env : 1024;
+        n_pieces = std::max(2, (count + sub - 1) / sub);   // (>= 32 scans each: count >= 64)
+    } else if (lanes > 1) {
+        n_pieces = lanes;
+    }
+    const int chunk = (count + n_pieces - 1) / n_pieces;
     std::vector<double> Twl(16 * (size_t)chunk);
+    // (the staging ring: a wrap in the middle of the call would drain the streams; wrap now if this call does not fit)
+    {
+        const size_t need = (7 + 16 + 12 + 6 + 8) * (size_t)count + 64 * (size_t)n_pieces + 1024;
+        if (ctx->stage_cursor + need > ctx->h_stage_doubles && need <= ctx->h_stage_doubles) {
+            int rw = mml_sync_all(ctx);
+            if (rw != MML_OK) return rw;
+            ctx->stage_cursor = 0;
+        }
+    }
     double* h_x = stage_alloc(ctx, 7 * (size_t)count + 1);  // pinned read-back area: poses, then the two stack-size arrays
     int* h_ftn = reinterpret_cast<int*>(h_x + 6 * (size_t)count);
     int rc = MML_OK;
-    // The stages are enqueued stage by stage across the lanes (each lane's stream keeps its own order): every lane has
-    // its first kernels in its queue within a few tens of microseconds, instead of lane 3 waiting for the host to finish
-    // enqueueing the whole chains of lanes 0..2.
-    // Entry points outside mml_step enqueue on stream 0 (mml_scan_upload's copies, a staged mml_extract ...): the other lanes
+    // Entry points outside mml_step enqueue on stream 0 (mml_scan_upload's copies, a staged mml_extract ...): the other streams
     // start behind whatever stream 0 holds at this point.  (Found by running 80 slots on the default two lanes straight
     // after their uploads: the last slot's copy was still in flight when lane 1 began to bucket it.)
     if (lanes > 1) {
         if (hipEventRecord(ctx->lane_mark[0], ctx->streams[0]) != hipSuccess) return MML_ERR_HIP;
-        for (int l = 1; l < lanes; ++l)
+        for (int l = 1; l < mml_ctx::MAX_LANES; ++l)
             if (hipStreamWaitEvent(ctx->streams[l], ctx->lane_mark[0], 0) != hipSuccess) return MML_ERR_HIP;
     }
-    auto lane_span = [&](int l, int& f, int& c) {
-        f = first_slot + l * chunk;
+    auto piece_span = [&](int p, int& f, int& c) {
+        f = first_slot + p * chunk;
         c = std::min(chunk, first_slot + count - f);
         return c > 0;
     };
-    for (int stage = 0; stage < 5 && rc == MML_OK; ++stage) {
-        for (int l = 0; l < lanes && rc == MML_OK; ++l) {
+    auto run_stage = [&](int stage, int f, int c) -> int {
+        const int off = f - first_slot;
+        switch (stage) {
+            case 0: return mml_launch_extract(ctx, f, c, false);
+            case 1: return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
+            case 2: return mml_launch_downsample(ctx, f, c);
+            case 3:
+                for (int i = 0; i < c; ++i) {
+                    double q[4];
+                    so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
+                    pose_to_Twl(q, x_inout + 6 * (size_t)(off + i), T_bl, &Twl[16 * (size_t)i]);
+                }
+                return mml_associate(ctx, f, c, Twl.data(), thres_dist, nullptr);
+            default: {
+                int r = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
+                if (r != MML_OK) return r;
+                hipError_t e = hipMemcpyAsync(h_x + 6 * (size_t)off, ctx->d_x + 6 * (size_t)f, sizeof(double) * 6 * c, hipMemcpyDeviceToHost,
+                                              MML_STREAM(ctx));
+                if (e != hipSuccess) {
+                    ctx->err = std::string("mml_step read-back: ") + hipGetErrorString(e);
+                    return MML_ERR_HIP;
+                }
+                return MML_OK;
+            }
+        }
+    };
+    if (pipe) {
+        // piece-major: a piece's stages in order, each on its stage's stream; an event wherever the chain changes streams
+        size_t ev = 0;
+        for (int p = 0; p < n_pieces && rc == MML_OK; ++p) {
             int f, c;
-            if (!lane_span(l, f, c)) break;
-            const int off = f - first_slot;
-            ctx->cur = l;
-            switch (stage) {
-                case 0: rc = mml_launch_extract(ctx, f, c, false); break;
-                case 1: rc = mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off); break;
-                case 2: rc = mml_launch_downsample(ctx, f, c); break;
-                case 3:
-                    for (int i = 0; i < c; ++i) {
-                        double q[4];
-                        so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
-                        pose_to_Twl(q, x_inout + 6 * (size_t)(off + i), T_bl, &Twl[16 * (size_t)i]);
-                    }
-                    rc = mml_associate(ctx, f, c, Twl.data(), thres_dist, nullptr);
-                    break;
-                default:
-                    rc = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
-                    if (rc == MML_OK) {
-                        hipError_t e = hipMemcpyAsync(h_x + 6 * (size_t)off, ctx->d_x + 6 * (size_t)f, sizeof(double) * 6 * c,
-                                                      hipMemcpyDeviceToHost, MML_STREAM(ctx));
-                        if (e != hipSuccess) {
-                            ctx->err = std::string("mml_step read-back: ") + hipGetErrorString(e);
+            if (!piece_span(p, f, c)) break;
+            for (int stage = 0; stage < 5 && rc == MML_OK; ++stage) {
+                ctx->cur = smap[stage];
+                if (stage > 0 && smap[stage] != smap[stage - 1]) {
+                    if (ev >= ctx->pipe_events.size()) {
+                        hipEvent_t e;
+                        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
                             rc = MML_ERR_HIP;
+                            break;
                         }
+                        ctx->pipe_events.push_back(e);
                     }
+                    hipEvent_t e = ctx->pipe_events[ev++];
+                    if (hipEventRecord(e, ctx->streams[smap[stage - 1]]) != hipSuccess ||
+                        hipStreamWaitEvent(ctx->streams[smap[stage]], e, 0) != hipSuccess) {
+                        rc = MML_ERR_HIP;
+                        break;
+                    }
+                }
+                rc = run_stage(stage, f, c);
+            }
+        }
+    } else {
+        // The stages are enqueued stage by stage across the lanes (each lane's stream keeps its own order): every lane has
+        // its first kernels in its queue within a few tens of microseconds, instead of lane 3 waiting for the host to finish
+        // enqueueing the whole chains of lanes 0..2.
+        for (int stage = 0; stage < 5 && rc == MML_OK; ++stage) {
+            for (int l = 0; l < n_pieces && rc == MML_OK; ++l) {
+                int f, c;
+                if (!piece_span(l, f, c)) break;
+                ctx->cur = l;
+                rc = run_stage(stage, f, c);
             }
         }
     }
