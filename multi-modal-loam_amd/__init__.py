@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmloam_hip.so")
+LIB_PATH = os.environ.get("MML_LIB_PATH") or os.path.join(_HERE, "libmmloam_hip.so")   # ($MML_LIB_PATH: an A/B build of the library)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmloam_hip.h")
 
 MML_OK, MML_ERR_INVALID, MML_ERR_NO_DEVICE, MML_ERR_HIP, MML_ERR_CAPACITY, MML_ERR_STATE = 0, -1, -2, -3, -4, -5

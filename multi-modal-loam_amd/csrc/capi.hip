@@ -101,7 +101,6 @@ void mml_destroy(mml_ctx* ctx) {
     for (auto& g : ctx->win_graphs) hipGraphExecDestroy(g.exec);
     for (auto& u : ctx->uploads) hipEventDestroy(u.done);
     for (auto e : ctx->upload_event_pool) hipEventDestroy(e);
-    for (auto e : ctx->pipe_events) hipEventDestroy(e);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
         if (ctx->lane_mark[l]) hipEventDestroy(ctx->lane_mark[l]);
         if (ctx->streams[l]) hipStreamDestroy(ctx->streams[l]);
@@ -1460,37 +1459,14 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     so.fixed_iterations = 1;
     so.huber_delta = 0.1 / 1.5e-3;
     so.plan_weight_tan = 0.0;
-    // How the five stages of the batch are spread over the context's streams (`lanes`, mml_set_lanes):
-    //   pipeline (default): the batch is cut into pieces of ~1024 scans; stream 0 runs the extraction of piece after piece, the
-    //     other streams the later stages of the pieces behind it, each piece's stages chained by events.  At any moment the
-    //     device holds an extraction kernel (instruction-issue or HBM bound: bucketing, stencil, selection) next to kernels of
-    //     the back end of an EARLIER piece (latency bound: down-sampling sort, 5-NN search, the ten serial solver iterations)
-    //     -- work that is limited by different things shares the CUs.
-    //   lanes ($MML_STEP_PIPE=0, the form of rounds 2-4): `lanes` contiguous sub-batches, each the whole chain on its own
-    //     stream.  All lanes start together and run the same kernels of the same length: assign next to assign, solve next
-    //     to solve -- like against like, which is why 2 lanes gained 14 % where the stage times promised far more.
-    // Scans are independent; the results do not depend on the schedule (tests/test_gpu_shapes.py, bench.py replica_check).
+    // Sub-batches on independent streams (`lanes`, mml_set_lanes): contiguous slot ranges, each the whole chain on its own
+    // stream, so that the tail of one kernel overlaps the head of another.  Scans are independent, results identical
+    // (tests/test_gpu_shapes.py, bench.py replica_check).  What the lanes do NOT buy is co-residency of unlike kernels: every
+    // kernel of the chain fills the CUs' registers / LDS by itself at these batch sizes.  Round 5 measured the other
+    // schedule -- pieces of 512 .. 2048 scans, stream 0 extracting piece i + 1 while other streams run the back end of piece
+    // i, 2 .. 5 streams, three stage-to-stream maps: 306 k .. 330 k scans/s against 355 k for two lanes (HISTORY.md).
     const int lanes = (count >= 64 && ctx->lanes_enabled) ? ctx->n_lanes : 1;
-    static const bool pipe_env = !(getenv("MML_STEP_PIPE") && atoi(getenv("MML_STEP_PIPE")) == 0);
-    const bool pipe = lanes > 1 && pipe_env;
-    // stage -> stream
-    int smap[5] = {0, 0, 0, 0, 0};
-    int n_pieces = 1;
-    if (pipe) {
-        static const char* map_env = getenv("MML_PIPE_MAP");  // e.g. "01122" (measurements)
-        if (map_env && strlen(map_env) == 5) {
-            for (int k = 0; k < 5; ++k) smap[k] = std::min(std::max(map_env[k] - '0', 0), mml_ctx::MAX_LANES - 1);
-        } else {
-            static const int maps[4][5] = {{0, 1, 1, 1, 1}, {0, 1, 1, 2, 2}, {0, 1, 1, 2, 3}, {0, 1, 2, 3, 4}};
-            const int* m = maps[std::min(lanes, 5) - 2];
-            for (int k = 0; k < 5; ++k) smap[k] = m[k];
-        }
-        static const int sub_env = getenv("MML_PIPE_SUB") ? atoi(getenv("MML_PIPE_SUB")) : 0;
-        const int sub = sub_env > 0 ? sub_env : 1024;
-        n_pieces = std::max(2, (count + sub - 1) / sub);   // (>= 32 scans each: count >= 64)
-    } else if (lanes > 1) {
-        n_pieces = lanes;
-    }
+    const int n_pieces = lanes;
     const int chunk = (count + n_pieces - 1) / n_pieces;
     std::vector<double> Twl(16 * (size_t)chunk);
     // (the staging ring: a wrap in the middle of the call would drain the streams; wrap now if this call does not fit)
@@ -1544,34 +1520,7 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
             }
         }
     };
-    if (pipe) {
-        // piece-major: a piece's stages in order, each on its stage's stream; an event wherever the chain changes streams
-        size_t ev = 0;
-        for (int p = 0; p < n_pieces && rc == MML_OK; ++p) {
-            int f, c;
-            if (!piece_span(p, f, c)) break;
-            for (int stage = 0; stage < 5 && rc == MML_OK; ++stage) {
-                ctx->cur = smap[stage];
-                if (stage > 0 && smap[stage] != smap[stage - 1]) {
-                    if (ev >= ctx->pipe_events.size()) {
-                        hipEvent_t e;
-                        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-                            rc = MML_ERR_HIP;
-                            break;
-                        }
-                        ctx->pipe_events.push_back(e);
-                    }
-                    hipEvent_t e = ctx->pipe_events[ev++];
-                    if (hipEventRecord(e, ctx->streams[smap[stage - 1]]) != hipSuccess ||
-                        hipStreamWaitEvent(ctx->streams[smap[stage]], e, 0) != hipSuccess) {
-                        rc = MML_ERR_HIP;
-                        break;
-                    }
-                }
-                rc = run_stage(stage, f, c);
-            }
-        }
-    } else {
+    {
         // The stages are enqueued stage by stage across the lanes (each lane's stream keeps its own order): every lane has
         // its first kernels in its queue within a few tens of microseconds, instead of lane 3 waiting for the host to finish
         // enqueueing the whole chains of lanes 0..2.

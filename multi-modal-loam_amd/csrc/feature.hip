@@ -68,6 +68,7 @@ struct FeatParams {
     int asb_stride;      // row stride of k_assign_b's LDS tile
     CropBlk* crop_cnt;   // [B][nblk_t] per-block counts / exclusive offsets of the crop passes
     unsigned* label_idx; // [B][2][cap] fused-cloud indices of the corner / surf labelled points
+    int label_cap;       // entries per list
     int nblk_t;
     unsigned* sel_scratch;  // global-memory scratch for lines longer than sel_cap: 4 x B*NT unsigned
     int sel_cap;            // points per line k_select keeps in LDS
@@ -231,6 +232,9 @@ __global__ void k_assign_init(FeatParams P, int count) {
         P.slot_flags[2 * (P.first + t)] = 0;  // an extracted cloud, not undistorted yet
         P.brk_cnt[P.first + t] = 0;   // the stencil's two queues start empty
         P.redo_cnt[P.first + t] = 0;
+        int* info = P.fu_info + 8 * (size_t)(P.first + t);  // point counts by k_assign_b, label counters by the selection kernels
+#pragma unroll
+        for (int q = 0; q < 8; ++q) info[q] = 0;
     }
 }
 
@@ -549,6 +553,9 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
             a->kept_velo = s_tot[nkeys + 1];
         else
             a->kept_livox = s_tot[nkeys + 1];
+        int* info = P.fu_info + 8 * (size_t)b;  // (zeroed by k_assign_init)
+        atomicAdd(&info[0], s_tot[nkeys + 1]);
+        if (sensor == 0) info[1] = s_tot[nkeys + 1];
     }
 }
 
@@ -1313,6 +1320,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_assign_tables(FeatParams P, int 
                 a->kept_velo = tk;
             else
                 a->kept_livox = tk;
+            // fu_info: fused points, Velodyne points; the label counters start at zero (the selection kernels add to them)
+            const int tk1 = __shfl(tk, 1);
+            if (lane == 0) {
+                int* info = P.fu_info + 8 * (size_t)b;
+                info[0] = tk + tk1;
+                info[1] = tk;
+#pragma unroll
+                for (int q = 2; q < 8; ++q) info[q] = 0;
+            }
             const int nk = lane == 0 ? P.n_rings : P.n_lines;
             P.seg_flat_n[((size_t)b * 2 + lane) * 2] = nb * nk;
             P.seg_flat_n[((size_t)b * 2 + lane) * 2 + 1] = nk;
@@ -2347,6 +2363,74 @@ __device__ __forceinline__ void p2_acc(const uint2 o, unsigned me, unsigned mk, 
 // and live in registers afterwards: the kernel is bound by the latency of dependent phases, not by bytes, and every
 // global load removed from a phase removes a full HBM round trip from the critical path of the workgroup.
 // K == 0: any length, per-point state in a global scratch, attributes re-read where needed.
+// ---- a8 without a pass of its own: union_cloud.msg counts and the label lists straight from the selection kernels ---------
+// Until round 4 k_crop swept the label bytes of a slot again (one workgroup per slot, 0.10 ms per 1024 scans, 40 us of the one-scan
+// chain) to count the labels and to list the labelled points for the voxel filter.  Both consumers of the lists (k_voxel, the
+// global-sort filter) order a voxel's points by the FUSED INDEX in their sort keys, so the order of a list is free: the wavefront
+// that decides a label appends it.  fu_info[b] = {fused points, velo points | velo corner, velo surf | livox corner, livox surf (kept
+// or beyond far_th, :925-940) | kept corner, kept surf}: words 0 .. 1 are written and 2 .. 7 zeroed by the bucketing's table kernel;
+// words 6 / 7 double as the lists' fill counters.  One 64-bit atomic per pair of counters.
+// `labs`: NW labels of this lane, 4 bits each (bit 3: Livox point beyond far_th: counted, not listed); pos[u]: storage position.
+template <int NW>
+__device__ __forceinline__ void label_append(const FeatParams& P, int b, bool velo_line, unsigned labs, const int (&pos)[NW]) {
+    static_assert(NW <= 8, "4 bits per label");
+#ifdef MML_T_NOAPPEND
+    return;
+#endif
+    // per lane: how many of its NW labels are corner (nibble 1), surf (2), far corner (9), far surf (10); bit 2 is never set
+    const unsigned m = 0x11111111u;
+    const unsigned is1 = labs & ~(labs >> 1) & ~(labs >> 3) & m, is2 = (labs >> 1) & ~labs & ~(labs >> 3) & m;
+    const unsigned far = (labs >> 3) & m;
+    const unsigned long long anyl = __ballot((is1 | is2 | far) != 0u);
+    if (anyl == 0ull) return;  // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    int* info = P.fu_info + 8 * (size_t)b;
+    // a lane's entries take consecutive places of the lists: one scan of the packed (corner | surf << 16) counts over the lanes
+    // instead of a ballot per label kind and point
+    // (the active lanes are a prefix of the wavefront -- all 64 except in the tail iteration of k_select's uncached loop, where a
+    //  wavefront's lanes hold ascending indices: the scan reads lower lanes only, the total sits in the last ACTIVE lane)
+    const int last = 63 - __clzll((long long)__ballot(true));
+    const int mine = (int)(__popc(is1) | (__popc(is2) << 16));
+    const int incl = wave_incl_scan(mine);
+    const int total = __builtin_amdgcn_readlane(incl, last);
+    int fc = 0, fs = 0;
+    if (__ballot(far != 0u)) {  // (rare: labelled Livox points beyond far_th are counted, not listed)
+        const int fm = (int)(__popc(labs & far) | (__popc((labs >> 1) & far) << 16));
+        const int ft = __builtin_amdgcn_readlane(wave_incl_scan(fm), last);
+        fc = ft & 0xffff;
+        fs = ft >> 16;
+    }
+    const int nc = total & 0xffff, ns = total >> 16;
+    unsigned long long base = 0;
+    if (lane == 0) {
+#ifdef MML_T_NOATOM
+        if (total) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(info + 6), ((unsigned long long)(unsigned)ns << 32) | (unsigned)nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        if (total) base = atomicAdd(reinterpret_cast<unsigned long long*>(info + 6), ((unsigned long long)(unsigned)ns << 32) | (unsigned)nc);
+#endif
+        atomicAdd(reinterpret_cast<unsigned long long*>(info + (velo_line ? 2 : 4)),
+                  ((unsigned long long)(unsigned)(ns + fs) << 32) | (unsigned)(nc + fc));
+    }
+    if (total == 0) return;
+    const int excl = incl - mine;
+    int dc = __builtin_amdgcn_readfirstlane((int)(unsigned)base) + (excl & 0xffff);
+    int ds = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32)) + (excl >> 16);
+    unsigned* list_c = P.label_idx + ((size_t)b * 2 + 0) * P.label_cap;
+    unsigned* list_s = P.label_idx + ((size_t)b * 2 + 1) * P.label_cap;
+    if (mine) {
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            if ((is1 >> (4 * u)) & 1u) {
+                if (dc < P.label_cap) list_c[dc] = (unsigned)pos[u];
+                ++dc;
+            } else if ((is2 >> (4 * u)) & 1u) {
+                if (ds < P.label_cap) list_s[ds] = (unsigned)pos[u];
+                ++ds;
+            }
+        }
+    }
+}
+
 template <int K, typename WP>
 __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line, int n, size_t base, WP W, WP R, int* s_sp,
                                             unsigned long long (*s_pm)[3], unsigned long long* s_minE,
@@ -2847,6 +2931,11 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
     SEL_MARK(10);
     // ---- phase 5: final value of the serial part (:521-539 (c)), overrides (150, 100/101), emit, label scatter ---------
     uint8_t* lnlab = P.ln_label + (size_t)b * P.NT;
+    // (the labels this thread decides, 4 bits each, and where they went: appended to the slot's lists below -- label_append)
+    constexpr int NCH = (KK + 7) / 8;
+    unsigned labs_arr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) labs_arr[c] = 0;
     FOR_POINTS(
         const unsigned me = W[2 * i + 1];
         const unsigned at = ATTR(i, k);
@@ -2886,8 +2975,27 @@ __device__ __forceinline__ void select_body(const FeatParams& P, int b, int line
                     labv = lab | 0x80;  // surf cloud the GICP refresh aligns (:296-312); k_crop counts these, nobody lists them
             }
         }
-        lnlab[xlate(i)] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
+        const int ps = xlate(i);
+        lnlab[ps] = (uint8_t)labv;  // every point of the line: nobody clears the label bytes beforehand
+        const unsigned code = (unsigned)((labv & 3) | ((labv & 0x80) ? 8 : 0));
+        if constexpr (CACHED) {
+            labs_arr[k / 8] |= code << (4 * (k % 8));
+        } else {
+            // (a wavefront's lanes hold ascending i: lane 0 is live whenever any lane is)
+            const int p1[1] = {ps};
+            label_append<1>(P, b, line < P.n_rings, code, p1);
+        }
     )
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            int pp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)  // (positions again from the records: kept in registers they cost k_select<4> a wavefront per SIMD)
+                pp[u] = ((labs_arr[c] >> (4 * u)) & 3u) ? xlate(tid + (8 * c + u) * SELP_THREADS) : 0;
+            label_append<8>(P, b, line < P.n_rings, labs_arr[c], pp);
+        }
+    }
     SEL_MARK(11);
 #undef FOR_POINTS
 #undef ATTR
@@ -2904,8 +3012,10 @@ __host__ __device__ inline size_t select_lds_bytes(int cap) { return (size_t)(ca
 #define MML_SEL_ROWS_V 256
 #define MML_SEL_ROWS_L 128
 #endif
+// (K <= 4, the ring variants of the 16-ring layout: held to the 128 registers of four wavefronts per SIMD, which they needed
+//  127 of before the label lists were appended here and 130 after)
 template <int K>
-__global__ __launch_bounds__(SELP_THREADS) void k_select(FeatParams P, int list_kind) {
+__global__ __launch_bounds__(SELP_THREADS) __attribute__((amdgpu_waves_per_eu(K <= 4 ? 4 : 1))) void k_select(FeatParams P, int list_kind) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_pm[50][3];
     __shared__ unsigned long long s_minE[50], s_minG[50];
@@ -3376,6 +3486,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) gi4[u] = gidx[ps4[u]];
+        unsigned labs = 0;  // the labels of this lane's eight points, 4 bits each (label_append)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int w = w4 + u, i = 64 * w + lane;
@@ -3404,7 +3515,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 }
             }
             lnlab[ps4[u]] = (uint8_t)labv;
+            labs |= (unsigned)((labv & 3) | ((labv & 0x80) ? 8 : 0)) << (4 * u);
         }
+        label_append<8>(P, b, line < P.n_rings, labs, ps4);
     }
     SP_MARK(7);
 #undef SP_SYNC
@@ -3594,6 +3707,26 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
     }
 }
 
+// The Livox extrinsic of mml_extract (:302-318): pcl::transformPointCloud (PCL 1.8.1 common/impl/transforms.hpp, float) on the
+// slot's Livox region once its livox_corner_num is known to exceed 100 -- i.e. after the selection kernels of the slot (points
+// the crop dropped are transformed along, nobody reads them).
+__global__ __launch_bounds__(256) void k_livox_extrinsic(FeatParams P) {
+    const int b = blockIdx.y + P.first;
+    if (!(P.fu_info[8 * (size_t)b + 4] > 100)) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P.cb_n[2 * b + 1]) return;
+    const float* e = P.extr;
+    const size_t o = (size_t)b * P.NT + P.NV + p;
+    float4 pt = P.ln_pts[o];
+    const float x = e[0] * pt.x + e[1] * pt.y + e[2] * pt.z + e[3];
+    const float y = e[4] * pt.x + e[5] * pt.y + e[6] * pt.z + e[7];
+    const float z = e[8] * pt.x + e[9] * pt.y + e[10] * pt.z + e[11];
+    pt.x = x;
+    pt.y = y;
+    pt.z = z;
+    P.ln_pts[o] = pt;
+}
+
 // single-line setup for mml_detect_line: slot 0 holds one line (ring 0) of n points already in ln_pts
 __global__ void k_setup_single_line(FeatParams P, int n) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3613,6 +3746,10 @@ __global__ void k_setup_single_line(FeatParams P, int n) {
     if (t == 0) {
         P.cb_n[0] = n;
         P.cb_n[1] = 0;
+        P.fu_info[0] = n;
+        P.fu_info[1] = n;
+#pragma unroll
+        for (int q = 2; q < 8; ++q) P.fu_info[q] = 0;
     }
 }
 
@@ -3657,6 +3794,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.asb_stride |= 1;
     P.crop_cnt = reinterpret_cast<CropBlk*>(ctx->crop_cnt);
     P.label_idx = reinterpret_cast<unsigned*>(ctx->vx_keys);
+    P.label_cap = ctx->VX_CAP;
     P.nblk_t = (ctx->NT + 255) / 256;
     P.sel_scratch = ctx->sel_scratch;
     P.sel_cap = ctx->sel_cap;
@@ -3804,12 +3942,10 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
                                    select_lds_bytes(ctx->sel_cap), s, Pl, -1);
         }
     }
-    {
-        MmlStageScope t(ctx, "crop_compact");
-        // label staging in chunks of at most MML_CROP_WORDS words
-        const int lab_words = (ctx->NT + 3) / 4;
-        const int lds_words = lab_words <= MML_CROP_WORDS ? lab_words : MML_CROP_WORDS;
-        hipLaunchKernelGGL(k_crop, dim3(count), dim3(CROP_THREADS), sizeof(uint32_t) * (size_t)lds_words, s, P, ctx->VX_CAP, lds_words);
+    // (no crop pass: the label counts of union_cloud.msg and the label lists were written by the selection kernels, label_append)
+    if (P.extr != nullptr && ctx->NL > 0) {
+        MmlStageScope t(ctx, "livox_extrinsic");
+        hipLaunchKernelGGL(k_livox_extrinsic, dim3((ctx->NL + 255) / 256, count), dim3(256), 0, s, P);
     }
     MML_HIP(hipGetLastError());
     return MML_OK;

@@ -102,7 +102,6 @@ struct mml_ctx {
     };
     std::vector<Upload> uploads;
     std::vector<hipEvent_t> upload_event_pool;
-    std::vector<hipEvent_t> pipe_events;  // mml_step's pipeline: one per (piece, change of stream), reused from call to call
     int n_lanes = 1;
     int cur = 0;
     bool lanes_enabled = true;
