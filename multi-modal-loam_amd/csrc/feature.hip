@@ -2374,9 +2374,6 @@ __device__ __forceinline__ void p2_acc(const uint2 o, unsigned me, unsigned mk, 
 template <int NW>
 __device__ __forceinline__ void label_append(const FeatParams& P, int b, bool velo_line, unsigned labs, const int (&pos)[NW]) {
     static_assert(NW <= 8, "4 bits per label");
-#ifdef MML_T_NOAPPEND
-    return;
-#endif
     // per lane: how many of its NW labels are corner (nibble 1), surf (2), far corner (9), far surf (10); bit 2 is never set
     const unsigned m = 0x11111111u;
     const unsigned is1 = labs & ~(labs >> 1) & ~(labs >> 3) & m, is2 = (labs >> 1) & ~labs & ~(labs >> 3) & m;
@@ -2403,11 +2400,7 @@ __device__ __forceinline__ void label_append(const FeatParams& P, int b, bool ve
     const int nc = total & 0xffff, ns = total >> 16;
     unsigned long long base = 0;
     if (lane == 0) {
-#ifdef MML_T_NOATOM
-        if (total) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(info + 6), ((unsigned long long)(unsigned)ns << 32) | (unsigned)nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         if (total) base = atomicAdd(reinterpret_cast<unsigned long long*>(info + 6), ((unsigned long long)(unsigned)ns << 32) | (unsigned)nc);
-#endif
         atomicAdd(reinterpret_cast<unsigned long long*>(info + (velo_line ? 2 : 4)),
                   ((unsigned long long)(unsigned)(ns + fs) << 32) | (unsigned)(nc + fc));
     }

@@ -71,74 +71,131 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, co
 // ------------------------------------------------------------------------------------------------------------
 constexpr int VX_TAIL = 64;
 
-// Bitonic sort of npad = KPT * VX_THREADS keys, ascending, element e = tid + VX_THREADS * k held by thread tid in
-// key[k].  The partner of element e at distance j is e ^ j: for j >= VX_THREADS that is another register of the same
-// thread, for j < 64 another lane of the same wavefront (two 32-bit shuffles), and only the four distances in between
-// go through LDS -- 22 barrier-separated exchanges for 8192 keys instead of 91.
-template <int VX_THREADS, int KPT, int DK>
-__device__ __forceinline__ void bitonic_reg_step(unsigned long long (&key)[KPT], int k, int tid) {
-    if constexpr (DK < KPT) {
+// inclusive scan over the 64 lanes of a wavefront
+__device__ __forceinline__ int vx_wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int a = 0; a < KPT; ++a) {
-            constexpr int dk = DK;
-            const int c = a ^ dk;
-            if (c > a) {
-                const bool up = ((tid + VX_THREADS * a) & k) == 0;
-                const unsigned long long x = key[a], y = key[c];
-                const bool sw = (x > y) == up;
-                key[a] = sw ? y : x;
-                key[c] = sw ? x : y;
-            }
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(v, o);
+        if (lane >= o) v += y;
+    }
+    return v;
+}
+
+// Stable LSD radix sort (8-bit digits) of the workgroup's cnt <= KPT * VX_THREADS keys on their bits [lo_bit, 64), ascending; the
+// sorted keys end up in lds[0, cnt).  Element e = (wave * KPT + a) * 64 + lane is key[a] of that lane: a wavefront holds a
+// contiguous run of the current order, so "stable" = (wavefront, round a, lane).  Per pass: the rank of an element among the
+// elements of its digit inside its round comes from eight ballots; a per-wavefront digit histogram (LDS, 16 bits a count) gives
+// the elements of the digit in earlier rounds of the wavefront; one scan over (digit, wavefront) gives the rest.  Digits on which all
+// keys agree are skipped (voxel indices of a room-sized scan vary in 17-20 bits: 5 passes, 4 barriers each, ~45 vector
+// instructions per key and pass -- the bitonic network this replaces ran 78 compare-exchange stages of ~10 instructions on
+// 64-bit keys with 44 barriers for 4096 keys: 55 % of the kernel's instructions).
+// hist: VX_WAVES x 256 u16 (LDS), wtot: VX_WAVES + 2 ints (LDS).
+template <int VX_THREADS, int KPT>
+__device__ __forceinline__ void radix_sort_lds(unsigned long long (&key)[KPT], int cnt, int lo_bit, unsigned long long* lds,
+                                               unsigned short* hist, int* wtot, unsigned long long* s_red) {
+    constexpr int VX_WAVES = VX_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // the bits on which the live keys differ
+    unsigned long long o = 0ull, n = ~0ull;
+#pragma unroll
+    for (int a = 0; a < KPT; ++a) {
+        const int e = (wave * KPT + a) * 64 + lane;
+        if (e < cnt) {
+            o |= key[a];
+            n &= key[a];
         }
     }
-}
-template <int VX_THREADS, int KPT>
-__device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT], unsigned long long* lds) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int NP = KPT * VX_THREADS;
-#pragma unroll 1
-    for (int k = 2; k <= NP; k <<= 1) {
-#pragma unroll 1
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= VX_THREADS) {
-                const int dk = j / VX_THREADS;  // 1, 2 or 4: register distance (compile-time in each branch)
-                if (dk == 1)
-                    bitonic_reg_step<VX_THREADS, KPT, 1>(key, k, tid);
-                else if (dk == 2)
-                    bitonic_reg_step<VX_THREADS, KPT, 2>(key, k, tid);
-                else
-                    bitonic_reg_step<VX_THREADS, KPT, 4>(key, k, tid);
-            } else if (j < 64) {
 #pragma unroll
-                for (int a = 0; a < KPT; ++a) {
-                    const unsigned long long x = key[a];
-                    const unsigned lo = __shfl_xor((unsigned)x, j), hi = __shfl_xor((unsigned)(x >> 32), j);
-                    const unsigned long long y = ((unsigned long long)hi << 32) | lo;
-                    const bool up = ((tid + VX_THREADS * a) & k) == 0;
-                    const bool lower = (lane & j) == 0;
-                    const unsigned long long mn = x < y ? x : y, mx = x < y ? y : x;
-                    key[a] = (lower == up) ? mn : mx;
-                }
-            } else {
-                __syncthreads();  // the previous LDS round has been read
-#pragma unroll
-                for (int a = 0; a < KPT; ++a) lds[tid + VX_THREADS * a] = key[a];
-                __syncthreads();
-#pragma unroll
-                for (int a = 0; a < KPT; ++a) {
-                    const int e = tid + VX_THREADS * a;
-                    const unsigned long long x = key[a], y = lds[e ^ j];
-                    const bool up = (e & k) == 0;
-                    const bool lower = (e & j) == 0;
-                    const unsigned long long mn = x < y ? x : y, mx = x < y ? y : x;
-                    key[a] = (lower == up) ? mn : mx;
-                }
-            }
-        }
+    for (int d = 32; d > 0; d >>= 1) {
+        o |= ((unsigned long long)__shfl_xor((unsigned)(o >> 32), d) << 32) | __shfl_xor((unsigned)o, d);
+        n &= ((unsigned long long)__shfl_xor((unsigned)(n >> 32), d) << 32) | __shfl_xor((unsigned)n, d);
+    }
+    if (lane == 0) {
+        s_red[2 * wave] = o;
+        s_red[2 * wave + 1] = n;
     }
     __syncthreads();
+    o = 0ull;
+    n = ~0ull;
 #pragma unroll
-    for (int a = 0; a < KPT; ++a) lds[tid + VX_THREADS * a] = key[a];
+    for (int w = 0; w < VX_WAVES; ++w) {
+        o |= s_red[2 * w];
+        n &= s_red[2 * w + 1];
+    }
+    const unsigned long long diff = (o ^ n) >> lo_bit << lo_bit;
+    bool in_lds = false;  // do the registers hold the current order (false) or was it just scattered to lds (true)?
+#pragma unroll 1
+    for (int shift = lo_bit; shift < 64; shift += 8) {
+        if (((diff >> shift) & 0xffull) == 0ull) continue;  // (workgroup-uniform)
+        if (in_lds) {
+            __syncthreads();  // the scatter of the previous pass has landed
+#pragma unroll
+            for (int a = 0; a < KPT; ++a) {
+                const int e = (wave * KPT + a) * 64 + lane;
+                if (e < cnt) key[a] = lds[e];
+            }
+        }
+        // this wavefront's histogram row
+        for (int k = lane; k < 256; k += 64) hist[wave * 256 + k] = 0;
+        unsigned rd[KPT];  // rank inside the wavefront (16 bits) | digit << 16
+#pragma unroll
+        for (int a = 0; a < KPT; ++a) {
+            const int e = (wave * KPT + a) * 64 + lane;
+            const bool live = e < cnt;
+            const unsigned d = (unsigned)(key[a] >> shift) & 255u;
+            unsigned long long eq = __ballot(live);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long m = __ballot((d >> bit) & 1u);
+                eq &= ((d >> bit) & 1u) ? m : ~m;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int before = live ? (int)hist[wave * 256 + d] : 0;  // elements of the digit in the earlier rounds of this wavefront
+            __builtin_amdgcn_wave_barrier();
+            if (live && (eq & lt) == 0ull) hist[wave * 256 + d] = (unsigned short)(before + __popcll(eq));
+            rd[a] = (unsigned)(before + __popcll(eq & lt)) | (d << 16);
+        }
+        __syncthreads();
+        // exclusive scan over (digit, wavefront), digit-major: thread t owns entries 4 t .. 4 t + 3 of that order
+        {
+            constexpr int PER = VX_WAVES * 256 / VX_THREADS;  // = 4
+            static_assert(PER == 4, "four (digit, wavefront) entries per thread");
+            int c[PER], run = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = PER * tid + q, d = idx / VX_WAVES, w = idx % VX_WAVES;
+                c[q] = hist[w * 256 + d];
+                run += c[q];
+            }
+            const int incl = vx_wave_incl_scan(run);
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            int base = incl - run;
+            for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = PER * tid + q, d = idx / VX_WAVES, w = idx % VX_WAVES;
+                hist[w * 256 + d] = (unsigned short)base;
+                base += c[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < KPT; ++a) {
+            const int e = (wave * KPT + a) * 64 + lane;
+            if (e < cnt) lds[(int)hist[wave * 256 + (rd[a] >> 16)] + (int)(rd[a] & 0xffffu)] = key[a];
+        }
+        in_lds = true;
+    }
+    if (!in_lds) {  // nothing to sort on (one key, or all equal above lo_bit): the keys go to lds as they are
+#pragma unroll
+        for (int a = 0; a < KPT; ++a) {
+            const int e = (wave * KPT + a) * 64 + lane;
+            if (e < cnt) lds[e] = key[a];
+        }
+    }
     __syncthreads();
 }
 
@@ -146,139 +203,184 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[KPT]
 // Two key layouts: scans up to 65536 points carry (voxel 32 | fused index 16 | bucketed position 16); larger ones (up to 2^20
 // points: 128 x 2048 rings) carry (voxel 31 | fused index 20 | place in the label list 13) and find the position through the
 // list -- their labelled clouds are no larger than a small scan's, only their indices are wider.
+struct VoxelArgs {
+    int kind0, first, NT, MF, B, cap_y0, cap_y1, list_stride;
+    const int* fu_info;
+    const float4* ln_pts;
+    const int* ln_gidx;
+    float leaf_corner, leaf_surf;
+    float4* ft0;
+    float4* ft1;
+    int* ft_n;
+    const unsigned* seq_scratch;
+};
 template <int VX_THREADS>
-__global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int NT, int MF, int B, int cap_y0, int cap_y1, int list_stride, const int* fu_info,
-                                                     const float4* ln_pts, const int* ln_gidx,
-                                                     float leaf_corner, float leaf_surf, float4* ft0, float4* ft1,
-                                                     int* ft_n, unsigned* seq_scratch) {
+struct VoxelLds {
+    static constexpr int VX_WAVES = VX_THREADS / 64;
+    // the radix sort's histograms and the centroid pass's staging rows never live at the same time
+    union {
+        float stage[3][VX_THREADS + VX_TAIL];
+        unsigned short hist[VX_WAVES * 256];
+    } u;
+    int wtot[VX_WAVES + 2];
+    unsigned long long red[2 * VX_WAVES];
+    float red6[6][VX_WAVES];
+    int base, nout;
+};
+
+// the part of k_voxel that depends on the number of keys per thread
+template <int VX_THREADS, int KPT>
+__device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREADS>& S, unsigned long long* keys, int b, int kind, int cnt,
+                                           const unsigned* seq2idx, const float4* px, const int* gx, bool wide, float leaf) {
     constexpr int VX_WAVES = VX_THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ int s_wtot[VX_WAVES];
-    __shared__ float s_stage[3][VX_THREADS + VX_TAIL];
-    __shared__ int s_base;
-    __shared__ float s_red6[6][VX_WAVES];
-    __shared__ int s_nout;
-
-    const int b = blockIdx.x + first;
-    const int kind = blockIdx.y + kind0;
-    const int cap = blockIdx.y == 0 ? cap_y0 : cap_y1;  // labelled points this workgroup sorts at most
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float4* px = ln_pts + (size_t)b * NT;
-    const int* gx = ln_gidx + (size_t)b * NT;
-    const float leaf = kind == 0 ? leaf_corner : leaf_surf;
-    float4* out = (kind == 0 ? ft0 : ft1) + (size_t)b * MF;
-    // the labelled points of this (slot, kind): their bucketed positions, listed by the crop pass
-    unsigned* seq2idx = seq_scratch + ((size_t)b * 2 + kind) * list_stride;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    static_assert(MML_VOXEL_LDS_CAP <= 8192, "the wide key layout carries the place in the label list in 13 bits");
-    const bool wide = NT > 65536;
-    const int vshift = wide ? 33 : 32;
-    auto key_pos = [&](unsigned long long k) -> unsigned { return wide ? seq2idx[(unsigned)k & 0x1fffu] : (unsigned)k & 0xffffu; };
-
-    // 1. the labelled points were listed by the crop pass (feature.hip k_crop_c) in fused-cloud order; min / max of
-    //    their coordinates (getMinMax3D)
-    const int nsel = fu_info[8 * b + 6 + kind];
-    int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
-    const bool overflow = nsel > cap;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    // four points of this thread's stride per round: the index loads, then the gathers, in flight together
-    for (int s0 = tid; s0 < cnt; s0 += 4 * VX_THREADS) {
-        unsigned id4[4];
+    // 1. the labelled points of this (slot, kind) were listed by the selection kernels (feature.hip label_append), in no particular
+    //    order; every lane fetches its KPT points ONCE (position, coordinates, fused index stay in registers), min / max of the
+    //    coordinates (getMinMax3D)
+    // (up to four points per lane stay in registers between the two uses; eight are fetched again for the keys -- from the L2 --:
+    //  their 40 registers across the reduction would not fit the 64 the kernel is held to)
+    constexpr bool KEEP = KPT <= 4;
+    constexpr int KR = KEEP ? KPT : 1;
+    unsigned pos[KPT];
+    float x[KR], y[KR], z[KR];
+    int gi[KR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) id4[u] = seq2idx[min(s0 + u * VX_THREADS, cnt - 1)];
+    for (int a = 0; a < KPT; ++a) pos[a] = seq2idx[min((wave * KPT + a) * 64 + lane, cnt - 1)];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int a0 = 0; a0 < KPT; a0 += 4) {
         float4 p4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p4[u] = px[id4[u]];
+        for (int a = a0; a < a0 + 4 && a < KPT; ++a) p4[a - a0] = px[pos[a]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // (a clamped repeat of the last point changes no extremum)
-            mn[0] = fminf(mn[0], p4[u].x);
-            mn[1] = fminf(mn[1], p4[u].y);
-            mn[2] = fminf(mn[2], p4[u].z);
-            mx[0] = fmaxf(mx[0], p4[u].x);
-            mx[1] = fmaxf(mx[1], p4[u].y);
-            mx[2] = fmaxf(mx[2], p4[u].z);
+        for (int a = a0; a < a0 + 4 && a < KPT; ++a) {  // (a clamped repeat of the last point changes no extremum)
+            const float4 p = p4[a - a0];
+            if constexpr (KEEP) {
+                x[a] = p.x;
+                y[a] = p.y;
+                z[a] = p.z;
+                gi[a] = gx[pos[a]];
+            }
+            mn[0] = fminf(mn[0], p.x);
+            mn[1] = fminf(mn[1], p.y);
+            mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x);
+            mx[1] = fmaxf(mx[1], p.y);
+            mx[2] = fmaxf(mx[2], p.z);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // the six extrema reduced together: one shuffle tree each, one exchange through LDS
     float gmn[3], gmx[3];
-    {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            for (int o = 32; o > 0; o >>= 1) {
-                mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-                mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
-            }
-            if (lane == 0) {
-                s_red6[c][wave] = mn[c];
-                s_red6[3 + c][wave] = mx[c];
-            }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
         }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float r0 = s_red6[c][0], r1 = s_red6[3 + c][0];
-            for (int w = 1; w < VX_WAVES; ++w) {
-                r0 = fminf(r0, s_red6[c][w]);
-                r1 = fmaxf(r1, s_red6[3 + c][w]);
-            }
-            gmn[c] = r0;
-            gmx[c] = r1;
+        if (lane == 0) {
+            S.red6[c][wave] = mn[c];
+            S.red6[3 + c][wave] = mx[c];
         }
     }
-    if (cnt == 0) {
-        if (tid == 0) ft_n[kind * B + b] = 0;
-        return;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r0 = S.red6[c][0], r1 = S.red6[3 + c][0];
+        for (int w = 1; w < VX_WAVES; ++w) {
+            r0 = fminf(r0, S.red6[c][w]);
+            r1 = fmaxf(r1, S.red6[3 + c][w]);
+        }
+        gmn[c] = r0;
+        gmx[c] = r1;
     }
     // 2. voxel index (PCL 1.8.1 voxel_grid.hpp applyFilter): inverse leaf in float, floor, int, min_b offset
     const float inv = 1.0f / leaf;
     int min_b[3], div_b[3];
     for (int c = 0; c < 3; ++c) {
         min_b[c] = static_cast<int>(floor(gmn[c] * inv));
-        int max_b = static_cast<int>(floor(gmx[c] * inv));
+        const int max_b = static_cast<int>(floor(gmx[c] * inv));
         div_b[c] = max_b - min_b[c] + 1;
     }
     const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
     const bool unfiltered = mml_voxel_grid_overflows(gmn, gmx, inv);  // (Estimator.cpp:1015-1024 then gets its input back)
-    // keys (voxel idx, fused index, position) of my elements e = tid + VX_THREADS * k; padding sorts to the end.  The
-    // fused index (the point's place in [velo_combine ; livox_combine]) orders the points of a voxel as the reference
-    // sums them; position and fused index both fit 16 bits on this path (NT <= 65536).
-    auto make_key = [&](int sidx) -> unsigned long long {
-        if (sidx >= cnt) return ~0ull;
-        const unsigned pos = seq2idx[sidx];
-        const float4 p = px[pos];
-        const int ijk0 = static_cast<int>(floor(p.x * inv) - static_cast<float>(min_b[0]));
-        const int ijk1 = static_cast<int>(floor(p.y * inv) - static_cast<float>(min_b[1]));
-        const int ijk2 = static_cast<int>(floor(p.z * inv) - static_cast<float>(min_b[2]));
-        // (unfiltered: every point its own voxel, in the order of the fused cloud -- the label list is in storage order)
-        const int idx = unfiltered ? gx[pos] : ijk0 + ijk1 * mul1 + ijk2 * mul2;
-        if (wide) return ((unsigned long long)(unsigned)idx << 33) | ((unsigned long long)(unsigned)gx[pos] << 13) | (unsigned)sidx;
-        return ((unsigned long long)(unsigned)idx << 32) | ((unsigned)gx[pos] << 16) | pos;
-    };
-    // 3. bitonic sort ascending on (voxel idx, sequence): equivalent to a stable sort by voxel idx
-    if (cnt <= VX_THREADS) {
-        unsigned long long k1[1] = {make_key(tid)};
-        bitonic_sort_regs<VX_THREADS, 1>(k1, keys);
-    } else if (cnt <= 2 * VX_THREADS) {
-        unsigned long long k2[2];
+    // keys (voxel idx, fused index, position).  The fused index (the point's place in [velo_combine ; livox_combine]) orders the
+    // points of a voxel as the reference sums them; it is unique, so the sorted order does not depend on the order of the list.
+    unsigned long long key[KPT];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) k2[a] = make_key(tid + VX_THREADS * a);
-        bitonic_sort_regs<VX_THREADS, 2>(k2, keys);
-    } else if (cnt <= 4 * VX_THREADS) {
-        unsigned long long k4[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) k4[a] = make_key(tid + VX_THREADS * a);
-        bitonic_sort_regs<VX_THREADS, 4>(k4, keys);
-    } else {
-        unsigned long long k8[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) k8[a] = make_key(tid + VX_THREADS * a);
-        bitonic_sort_regs<VX_THREADS, 8>(k8, keys);
+    for (int a = 0; a < KPT; ++a) {
+        const int sidx = (wave * KPT + a) * 64 + lane;
+        float px_, py_, pz_;
+        int g;
+        if constexpr (KEEP) {
+            px_ = x[a];
+            py_ = y[a];
+            pz_ = z[a];
+            g = gi[a];
+        } else {
+            const float4 p = px[pos[a]];
+            px_ = p.x;
+            py_ = p.y;
+            pz_ = p.z;
+            g = gx[pos[a]];
+        }
+        const int ijk0 = static_cast<int>(floor(px_ * inv) - static_cast<float>(min_b[0]));
+        const int ijk1 = static_cast<int>(floor(py_ * inv) - static_cast<float>(min_b[1]));
+        const int ijk2 = static_cast<int>(floor(pz_ * inv) - static_cast<float>(min_b[2]));
+        // (unfiltered: every point its own voxel, in the order of the fused cloud)
+        const int idx = unfiltered ? g : ijk0 + ijk1 * mul1 + ijk2 * mul2;
+        key[a] = wide ? (((unsigned long long)(unsigned)idx << 33) | ((unsigned long long)(unsigned)g << 13) | (unsigned)sidx)
+                      : (((unsigned long long)(unsigned)idx << 32) | ((unsigned)g << 16) | pos[a]);
     }
+    // 3. ascending on (voxel idx, fused index): a stable sort by voxel idx of the fused order
+    radix_sort_lds<VX_THREADS, KPT>(key, cnt, wide ? 13 : 16, keys, S.u.hist, S.wtot, S.red);
+}
+
+// (two 1024-thread workgroups per CU -- eight wavefronts per SIMD -- is what hides this kernel's barriers and gathers: held to 64 registers)
+#ifndef MML_VOXEL_WAVES
+#define MML_VOXEL_WAVES 8
+#endif
+template <int VX_THREADS>
+__global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_VOXEL_WAVES))) void k_voxel(VoxelArgs A) {
+    constexpr int VX_WAVES = VX_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ VoxelLds<VX_THREADS> S;
+
+    const int b = blockIdx.x + A.first;
+    const int kind = blockIdx.y + A.kind0;
+    const int cap = blockIdx.y == 0 ? A.cap_y0 : A.cap_y1;  // labelled points this workgroup sorts at most
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = A.NT, MF = A.MF;
+    const float4* px = A.ln_pts + (size_t)b * NT;
+    const int* gx = A.ln_gidx + (size_t)b * NT;
+    const float leaf = kind == 0 ? A.leaf_corner : A.leaf_surf;
+    float4* out = (kind == 0 ? A.ft0 : A.ft1) + (size_t)b * MF;
+    const unsigned* seq2idx = A.seq_scratch + ((size_t)b * 2 + kind) * A.list_stride;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    static_assert(MML_VOXEL_LDS_CAP <= 8192, "the wide key layout carries the place in the label list in 13 bits");
+    const bool wide = NT > 65536;
+    const int vshift = wide ? 33 : 32;
+    auto key_pos = [&](unsigned long long k) -> unsigned { return wide ? seq2idx[(unsigned)k & 0x1fffu] : (unsigned)k & 0xffffu; };
+
+    const int nsel = A.fu_info[8 * b + 6 + kind];
+    const int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
+    const bool overflow = nsel > cap;
+    if (cnt == 0) {
+        if (tid == 0) A.ft_n[kind * A.B + b] = 0;
+        return;
+    }
+    if (cnt <= VX_THREADS)
+        voxel_sort<VX_THREADS, 1>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+    else if (cnt <= 2 * VX_THREADS)
+        voxel_sort<VX_THREADS, 2>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+    else if (cnt <= 4 * VX_THREADS)
+        voxel_sort<VX_THREADS, 4>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+    else
+        voxel_sort<VX_THREADS, 8>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
     // 4. one lane per voxel head: centroid in input order (AccumulatorXYZ: float sum, then / n)
     if (tid == 0) {
-        s_base = 0;
-        s_nout = 0;
+        S.base = 0;
+        S.nout = 0;
     }
     __syncthreads();
     for (int c0 = 0; c0 < cnt; c0 += VX_THREADS) {
@@ -296,16 +398,16 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
             const int e = c0 + t;
             if (e < cnt) {
                 const float4 p = px[key_pos(keys[e])];
-                s_stage[0][t] = p.x;
-                s_stage[1][t] = p.y;
-                s_stage[2][t] = p.z;
+                S.u.stage[0][t] = p.x;
+                S.u.stage[1][t] = p.y;
+                S.u.stage[2][t] = p.z;
             }
         }
         unsigned long long m = __ballot(head);
-        if (lane == 0) s_wtot[wave] = __popcll(m);
+        if (lane == 0) S.wtot[wave] = __popcll(m);
         __syncthreads();
-        int dst = s_base;
-        for (int w = 0; w < wave; ++w) dst += s_wtot[w];
+        int dst = S.base;
+        for (int w = 0; w < wave; ++w) dst += S.wtot[w];
         dst += __popcll(m & lt);
         if (head && dst < MF) {
             float sx = 0, sy = 0, sz = 0;
@@ -313,9 +415,9 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
             while (e < cnt && (unsigned)(keys[e] >> vshift) == vox) {
                 const int t = e - c0;
                 if (t < VX_THREADS + VX_TAIL) {
-                    sx += s_stage[0][t];
-                    sy += s_stage[1][t];
-                    sz += s_stage[2][t];
+                    sx += S.u.stage[0][t];
+                    sy += S.u.stage[1][t];
+                    sz += S.u.stage[2][t];
                 } else {  // a voxel with more than VX_TAIL points across the chunk edge
                     const float4 p = px[key_pos(keys[e])];
                     sx += p.x;
@@ -330,15 +432,15 @@ __global__ __launch_bounds__(VX_THREADS) void k_voxel(int kind0, int first, int 
         __syncthreads();
         if (tid == 0) {
             int t = 0;
-            for (int w = 0; w < VX_WAVES; ++w) t += s_wtot[w];
-            s_base += t;
+            for (int w = 0; w < VX_WAVES; ++w) t += S.wtot[w];
+            S.base += t;
         }
         __syncthreads();
     }
     if (tid == 0) {
-        int nout = s_base;
+        int nout = S.base;
         if (overflow || nout > MF) nout = -1;  // MML_ERR_CAPACITY at the host
-        ft_n[kind * B + b] = nout;
+        A.ft_n[kind * A.B + b] = nout;
     }
 }
 
@@ -365,23 +467,35 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     // workgroups holding 64 KB of keys -- two per CU, and in the pipelined step they wait for that room.  (Scans beyond 65536
     // points -- 128 rings: up to 12 800 corner candidates -- get the large workgroup for both kinds.)
     const int cap_surf = MML_VOXEL_LDS_CAP, cap_corner = mml_voxel_cap_corner(ctx);
-    auto pad = [](int cap) {
-        int npad = 1;
-        while (npad < cap) npad <<= 1;
-        return (size_t)npad * sizeof(unsigned long long);
-    };
+    auto lds = [](int cap) { return (size_t)cap * sizeof(unsigned long long); };
+    VoxelArgs A;
+    A.first = first;
+    A.NT = ctx->NT;
+    A.MF = ctx->MF;
+    A.B = ctx->B;
+    A.list_stride = ctx->VX_CAP;
+    A.fu_info = ctx->fu_info;
+    A.ln_pts = ctx->ln_pts;
+    A.ln_gidx = ctx->ln_gidx;
+    A.leaf_corner = ctx->cfg.leaf_corner;
+    A.leaf_surf = ctx->cfg.leaf_surf;
+    A.ft0 = ctx->ft_xyz[0];
+    A.ft1 = ctx->ft_xyz[1];
+    A.ft_n = ctx->ft_n;
+    A.seq_scratch = reinterpret_cast<const unsigned*>(ctx->vx_keys);
     if (cap_corner == cap_surf || count <= 16) {
         // (one launch for both kinds: a handful of scans are a chain of launches, not a question of room on the CUs)
-        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 2), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
-                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
-                           ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+        A.kind0 = 0;
+        A.cap_y0 = cap_corner;
+        A.cap_y1 = cap_surf;
+        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 2), dim3(1024), lds(cap_surf), MML_STREAM(ctx), A);
     } else {
-        hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), pad(cap_corner), MML_STREAM(ctx), 0, first, ctx->NT, ctx->MF, ctx->B, cap_corner,
-                           cap_corner, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
-                           ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
-        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), pad(cap_surf), MML_STREAM(ctx), 1, first, ctx->NT, ctx->MF, ctx->B, cap_surf,
-                           cap_surf, ctx->VX_CAP, ctx->fu_info, ctx->ln_pts, ctx->ln_gidx, ctx->cfg.leaf_corner, ctx->cfg.leaf_surf, ctx->ft_xyz[0],
-                           ctx->ft_xyz[1], ctx->ft_n, reinterpret_cast<unsigned*>(ctx->vx_keys));
+        A.kind0 = 0;
+        A.cap_y0 = A.cap_y1 = cap_corner;
+        hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), lds(cap_corner), MML_STREAM(ctx), A);
+        A.kind0 = 1;
+        A.cap_y0 = A.cap_y1 = cap_surf;
+        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), lds(cap_surf), MML_STREAM(ctx), A);
     }
     MML_HIP(hipGetLastError());
     return MML_OK;
