@@ -1242,6 +1242,8 @@ __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass(FeatParams P) {
         assign_onepass_body<1>(P, S);
 }
 // ... and one per sensor for batches (the combined kernel is 14 % slower at 1024 scans: 0.64 against 0.56 ms)
+// (116 / 104 registers: four wavefronts per SIMD, two workgroups per CU.  Held to 80 for three workgroups it spills 176 bytes per lane
+//  and takes 0.98 ms instead of 0.59 per 1024 scans; 16-bit counts in LDS -- under 40 KB -- change nothing: registers bound it.)
 template <int SENSOR>
 __global__ __launch_bounds__(OP_THREADS) void k_assign_onepass_s(FeatParams P) {
     __shared__ OnepassLds S;

@@ -868,7 +868,16 @@ constexpr int HARD_REDO = 1 << 30;   // queue entry: search again in the local m
 constexpr int HARD_FRESH = 1 << 29;  // queue entry: nothing searched yet, start at ring 0 without a list
 // Search only: the model fit (double-precision eigen / QR code, ~150 registers) lives in k_associate_fit_all, so this
 // kernel keeps a small register footprint and enough wavefronts in flight to hide its dependent gathers.
-__global__ __launch_bounds__(128) void k_associate(AssocParams P) {
+// Occupancy the three association kernels are compiled for (wavefronts per SIMD).  The search is a chain of dependent gathers
+// (cell offsets, then rows of points): 77 registers gave six wavefronts per SIMD; held to 64 (36 bytes of scratch) it runs
+// eight and is 10 % faster (0.289 -> 0.259 ms per 1024 scans); the fit 136 -> 128 registers (three -> four): 0.087 -> 0.080.
+// The far-query search loses at 6 (0.073 -> 0.086: 96 bytes of scratch inside its shell loop) and is indifferent at 5.
+#ifndef MML_AW_SEARCH
+#define MML_AW_SEARCH 8
+#define MML_AW_FIT 4
+#define MML_AW_HARD 1
+#endif
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MML_AW_SEARCH))) void k_associate(AssocParams P) {
     const int nitems = 2 * P.count;
     const int total = P.work_off[nitems];
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -938,7 +947,7 @@ __global__ __launch_bounds__(128) void k_associate(AssocParams P) {
 
 // Model fit of every feature pass 1 finished itself, one lane each.  A feature whose cube neighbourhood (stage 0) yields
 // no model is appended to the far-query list with the "search again in the local map" mark (:283 / :702).
-__global__ __launch_bounds__(128) void k_associate_fit_all(AssocParams P) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MML_AW_FIT))) void k_associate_fit_all(AssocParams P) {
     const int nitems = 2 * P.count;
     const int total = P.work_off[nitems];
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(128) void k_associate_fit_all(AssocParams P) {
 // SPAN = lanes that share one query (they split the rows of every shell): 16 for batches -- many queries, throughput --, 64 for
 // the live path's handful of scans, where the kernel lasts as long as its slowest query and a far query walks up to 169 rows a shell.
 template <int SPAN>
-__global__ __launch_bounds__(256) void k_associate_hard(AssocParams P, int round) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MML_AW_HARD))) void k_associate_hard(AssocParams P, int round) {
     const int gl = threadIdx.x & (SPAN - 1);
     const int group = (blockIdx.x * 256 + threadIdx.x) / SPAN;
     const int ngroups = (gridDim.x * 256) / SPAN;
