@@ -516,8 +516,10 @@ def run_throughput(args, rank, local_rank, world, dist):
                     tot_a += ab
                     if ab > 0:
                         traffic_ratio[st] = tr[st] * scale / ab
-            traffic_ratio["step"] = tot_t / tot_a if tot_a > 0 else None
+            traffic_ratio["step"] = tot_t / tot_a if tot_a > 0 else None          # against the per-kernel budgets of STAGE_BYTES
             traffic_ratio["step_traffic_bytes_per_launch"] = tot_t
+            # ... and against SURVEY 8(d)'s per-scan figure (48 N + 112 F + 72 F I), which counts no intermediate array at all
+            traffic_ratio["step_vs_survey_8d"] = tot_t / ((48 * (n_v + n_l) + 112 * nf + 72 * nf * gn_iters) or 1.0)
         except Exception as e:
             errors.append("traffic_ratio: " + repr(e)[:200])
     hbm_frac = achieved / HBM_PEAK_GBPS

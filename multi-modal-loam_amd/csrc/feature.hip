@@ -2120,13 +2120,51 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
 #undef WAVE_SYNC
 }
 
+// ---- the stencil's two queues, worked off -----------------------------------------------------------------------------------
+// Per slot the queues are short -- ~110 uncertain points, ~1000 break-point candidates of a 52.8 k-point scan -- and a launch of one
+// (or four) 256-thread workgroups per slot runs mostly empty wavefronts that still wait for 118 registers each: 0.047 + 0.027 ms
+// per 1024 scans, and in the two-lane timed region the redo kernel showed up as long as k_stencil itself.  Batches therefore walk
+// ONE list per launch: k_queue_prefix turns the per-slot counts into offsets, a grid sized for the expected fill walks the
+// concatenation with full wavefronts (entry e -> slot by a binary search over the offsets).  A handful of scans keep the per-slot grid.
+__global__ __launch_bounds__(1024) void k_queue_prefix(int first, int count, const int* cnt, int* off) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int acc = 0;
+    for (int t0 = 0; t0 < count; t0 += 1024) {
+        const int it = t0 + tid;
+        const int v = it < count ? cnt[first + it] : 0;
+        const int x = wave_incl_scan(v);
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        int base = 0, tile = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) base += s_w[w];
+            tile += s_w[w];
+        }
+        if (it < count) off[it] = acc + base + x - v;
+        acc += tile;
+        __syncthreads();
+    }
+    if (tid == 0) off[count] = acc;
+}
+// entry e of the concatenated queues -> (slot, place in the slot's queue)
+__device__ __forceinline__ int queue_slot(const int* off, int count, int e, int& k) {
+    int lo = 0, hi = count;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= e)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    k = e - off[lo];
+    return lo;
+}
+
 // the points whose float pre-decisions were not certain, one per lane, with the full decision chain
-__global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {
-    const int b = blockIdx.y + P.first;
-    const int cnt = P.redo_cnt[b];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
-        const unsigned entry = P.redo_queue[(size_t)b * P.NT + e];  // (line, index inside the line): an inner point, 5 <= i < n - 5
-        const int line = (int)(entry >> 24), i = (int)(entry & 0xffffffu);
+__device__ __forceinline__ void stencil_redo_entry(const FeatParams& P, int b, unsigned entry) {
+    {
+        const int line = (int)(entry >> 24), i = (int)(entry & 0xffffffu);  // (line, index inside the line): an inner point, 5 <= i < n - 5
         const size_t pos = (size_t)b * P.NT + P.line_start[(size_t)b * P.L + line] + i;  // line order
         const float4* slot_pts = P.ln_pts + (size_t)b * P.NT;
         float4 q[11];
@@ -2144,15 +2182,24 @@ __global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {
         if (brk) P.brk_queue[(size_t)b * P.NT + atomicAdd(&P.brk_cnt[b], 1)] = entry;
     }
 }
-
+__global__ __launch_bounds__(256) void k_stencil_redo(FeatParams P) {  // per-slot grid (blocks, slots)
+    const int b = blockIdx.y + P.first;
+    const int cnt = P.redo_cnt[b];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) stencil_redo_entry(P, b, P.redo_queue[(size_t)b * P.NT + e]);
+}
+__global__ __launch_bounds__(64) void k_stencil_redo_list(FeatParams P, int count, const int* off) {  // one list per launch
+    const int total = off[count];
+    for (int e = blockIdx.x * 64 + threadIdx.x; e < total; e += gridDim.x * 64) {
+        int k;
+        const int b = P.first + queue_slot(off, count, e, k);
+        stencil_redo_entry(P, b, P.redo_queue[(size_t)b * P.NT + k]);
+    }
+}
 
 // the queued break-point candidates (:651-806), one per lane
-__global__ __launch_bounds__(256) void k_stencil_break(FeatParams P) {
-    const int b = blockIdx.y + P.first;
-    const int cnt = P.brk_cnt[b];
+__device__ __forceinline__ void stencil_break_entry(const FeatParams& P, int b, unsigned entry) {
     const float thBreakCornerDis = 1;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
-        const unsigned entry = P.brk_queue[(size_t)b * P.NT + e];
+    {
         const int line = (int)(entry >> 24), i = (int)(entry & 0xffffffu);
         const size_t pos = (size_t)b * P.NT + P.line_start[(size_t)b * P.L + line] + i;  // line order
         const float4* slot_pts = P.ln_pts + (size_t)b * P.NT;
@@ -2230,6 +2277,19 @@ __global__ __launch_bounds__(256) void k_stencil_break(FeatParams P) {
         }
         if (f5) P.ln_attr[pos] = (uint16_t)(P.ln_attr[pos] | (f5 << A_F5_SHIFT));
 #undef PT
+    }
+}
+__global__ __launch_bounds__(256) void k_stencil_break(FeatParams P) {  // per-slot grid (blocks, slots)
+    const int b = blockIdx.y + P.first;
+    const int cnt = P.brk_cnt[b];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) stencil_break_entry(P, b, P.brk_queue[(size_t)b * P.NT + e]);
+}
+__global__ __launch_bounds__(256) void k_stencil_break_list(FeatParams P, int count, const int* off) {  // one list per launch
+    const int total = off[count];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        int k;
+        const int b = P.first + queue_slot(off, count, e, k);
+        stencil_break_entry(P, b, P.brk_queue[(size_t)b * P.NT + k]);
     }
 }
 
@@ -3898,8 +3958,22 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
             hipLaunchKernelGGL(k_stencil<1>, grid, dim3(64 * ST_LINES), 0, s, P);
             hipLaunchKernelGGL(k_stencil<2>, grid, dim3(64 * ST_LINES), 0, s, P);
         }
-        hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
+        if (count > ST_SEGMENT_MAX_SLOTS) {
+            // one list per launch and queue (offsets sliced like work_off: by first slot and lane); the grids are sized for twice the
+            // usual fill (0.2 % / 2 % of the points) and stride over whatever more there is
+            int* off_r = ctx->queue_off + (size_t)first + ctx->cur;
+            int* off_b = off_r + (ctx->B + mml_ctx::MAX_LANES + 1);
+            const long pts = (long)count * ctx->NT;
+            const int g_r = (int)std::min<long>(std::max<long>(pts / 250 / 64, 64), 1 << 16);
+            const int g_b = (int)std::min<long>(std::max<long>(pts / 25 / 256, 64), 1 << 16);
+            hipLaunchKernelGGL(k_queue_prefix, dim3(1), dim3(1024), 0, s, first, count, P.redo_cnt, off_r);
+            hipLaunchKernelGGL(k_stencil_redo_list, dim3(g_r), dim3(64), 0, s, P, count, off_r);
+            hipLaunchKernelGGL(k_queue_prefix, dim3(1), dim3(1024), 0, s, first, count, P.brk_cnt, off_b);  // (the redo pass appends)
+            hipLaunchKernelGGL(k_stencil_break_list, dim3(g_b), dim3(256), 0, s, P, count, off_b);
+        } else {
+            hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
+            hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
+        }
     }
     {
         MmlStageScope t(ctx, "select");

@@ -154,6 +154,7 @@ struct mml_ctx {
     int sel_cap_velo = 0;
     unsigned* brk_queue = nullptr;  // B * NT: queued break-point candidates of k_stencil
     int* brk_cnt = nullptr;         // 2 B: break-point queue sizes, then redo queue sizes
+    int* queue_off = nullptr;       // 2 (B + MAX_LANES + 1): per launch the offsets of the slots' redo / break-point queues in their concatenation
     unsigned* redo_queue = nullptr; // B * NT: points k_stencil left to k_stencil_redo
     uint8_t* sel_done = nullptr;       // B * L: lines finished by k_select_part
     bool select_part = true;
