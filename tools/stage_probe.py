@@ -11,13 +11,28 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def main(B=1024, reps=4):
+def main(B=1024, reps=4, extract_only=0):
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
     cfg = dict(bench.CONFIGS[1])
     args = type("A", (), dict(cell_corner=0.0, cell_surf=0.0))()
     ctx = bench.make_context(M, cfg, B, 0, args, cfg["map_points"])
     scans = [bench.make_scan(synth, cfg, 100 + k) for k in range(16)]
+    if extract_only:   # (builds whose label lists are wrong on purpose: the extraction stages only)
+        for s in range(B):
+            ctx.scan_upload(s, scans[s % 16][0], scans[s % 16][1])
+        ctx.synchronize()
+        ctx.set_lanes(1)
+        for _ in range(2):
+            ctx.extract(0, B)
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(reps):
+            ctx.extract(0, B)
+        prof = ctx.profile_get()
+        st = {k: v[0] / reps for k, v in prof.items() if v[1] > 0}
+        print(os.environ.get("MML_LIB_PATH", "default"), "extract sum %.3f" % sum(st.values()), " ".join("%s %.3f" % (k, v) for k, v in st.items()))
+        return
     cm, sm, tiles_n = bench.build_maps(ctx, synth, cfg, 100, cfg["map_points"])
     ctx.map_set_local(0, cm)
     ctx.map_set_local(1, sm)
@@ -45,4 +60,4 @@ def main(B=1024, reps=4):
 
 
 if __name__ == "__main__":
-    main(*[int(a) for a in sys.argv[1:3]])
+    main(*[int(a) for a in sys.argv[1:4]])
