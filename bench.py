@@ -374,7 +374,8 @@ def run_throughput(args, rank, local_rank, world, dist):
     # The map is the scene tiled on a lattice: unless --no-spread, consecutive groups of slots sit on different tiles
     # (their initial poses are shifted by the tile offset, the sensor-frame points are what they are), so the
     # association of a batch touches the whole map, not the one tile around the origin.
-    tiles = synth.tile_offsets(1 if args.no_spread else full_tiles)
+    # (at most B / (2 nd) tiles, so that every (scan, tile) pair occurs in at least two slots: the replica check below compares them)
+    tiles = synth.tile_offsets(1 if args.no_spread else max(1, min(full_tiles, B // (2 * nd))))
     dR = np.zeros((B, 9))
     dt = np.zeros((B, 3))
     x0 = np.zeros((B, 6))

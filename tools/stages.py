@@ -7,7 +7,7 @@ PREFIX = [
     ("k_seg_records", "assign_tables"),
     ("k_assign_init", "assign_count"), ("k_assign_a", "assign_count"), ("k_assign_b", "assign_scan"),
     ("k_assign_c_direct", "assign_scatter"), ("k_assign_c_staged", "assign_scatter"), ("k_assign_c", "assign_scatter"),
-    ("k_stencil_break", "stencil"), ("k_stencil_redo", "stencil"), ("k_stencil", "stencil"),
+    ("k_stencil_break", "stencil"), ("k_stencil_redo", "stencil"), ("k_stencil", "stencil"), ("k_queue_prefix", "stencil"),
     ("k_select", "select"), ("k_crop", "crop_compact"), ("k_livox_extrinsic", "livox_extrinsic"),
     ("k_undistort_prep", "undistort"), ("k_undistort", "undistort"),
     ("k_voxel", "voxel_downsample"), ("k_seg_", "voxel_downsample"),
