@@ -31,6 +31,9 @@
 #include "lidar_eval.h"
 #include "mml_internal.h"
 
+// k_fw_step -- the dense 15 W-dimensional trust-region iteration -- keeps 256 threads; the lidar evaluation (k_fw_eval: eval_frame +
+// block_reduce28, shared with k_solve / k_linearize / k_window_round so that all of them sum in the same order) runs SOLVE_THREADS.
+constexpr int FW_THREADS = 256;
 namespace {
 
 constexpr int FW_N = 15 * MAXW;  // 120 parameters at most
@@ -410,7 +413,7 @@ __device__ int fw_propose(const FwDevParams* P, FwShared& sh, int n) {
             __syncthreads();
             const double mu = S.mu;
             if (!(mu < 1.0)) break;
-            for (int o = tid; o < n * 30; o += SOLVE_THREADS) {
+            for (int o = tid; o < n * 30; o += FW_THREADS) {
                 const int i = o / 30, k = band0(i) + (o - 30 * i);
                 if (k < 0 || k > i) continue;
                 double a = sh.H[i * FW_BW + (k - band0(i))] * V.scale[i] * V.scale[k];
@@ -564,7 +567,7 @@ __device__ bool fw_decide(const FwKernelArgs& A, FwShared& sh, int n) {
             S.flag = stop;
         }
     } else {
-        for (int o = tid; o < n * FW_BW; o += SOLVE_THREADS) sh.H[o] = A.G->Hb[cur_slot][o];
+        for (int o = tid; o < n * FW_BW; o += FW_THREADS) sh.H[o] = A.G->Hb[cur_slot][o];
         if (tid == 0) {
             S.radius *= 0.5;
             S.reuse = 1;
@@ -575,7 +578,7 @@ __device__ bool fw_decide(const FwKernelArgs& A, FwShared& sh, int n) {
     return S.flag != 0;
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_fw_step(FwKernelArgs A) {
+__global__ __launch_bounds__(FW_THREADS) void k_fw_step(FwKernelArgs A) {
     __shared__ FwShared sh;
     const FwDevParams* P = A.P;
     FwGlobal* G = A.G;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_fw_step(FwKernelArgs A) {
     {
         const double* src = reinterpret_cast<const double*>(&G->v);
         double* dst = reinterpret_cast<double*>(&V);
-        for (int i = tid; i < (int)(sizeof(FwVectors) / sizeof(double)); i += SOLVE_THREADS) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(FwVectors) / sizeof(double)); i += FW_THREADS) dst[i] = src[i];
         if (tid == 0) S = G->s;
     }
     __syncthreads();
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_fw_step(FwKernelArgs A) {
     unsigned have = 0;  // bit f: IMU factor f present
     for (int f = 1; f < W; ++f) have |= P->have_imu[f] ? 1u << f : 0u;
 #pragma unroll 4
-    for (int o = tid; o < n * FW_BW; o += SOLVE_THREADS) {
+    for (int o = tid; o < n * FW_BW; o += FW_THREADS) {
         const int a = o / FW_BW, F = a / 15, la = a - 15 * F;
         const int b = 15 * (F - 1) + (o - FW_BW * a);
         const bool inb = b >= 0 && b < n;
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_fw_step(FwKernelArgs A) {
         if (F == 0 && P->has_prior) g += G->gp[la];
         V.g[e][tid] = g;
     }
-    if (tid == SOLVE_THREADS - 1) {
+    if (tid == FW_THREADS - 1) {
         double cost = 0;
         for (int f = 0; f < W; ++f) cost += G->rec[f][27];
         for (int f = 1; f < W; ++f)
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_fw_step(FwKernelArgs A) {
     {
         double* dst = reinterpret_cast<double*>(&G->v);
         const double* src = reinterpret_cast<const double*>(&V);
-        for (int i = tid; i < (int)(sizeof(FwVectors) / sizeof(double)); i += SOLVE_THREADS) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(FwVectors) / sizeof(double)); i += FW_THREADS) dst[i] = src[i];
     }
     if (done || A.last) {
         if (tid < n) A.out->x[tid] = V.x[tid];
@@ -810,7 +813,7 @@ extern "C" int mml_fullwindow_solve(mml_ctx* ctx, mml_fullwindow* fw, int first_
         a.round = r;
         a.last = r + 1 == rounds;
         hipLaunchKernelGGL(k_fw_eval, dim3(2 * W), dim3(SOLVE_THREADS), 0, s, a);
-        hipLaunchKernelGGL(k_fw_step, dim3(1), dim3(SOLVE_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_fw_step, dim3(1), dim3(FW_THREADS), 0, s, a);
         if ((r & 3) == 3 && r + 1 < rounds) {
             MML_HIP(hipGetLastError());
             MML_HIP(hipMemcpyAsync(&d->h_out->pad_, &d->d_state->s.go, sizeof(int), hipMemcpyDeviceToHost, s));

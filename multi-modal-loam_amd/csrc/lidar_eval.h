@@ -12,7 +12,16 @@
 
 namespace {
 
-constexpr int SOLVE_THREADS = 256;
+// Threads per one-frame evaluation (eval_frame + block_reduce28): every kernel that evaluates lidar factors -- k_solve, k_linearize,
+// k_window_round, k_fw_eval -- uses this one number, so that all of them accumulate a frame's 28 sums in the same order (they are held
+// bit-identical, tests/test_gpu_multi.py).  128 since round 5: with 256 three of a problem's four wavefronts idle through the
+// trust-region proposal (40 % of k_solve's time) while holding their 256 registers; two-wavefront workgroups put four problems on a CU
+// instead of two: k_solve 0.325 -> 0.226 ms per 1024 problems (64 threads: 0.321).  The price is the single-problem latency: the
+// factor pass of ONE problem takes twice as long (configs[2]: 0.82 -> 0.85 ms per scan).
+#ifndef MML_SOLVE_THREADS
+#define MML_SOLVE_THREADS 128
+#endif
+constexpr int SOLVE_THREADS = MML_SOLVE_THREADS;
 constexpr int SOLVE_WAVES = SOLVE_THREADS / 64;
 constexpr int MAXW = 8;  // frames per window problem
 constexpr double kLidarM = 1.5e-3;  // IMUIntegrator.h:83
