@@ -205,6 +205,7 @@ __device__ __forceinline__ void radix_sort_lds(unsigned long long (&key)[KPT], i
 // list -- their labelled clouds are no larger than a small scan's, only their indices are wider.
 struct VoxelArgs {
     int kind0, first, NT, MF, B, cap_y0, cap_y1, list_stride;
+    int skip_above, only_above;  // > 0: leave the slots with more / with no more labelled points than this to another launch
     const int* fu_info;
     const float4* ln_pts;
     const int* ln_gidx;
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
     auto key_pos = [&](unsigned long long k) -> unsigned { return wide ? seq2idx[(unsigned)k & 0x1fffu] : (unsigned)k & 0xffffu; };
 
     const int nsel = A.fu_info[8 * b + 6 + kind];
+    if ((A.skip_above > 0 && nsel > A.skip_above) || (A.only_above > 0 && nsel <= A.only_above)) return;  // (workgroup-uniform)
     const int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
     const bool overflow = nsel > cap;
     if (cnt == 0) {
@@ -483,6 +485,8 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     A.ft1 = ctx->ft_xyz[1];
     A.ft_n = ctx->ft_n;
     A.seq_scratch = reinterpret_cast<const unsigned*>(ctx->vx_keys);
+    A.skip_above = 0;
+    A.only_above = 0;
     if (cap_corner == cap_surf || count <= 16) {
         // (one launch for both kinds: a handful of scans are a chain of launches, not a question of room on the CUs)
         A.kind0 = 0;
@@ -493,8 +497,18 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
         A.kind0 = 0;
         A.cap_y0 = A.cap_y1 = cap_corner;
         hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), lds(cap_corner), MML_STREAM(ctx), A);
+        // The surf lists of a 52.8 k-point scan hold ~3 000 points: they get 512-thread workgroups with room for 4096 keys (32 KB:
+        // four per CU where the 1024-thread form with its 64 KB runs two; 0.222 -> 0.178 ms per 1024 scans); the slots with more
+        // are left to a second launch of the large form, whose workgroups return at once everywhere else.
+        constexpr int cap_mid = 4096;
+        static_assert(cap_mid < MML_VOXEL_LDS_CAP, "the 512-thread form takes the short lists only");
         A.kind0 = 1;
+        A.cap_y0 = A.cap_y1 = cap_mid;
+        A.skip_above = cap_mid;
+        hipLaunchKernelGGL(k_voxel<512>, dim3(count, 1), dim3(512), lds(cap_mid), MML_STREAM(ctx), A);
         A.cap_y0 = A.cap_y1 = cap_surf;
+        A.skip_above = 0;
+        A.only_above = cap_mid;
         hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), lds(cap_surf), MML_STREAM(ctx), A);
     }
     MML_HIP(hipGetLastError());
