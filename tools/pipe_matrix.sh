@@ -15,6 +15,6 @@ except Exception as e:
 PY
 }
 for spec in "$@"; do
-  L=$(echo "$spec" | tr ' =' '__')
+  L=$(echo "$spec" | tr ' =/' '___')
   run "$L" $spec
 done | tee $OUT/matrix.txt
