@@ -224,6 +224,10 @@ __device__ __forceinline__ void crop_test(const FeatParams& P, float x, float y,
 
 __global__ void k_assign_init(FeatParams P, int count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {  // the launch's two lists of lines left to k_select start empty (k_select_list fills them)
+        P.sel_list_cnt[2 * P.first] = 0;
+        P.sel_list_cnt[2 * P.first + 1] = 0;
+    }
     if (t < count) {
         AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + (P.first + t);
         a->first_finite = 0x7fffffff;
@@ -1013,10 +1017,16 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
             xw[r] = 0;
             info[r] = 255;
             if (i < n) {
-                const mml_livox_point q = in[i];
-                pt[r] = make_float4(q.x, q.y, q.z, (float)q.reflectivity);  // (the float it becomes at :994)
-                xw[r] = q.offset_time;
-                info[r] = q.line;
+                // (the record as a 16-byte and a 4-byte request: left to itself the compiler fetches the two bytes it needs of the
+                //  last word with a byte load each -- three requests per record)
+                typedef unsigned lv_u4 __attribute__((ext_vector_type(4), aligned(4)));
+                const unsigned* w = reinterpret_cast<const unsigned*>(in + i);
+                const lv_u4 head = *reinterpret_cast<const lv_u4*>(w);
+                const unsigned tail = w[4];  // reflectivity | tag << 8 | line << 16 | pad << 24
+                pt[r] = make_float4(__uint_as_float(head.y), __uint_as_float(head.z), __uint_as_float(head.w),
+                                    (float)(tail & 255u));  // (the float the reflectivity becomes at :994)
+                xw[r] = head.x;             // offset_time
+                info[r] = (tail >> 16) & 255u;  // line
             }
         }
     }
@@ -1261,6 +1271,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_assign_tables(FeatParams P, int 
     const int t = blockIdx.x;
     if (t >= count) return;
     const int b = P.first + t, tid = threadIdx.x;
+    if (t == 0 && tid == 64) {  // the launch's two lists of lines left to k_select start empty (k_select_list fills them)
+        P.sel_list_cnt[2 * P.first] = 0;
+        P.sel_list_cnt[2 * P.first + 1] = 0;
+    }
     if (tid < 64) {
         const int lane = tid;
         const bool in = lane < P.L;
@@ -3993,7 +4007,7 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         if (part) {
             // lines whose partitions hold 3 .. 64 / .. 128 points: one partition per lane; what is left over (short, very long or
             // ragged lines) is listed and goes through k_select, a small grid walking the two lists
-            MML_HIP(hipMemsetAsync(ctx->sel_list_cnt + 2 * (size_t)first, 0, 2 * sizeof(int), s));
+            // (the two list counters of the launch were zeroed by the bucketing: k_assign_tables / k_assign_init)
             hipLaunchKernelGGL((k_select_part<u64m, SP_LINES, SP_MAXWIN>), dim3((ctx->L + SP_LINES - 1) / SP_LINES, count), dim3(64 * SP_LINES), 0, s,
                                P, ctx->L);
             hipLaunchKernelGGL((k_select_part<u128m, SP_LINES_WIDE, SP_MAXWIN_WIDE>), dim3((ctx->L + SP_LINES_WIDE - 1) / SP_LINES_WIDE, count),
