@@ -138,6 +138,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ctx->VX_CAP = (int)ctx->NT;
     ctx->h_n_in.assign((size_t)ctx->B * 2, 0);
     ctx->raw_extracted.assign((size_t)ctx->B, 0);
+    ctx->stats_stale.assign((size_t)ctx->B, 1);
     auto fail = [&](hipError_t e, const char* what) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);
         // keep ctx alive so the caller can read the message? No: report through the return code only.
@@ -1088,15 +1089,19 @@ static void finish_stats(const double* s, mml_assoc_stats* o) {
     o->is_degenerate = o->min_singular < 3.0 ? 1 : 0;  // Estimator.cpp:772-775
 }
 
-int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, double thres_dist,
-                  mml_assoc_stats* stats) {
+static int associate_enqueue(mml_ctx* ctx, int first_slot, int count, const double* T_wl, double thres_dist, bool with_stats) {
     CHECK_SLOTS(first_slot, count);
     MML_REQUIRE(T_wl != nullptr, MML_ERR_INVALID, "null T_wl");
     MML_REQUIRE(ctx->have_map[0] && ctx->have_map[1], MML_ERR_STATE, "mml_associate before both maps were set");
     double* d_T = ctx->d_pose_in + 64 * (size_t)first_slot;
     int rc = upload_doubles(ctx, d_T, T_wl, 16 * (size_t)count);
     if (rc != MML_OK) return rc;
-    rc = mml_launch_associate(ctx, first_slot, count, d_T, thres_dist);
+    return mml_launch_associate(ctx, first_slot, count, d_T, thres_dist, with_stats);
+}
+
+int mml_associate(mml_ctx* ctx, int first_slot, int count, const double* T_wl, double thres_dist,
+                  mml_assoc_stats* stats) {
+    int rc = associate_enqueue(ctx, first_slot, count, T_wl, thres_dist, true);
     if (rc != MML_OK) return rc;
     if (stats) {
         double* h = stage_alloc(ctx, 16 * (size_t)count);  // pinned
@@ -1112,6 +1117,7 @@ int mml_factors_upload(mml_ctx* ctx, int slot, int kind, const double* rec, int 
     CHECK_SLOTS(slot, 1);
     MML_REQUIRE((kind == 0 || kind == 1) && n >= 0 && (n == 0 || rec), MML_ERR_INVALID, "bad arguments");
     MML_REQUIRE(n <= ctx->MF, MML_ERR_CAPACITY, "more factors than max_features");
+    ctx->stats_stale[slot] = 1;  // (the slot's statistics no longer describe its factors: recomputed when asked for)
     if (kind == 0) {
         std::vector<MmlLineFactor> h(n ? n : 1);
         for (int i = 0; i < n; ++i) {
@@ -1507,7 +1513,7 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
                     so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
                     pose_to_Twl(q, x_inout + 6 * (size_t)(off + i), T_bl, &Twl[16 * (size_t)i]);
                 }
-                return mml_associate(ctx, f, c, Twl.data(), thres_dist, nullptr);
+                return associate_enqueue(ctx, f, c, Twl.data(), thres_dist, false);  // (nobody reads the statistics of a step)
             default: {
                 int r = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
                 if (r != MML_OK) return r;

@@ -1415,7 +1415,7 @@ int mml_launch_time_offset(mml_ctx* ctx, MmlGrid& g, float4* d_velo4, const floa
     return MML_OK;
 }
 
-int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist) {
+int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist, bool with_stats) {
     AssocParams P;
     P.first = first;
     P.B = ctx->B;
@@ -1481,11 +1481,27 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
             hipLaunchKernelGGL(k_associate_fit, dim3(512), dim3(128), 0, MML_STREAM(ctx), P, 1);
         }
     }
-    {
-        MmlStageScope t(ctx, "assoc_stats");
-        hipLaunchKernelGGL(k_assoc_stats, dim3(count), dim3(256), 0, MML_STREAM(ctx), first, ctx->B, ctx->MF, ctx->ft_n,
-                           ctx->lf, ctx->pf, ctx->assoc_stats);
-    }
+    for (int i = 0; i < count; ++i) ctx->stats_stale[first + i] = 1;
     MML_HIP(hipGetLastError());
+    if (with_stats) return mml_ensure_assoc_stats(ctx, first, count);
+    return MML_OK;
+}
+
+// n_line / n_plane / used counts / normal Gram matrix of the slots' current factors (checkLocalizability's input, Estimator.cpp:536-565;
+// the counts k_linearize copies into its records), on the context's current stream, for the slots of the range whose factors changed
+// since they were last computed.  mml_step does not ask for them (0.02 ms per 1024 scans of a kernel whose output it never reads).
+int mml_ensure_assoc_stats(mml_ctx* ctx, int first, int count) {
+    int lo = -1, hi = -1;
+    for (int i = 0; i < count; ++i)
+        if (ctx->stats_stale[first + i]) {
+            if (lo < 0) lo = first + i;
+            hi = first + i;
+        }
+    if (lo < 0) return MML_OK;
+    MmlStageScope t(ctx, "assoc_stats");
+    hipLaunchKernelGGL(k_assoc_stats, dim3(hi - lo + 1), dim3(256), 0, MML_STREAM(ctx), lo, ctx->B, ctx->MF, ctx->ft_n, ctx->lf, ctx->pf,
+                       ctx->assoc_stats);
+    MML_HIP(hipGetLastError());
+    for (int b = lo; b <= hi; ++b) ctx->stats_stale[b] = 0;
     return MML_OK;
 }

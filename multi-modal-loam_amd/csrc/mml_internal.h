@@ -114,6 +114,7 @@ struct mml_ctx {
     mml_livox_point* livox_in = nullptr;  // B * NL
     int* d_n_in = nullptr;                // B * 2 (velo, livox)
     std::vector<int> h_n_in;
+    std::vector<char> stats_stale;        // B: 1 while assoc_stats of the slot do not describe its current factors (mml_ensure_assoc_stats)
     std::vector<char> raw_extracted;      // B: 1 while the slot's raw buffers are the ones its extracted state was made from
 
     // per raw point scratch
@@ -328,7 +329,10 @@ int mml_cube_store_increment(mml_ctx* ctx, const double* T_wl, int* n_out);
 int mml_cube_store_download(mml_ctx* ctx, int kind, float* xyz, int* cube, int capacity, int* n, int* cen);
 int mml_cube_store_reset(mml_ctx* ctx);
 int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_d2, int* d_idx, float* d_d2);
-int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist);
+// with_stats = false (mml_step, which reads none of them): the per-slot statistics (counts, normal Gram matrix) are left stale and
+// computed by mml_ensure_assoc_stats when a consumer asks (mml_linearize*, the next mml_associate with statistics)
+int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist, bool with_stats = true);
+int mml_ensure_assoc_stats(mml_ctx* ctx, int first, int count);
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
                      bool want_trace);
 int mml_window_solve_continue(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts);

@@ -1242,6 +1242,10 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
 
 int mml_launch_linearize(mml_ctx* ctx, int slot, const double* d_x, const double* d_Tbl, double w_tan, double huber,
                          double* d_record, int frames) {
+    {  // (the records carry the used-factor counts of the association's statistics)
+        const int rs = mml_ensure_assoc_stats(ctx, slot, frames);
+        if (rs != MML_OK) return rs;
+    }
     MmlStageScope t(ctx, "linearize");
     hipLaunchKernelGGL(k_linearize, dim3(frames), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), slot, ctx->B, ctx->MF, ctx->ft_n,
                        ctx->lf, ctx->pf, d_x, d_Tbl, w_tan, huber, ctx->assoc_stats, d_record);
