@@ -60,10 +60,11 @@ STAGE_BYTES = {
     "assign_onepass":   lambda n_v, n_l, nf, it: 16 * n_v + 20 * n_l + 24 * (n_v + n_l),
     "assign_tables":    lambda n_v, n_l, nf, it: 0,
     "stencil":          lambda n_v, n_l, nf, it: 16 * (n_v + n_l),     # read xyzi of every bucketed point
-    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),     # attr 2 B + 2 order keys 8 B + label 1 B
-    "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),      # write the 4 B label/line/time record
+    "select":           lambda n_v, n_l, nf, it: 11 * (n_v + n_l),     # attr 2 B + 2 order keys 8 B + label 1 B (+ 4 B per labelled point)
+    "crop_compact":     lambda n_v, n_l, nf, it: 4 * (n_v + n_l),      # (k_crop: behind mml_cloud_upload only since round 5)
     "undistort":        lambda n_v, n_l, nf, it: 28 * (n_v + n_l),
-    "voxel_downsample": lambda n_v, n_l, nf, it: 17 * (n_v + n_l),     # label scan + xyz of labelled points
+    # list entry 4 B + point 16 B + fused index 4 B per labelled point (~7 % of the points: taken as 0.07 N) + 16 B per feature out
+    "voxel_downsample": lambda n_v, n_l, nf, it: 24 * 0.07 * (n_v + n_l) + 16 * nf,
     "associate":        lambda n_v, n_l, nf, it: 112 * nf,
     "associate_far":    lambda n_v, n_l, nf, it: 0,                    # queue of the few far queries (bytes counted in associate)
     "associate_fit":    lambda n_v, n_l, nf, it: 0,                    # model fit of the searched features (bytes counted in associate)
