@@ -198,6 +198,15 @@ def test_full_size_step_properties(M, O, scene, synth):
             _check_after_step(c, s, ora[s % 4], x1[s])
         for s in range(4):
             assert np.abs(x1[s][:3] - frames[s]["T_gt"][:3, 3]).max() < 0.02
+        # mml_step does not compute the association's statistics (nothing in it reads them): a record linearised straight after
+        # the step gets them on demand and must equal the record after an association that computes them eagerly
+        rec_lazy = c.linearize_window(0, 4, x1[:4], np.eye(4))
+        st = c.associate(0, 4, np.stack([cases[s]["T0"] for s in range(4)]), 25.0)
+        rec_eager = c.linearize_window(0, 4, x1[:4], np.eye(4))
+        # (the eager association starts from T0, the step from the rotation vector of T0: the same factors up to the last bit of the pose)
+        assert np.allclose(rec_lazy, rec_eager, rtol=1e-9, atol=1e-9) and np.array_equal(rec_lazy[:, 28:30], rec_eager[:, 28:30])
+        assert [int(r[28]) for r in rec_lazy] == [q.n_line_used for q in st] and [int(r[29]) for r in rec_lazy] == [q.n_plane_used for q in st]
+        assert all(q.n_plane_used > 100 for q in st)
     finally:
         c.close()
 

@@ -9,7 +9,7 @@ GROUPS = [("assign", ["assign_count", "assign_scan", "assign_scatter", "assign_e
           ("stencil (3 kernels)", ["stencil"]),
           ("select", ["select"]), ("undistort", ["undistort"]), ("solve", ["solve"]),
           ("associate + fit + far", ["associate", "associate_fit", "associate_far"]), ("voxel", ["voxel_downsample"]),
-          ("crop, stats", ["crop_compact", "assoc_stats"])]
+          ("crop, stats", ["crop_compact", "assoc_stats", "livox_extrinsic"])]
 
 
 def main(bench, sq, traffic):
@@ -22,6 +22,8 @@ def main(bench, sq, traffic):
     tv = tb = tm = 0.0
     for name, keys in GROUPS:
         keys = [k for k in keys if k in st]   # (three-pass or one-pass bucketing: whichever stages the run had)
+        if not keys:
+            continue
         ms = sum(st[k] for k in keys)
         v = sum(sq[k]["valu_wave_instr"] for k in keys if k in sq)
         by = sum(tr[k] for k in keys if k in tr)
