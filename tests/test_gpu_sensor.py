@@ -47,7 +47,7 @@ def test_sensor_golden(M):
 def test_batch72_sensor_faithful_scans_match_oracle(M, O, synth):
     """72 slots = 24 distinct sensor-faithful fused scans x 3 (1.2 M distinct points): no-returns absent / NaN / (0,0,0) by
     turns, a third of them with intra-sweep motion.  Reaches the batch kernels (k_stencil<0>, batch k_select_part,
-    k_select_list, k_voxel<256>/<1024>, lane search, 4 stream lanes of 18 slots).  Extraction bit for bit on every slot; after
+    k_select_list, k_voxel<256>/<512>, lane search, the default 2 stream lanes of 36 slots).  Extraction bit for bit on every slot; after
     mml_step the undistorted clouds, labels, stacks, factor records and poses against the oracle pipeline."""
     B, ND = 72, 24
     modes = ("skip", "nan", "zero")
@@ -65,8 +65,7 @@ def test_batch72_sensor_faithful_scans_match_oracle(M, O, synth):
     assert sum(len(o["xyzi"]) for o in ora) > 1_000_000
     c = M.Context(max_scans=B, max_velo_points=NV, max_livox_points=24000)
     try:
-        c.set_lanes(4)
-        c.map_set_local(0, cm)
+        c.map_set_local(0, cm)       # (no set_lanes: the library's default two lanes, 36 slots each)
         c.map_set_local(1, sm)
         for s in range(B):
             c.scan_upload(s, cases[s % ND]["velo"], cases[s % ND]["livox"])
