@@ -328,6 +328,7 @@ __device__ __forceinline__ float neg_atan2_f(float yf, float xf) {
     return (float)(-atan2(y, x));
 }
 
+template <int PPT>
 __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __shared__ int s_bcnt[MAX_LINES];
     __shared__ int s_valid, s_keep;
@@ -348,14 +349,26 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __syncthreads();
     // (dense layouts: four points per thread -- a 130-entry histogram record per 1024 points instead of per 256: the records were a
     //  quarter of this pass's written bytes and all of pass B's work)
-    const int ppt = sensor == 0 ? P.ab_ppt : 1;
-    for (int r = 0; r < ppt; ++r) {
+    // (PPT = P.ab_ppt as a template parameter, round 5: the thread's four records are requested together -- with the run-time
+    //  trip count every round waited for its own load, one kilobyte in flight per wavefront)
+    const int ppt = sensor == 0 ? PPT : 1;
+    float4 pv[PPT];
+    if (sensor == 0) {
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            const int i = (blockIdx.x * PPT + r) * AB_THREADS + tid;
+            pv[r] = i < n ? nt_load4(P.velo_in + (size_t)b * P.NV + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+    if (r >= ppt) break;
     const int i = (blockIdx.x * ppt + r) * AB_THREADS + tid;
     bool valid = false, keep = false, near_ok = false;
     int key = 0;
     if (i < n) {
         if (sensor == 0) {
-            const float4 p = nt_load4(P.velo_in + (size_t)b * P.NV + i);
+            const float4 p = pv[r];
             const bool fin = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
             int ring = 255;  // 255: non-finite (removed at :1133), 254: finite but outside the ring table (:1163-1166)
             float ori = 0.f;
@@ -384,6 +397,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     const unsigned long long vm = __ballot(valid), km = __ballot(keep);
     if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
     if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
+    __builtin_amdgcn_sched_barrier(0);  // (one point at a time: the evaluations' temporaries do not overlap)
     }
     __syncthreads();
     int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
@@ -3945,7 +3959,10 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
     {
         MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
-        hipLaunchKernelGGL(k_assign_a, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+        if (P.ab_ppt == 4)
+            hipLaunchKernelGGL(k_assign_a<4>, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+        else
+            hipLaunchKernelGGL(k_assign_a<1>, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
     }
     {
         MmlStageScope t(ctx, "assign_scan");
@@ -4088,7 +4105,10 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
 // histograms land in blk_cnt, which nobody reads afterwards)
 int mml_launch_raw_lines(mml_ctx* ctx, int slot) {
     FeatParams P = make_params(ctx, slot);
-    hipLaunchKernelGGL(k_assign_a, dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+    if (P.ab_ppt == 4)
+        hipLaunchKernelGGL(k_assign_a<4>, dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+    else
+        hipLaunchKernelGGL(k_assign_a<1>, dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }

@@ -1,5 +1,5 @@
 """Stage times (HIP events, one stream) of a 1024-scan configs[1] step without bench.py's checks: for A/B builds whose results need
-not be right ($MML_LIB_PATH selects the library).  python tools/stage_probe.py [slots] [reps]"""
+not be right ($MML_LIB_PATH selects the library).  python tools/stage_probe.py [slots] [reps] [extract only: 0 | 1] [config: 1 | 3 | 4]"""
 import importlib
 import os
 import sys
@@ -11,10 +11,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def main(B=1024, reps=4, extract_only=0):
+def main(B=1024, reps=4, extract_only=0, config=1):
     M = importlib.import_module("multi-modal-loam_amd")
     synth = importlib.import_module("multi-modal-loam_amd.synth")
-    cfg = dict(bench.CONFIGS[1])
+    cfg = dict(bench.CONFIGS[config])
     args = type("A", (), dict(cell_corner=0.0, cell_surf=0.0))()
     ctx = bench.make_context(M, cfg, B, 0, args, cfg["map_points"])
     scans = [bench.make_scan(synth, cfg, 100 + k) for k in range(16)]
@@ -49,15 +49,15 @@ def main(B=1024, reps=4, extract_only=0):
     ctx.synchronize()
     ctx.set_lanes(1)
     for _ in range(2):
-        ctx.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
+        ctx.step(0, B, dR, dt, np.eye(4), 25.0, cfg.get("gn_iters", 10), x0)
     ctx.profile_enable(True)
     ctx.profile_reset()
     for _ in range(reps):
-        ctx.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
+        ctx.step(0, B, dR, dt, np.eye(4), 25.0, cfg.get("gn_iters", 10), x0)
     prof = ctx.profile_get()
     st = {k: v[0] / reps for k, v in prof.items() if v[1] > 0}
     print(os.environ.get("MML_LIB_PATH", "default"), "sum %.3f" % sum(st.values()), " ".join("%s %.3f" % (k, v) for k, v in st.items()))
 
 
 if __name__ == "__main__":
-    main(*[int(a) for a in sys.argv[1:4]])
+    main(*[int(a) for a in sys.argv[1:5]])
