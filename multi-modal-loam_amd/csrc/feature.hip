@@ -981,8 +981,34 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     auto& s_out = S.out;
     const int b = blockIdx.y + P.first, blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = P.n_in[2 * b + SENSOR];
     const int i0 = blk * MML_OP_BLK;
+    // ---- 1. the block's records, all loads in flight together ----
+    // (requested before the slot's point count is known -- the index clamped to the slot's buffer, the count decides later which
+    //  lanes hold a point: the block's first memory round trip is the records themselves, not the count in front of them)
+    float4 pt[OP_PPT];
+    unsigned xw[OP_PPT];    // velodyne: the raw azimuth (float bits), Livox: offset_time
+    unsigned info[OP_PPT];  // [0:7] line id, OPI_* flags, rank among the points of the line / among the kept points in the wavefront round
+    if constexpr (SENSOR == 0) {
+        const float4* in = P.velo_in + (size_t)b * P.NV;
+#pragma unroll
+        for (int r = 0; r < OP_PPT; ++r) pt[r] = nt_load4(in + min(i0 + r * OP_THREADS + tid, P.NV - 1));
+    } else {
+        const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
+#pragma unroll
+        for (int r = 0; r < OP_PPT; ++r) {
+            // (the record as a 16-byte and a 4-byte request: left to itself the compiler fetches the two bytes it needs of the
+            //  last word with a byte load each -- three requests per record)
+            typedef unsigned lv_u4 __attribute__((ext_vector_type(4), aligned(4)));
+            const unsigned* w = reinterpret_cast<const unsigned*>(in + min(i0 + r * OP_THREADS + tid, P.NL - 1));
+            const lv_u4 head = *reinterpret_cast<const lv_u4*>(w);
+            const unsigned tail = w[4];  // reflectivity | tag << 8 | line << 16 | pad << 24
+            pt[r] = make_float4(__uint_as_float(head.y), __uint_as_float(head.z), __uint_as_float(head.w),
+                                (float)(tail & 255u));  // (the float the reflectivity becomes at :994)
+            xw[r] = head.x;                 // offset_time
+            info[r] = (tail >> 16) & 255u;  // line
+        }
+    }
+    const int n = P.n_in[2 * b + SENSOR];
     // the per-slot resets (one block of the slot: the first Velodyne block, or the first Livox block of a scan without a Velodyne part)
     if (blk == 0 && tid == 0 && (SENSOR == 0 || P.n_in[2 * b] <= 0)) {
         P.slot_flags[2 * b] = 0;  // an extracted cloud, not undistorted yet
@@ -1011,39 +1037,6 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     struct {
         float startOri, endOri;
     } aux;
-    // ---- 1. the block's records, all loads in flight together ----
-    float4 pt[OP_PPT];
-    unsigned xw[OP_PPT];    // velodyne: the raw azimuth (float bits), Livox: offset_time
-    unsigned info[OP_PPT];  // [0:7] line id, OPI_* flags, rank among the points of the line / among the kept points in the wavefront round
-    if constexpr (SENSOR == 0) {
-        const float4* in = P.velo_in + (size_t)b * P.NV;
-#pragma unroll
-        for (int r = 0; r < OP_PPT; ++r) {
-            const int i = i0 + r * OP_THREADS + tid;
-            pt[r] = i < n ? nt_load4(in + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    } else {
-        const mml_livox_point* in = P.livox_in + (size_t)b * P.NL;
-#pragma unroll
-        for (int r = 0; r < OP_PPT; ++r) {
-            const int i = i0 + r * OP_THREADS + tid;
-            pt[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xw[r] = 0;
-            info[r] = 255;
-            if (i < n) {
-                // (the record as a 16-byte and a 4-byte request: left to itself the compiler fetches the two bytes it needs of the
-                //  last word with a byte load each -- three requests per record)
-                typedef unsigned lv_u4 __attribute__((ext_vector_type(4), aligned(4)));
-                const unsigned* w = reinterpret_cast<const unsigned*>(in + i);
-                const lv_u4 head = *reinterpret_cast<const lv_u4*>(w);
-                const unsigned tail = w[4];  // reflectivity | tag << 8 | line << 16 | pad << 24
-                pt[r] = make_float4(__uint_as_float(head.y), __uint_as_float(head.z), __uint_as_float(head.w),
-                                    (float)(tail & 255u));  // (the float the reflectivity becomes at :994)
-                xw[r] = head.x;             // offset_time
-                info[r] = (tail >> 16) & 255u;  // line
-            }
-        }
-    }
     __syncthreads();  // (the counters are zero, the sweep's ends are known)
     aux.startOri = S.ori[0];
     aux.endOri = S.ori[1];
