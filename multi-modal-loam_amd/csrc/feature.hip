@@ -960,6 +960,31 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+#ifdef MML_OP_TIMING
+// phase clocks of one bucketing block (the Velodyne block MML_OP_TIMING of the 518th slot of the launch; tools/assign_phases.py):
+// [0..9] its second wavefront, [10..12] the look-back section of the first one
+__device__ unsigned long long g_op_dbg[16];
+#define OP_MARK_(flag, prev, id)                       \
+    do {                                               \
+        if (flag) {                                    \
+            const unsigned long long now_ = clock64(); \
+            g_op_dbg[id] += now_ - prev;               \
+            prev = now_;                               \
+        }                                              \
+    } while (0)
+#define OP_MARK(id) OP_MARK_(op_dbg, op_prev, id)
+#define OP_MARK0(id) OP_MARK_(op_dbg0, op_prev0, id)
+extern "C" int mml_debug_op_timing(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_op_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_op_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#else
+#define OP_MARK(id)
+#define OP_MARK0(id)
+#endif
 struct OnepassLds {
     int cnt[OP_GROUPS][OP_CSTRIDE];  // points per (group, line); after the scan: points of the line in the groups before
     int gv[OP_GROUPS], gk[OP_GROUPS];  // valid / kept points per group -> exclusive over the groups
@@ -982,6 +1007,11 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     const int b = blockIdx.y + P.first, blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blk * MML_OP_BLK;
+#ifdef MML_OP_TIMING
+    const bool op_dbg = SENSOR == 0 && tid == 64 && blk == MML_OP_TIMING && b == P.first + 517;
+    const bool op_dbg0 = SENSOR == 0 && tid == 0 && blk == MML_OP_TIMING && b == P.first + 517;
+    unsigned long long op_prev = clock64(), op_prev0 = op_prev;
+#endif
     // ---- 1. the block's records, all loads in flight together ----
     // (requested before the slot's point count is known -- the index clamped to the slot's buffer, the count decides later which
     //  lanes hold a point: the block's first memory round trip is the records themselves, not the count in front of them)
@@ -1037,7 +1067,9 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     struct {
         float startOri, endOri;
     } aux;
+    OP_MARK(0);
     __syncthreads();  // (the counters are zero, the sweep's ends are known)
+    OP_MARK(1);
     aux.startOri = S.ori[0];
     aux.endOri = S.ori[1];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1093,8 +1125,10 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
         //  wavefronts per SIMD)
         __builtin_amdgcn_sched_barrier(0);
     }
+    OP_MARK(2);
     if (lane == 0) s_cond[wave] = cond_min;
     __syncthreads();
+    OP_MARK(3);
     // ---- 2. per line: exclusive scan over the 64 groups (lane = group) ----
     const bool gl = lane < OP_GROUPS;
     for (int k = wave; k < nkeys; k += OP_WAVES) {
@@ -1112,9 +1146,12 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
         if (gl) s_gk[lane] = x - v;
         if (lane == 63) s_hist[nkeys + 1] = x;
     }
+    OP_MARK(4);
     __syncthreads();
+    OP_MARK(5);
     // ---- 3. offsets of the lines inside the block; publish; look back ----
     if (wave == 0) {
+        OP_MARK0(10);
         const int h = lane < nkeys ? s_hist[lane] : 0;
         const int koff = wave_incl_scan(h) - h;
         if (lane < nkeys) s_koff[lane] = koff;
@@ -1149,6 +1186,7 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+        OP_MARK0(11);
         int pv = lane < blk ? (int)(w & 0x1fffu) : 0;
         int pk = lane < blk ? (int)((w >> 13) & 0x1fffu) : 0;
         int pc = 0x7fffffff;
@@ -1193,7 +1231,9 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
             rec[MAX_LINES + 1] = tk;
         }
     }
+    OP_MARK0(12);
     __syncthreads();
+    OP_MARK(6);
     // ---- 4. the points leave ----
     const int base_valid = region + s_base[0], base_keep = s_base[1], trig = s_base[2];
     double timeSpan = 1.0;
@@ -1237,7 +1277,9 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
         s_out[1][q] = __float_as_int(rel);
         __builtin_amdgcn_sched_barrier(0);
     }
+    OP_MARK(7);
     __syncthreads();
+    OP_MARK(8);
     {
         const int tv = s_hist[nkeys];
         int* og = P.ln_gidx + (size_t)b * P.NT + base_valid;
@@ -1247,6 +1289,10 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
             orl[k] = s_out[1][k];
         }
     }
+#ifdef MML_OP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left the wavefront)
+    OP_MARK(9);
+#endif
 }
 
 // one launch for both sensors (a handful of scans: one launch less in the chain): z = 0 the Velodyne blocks, z = 1 the Livox blocks,

@@ -17,9 +17,9 @@ R = 5
 for _ in range(R): ctx.extract(0, B)
 ctx.synchronize()
 lib.mml_debug_op_timing(out, 0)
-names = ["loads issued", "barrier 1", "evaluate 8 points (waits for its loads)", "barrier 2", "scan over groups", "barrier 3",
+names = ["records requested, point count read, counters zeroed", "barrier 1", "evaluate 8 points (waits for its records)", "barrier 2", "scan over groups", "barrier 3",
          "barrier 4 (wavefront 0: publish, look back)", "16-byte stores + LDS rows", "barrier 5", "row stores + drain"]
 tot = sum(out[i] for i in range(10))
-print("k_assign_onepass_s<0>, second wavefront of one block: cycles per launch (100 MHz clock64 ticks), total %d" % (tot // R))
+print("k_assign_onepass_s<0>, second wavefront of one block: clock64 ticks per launch, total %d" % (tot // R))
 for i, nme in enumerate(names): print("  %-48s %8d  %5.1f%%" % (nme, out[i] // R, 100.0 * out[i] / max(tot, 1)))
-print("first wavefront's serial section: tables+publish %d, look-back poll %d, reduce+record %d" % (out[10] // R, out[11] // R, out[12] // R))
+print("first wavefront: from the kernel's start to its serial section %d, publish + look-back poll %d, reduce + block record %d" % (out[10] // R, out[11] // R, out[12] // R))
