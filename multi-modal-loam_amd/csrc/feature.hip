@@ -335,9 +335,18 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     const int b = blockIdx.y + P.first;
     const int sensor = blockIdx.z;  // 0 velodyne, 1 livox
     const int tid = threadIdx.x, lane = tid & 63;
-    const int n = P.n_in[2 * b + sensor];
     const int nblk = sensor == 0 ? P.nblk_v : P.nblk_l;
     if ((int)blockIdx.x >= nblk) return;
+    // (PPT = P.ab_ppt as a template parameter, round 5: the thread's four records are requested together -- with the run-time
+    //  trip count every round waited for its own load, one kilobyte in flight per wavefront -- and before the slot's point count
+    //  is read, the index clamped to the slot's buffer: the block's first round trip to memory is the records themselves)
+    float4 pv[PPT];
+    if (sensor == 0) {
+#pragma unroll
+        for (int r = 0; r < PPT; ++r)
+            pv[r] = nt_load4(P.velo_in + (size_t)b * P.NV + min((int)((blockIdx.x * PPT + r) * AB_THREADS + tid), P.NV - 1));
+    }
+    const int n = P.n_in[2 * b + sensor];
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
     const int nbits = sensor == 0 ? P.ring_bits : P.line_bits;
     static_assert(MAX_LINES <= AB_THREADS, "one key per thread");
@@ -349,17 +358,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __syncthreads();
     // (dense layouts: four points per thread -- a 130-entry histogram record per 1024 points instead of per 256: the records were a
     //  quarter of this pass's written bytes and all of pass B's work)
-    // (PPT = P.ab_ppt as a template parameter, round 5: the thread's four records are requested together -- with the run-time
-    //  trip count every round waited for its own load, one kilobyte in flight per wavefront)
     const int ppt = sensor == 0 ? PPT : 1;
-    float4 pv[PPT];
-    if (sensor == 0) {
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            const int i = (blockIdx.x * PPT + r) * AB_THREADS + tid;
-            pv[r] = i < n ? nt_load4(P.velo_in + (size_t)b * P.NV + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
     if (r >= ppt) break;
@@ -726,6 +725,25 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
     const int b = by + P.first;
     const int sensor = blockIdx.z + P.sensor_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the keys and the records of the lane's own points are requested first (the record whether or not the key will call it valid:
+    // the few invalid ones cost nothing, and the load does not wait for the key) -- for the Velodyne part before the slot's point
+    // count is read, the index clamped to the slot's buffer: the count decides below which lanes hold a point
+    const int region = sensor == 0 ? 0 : P.NV;
+    int key[CB_TP];
+    float4 praw[CB_TP];
+    float ori[CB_TP];
+    uint32_t off_time[CB_TP];
+    double timeSpan = 1.0;
+    if (sensor == 0) {
+#pragma unroll
+        for (int r = 0; r < CB_TP; ++r) {
+            const int ic = min((int)(bx * CB_TILE + r * CB_THREADS + tid), P.NV - 1);
+            key[r] = P.raw_line[(size_t)b * P.NT + ic];
+            praw[r] = nt_load4(P.velo_in + (size_t)b * P.NV + ic);
+            ori[r] = P.raw_ori[(size_t)b * P.NV + ic];
+            off_time[r] = 0;
+        }
+    }
     const int n = P.n_in[2 * b + sensor];
     if ((int)(bx * CB_TILE) >= n) return;
     const int nkeys = sensor == 0 ? P.n_rings : P.n_lines;
@@ -748,27 +766,18 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
     for (int k = tid; k < nkeys; k += CB_THREADS) s_ls[k] = P.line_start[(size_t)b * P.L + (sensor == 0 ? 0 : P.n_rings) + k];
     if (tid < sub_n) s_cnt[tid][MAX_LINES + 1] = (bx * sub_n + tid < nblk) ? cnt0[(size_t)tid * BLK_STRIDE + MAX_LINES + 1] : 0;
     const AssignAux aux = *(reinterpret_cast<const AssignAux*>(P.assign_aux) + b);
-    // ... and so are the keys and the records of the lane's own points (the record whether or not the key will call it valid:
-    // the few invalid ones cost nothing, and the load no longer waits for the key)
-    const int region = sensor == 0 ? 0 : P.NV;
-    int key[CB_TP];
-    float4 praw[CB_TP];
-    float ori[CB_TP];
-    uint32_t off_time[CB_TP];
-    double timeSpan = 1.0;
 #pragma unroll
     for (int r = 0; r < CB_TP; ++r) {
         const int i = bx * CB_TILE + r * CB_THREADS + tid;
-        key[r] = 255;
-        praw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ori[r] = 0.f;
-        off_time[r] = 0;
-        if (i < n) {
-            key[r] = P.raw_line[(size_t)b * P.NT + region + i];
-            if (sensor == 0) {
-                praw[r] = nt_load4(P.velo_in + (size_t)b * P.NV + i);
-                ori[r] = P.raw_ori[(size_t)b * P.NV + i];
-            } else {
+        if (sensor == 0) {
+            if (i >= n) key[r] = 255;
+        } else {
+            key[r] = 255;
+            praw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ori[r] = 0.f;
+            off_time[r] = 0;
+            if (i < n) {
+                key[r] = P.raw_line[(size_t)b * P.NT + region + i];
                 const mml_livox_point q = P.livox_in[(size_t)b * P.NL + i];
                 praw[r] = make_float4(q.x, q.y, q.z, (float)q.reflectivity);
                 off_time[r] = q.offset_time;
