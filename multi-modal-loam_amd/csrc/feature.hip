@@ -1352,15 +1352,25 @@ __global__ __launch_bounds__(TB_THREADS) void k_assign_tables(FeatParams P, int 
             int* cum = P.seg_cum + lo * (MML_SEG_MAX + 1);
             int* pos = P.seg_pos + lo * MML_SEG_MAX;
             int* flat = P.seg_flat + ((size_t)b * 2 + sensor) * MML_SEG_FLAT;
-            for (int k = 0; k < nblk; ++k) {
-                const int* rec = rec0 + (size_t)k * BLK_STRIDE;
-                const int p = rec[OP_REC_POS + key];
+            // (the blocks' records are requested together: between the stores below the compiler keeps every load where it stands,
+            //  and the loop was a chain of up to sixteen round trips)
+            int rp[MML_SEG_MAX], rc[MML_SEG_MAX];
+#pragma unroll
+            for (int k = 0; k < MML_SEG_MAX; ++k) {
+                const int* rec = rec0 + (size_t)(k < nblk ? k : 0) * BLK_STRIDE;
+                rp[k] = rec[OP_REC_POS + key];
+                rc[k] = rec[key];
+            }
+#pragma unroll
+            for (int k = 0; k < MML_SEG_MAX; ++k) {
+                if (k >= nblk) break;
+                const int p = rp[k];
                 cum[k] = acc;
                 pos[k] = p;
                 s_cum[lane][k] = acc;
                 s_pos[lane][k] = p;
                 flat[k * nkeys + key] = p;
-                acc += rec[key];
+                acc += rc[k];
             }
             cum[nblk] = acc;
             s_cum[lane][nblk] = acc;
@@ -1388,9 +1398,12 @@ __global__ __launch_bounds__(TB_THREADS) void k_assign_tables(FeatParams P, int 
             const int nb = (ns + MML_OP_BLK - 1) / MML_OP_BLK;
             const int* r0 = P.blk_cnt + ((size_t)(b * 2 + lane) * P.nblk_max) * BLK_STRIDE;
             int tv = 0, tk = 0;
-            for (int k = 0; k < nb; ++k) {
-                tv += r0[(size_t)k * BLK_STRIDE + MAX_LINES];
-                tk += r0[(size_t)k * BLK_STRIDE + MAX_LINES + 1];
+#pragma unroll
+            for (int k = 0; k < MML_SEG_MAX; ++k) {
+                const size_t o = (size_t)(k < nb ? k : 0) * BLK_STRIDE;
+                const int v = r0[o + MAX_LINES], kk = r0[o + MAX_LINES + 1];
+                tv += k < nb ? v : 0;
+                tk += k < nb ? kk : 0;
             }
             P.cb_n[2 * b + lane] = tv;
             AssignAux* a = reinterpret_cast<AssignAux*>(P.assign_aux) + b;
