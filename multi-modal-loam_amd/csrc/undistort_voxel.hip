@@ -68,6 +68,31 @@ __global__ __launch_bounds__(256) void k_undistort(int first, int NT, int NV, co
     __builtin_nontemporal_store(outv, pp);
 }
 
+#ifdef MML_VX_TIMING
+// phase clocks of one k_voxel workgroup (kind MML_VX_TIMING of the 518th slot of the launch; tools/voxel_phases.py)
+__device__ unsigned long long g_vx_dbg[16];
+#define VX_MARK(id)                                    \
+    do {                                               \
+        if (vx_dbg) {                                  \
+            const unsigned long long now_ = clock64(); \
+            g_vx_dbg[id] += now_ - vx_prev;            \
+            vx_prev = now_;                            \
+        }                                              \
+    } while (0)
+extern "C" int mml_debug_vx_timing(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_vx_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vx_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#define VX_DBG_PARAMS , bool vx_dbg, unsigned long long& vx_prev
+#define VX_DBG_ARGS , vx_dbg, vx_prev
+#else
+#define VX_MARK(id)
+#define VX_DBG_PARAMS
+#define VX_DBG_ARGS
+#endif
 // ------------------------------------------------------------------------------------------------------------
 constexpr int VX_TAIL = 64;
 
@@ -93,7 +118,7 @@ __device__ __forceinline__ int vx_wave_incl_scan(int v) {
 // hist: VX_WAVES x 256 u16 (LDS), wtot: VX_WAVES + 2 ints (LDS).
 template <int VX_THREADS, int KPT>
 __device__ __forceinline__ void radix_sort_lds(unsigned long long (&key)[KPT], int cnt, int lo_bit, unsigned long long* lds,
-                                               unsigned short* hist, int* wtot, unsigned long long* s_red) {
+                                               unsigned short* hist, int* wtot, unsigned long long* s_red VX_DBG_PARAMS) {
     constexpr int VX_WAVES = VX_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -232,7 +257,7 @@ struct VoxelLds {
 // the part of k_voxel that depends on the number of keys per thread
 template <int VX_THREADS, int KPT>
 __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREADS>& S, unsigned long long* keys, int b, int kind, int cnt,
-                                           const unsigned* seq2idx, const float4* px, const int* gx, bool wide, float leaf) {
+                                           const unsigned* seq2idx, const float4* px, const int* gx, bool wide, float leaf VX_DBG_PARAMS) {
     constexpr int VX_WAVES = VX_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1. the labelled points of this (slot, kind) were listed by the selection kernels (feature.hip label_append), in no particular
@@ -271,6 +296,7 @@ __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREA
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    VX_MARK(4);
     float gmn[3], gmx[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -294,6 +320,7 @@ __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREA
         gmn[c] = r0;
         gmx[c] = r1;
     }
+    VX_MARK(5);
     // 2. voxel index (PCL 1.8.1 voxel_grid.hpp applyFilter): inverse leaf in float, floor, int, min_b offset
     const float inv = 1.0f / leaf;
     int min_b[3], div_b[3];
@@ -333,7 +360,9 @@ __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREA
                       : (((unsigned long long)(unsigned)idx << 32) | ((unsigned)g << 16) | pos[a]);
     }
     // 3. ascending on (voxel idx, fused index): a stable sort by voxel idx of the fused order
-    radix_sort_lds<VX_THREADS, KPT>(key, cnt, wide ? 13 : 16, keys, S.u.hist, S.wtot, S.red);
+    VX_MARK(6);
+    radix_sort_lds<VX_THREADS, KPT>(key, cnt, wide ? 13 : 16, keys, S.u.hist, S.wtot, S.red VX_DBG_ARGS);
+    VX_MARK(7);
 }
 
 // (two 1024-thread workgroups per CU -- eight wavefronts per SIMD -- is what hides this kernel's barriers and gathers: held to 64 registers)
@@ -363,6 +392,10 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
     const int vshift = wide ? 33 : 32;
     auto key_pos = [&](unsigned long long k) -> unsigned { return wide ? seq2idx[(unsigned)k & 0x1fffu] : (unsigned)k & 0xffffu; };
 
+#ifdef MML_VX_TIMING
+    const bool vx_dbg = tid == 64 && kind == MML_VX_TIMING && blockIdx.x == 517 && VX_THREADS == 512;
+    unsigned long long vx_prev = clock64();
+#endif
     const int nsel = A.fu_info[8 * b + 6 + kind];
     if ((A.skip_above > 0 && nsel > A.skip_above) || (A.only_above > 0 && nsel <= A.only_above)) return;  // (workgroup-uniform)
     const int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
@@ -372,13 +405,14 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
         return;
     }
     if (cnt <= VX_THREADS)
-        voxel_sort<VX_THREADS, 1>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+        voxel_sort<VX_THREADS, 1>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
     else if (cnt <= 2 * VX_THREADS)
-        voxel_sort<VX_THREADS, 2>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+        voxel_sort<VX_THREADS, 2>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
     else if (cnt <= 4 * VX_THREADS)
-        voxel_sort<VX_THREADS, 4>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+        voxel_sort<VX_THREADS, 4>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
     else
-        voxel_sort<VX_THREADS, 8>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf);
+        voxel_sort<VX_THREADS, 8>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
+    VX_MARK(0);
     // 4. one lane per voxel head: centroid in input order (AccumulatorXYZ: float sum, then / n)
     if (tid == 0) {
         S.base = 0;
@@ -408,6 +442,7 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
         unsigned long long m = __ballot(head);
         if (lane == 0) S.wtot[wave] = __popcll(m);
         __syncthreads();
+        VX_MARK(1);
         int dst = S.base;
         for (int w = 0; w < wave; ++w) dst += S.wtot[w];
         dst += __popcll(m & lt);
@@ -431,7 +466,9 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
             float c = static_cast<float>(e - s);
             out[dst] = make_float4(sx / c, sy / c, sz / c, 0.f);
         }
+        VX_MARK(2);
         __syncthreads();
+        VX_MARK(3);
         if (tid == 0) {
             int t = 0;
             for (int w = 0; w < VX_WAVES; ++w) t += S.wtot[w];
