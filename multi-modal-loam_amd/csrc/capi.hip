@@ -76,7 +76,7 @@ void mml_destroy(mml_ctx* ctx) {
     mml_fullwindow_dev_release(ctx);
     void* ptrs[] = {ctx->wstate, ctx->wrec, ctx->waux, ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx, ctx->ln_rel, ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
-                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
+                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->vx_big, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
                     ctx->cb_n,     ctx->queue_off, ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
@@ -199,6 +199,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->queue_off, 2 * ((size_t)B + mml_ctx::MAX_LANES + 1));
     ALLOC(ctx->redo_queue, B * NT);
     ALLOC(ctx->st_exit, B * (NT / 256 + L + 8));
+    ALLOC(ctx->vx_big, 2 * B);
     ALLOC(ctx->sel_done, B * L + 8);
     ALLOC(ctx->sel_list, 4 * B * L + 8);
     ALLOC(ctx->sel_list_cnt, 2 * B + 8);

@@ -2220,22 +2220,40 @@ __global__ __launch_bounds__(64 * ST_LINES) void k_stencil(FeatParams P) {
 // per 1024 scans, and in the two-lane timed region the redo kernel showed up as long as k_stencil itself.  Batches therefore walk
 // ONE list per launch: k_queue_prefix turns the per-slot counts into offsets, a grid sized for the expected fill walks the
 // concatenation with full wavefronts (entry e -> slot by a binary search over the offsets).  A handful of scans keep the per-slot grid.
-__global__ __launch_bounds__(1024) void k_queue_prefix(int first, int count, const int* cnt, int* off) {
-    __shared__ int s_w[16];
+// (256 threads, four items per thread: ONE workgroup of sixteen wavefronts found no CU with four free wave slots on every SIMD while
+//  the other lane's kernel kept refilling the slots its four-wavefront workgroups freed -- 0.2 ms on average, up to 0.8, per call in
+//  the two-lane timed region for 5 us of work; a four-wavefront workgroup is placed at once)
+constexpr int QP_THREADS = 256;
+__global__ __launch_bounds__(QP_THREADS) void k_queue_prefix(int first, int count, const int* cnt, int* off) {
+    __shared__ int s_w[16];  // totals of the sixteen (slab, wavefront) groups of a 1024-item turn, in item order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int acc = 0;
-    for (int t0 = 0; t0 < count; t0 += 1024) {
-        const int it = t0 + tid;
-        const int v = it < count ? cnt[first + it] : 0;
-        const int x = wave_incl_scan(v);
-        if (lane == 63) s_w[wave] = x;
-        __syncthreads();
-        int base = 0, tile = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) base += s_w[w];
-            tile += s_w[w];
+    for (int t0 = 0; t0 < count; t0 += 4 * QP_THREADS) {
+        int v[4], x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int it = t0 + q * QP_THREADS + tid;
+            v[q] = it < count ? cnt[first + it] : 0;
         }
-        if (it < count) off[it] = acc + base + x - v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x[q] = wave_incl_scan(v[q]);
+            if (lane == 63) s_w[q * 4 + wave] = x[q];
+        }
+        __syncthreads();
+        int tile = 0, base[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_w[w];
+            tile += t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) base[q] += w < q * 4 + wave ? t : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int it = t0 + q * QP_THREADS + tid;
+            if (it < count) off[it] = acc + base[q] + x[q] - v[q];
+        }
         acc += tile;
         __syncthreads();
     }
@@ -4063,9 +4081,9 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
             const long pts = (long)count * ctx->NT;
             const int g_r = (int)std::min<long>(std::max<long>(pts / 250 / 64, 64), 1 << 16);
             const int g_b = (int)std::min<long>(std::max<long>(pts / 25 / 256, 64), 1 << 16);
-            hipLaunchKernelGGL(k_queue_prefix, dim3(1), dim3(1024), 0, s, first, count, P.redo_cnt, off_r);
+            hipLaunchKernelGGL(k_queue_prefix, dim3(1), dim3(QP_THREADS), 0, s, first, count, P.redo_cnt, off_r);
             hipLaunchKernelGGL(k_stencil_redo_list, dim3(g_r), dim3(64), 0, s, P, count, off_r);
-            hipLaunchKernelGGL(k_queue_prefix, dim3(1), dim3(1024), 0, s, first, count, P.brk_cnt, off_b);  // (the redo pass appends)
+            hipLaunchKernelGGL(k_queue_prefix, dim3(1), dim3(QP_THREADS), 0, s, first, count, P.brk_cnt, off_b);  // (the redo pass appends)
             hipLaunchKernelGGL(k_stencil_break_list, dim3(g_b), dim3(256), 0, s, P, count, off_b);
         } else {
             hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);

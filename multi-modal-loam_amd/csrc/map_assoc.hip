@@ -805,37 +805,53 @@ __device__ __forceinline__ bool fit_and_store(const AssocParams& P, int kind, in
 // work decomposition: item = (kind, slot) pair, ceil(nf / 128) workgroup-sized chunks each; work_off is the exclusive
 // prefix over the 2 * count items.  A fixed-size grid walks the chunks, so no empty workgroups are dispatched
 // (with max_features = 8192 the dense grid spent more time retiring ~30 k empty workgroups than computing).
-__global__ __launch_bounds__(1024) void k_assoc_prefix(int first, int count, int B, const int* ft_n, int* work_off, int* hard_count) {
-    __shared__ int s_wsum[16];
+// (256 threads, four items per thread -- as k_queue_prefix: a sixteen-wavefront workgroup waits for a CU with four free wave slots
+//  on every SIMD while another lane's kernel keeps refilling them)
+constexpr int AP_THREADS = 256;
+__global__ __launch_bounds__(AP_THREADS) void k_assoc_prefix(int first, int count, int B, const int* ft_n, int* work_off, int* hard_count) {
+    __shared__ int s_wsum[16];  // totals of the sixteen (slab, wavefront) groups of a 1024-item turn, in item order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *hard_count = 0;  // the far-query list of this call starts empty
     const int nitems = 2 * count;
     int acc = 0;  // running prefix over tiles of 1024 items
-    for (int t0 = 0; t0 < nitems; t0 += 1024) {
-        const int it = t0 + tid;
-        int v = 0;
-        if (it < nitems) {
-            const int kind = it / count, slot = it % count;
-            const int nf = ft_n[kind * B + first + slot];
-            v = nf > 0 ? (nf + 127) / 128 : 0;
-        }
-        // inclusive scan inside the wavefront (shuffles), then the 16 wavefront totals
-        int x = v;
+    for (int t0 = 0; t0 < nitems; t0 += 4 * AP_THREADS) {
+        int v[4], x[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(x, o);
-            if (lane >= o) x += y;
+        for (int q = 0; q < 4; ++q) {
+            const int it = t0 + q * AP_THREADS + tid;
+            v[q] = 0;
+            if (it < nitems) {
+                const int kind = it / count, slot = it % count;
+                const int nf = ft_n[kind * B + first + slot];
+                v[q] = nf > 0 ? (nf + 127) / 128 : 0;
+            }
         }
-        if (lane == 63) s_wsum[wave] = x;
+        // inclusive scan inside the wavefront (shuffles), then the 16 group totals
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int xx = v[q];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(xx, o);
+                if (lane >= o) xx += y;
+            }
+            x[q] = xx;
+            if (lane == 63) s_wsum[q * 4 + wave] = xx;
+        }
         __syncthreads();
-        int base = 0, tile = 0;
+        int tile = 0, base[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
             const int t = s_wsum[w];
-            base += w < wave ? t : 0;
             tile += t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) base[q] += w < q * 4 + wave ? t : 0;
         }
-        if (it < nitems) work_off[it] = acc + base + x - v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int it = t0 + q * AP_THREADS + tid;
+            if (it < nitems) work_off[it] = acc + base[q] + x[q] - v[q];
+        }
         acc += tile;
         __syncthreads();
     }
@@ -1453,7 +1469,7 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
     P.work_off = work_off;
     {
         MmlStageScope t(ctx, "associate");
-        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(1024), 0, MML_STREAM(ctx), first, count, ctx->B, ctx->ft_n, work_off, P.hard_count);
+        hipLaunchKernelGGL(k_assoc_prefix, dim3(1), dim3(AP_THREADS), 0, MML_STREAM(ctx), first, count, ctx->B, ctx->ft_n, work_off, P.hard_count);
         hipLaunchKernelGGL(k_associate, dim3(4096), dim3(128), 0, MML_STREAM(ctx), P);
     }
     {

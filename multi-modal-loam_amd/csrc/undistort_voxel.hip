@@ -230,7 +230,9 @@ __device__ __forceinline__ void radix_sort_lds(unsigned long long (&key)[KPT], i
 // list -- their labelled clouds are no larger than a small scan's, only their indices are wider.
 struct VoxelArgs {
     int kind0, first, NT, MF, B, cap_y0, cap_y1, list_stride;
-    int skip_above, only_above;  // > 0: leave the slots with more / with no more labelled points than this to another launch
+    int skip_above, only_above;  // > 0: leave the slots with more labelled points than this to another launch / take only those
+    int zero_big;                // this launch resets the counter of the list below (the first launch of the chain)
+    int* big;                    // [2 B]: big[first] = number of slots the short form left, big[B + first + k] = the k-th of them
     const int* fu_info;
     const float4* ln_pts;
     const int* ln_gidx;
@@ -369,16 +371,10 @@ __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREA
 #ifndef MML_VOXEL_WAVES
 #define MML_VOXEL_WAVES 8
 #endif
+// one (slot, kind) by one workgroup
 template <int VX_THREADS>
-__global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_VOXEL_WAVES))) void k_voxel(VoxelArgs A) {
+__device__ __forceinline__ void voxel_slot(const VoxelArgs& A, VoxelLds<VX_THREADS>& S, unsigned long long* keys, int b, int kind, int cap) {
     constexpr int VX_WAVES = VX_THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ VoxelLds<VX_THREADS> S;
-
-    const int b = blockIdx.x + A.first;
-    const int kind = blockIdx.y + A.kind0;
-    const int cap = blockIdx.y == 0 ? A.cap_y0 : A.cap_y1;  // labelled points this workgroup sorts at most
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = A.NT, MF = A.MF;
     const float4* px = A.ln_pts + (size_t)b * NT;
@@ -397,7 +393,10 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
     unsigned long long vx_prev = clock64();
 #endif
     const int nsel = A.fu_info[8 * b + 6 + kind];
-    if ((A.skip_above > 0 && nsel > A.skip_above) || (A.only_above > 0 && nsel <= A.only_above)) return;  // (workgroup-uniform)
+    if (A.skip_above > 0 && nsel > A.skip_above) {  // (workgroup-uniform) listed for the launch of the large form
+        if (tid == 0) A.big[A.B + A.first + atomicAdd(&A.big[A.first], 1)] = b;
+        return;
+    }
     const int cnt = nsel > cap ? cap : nsel;  // capacity overflow is reported through ft_n (negative)
     const bool overflow = nsel > cap;
     if (cnt == 0) {
@@ -482,6 +481,27 @@ __global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_
         A.ft_n[kind * A.B + b] = nout;
     }
 }
+template <int VX_THREADS, bool LIST = false>
+__global__ __launch_bounds__(VX_THREADS) __attribute__((amdgpu_waves_per_eu(MML_VOXEL_WAVES))) void k_voxel(VoxelArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ VoxelLds<VX_THREADS> S;
+    const int kind = blockIdx.y + A.kind0;
+    const int cap = blockIdx.y == 0 ? A.cap_y0 : A.cap_y1;  // labelled points this workgroup sorts at most
+    if constexpr (LIST) {
+        // the slots the short form listed, by a grid that does not grow with the batch: a launch of one 1024-thread workgroup with
+        // 79 KB of LDS per slot -- nearly all of them returning at once -- waited for that room on a CU 4096 times over (0.63 ms per
+        // 4096-slot launch next to the other lane's kernels, 0.085 on an empty device)
+        const int nbig = A.big[A.first];
+        for (int e = blockIdx.x; e < nbig; e += gridDim.x) {
+            voxel_slot<VX_THREADS>(A, S, keys, __builtin_amdgcn_readfirstlane(A.big[A.B + A.first + e]), kind, cap);
+            __syncthreads();  // (the keys and the staging rows are free again)
+        }
+    } else {
+        if (A.zero_big && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) A.big[A.first] = 0;
+        voxel_slot<VX_THREADS>(A, S, keys, (int)blockIdx.x + A.first, kind, cap);
+    }
+}
 
 }  // namespace
 
@@ -524,6 +544,8 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     A.seq_scratch = reinterpret_cast<const unsigned*>(ctx->vx_keys);
     A.skip_above = 0;
     A.only_above = 0;
+    A.zero_big = 0;
+    A.big = ctx->vx_big;
     if (cap_corner == cap_surf || count <= 16) {
         // (one launch for both kinds: a handful of scans are a chain of launches, not a question of room on the CUs)
         A.kind0 = 0;
@@ -533,10 +555,12 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     } else {
         A.kind0 = 0;
         A.cap_y0 = A.cap_y1 = cap_corner;
+        A.zero_big = 1;  // (the list of this launch chain starts empty: launches of other lanes cover other slots, big[first] is theirs alone)
         hipLaunchKernelGGL(k_voxel<256>, dim3(count, 1), dim3(256), lds(cap_corner), MML_STREAM(ctx), A);
+        A.zero_big = 0;
         // The surf lists of a 52.8 k-point scan hold ~3 000 points: they get 512-thread workgroups with room for 4096 keys (32 KB:
         // four per CU where the 1024-thread form with its 64 KB runs two; 0.222 -> 0.178 ms per 1024 scans); the slots with more
-        // are left to a second launch of the large form, whose workgroups return at once everywhere else.
+        // are listed by it and left to a second launch of the large form: a grid of at most one workgroup per CU that walks the list.
         constexpr int cap_mid = 4096;
         static_assert(cap_mid < MML_VOXEL_LDS_CAP, "the 512-thread form takes the short lists only");
         A.kind0 = 1;
@@ -546,7 +570,7 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
         A.cap_y0 = A.cap_y1 = cap_surf;
         A.skip_above = 0;
         A.only_above = cap_mid;
-        hipLaunchKernelGGL(k_voxel<1024>, dim3(count, 1), dim3(1024), lds(cap_surf), MML_STREAM(ctx), A);
+        hipLaunchKernelGGL((k_voxel<1024, true>), dim3(count < 256 ? count : 256, 1), dim3(1024), lds(cap_surf), MML_STREAM(ctx), A);
     }
     MML_HIP(hipGetLastError());
     return MML_OK;
