@@ -3,7 +3,8 @@
 Batch size routes the path to different kernels in five places:
   * count > 16  -> k_stencil<0> (one wavefront per scan line)            instead of k_stencil<1>/<2> (tile per wavefront)
   * count > 16  -> batch k_select_part<u64/u128> grid + k_select_list + list-mode k_select   instead of direct k_select
-  * count > 16  -> k_voxel<256> for the corner lists + k_voxel<1024> for the surf lists      instead of one k_voxel<1024>
+  * count > 16  -> k_voxel<256> for the corner lists + k_voxel<512> for the surf lists up to 4096 labelled points + the list-walking
+                   k_voxel<1024> launch for the slots with more                         instead of one k_voxel<1024>
   * count > 8   -> lane-per-feature k_associate search                   instead of the <= 8-slot group search
   * count >= 64 -> mml_step pipelines sub-batches over stream lanes (set to 4 in some tests; test_full_size_step_properties and
     test_gpu_shapes.py run the library's default of 2) instead of one stream
@@ -62,6 +63,8 @@ def test_batch96_default_layout_matches_oracle(M, O, synth, scene):
     tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
     ora = [oracle_pipeline(O, cs, tc, ts) for cs in cases]
     assert 1024 < (ora[10]["label"] == 1).sum() < 2048 < (ora[11]["label"] == 1).sum()
+    # (more than 4096 surf labels: the slot k_voxel<512> lists for the list-walking launch of the large form, k_voxel<1024, true>)
+    assert (ora[10]["label"] == 2).sum() < 4096 < (ora[11]["label"] == 2).sum()
     c = M.Context(max_scans=B)
     try:
         c.map_set_local(0, scene["corner_map"])
