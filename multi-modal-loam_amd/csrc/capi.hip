@@ -103,6 +103,8 @@ void mml_destroy(mml_ctx* ctx) {
     for (auto e : ctx->upload_event_pool) hipEventDestroy(e);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
         if (ctx->lane_mark[l]) hipEventDestroy(ctx->lane_mark[l]);
+        if (ctx->fork_ev[l]) hipEventDestroy(ctx->fork_ev[l]);
+        if (ctx->join_ev[l]) hipEventDestroy(ctx->join_ev[l]);
         if (ctx->streams[l]) hipStreamDestroy(ctx->streams[l]);
     }
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -150,6 +152,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     // (two lanes: with calls of ~2000 scans two to four lanes give the same rate, with 8192 two give 360 k scans/s against 351 k for
     //  four, and a call of a few hundred scans splits into launches that still fill the device)
     ctx->n_lanes = 2;
+    if (const char* e_f = getenv("MML_UND_FORK")) ctx->und_fork_enabled = atoi(e_f) != 0;
     if (const char* e_l = getenv("MML_LANES")) {  // tuning knob: number of stream lanes mml_step pipelines over
         int v = atoi(e_l);
         if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;
@@ -159,6 +162,8 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
             return fail(e, "hipStreamCreate");
         if ((e = hipEventCreateWithFlags(&ctx->lane_mark[l], hipEventDisableTiming)) != hipSuccess)
             return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&ctx->fork_ev[l], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&ctx->join_ev[l], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
     }
     if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     const size_t B = ctx->B, NV = ctx->NV, NL = ctx->NL, NT = ctx->NT, L = ctx->L, MF = ctx->MF, MM = ctx->MM;
@@ -1475,6 +1480,10 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     // i, 2 .. 5 streams, three stage-to-stream maps: 306 k .. 330 k scans/s against 355 k for two lanes (HISTORY.md).
     const int lanes = (count >= 64 && ctx->lanes_enabled) ? ctx->n_lanes : 1;
     const int n_pieces = lanes;
+    // The undistortion (HBM-bound, 24 registers, no LDS) next to the selection kernels (their own instructions and memory round
+    // trips, little traffic): the selection reads neither the points nor their times, so the lane's sibling stream can rewrite them
+    // as soon as the stencil is through.  Not while stage times are being taken (one stream, stage by stage).
+    const bool fork = ctx->und_fork_enabled && count > 16 && lanes <= mml_ctx::MAX_LANES / 2 && !ctx->profiling;
     const int chunk = (count + n_pieces - 1) / n_pieces;
     std::vector<double> Twl(16 * (size_t)chunk);
     // (the staging ring: a wrap in the middle of the call would drain the streams; wrap now if this call does not fit)
@@ -1505,8 +1514,21 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     auto run_stage = [&](int stage, int f, int c) -> int {
         const int off = f - first_slot;
         switch (stage) {
-            case 0: return mml_launch_extract(ctx, f, c, false);
-            case 1: return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
+            case 0: {
+                ctx->und_fork = fork ? 1 : 0;
+                ctx->und_dR = dR + 9 * (size_t)off;
+                ctx->und_dt = dt + 3 * (size_t)off;
+                ctx->und_first = f;
+                const int r = mml_launch_extract(ctx, f, c, false);
+                ctx->und_fork = 0;
+                return r;
+            }
+            case 1:
+                if (fork) {  // enqueued on the sibling stream by the extraction, behind the stencil: the lane waits for it here
+                    if (hipStreamWaitEvent(MML_STREAM(ctx), ctx->join_ev[ctx->cur], 0) != hipSuccess) return MML_ERR_HIP;
+                    return MML_OK;
+                }
+                return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
             case 2: return mml_launch_downsample(ctx, f, c);
             case 3:
                 for (int i = 0; i < c; ++i) {

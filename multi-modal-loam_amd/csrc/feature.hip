@@ -4090,6 +4090,18 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
             hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
         }
     }
+    if (ctx->und_fork) {
+        // mml_step: the stencil was the last reader of the raw points; the selection below touches neither them nor their times.
+        // The lane's sibling stream undistorts the slots meanwhile (mml_step joins it in front of the down-sampler).
+        const int lane = ctx->cur, side = lane + mml_ctx::MAX_LANES / 2;
+        MML_HIP(hipEventRecord(ctx->fork_ev[lane], s));
+        MML_HIP(hipStreamWaitEvent(ctx->streams[side], ctx->fork_ev[lane], 0));
+        ctx->cur = side;
+        const int r = mml_undistort(ctx, first, count, ctx->und_dR, ctx->und_dt);
+        ctx->cur = lane;
+        if (r != MML_OK) return r;
+        MML_HIP(hipEventRecord(ctx->join_ev[lane], ctx->streams[side]));
+    }
     {
         MmlStageScope t(ctx, "select");
         // rings and Livox lines have different nominal lengths: each group runs the variant whose LDS block fits it, so the

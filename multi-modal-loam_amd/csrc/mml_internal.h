@@ -96,6 +96,14 @@ struct mml_ctx {
     // another; an entry point that touches a slot range first makes the lanes wait for the uploads still in flight on it
     hipStream_t copy_stream = nullptr;
     hipEvent_t lane_mark[MAX_LANES] = {};
+    // mml_step: the undistortion of a lane's slots runs on a sibling stream (lane + MAX_LANES / 2) next to the lane's selection
+    // kernels -- forked behind the stencil, the last reader of the raw points, joined in front of the down-sampler
+    hipEvent_t fork_ev[MAX_LANES] = {}, join_ev[MAX_LANES] = {};
+    int und_fork = 0;                  // set by mml_step around its extraction stage
+    const double* und_dR = nullptr;    // the caller's motion arrays, indexed from und_first
+    const double* und_dt = nullptr;
+    int und_first = 0;
+    int und_fork_enabled = 1;          // $MML_UND_FORK=0 turns it off
     struct Upload {
         int first, count;
         hipEvent_t done;
