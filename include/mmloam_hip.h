@@ -338,7 +338,9 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
  * iterations (fixed count).  Everything stays on the device; poses: count x 6 ([t,phi], device-updated,
  * copied back).  This is what bench.py times.  The batch is spread over the context's stream lanes (mml_set_lanes), every
  * lane ordered behind whatever the context's stream holds when the call is made (no synchronisation is needed between
- * mml_scan_upload and mml_step).  The association statistics of mml_associate (counts, normal Gram matrix) are not part of
+ * mml_scan_upload and mml_step).  Inside a lane the undistortion runs on a sibling stream next to the selection kernels
+ * (which read neither the points nor their times) and is joined in front of the down-sampler; the call returns with every
+ * stream of the context drained.  The association statistics of mml_associate (counts, normal Gram matrix) are not part of
  * the step; an entry point that needs them afterwards (mml_linearize*, mml_associate with `stats`) computes them on demand. */
 int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt,
              const double* exTlb, double thres_dist, int gn_iters, double* x_inout);
