@@ -152,7 +152,6 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     // (two lanes: with calls of ~2000 scans two to four lanes give the same rate, with 8192 two give 360 k scans/s against 351 k for
     //  four, and a call of a few hundred scans splits into launches that still fill the device)
     ctx->n_lanes = 2;
-    if (const char* e_f = getenv("MML_UND_FORK")) ctx->und_fork_enabled = atoi(e_f) != 0;
     if (const char* e_l = getenv("MML_LANES")) {  // tuning knob: number of stream lanes mml_step pipelines over
         int v = atoi(e_l);
         if (v >= 1 && v <= mml_ctx::MAX_LANES) ctx->n_lanes = v;
@@ -1483,7 +1482,9 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     // The undistortion (HBM-bound, 24 registers, no LDS) next to the selection kernels (their own instructions and memory round
     // trips, little traffic): the selection reads neither the points nor their times, so the lane's sibling stream can rewrite them
     // as soon as the stencil is through.  Not while stage times are being taken (one stream, stage by stage).
-    const bool fork = ctx->und_fork_enabled && count > 16 && lanes <= mml_ctx::MAX_LANES / 2 && !ctx->profiling;
+    // ($MML_UND_FORK=0, read at every call so that one process can compare the two schedules, keeps it on the lane's own stream)
+    const char* e_fork = getenv("MML_UND_FORK");
+    const bool fork = !(e_fork && atoi(e_fork) == 0) && count > 16 && lanes <= mml_ctx::MAX_LANES / 2 && !ctx->profiling;
     const int chunk = (count + n_pieces - 1) / n_pieces;
     std::vector<double> Twl(16 * (size_t)chunk);
     // (the staging ring: a wrap in the middle of the call would drain the streams; wrap now if this call does not fit)

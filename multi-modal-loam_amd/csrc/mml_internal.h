@@ -103,7 +103,6 @@ struct mml_ctx {
     const double* und_dR = nullptr;    // the caller's motion arrays, indexed from und_first
     const double* und_dt = nullptr;
     int und_first = 0;
-    int und_fork_enabled = 1;          // $MML_UND_FORK=0 turns it off
     struct Upload {
         int first, count;
         hipEvent_t done;
