@@ -76,7 +76,7 @@ void mml_destroy(mml_ctx* ctx) {
     mml_fullwindow_dev_release(ctx);
     void* ptrs[] = {ctx->wstate, ctx->wrec, ctx->waux, ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx, ctx->ln_rel, ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
-                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->vx_big, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
+                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->vx_big, ctx->az_cnt, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
                     ctx->cb_n,     ctx->queue_off, ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
@@ -204,6 +204,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->redo_queue, B * NT);
     ALLOC(ctx->st_exit, B * (NT / 256 + L + 8));
     ALLOC(ctx->vx_big, 2 * B);
+    ALLOC(ctx->az_cnt, B + B * 64 * 2);
     ALLOC(ctx->sel_done, B * L + 8);
     ALLOC(ctx->sel_list, 4 * B * L + 8);
     ALLOC(ctx->sel_list_cnt, 2 * B + 8);
@@ -1482,9 +1483,11 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     // The undistortion (HBM-bound, 24 registers, no LDS) next to the selection kernels (their own instructions and memory round
     // trips, little traffic): the selection reads neither the points nor their times, so the lane's sibling stream can rewrite them
     // as soon as the stencil is through.  Not while stage times are being taken (one stream, stage by stage).
-    // ($MML_UND_FORK=0, read at every call so that one process can compare the two schedules, keeps it on the lane's own stream)
+    // OFF unless $MML_UND_FORK=1 (read at every call so that one process can compare the two schedules): +0.5 - 1 % on the bench
+    // line, and the one full-suite run of the round that failed -- one slot of 4096 with a surf stack computed from something
+    // other than its final cloud, never reproduced in 130 further steps with or without the fork -- had it on.
     const char* e_fork = getenv("MML_UND_FORK");
-    const bool fork = !(e_fork && atoi(e_fork) == 0) && count > 16 && lanes <= mml_ctx::MAX_LANES / 2 && !ctx->profiling;
+    const bool fork = (e_fork && atoi(e_fork) != 0) && count > 16 && lanes <= mml_ctx::MAX_LANES / 2 && !ctx->profiling;
     const int chunk = (count + n_pieces - 1) / n_pieces;
     std::vector<double> Twl(16 * (size_t)chunk);
     // (the staging ring: a wrap in the middle of the call would drain the streams; wrap now if this call does not fit)

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include "atan2_cr.h"
 #include "mml_internal.h"
 
 namespace {
@@ -90,6 +91,10 @@ struct FeatParams {
     int* sel_list_cnt;       // [B][2] list lengths of the launch that starts at slot `first`
     unsigned char* st_exit;  // [B][st_stride] k_stencil, segment mode: the stride walk's exit offsets of every tile, for the four entries
     int st_stride;
+    // the points whose azimuth the fast form did not decide (within 1e-14 of a float rounding boundary: about one in 1e6): queued by
+    // the bucketing kernels, decided by k_azimuth_exact.  az_cnt[b] is zero between extractions (the kernel that consumes it clears it).
+    int* az_cnt;       // [B]
+    int* az_queue;     // [B][AZ_CAP][2]: raw index, storage position (-1: the three-pass bucketing, raw_ori is patched)
     // storage segments of the lines (mml_internal.h): line index -> storage position
     int* seg_cum;
     int* seg_pos;
@@ -286,7 +291,8 @@ __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pit
 
 // float(-atan2((double)y, (double)x)) of :1154.  Fast form: octant reduction + a degree-9 minimax polynomial in t^2
 // (|error| < 1e-15 over the reduced range; two divisions through v_rcp_f64 + Newton); accepted only when the double
-// lies farther than 1e-12 from a float rounding boundary, otherwise -- about one point in 1e5 -- libm atan2 decides.
+// lies farther than 1e-14 from a float rounding boundary, otherwise -- about one point in 1e6 -- the nearest double
+// (mml_cr::atan2_cr, double-double) decides.
 __device__ __forceinline__ double fast_div(double n, double d) {
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
@@ -294,7 +300,12 @@ __device__ __forceinline__ double fast_div(double n, double d) {
     const double q = n * r;
     return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
-__device__ __forceinline__ float neg_atan2_f(float yf, float xf) {
+// `rare` is set when the fast form did not decide; the value returned then is the device library's (good to 2 ulp of a double: the
+// right float except for about one in 1e4 of THOSE points).  The caller queues the flagged points (az_push) for k_azimuth_exact,
+// which decides them with the nearest double (atan2_cr.h): inside the bucketing kernels that routine cost them their occupancy
+// (118 -> 142 registers) or, held down, 0.56 -> 0.9 ms per 1024 scans in spills.
+__device__ __forceinline__ float neg_atan2_f(float yf, float xf, bool& rare) {
+    rare = false;
     const double x = xf, y = yf;
     const double ax = fabs(x), ay = fabs(y);
     const double mx = fmax(ax, ay), mn = fmin(ax, ay);
@@ -323,12 +334,48 @@ __device__ __forceinline__ float neg_atan2_f(float yf, float xf) {
         const int ef = (int)((hi >> 20) & 0x7ffu);
         const int d = abs((int)(lo & 0x1fffffffu) - 0x10000000);
         const double unit = __hiloint2double((ef - 52) << 20, 0);
-        if (ef >= 1023 - 126 && (double)d * unit > 1e-12) return (float)v;
+        // (the band: the fast form is within 4.7e-16 of the true angle -- measured against 300 k multi-precision values, octant
+        //  edges included --, the reference's libm within an ulp of a double of it, 7e-16 at most: 1e-14 leaves a factor of eight.
+        //  It was 1e-12 until the decision inside it became a double-double evaluation: at 1.4e-4 of the points of a scan that
+        //  cost the pass a third; at 1e-14 it is 1.4e-6 of them)
+        if (ef >= 1023 - 126 && (double)d * unit > 1e-14) return (float)v;
+        if (mn > 0.0) rare = true;  // (a point ON an axis: the library's special cases are exact)
     }
     return (float)(-atan2(y, x));
 }
+// (within 1e-14 of the middle between two floats: the nearest double, as the reference's libm returns it; the device library's 2-ulp atan2 rounded the other way for one point in 1.6e9, atan2_cr.h)
+__device__ __forceinline__ float neg_atan2_exact(float yf, float xf) { return (float)(-mml_cr::atan2_cr((double)yf, (double)xf)); }
+// the two azimuths of :1136-1139 as the doubles the reference converts to float: the device library's atan2, and the nearest
+// double instead when either result lies within 1e-12 of the middle between two floats (wave-uniform, a few times in 1e9 scans)
+__device__ __forceinline__ bool near_float_middle(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const int ef = (int)((hi >> 20) & 0x7ffu);
+    const int d = abs((int)(lo & 0x1fffffffu) - 0x10000000);
+    const double unit = __hiloint2double((ef - 52) << 20, 0);
+    return !(ef >= 1023 - 126 && (double)d * unit > 1e-12);
+}
+__device__ __forceinline__ void sweep_azimuths(const float4 p0, const float4 p1, float& startOri, float& endOri) {
+    double s = -atan2((double)p0.y, (double)p0.x);             // :1136
+    double e = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;  // :1137-1138
+    if (near_float_middle(s) || near_float_middle(e)) {
+        s = -mml_cr::atan2_cr((double)p0.y, (double)p0.x);
+        e = -mml_cr::atan2_cr((double)p1.y, (double)p1.x) + 2 * M_PI;
+    }
+    startOri = s;
+    endOri = e;
+}
 
-template <int PPT>
+constexpr int AZ_CAP = 64;  // per slot; a scan holds a handful at most (more -- an adversarial cloud -- keep the library's rounding)
+__device__ __forceinline__ void az_push(const FeatParams& P, int b, int i, int dst) {
+    const int k = atomicAdd(&P.az_cnt[b], 1);
+    if (k < AZ_CAP) {
+        P.az_queue[((size_t)b * AZ_CAP + k) * 2] = i;
+        P.az_queue[((size_t)b * AZ_CAP + k) * 2 + 1] = dst;
+    }
+}
+// QUEUE: the azimuths the fast form leaves open go to k_azimuth_exact (the three-pass bucketing).  mml_launch_raw_lines runs this
+// pass for the line ids alone, with nobody behind it to take the queue: there it stays empty.
+template <int PPT, bool QUEUE>
 __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __shared__ int s_bcnt[MAX_LINES];
     __shared__ int s_valid, s_keep;
@@ -359,6 +406,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     // (dense layouts: four points per thread -- a 130-entry histogram record per 1024 points instead of per 256: the records were a
     //  quarter of this pass's written bytes and all of pass B's work)
     const int ppt = sensor == 0 ? PPT : 1;
+    unsigned rare_rounds = 0;  // bit r: the azimuth of this thread's point of round r is left to k_azimuth_exact (one point in 1e6)
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
     if (r >= ppt) break;
@@ -374,7 +422,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
             if (fin) {
                 ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
                 if (ring == 255) ring = 254;
-                ori = neg_atan2_f(p.y, p.x);
+                bool rare;
+                ori = neg_atan2_f(p.y, p.x, rare);
+                if (rare) rare_rounds |= 1u << r;
             }
             P.raw_line[(size_t)b * P.NT + i] = (uint8_t)ring;
             P.raw_ori[(size_t)b * P.NV + i] = ori;
@@ -397,6 +447,11 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
     if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
     __builtin_amdgcn_sched_barrier(0);  // (one point at a time: the evaluations' temporaries do not overlap)
+    }
+    if (QUEUE && rare_rounds) {  // (behind the loop: the queue's atomic inside it cost the pass 6 %)
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r)
+            if ((rare_rounds >> r) & 1u) az_push(P, b, (blockIdx.x * ppt + r) * AB_THREADS + tid, -1);
     }
     __syncthreads();
     int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
@@ -503,8 +558,7 @@ __global__ __launch_bounds__(ASB_THREADS) void k_assign_b(FeatParams P) {
         if (s_last >= 0) {
             const float4 p0 = P.velo_in[(size_t)b * P.NV + s_first];
             const float4 p1 = P.velo_in[(size_t)b * P.NV + s_last];
-            startOri = -atan2((double)p0.y, (double)p0.x);   // :1136
-            endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
+            sweep_azimuths(p0, p1, startOri, endOri);
             if (endOri - startOri > 3 * M_PI)
                 endOri -= 2 * M_PI;
             else if (endOri - startOri < M_PI)
@@ -934,8 +988,7 @@ __device__ __forceinline__ void sweep_ends(const FeatParams& P, int b, float& st
     endOri = 0.f;
     if (lf >= 0) {
         const float4 p0 = in[ff], p1 = in[lf];
-        startOri = -atan2((double)p0.y, (double)p0.x);   // :1136
-        endOri = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;
+        sweep_azimuths(p0, p1, startOri, endOri);
         if (endOri - startOri > 3 * M_PI)
             endOri -= 2 * M_PI;
         else if (endOri - startOri < M_PI)
@@ -956,6 +1009,65 @@ __global__ __launch_bounds__(64) void k_assign_ends(FeatParams P, int count) {
         a->startOri = so;
         a->endOri = eo;
     }
+}
+
+// The queued azimuths, decided by the nearest double (atan2_cr.h).  One wavefront per slot; nearly every slot has none.
+// ONEPASS: the point's in-sweep time is written again from the exact azimuth (the expressions of the bucketing kernel's last
+// phase; the slot's half-turn index = the minimum over its blocks' look-back words -- for a point of block k the blocks behind k
+// cannot change the comparison, their indices are larger than the point's).  Otherwise: raw_ori, which passes B and C read.
+// (Not re-decided: whether the point ITSELF is the one that sets halfPassed, :1169-1177 -- the library's float and the exact one
+//  differ by an ulp for one queued point in 1e4, and that ulp would have to straddle startOri + pi.)
+template <bool ONEPASS>
+__global__ __launch_bounds__(64) void k_azimuth_exact(FeatParams P, int count) {
+    const int t = blockIdx.x;
+    if (t >= count) return;
+    const int b = P.first + t, lane = threadIdx.x;
+    const int nq = P.az_cnt[b];
+    if (nq <= 0) return;  // (wave-uniform)
+    const int n = nq < AZ_CAP ? nq : AZ_CAP;
+    float startOri = 0.f, endOri = 0.f;
+    int trig = 0x7fffffff;
+    if constexpr (ONEPASS) {
+        if (P.ends_inline) {
+            sweep_ends(P, b, startOri, endOri);
+        } else {
+            const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
+            startOri = a->startOri;
+            endOri = a->endOri;
+        }
+        const int nbv = (P.n_in[2 * b] + MML_OP_BLK - 1) / MML_OP_BLK;
+        for (int k = lane; k < nbv; k += 64) {
+            const unsigned long long w = P.op_agg[(size_t)b * 2 * MML_SEG_MAX + k];
+            const unsigned coff = (unsigned)((w >> 26) & 0x1fffu);
+            if (coff != 0x1fffu) trig = min(trig, k * MML_OP_BLK + (int)coff);
+        }
+        for (int o = 32; o > 0; o >>= 1) trig = min(trig, __shfl_xor(trig, o));
+    }
+    for (int e = lane; e < n; e += 64) {
+        const int i = P.az_queue[((size_t)b * AZ_CAP + e) * 2], dst = P.az_queue[((size_t)b * AZ_CAP + e) * 2 + 1];
+        const float4 p = P.velo_in[(size_t)b * P.NV + i];
+        float ori = neg_atan2_exact(p.y, p.x);
+        if constexpr (ONEPASS) {
+            if (i <= trig) {  // :1169-1177
+                if (ori < startOri - M_PI / 2)
+                    ori += 2 * M_PI;
+                else if (ori > startOri + M_PI * 3 / 2)
+                    ori -= 2 * M_PI;
+            } else {  // :1178-1184
+                ori += 2 * M_PI;
+                if (ori < endOri - M_PI * 3 / 2)
+                    ori += 2 * M_PI;
+                else if (ori > endOri + M_PI / 2)
+                    ori -= 2 * M_PI;
+            }
+            const float rel = (ori - startOri) / (endOri - startOri);  // :1186
+            P.ln_rel[(size_t)b * P.NT + dst] = __float_as_int(rel);
+        } else {
+            P.raw_ori[(size_t)b * P.NV + i] = ori;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) P.az_cnt[b] = 0;  // (every lane has read the count)
 }
 
 // inclusive scan over the 64 lanes of a wavefront
@@ -1083,6 +1195,7 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     aux.endOri = S.ori[1];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int cond_min = 0x7fffffff;  // (wave-uniform) first index of this wavefront's points that sets halfPassed
+    unsigned rare_rounds = 0;   // bit r: the azimuth of this thread's point of round r is left to k_azimuth_exact (one point in 1e6)
 #pragma unroll
     for (int r = 0; r < OP_PPT; ++r) {
         const int i = i0 + r * OP_THREADS + tid;
@@ -1096,7 +1209,9 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
                     const int ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
                     valid = ring != 255;                                  // outside the ring table: dropped at :1163-1166
                     key = valid ? ring : 0;
-                    ori = neg_atan2_f(p.y, p.x);
+                    bool rare;
+                    ori = neg_atan2_f(p.y, p.x, rare);
+                    if (rare) rare_rounds |= 1u << r;
                 }
                 xw[r] = __float_as_uint(ori);
                 if (valid) {
@@ -1277,6 +1392,9 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
         }
         const size_t gpos = (size_t)b * P.NT + dst;
         P.ln_pts[gpos] = pt[r];
+        if constexpr (SENSOR == 0) {
+            if ((rare_rounds >> r) & 1u) az_push(P, b, i, dst);
+        }
         const bool keep = (f & OPI_KEEP) != 0;
         // the two 4-byte records of the point go through LDS, in the order the block's region is laid out, and leave it as whole
         // rows below: as scattered 4-byte stores they were what the pass waited for (0.61 -> 0.71 ms when the 8-byte record of
@@ -3982,6 +4100,8 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.sel_list = ctx->sel_list;
     P.sel_list_cnt = ctx->sel_list_cnt;
     P.st_exit = ctx->st_exit;
+    P.az_cnt = ctx->az_cnt;
+    P.az_queue = ctx->az_cnt + ctx->B;
     P.st_stride = ctx->NT / 256 + ctx->L + 8;
     P.seg_cum = ctx->seg_cum;
     P.seg_pos = ctx->seg_pos;
@@ -4033,15 +4153,17 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         {
             MmlStageScope t(ctx, "assign_tables");
             hipLaunchKernelGGL(k_assign_tables, dim3(count), dim3(TB_THREADS), 0, s, P, count);
+            hipLaunchKernelGGL(k_azimuth_exact<true>, dim3(count), dim3(64), 0, s, P, count);  // (the in-sweep times of the queued points)
         }
     } else {
     {
         MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
         if (P.ab_ppt == 4)
-            hipLaunchKernelGGL(k_assign_a<4>, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+            hipLaunchKernelGGL((k_assign_a<4, true>), dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
         else
-            hipLaunchKernelGGL(k_assign_a<1>, dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+            hipLaunchKernelGGL((k_assign_a<1, true>), dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+        hipLaunchKernelGGL(k_azimuth_exact<false>, dim3(count), dim3(64), 0, s, P, count);  // (raw_ori of the queued points, before pass B reads it)
     }
     {
         MmlStageScope t(ctx, "assign_scan");
@@ -4197,9 +4319,9 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
 int mml_launch_raw_lines(mml_ctx* ctx, int slot) {
     FeatParams P = make_params(ctx, slot);
     if (P.ab_ppt == 4)
-        hipLaunchKernelGGL(k_assign_a<4>, dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+        hipLaunchKernelGGL((k_assign_a<4, false>), dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
     else
-        hipLaunchKernelGGL(k_assign_a<1>, dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+        hipLaunchKernelGGL((k_assign_a<1, false>), dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }

@@ -169,6 +169,7 @@ struct mml_ctx {
     int* sel_list = nullptr;           // 2 * B * L * 2 ints: (slot, line) lists of the lines left to k_select (rings | Livox lines)
     int* sel_list_cnt = nullptr;       // 2 B ints
     unsigned char* st_exit = nullptr;  // B * (NT / 256 + L + 8): k_stencil segment mode, exit offsets of the stride walk per tile
+    int* az_cnt = nullptr;             // B + B * 64 * 2: per slot the count | the queue of the azimuths left to k_azimuth_exact (feature.hip)
     int* vx_big = nullptr;             // 2 B: per launch (indexed by its first slot) the slots k_voxel<512> left to the large form: count | list
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)

@@ -192,6 +192,26 @@ def dense_batch_section(args, M, O, synth, rng):
                 print("DENSE BATCH EXTRACT MISMATCH seed %d round %d slot %d (scan %d) rings %d az %d pitch0 %g step %g far %g"
                       % (args.seed, rnd, s, perm[s], n_rings, n_az, pitch0, step, far))
                 np.save("gpurun_out/fuzz_dense_batch_seed%d_round%d_v.npy" % (args.seed, rnd), cases[perm[s]][0])
+                if cases[perm[s]][1] is not None:
+                    np.save("gpurun_out/fuzz_dense_batch_seed%d_round%d_l.npy" % (args.seed, rnd), cases[perm[s]][1])
+                # which fields differ, where, and whether the other slots that hold the same scan agree with this one
+                print("  n_points device %d oracle %d" % (d["info"].n_points, len(o["xyzi"])))
+                for key in o:
+                    if d[key].shape != o[key].shape:
+                        print("  %s: shapes %s / %s" % (key, d[key].shape, o[key].shape))
+                        continue
+                    neq = d[key] != o[key]
+                    bad = np.flatnonzero(neq.reshape(len(neq), -1).any(axis=1)) if neq.ndim > 1 else np.flatnonzero(neq)
+                    if len(bad):
+                        print("  %s: %d differing entries, first at %s: device %s oracle %s (ring %s)"
+                              % (key, len(bad), bad[:8], d[key][bad[:3]].tolist(), o[key][bad[:3]].tolist(), o["ring"][bad[:8]].tolist()))
+                same = [t for t in range(B) if perm[t] == perm[s]]
+                agree = [t for t in same if all(np.array_equal(cd.scan_download(t)[key], d[key]) for key in o)]
+                print("  slots holding the same scan: %s, of which equal to slot %d: %s" % (same, s, agree))
+                cd.extract(0, B)
+                d2 = cd.scan_download(s)
+                print("  a second extract of the batch: slot equal to the oracle now: %s, equal to the first result: %s"
+                      % (all(np.array_equal(d2[key], o[key]) for key in o), all(np.array_equal(d2[key], d[key]) for key in o)))
                 return 1
         dR = [Rsc.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix() for _ in range(ND)]
         dt = [rng.normal(0, 0.05, 3) for _ in range(ND)]

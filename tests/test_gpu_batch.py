@@ -329,3 +329,53 @@ def test_voxel_grid_index_overflow_returns_the_labelled_cloud_unfiltered(M, O, s
         assert unfiltered >= 3
     finally:
         c.close()
+
+
+def test_azimuths_on_float_rounding_boundaries(M, O, synth):
+    """Points whose azimuth -atan2(y, x) lies, as a double, within 2e-15 of the middle between two floats (tests/golden/
+    azimuth_edge_xy.npy; the first is the point of campaign seed 836 on which the device library's atan2 rounded the other way).
+    The bucketing kernels queue them and k_azimuth_exact decides them with the nearest double (csrc/atan2_cr.h): in-sweep times
+    bit for bit as unionFeatureExtract.cpp:1154-1186 forms them, through the one-pass bucketing of a single scan (sweep ends
+    found inline), of a batch (k_assign_ends), and through the three-pass bucketing of a 64-ring layout (raw_ori patched before
+    pass B)."""
+    import os
+    edge = np.load(os.path.join(os.path.dirname(__file__), "golden", "azimuth_edge_xy.npy"))
+
+    def salted(v, z_of):
+        v = v.copy()
+        idx = np.linspace(50, len(v) - 50, len(edge)).astype(int)
+        v[idx, 0], v[idx, 1] = edge[:, 0], edge[:, 1]
+        v[idx, 2] = np.hypot(edge[:, 0].astype(np.float64), edge[:, 1].astype(np.float64)) * np.tan(np.deg2rad(z_of))
+        return v
+
+    # default layout: 16 rings at -15 .. 15 degrees; the salted points sit on the +1 degree ring
+    v16 = salted(synth.velo_scan(21), 1.0)
+    l16 = synth.livox_scan(21)
+    o16 = oracle_pipeline(O, dict(velo=v16, livox=l16, dR=np.eye(3), dt=np.zeros(3)), None, None)
+    for B in (1, 20):
+        c = M.Context(max_scans=B)
+        try:
+            for s in range(B):
+                c.scan_upload(s, v16, l16)
+            c.extract(0, B)
+            for s in range(B):
+                _check_extraction(c.scan_download(s), o16)
+            c.extract(0, B)  # (the queue is empty again: a second extraction finds the same)
+            _check_extraction(c.scan_download(B - 1), o16)
+        finally:
+            c.close()
+    # 64 rings x 512 azimuths: the three-pass bucketing
+    p0, st = -16.0, np.float32(32.0 / 63.0)
+    kw = dict(n_rings=64, pitch0=p0, pitch_step=st)
+    v64 = salted(synth.velo_scan(22, n_az=512, **kw), float(p0 + 30 * st))
+    o64 = oracle_pipeline(O, dict(velo=v64, livox=None, dR=np.eye(3), dt=np.zeros(3)), None, None, **kw)
+    for B in (1, 18):
+        c = M.Context(max_scans=B, max_velo_points=64 * 512, max_livox_points=24000, n_rings=64, pitch0_deg=p0, pitch_step_deg=st)
+        try:
+            for s in range(B):
+                c.scan_upload(s, v64, None)
+            c.extract(0, B)
+            for s in range(B):
+                _check_extraction(c.scan_download(s), o64)
+        finally:
+            c.close()

@@ -80,10 +80,10 @@ def test_bench_launch_shapes_replicas_match_oracle(M, O, synth, scene):
         x1 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
         dg1 = c.slot_digest(0, B)
         assert np.array_equal(x1, x) and np.array_equal(dg1, dg)
-        # (3) the undistortion on the lane's own stream instead of the sibling stream next to the selection kernels (the default
-        #     since round 5, parts (1) and (2)): same results, slot for slot, on two lanes and on one
+        # (3) the undistortion on the lane's sibling stream next to the selection kernels ($MML_UND_FORK=1; off by default):
+        #     same results, slot for slot, on one lane and on two
         import os
-        os.environ["MML_UND_FORK"] = "0"
+        os.environ["MML_UND_FORK"] = "1"
         try:
             x2 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
             assert np.array_equal(x2, x) and np.array_equal(c.slot_digest(0, B), dg)

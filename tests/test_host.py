@@ -309,3 +309,39 @@ def test_one_hip_runtime_and_one_rccl_whatever_the_import_order(tmp_path, order)
     probe = [ln for ln in out.stdout.splitlines() if ln.startswith("PROBE")][0].split()
     assert probe[1] == "1" and probe[2] == "1", out.stdout
     assert int(probe[3]) >= 20000
+
+
+def test_atan2_cr_is_the_nearest_double(tmp_path):
+    """csrc/atan2_cr.h (host and device source): atan2 of two floats rounded to the nearest double, the value the bucketing's
+    k_azimuth_exact converts to float where the fast form cannot decide -- against mpmath on random pairs, octant and table edges,
+    and the (x, y) pairs of tests/golden/azimuth_edge_xy.npy (angles within 2e-15 of the middle between two floats; the first of
+    them is the point of the campaign's seed 836 on which the device math library's 2-ulp atan2 rounded the other way)."""
+    mp = pytest.importorskip("mpmath")
+    import ctypes
+    import math
+    src = tmp_path / "cr.cpp"
+    src.write_text('#include "atan2_cr.h"\nextern "C" double cr_atan2(double y, double x) { return mml_cr::atan2_cr(y, x); }\n')
+    so = tmp_path / "libcr.so"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "multi-modal-loam_amd", "csrc"), str(src), "-o", str(so)],
+                   check=True)
+    L = ctypes.CDLL(str(so))
+    L.cr_atan2.restype = ctypes.c_double
+    L.cr_atan2.argtypes = [ctypes.c_double, ctypes.c_double]
+    mp.mp.prec = 300
+    rng = np.random.default_rng(7)
+    pairs = [(np.float32(rng.normal() * 10 ** rng.uniform(-3, 3)), np.float32(rng.normal() * 10 ** rng.uniform(-3, 3))) for _ in range(3000)]
+    pairs += [(np.float32(a), np.float32(b)) for a, b in ((1, 1), (1, -1), (-1, -1), (-1, 1), (1e-20, 1), (1, 1e-20), (3, 4), (0.41421357, 1),
+                                                           (0.41421354, 1), (0.0625, 1), (0.1875, 1), (0.3125, 1), (0.125, 1), (0.25, 1), (0.375, 1))]
+    edge = np.load(os.path.join(ROOT, "tests", "golden", "azimuth_edge_xy.npy"))
+    pairs += [(xy[1], xy[0]) for xy in edge]
+    n_libm = 0
+    for y, x in pairs:
+        if x == 0 or y == 0:
+            continue
+        want = float(mp.atan2(mp.mpf(float(y)), mp.mpf(float(x))))
+        assert L.cr_atan2(float(y), float(x)) == want, (float(y), float(x))
+        n_libm += int(math.atan2(float(y), float(x)) != want)
+    # (this box's libm is the nearest double nearly always, not always: what the oracle -- and the reference -- round is libm's)
+    assert n_libm < len(pairs) // 100
+    # the special cases stay the library's
+    assert L.cr_atan2(0.0, -1.0) == np.pi and L.cr_atan2(1.0, 0.0) == np.pi / 2 and L.cr_atan2(0.0, 1.0) == 0.0

@@ -10,7 +10,7 @@ echo "python tests/gpu_fuzz.py --seed S $ARGS"
 for S in "$@"; do
   echo "== seed $S"
   python tests/gpu_fuzz.py --seed $S $ARGS 2>&1 | grep -v amdgpu.ids
-  echo "rc $?"
+  echo "rc ${PIPESTATUS[0]}"
 done
 } > $OUT/fuzz_campaign.txt
 tail -15 $OUT/fuzz_campaign.txt
