@@ -1,9 +1,9 @@
 """Replica stress: 4096 slots holding 20 distinct scans, mml_step repeated; every slot must equal the first slot of its scan in all ten
-digest words, every time.  python tools/replica_stress.py [rounds] -- run with MML_UND_FORK=0 / 1 and MML_LANES=1 / 2 to compare."""
+digest words, every time.  python tests/replica_stress.py [rounds] -- run with MML_UND_FORK=0 / 1 and MML_LANES=1 / 2 to compare."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # (test infrastructure: builds its maps with the oracle)
 import conftest
 M = importlib.import_module("multi-modal-loam_amd"); synth = importlib.import_module("multi-modal-loam_amd.synth")
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
