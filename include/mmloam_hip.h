@@ -338,8 +338,7 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
  * iterations (fixed count).  Everything stays on the device; poses: count x 6 ([t,phi], device-updated,
  * copied back).  This is what bench.py times.  The batch is spread over the context's stream lanes (mml_set_lanes), every
  * lane ordered behind whatever the context's stream holds when the call is made (no synchronisation is needed between
- * mml_scan_upload and mml_step).  Inside a lane the undistortion runs on a sibling stream next to the selection kernels
- * (which read neither the points nor their times) and is joined in front of the down-sampler; the call returns with every
+ * mml_scan_upload and mml_step); inside a lane the stages run in order on the lane's stream; the call returns with every
  * stream of the context drained.  The association statistics of mml_associate (counts, normal Gram matrix) are not part of
  * the step; an entry point that needs them afterwards (mml_linearize*, mml_associate with `stats`) computes them on demand. */
 int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const double* dt,
@@ -510,6 +509,10 @@ int mml_profile_get(mml_ctx* ctx, mml_profile* out);
  * predicate fell inside its guard band and were recomputed with the full decision chain (k_stencil_redo), `brk` = break-point
  * candidates finished by k_stencil_break (unionFeatureExtract.cpp:651-806).  Either may be NULL. */
 int mml_extract_queue_counts(mml_ctx* ctx, int slot, int* redo, int* brk);
+/* Test hook: the device's copies of the two libm routines the ring / azimuth assignment calls (csrc/libm_f32.h: glibc's atanf and
+ * atan2f, the float overloads unionFeatureExtract.cpp:1136-1139,1159,1168 resolve to), evaluated on n host values on the
+ * context's device.  out_atan2[i] = atan2f(y[i], x[i]), out_atan[i] = atanf(y[i]); either output may be NULL. */
+int mml_libm_f32(mml_ctx* ctx, const float* y, const float* x, long n, float* out_atan2, float* out_atan);
 /* Device facts for bench.py: name, CU count, total HBM bytes. */
 int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes);
 /* Device-to-device copy bandwidth probe (GB/s, read + write counted) over `bytes` bytes, `reps` repetitions: the better of a

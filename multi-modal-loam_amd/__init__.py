@@ -623,6 +623,14 @@ class Context:
         self._ck(lib().mml_extract_queue_counts(self._h, C.c_int(slot), C.byref(r), C.byref(b)))
         return r.value, b.value
 
+    def libm_f32(self, y, x):
+        """(atan2f(y, x), atanf(y)) evaluated by the device's copies of the two libm routines (mml_libm_f32, a test hook)."""
+        y, x = np.ascontiguousarray(y, np.float32).ravel(), np.ascontiguousarray(x, np.float32).ravel()
+        assert len(x) == len(y)
+        o2, o1 = np.empty_like(x), np.empty_like(x)
+        self._ck(lib().mml_libm_f32(self._h, _p(y), _p(x), C.c_long(len(x)), _p(o2), _p(o1)))
+        return o2, o1
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus = C.c_int(0)

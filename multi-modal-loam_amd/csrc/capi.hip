@@ -76,7 +76,7 @@ void mml_destroy(mml_ctx* ctx) {
     mml_fullwindow_dev_release(ctx);
     void* ptrs[] = {ctx->wstate, ctx->wrec, ctx->waux, ctx->hard_knn, ctx->d_und, ctx->crop_cnt, ctx->velo_in,  ctx->livox_in, ctx->d_n_in,   ctx->raw_line, ctx->raw_ori,  ctx->ln_pts,
                     ctx->ln_gidx, ctx->ln_rel, ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
-                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->vx_big, ctx->az_cnt, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
+                    ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->vx_big, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
                     ctx->cb_n,     ctx->queue_off, ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
@@ -103,8 +103,6 @@ void mml_destroy(mml_ctx* ctx) {
     for (auto e : ctx->upload_event_pool) hipEventDestroy(e);
     for (int l = 0; l < mml_ctx::MAX_LANES; ++l) {
         if (ctx->lane_mark[l]) hipEventDestroy(ctx->lane_mark[l]);
-        if (ctx->fork_ev[l]) hipEventDestroy(ctx->fork_ev[l]);
-        if (ctx->join_ev[l]) hipEventDestroy(ctx->join_ev[l]);
         if (ctx->streams[l]) hipStreamDestroy(ctx->streams[l]);
     }
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -161,8 +159,6 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
             return fail(e, "hipStreamCreate");
         if ((e = hipEventCreateWithFlags(&ctx->lane_mark[l], hipEventDisableTiming)) != hipSuccess)
             return fail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&ctx->fork_ev[l], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&ctx->join_ev[l], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
     }
     if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     const size_t B = ctx->B, NV = ctx->NV, NL = ctx->NL, NT = ctx->NT, L = ctx->L, MF = ctx->MF, MM = ctx->MM;
@@ -204,7 +200,6 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->redo_queue, B * NT);
     ALLOC(ctx->st_exit, B * (NT / 256 + L + 8));
     ALLOC(ctx->vx_big, 2 * B);
-    ALLOC(ctx->az_cnt, B + B * 64 * 2);
     ALLOC(ctx->sel_done, B * L + 8);
     ALLOC(ctx->sel_list, 4 * B * L + 8);
     ALLOC(ctx->sel_list_cnt, 2 * B + 8);
@@ -1480,14 +1475,6 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     // i, 2 .. 5 streams, three stage-to-stream maps: 306 k .. 330 k scans/s against 355 k for two lanes (HISTORY.md).
     const int lanes = (count >= 64 && ctx->lanes_enabled) ? ctx->n_lanes : 1;
     const int n_pieces = lanes;
-    // The undistortion (HBM-bound, 24 registers, no LDS) next to the selection kernels (their own instructions and memory round
-    // trips, little traffic): the selection reads neither the points nor their times, so the lane's sibling stream can rewrite them
-    // as soon as the stencil is through.  Not while stage times are being taken (one stream, stage by stage).
-    // OFF unless $MML_UND_FORK=1 (read at every call so that one process can compare the two schedules): +0.5 - 1 % on the bench
-    // line, and the one full-suite run of the round that failed -- one slot of 4096 with a surf stack computed from something
-    // other than its final cloud, never reproduced in 130 further steps with or without the fork -- had it on.
-    const char* e_fork = getenv("MML_UND_FORK");
-    const bool fork = (e_fork && atoi(e_fork) != 0) && count > 16 && lanes <= mml_ctx::MAX_LANES / 2 && !ctx->profiling;
     const int chunk = (count + n_pieces - 1) / n_pieces;
     std::vector<double> Twl(16 * (size_t)chunk);
     // (the staging ring: a wrap in the middle of the call would drain the streams; wrap now if this call does not fit)
@@ -1518,21 +1505,8 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     auto run_stage = [&](int stage, int f, int c) -> int {
         const int off = f - first_slot;
         switch (stage) {
-            case 0: {
-                ctx->und_fork = fork ? 1 : 0;
-                ctx->und_dR = dR + 9 * (size_t)off;
-                ctx->und_dt = dt + 3 * (size_t)off;
-                ctx->und_first = f;
-                const int r = mml_launch_extract(ctx, f, c, false);
-                ctx->und_fork = 0;
-                return r;
-            }
-            case 1:
-                if (fork) {  // enqueued on the sibling stream by the extraction, behind the stencil: the lane waits for it here
-                    if (hipStreamWaitEvent(MML_STREAM(ctx), ctx->join_ev[ctx->cur], 0) != hipSuccess) return MML_ERR_HIP;
-                    return MML_OK;
-                }
-                return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
+            case 0: return mml_launch_extract(ctx, f, c, false);
+            case 1: return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
             case 2: return mml_launch_downsample(ctx, f, c);
             case 3:
                 for (int i = 0; i < c; ++i) {

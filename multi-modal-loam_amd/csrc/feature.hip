@@ -23,7 +23,7 @@
 #include <algorithm>
 #include <stdlib.h>
 
-#include "atan2_cr.h"
+#include "libm_f32.h"
 #include "mml_internal.h"
 
 namespace {
@@ -91,10 +91,6 @@ struct FeatParams {
     int* sel_list_cnt;       // [B][2] list lengths of the launch that starts at slot `first`
     unsigned char* st_exit;  // [B][st_stride] k_stencil, segment mode: the stride walk's exit offsets of every tile, for the four entries
     int st_stride;
-    // the points whose azimuth the fast form did not decide (within 1e-14 of a float rounding boundary: about one in 1e6): queued by
-    // the bucketing kernels, decided by k_azimuth_exact.  az_cnt[b] is zero between extractions (the kernel that consumes it clears it).
-    int* az_cnt;       // [B]
-    int* az_queue;     // [B][AZ_CAP][2]: raw index, storage position (-1: the three-pass bucketing, raw_ori is patched)
     // storage segments of the lines (mml_internal.h): line index -> storage position
     int* seg_cum;
     int* seg_pos;
@@ -248,10 +244,11 @@ __global__ void k_assign_init(FeatParams P, int count) {
 }
 
 // getVeloFeature per-point part (:1133, :1154-1168) -- ring id through a float estimate of the pitch, the reference
-// expression (double atan) only when the estimate is within 2e-4 ring widths of a rounding boundary.
+// expression (glibc's atanf, a float division, sqrtf: the float overloads the reference TU resolves to, libm_f32.h) only when the
+// estimate is within 2e-4 ring widths of a rounding boundary.
 // (the estimate is built from the raw v_rsq / v_rcp instructions and an eight-term odd polynomial: |error| < 4e-7 rad in all,
-//  2.3e-5 degrees, which the guard band below covers five times over for any ring spacing; the IEEE sqrtf / two divisions /
-//  atanf it replaces were 70 of the pass's 163 vector instructions per point)
+//  2.3e-5 degrees; the reference's own float evaluation is within 1e-5 degrees of the true pitch: the guard band below covers the
+//  sum 3.6 times over for any ring spacing; the IEEE sqrtf / two divisions / atanf it replaces are 70 vector instructions per point)
 __device__ __forceinline__ float atan_est(float a) {
     const float aa = fabsf(a);
     const bool inv = aa > 1.0f;
@@ -279,7 +276,9 @@ __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pit
     if (fabsf(t - rintf(t)) > guard && fabsf(t) < 1e6f) {
         scanID = (int)t;
     } else {
-        const float angle = atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI;
+        // :1159 `atan(point.z / sqrt(point.x * point.x + point.y * point.y)) * 180 / M_PI` with the float overloads: the product
+        // with 180 in float, the division by M_PI in double, rounded to float on assignment
+        const float angle = (float)((double)(mml_libm::atanf_fd(p.z / sqrtf(p.x * p.x + p.y * p.y)) * 180.0f) / M_PI);
         // int() of a NaN -- the (0,0,0) no-return records of some drivers: atan(0 / 0) -- or of a value beyond the int range is
         // "integer indefinite" = INT_MIN on the reference's x86-64 (the point then fails the range test and is dropped), where
         // v_cvt_i32_f64 returns 0 / saturates: DESIGN.md parity convention 8
@@ -289,93 +288,24 @@ __device__ __forceinline__ int velo_ring(const float4 p, float pitch0, float pit
     return (scanID > (R - 1) || scanID < 0) ? 255 : scanID;
 }
 
-// float(-atan2((double)y, (double)x)) of :1154.  Fast form: octant reduction + a degree-9 minimax polynomial in t^2
-// (|error| < 1e-15 over the reduced range; two divisions through v_rcp_f64 + Newton); accepted only when the double
-// lies farther than 1e-14 from a float rounding boundary, otherwise -- about one point in 1e6 -- the nearest double
-// (mml_cr::atan2_cr, double-double) decides.
-__device__ __forceinline__ double fast_div(double n, double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    const double q = n * r;
-    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
-}
-// `rare` is set when the fast form did not decide; the value returned then is the device library's (good to 2 ulp of a double: the
-// right float except for about one in 1e4 of THOSE points).  The caller queues the flagged points (az_push) for k_azimuth_exact,
-// which decides them with the nearest double (atan2_cr.h): inside the bucketing kernels that routine cost them their occupancy
-// (118 -> 142 registers) or, held down, 0.56 -> 0.9 ms per 1024 scans in spills.
-__device__ __forceinline__ float neg_atan2_f(float yf, float xf, bool& rare) {
-    rare = false;
-    const double x = xf, y = yf;
-    const double ax = fabs(x), ay = fabs(y);
-    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-    if (mx > 1e-300 && mx < 1e300) {
-        const double a = fast_div(mn, mx);
-        const bool big = a > 0.41421356237309503;
-        const double t = big ? fast_div(a - 1.0, a + 1.0) : a;
-        const double z = t * t;
-        double p = mml_und::sconst(2.25838847748916528e-02);
-        p = __builtin_fma(p, z, mml_und::sconst(-4.46976301461388392e-02));
-        p = __builtin_fma(p, z, mml_und::sconst(5.73167296507084492e-02));
-        p = __builtin_fma(p, z, mml_und::sconst(-6.64873778438867108e-02));
-        p = __builtin_fma(p, z, mml_und::sconst(7.69095714550778464e-02));
-        p = __builtin_fma(p, z, mml_und::sconst(-9.09084591627817573e-02));
-        p = __builtin_fma(p, z, mml_und::sconst(1.11111093716489140e-01));
-        p = __builtin_fma(p, z, mml_und::sconst(-1.42857142603585840e-01));
-        p = __builtin_fma(p, z, mml_und::sconst(1.99999999998416944e-01));
-        p = __builtin_fma(p, z, mml_und::sconst(-3.33333333333330928e-01));
-        double r = (big ? 0.78539816339744831 : 0.0) + __builtin_fma(t * z, p, t);
-        if (ay > ax) r = 1.5707963267948966 - r;
-        if (x < 0.0) r = 3.141592653589793 - r;
-        if (y < 0.0) r = -r;
-        const double v = -r;
-        // float rounding boundary test on the bit pattern (see undistort_voxel.hip): low 29 mantissa bits vs 2^28
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        const int ef = (int)((hi >> 20) & 0x7ffu);
-        const int d = abs((int)(lo & 0x1fffffffu) - 0x10000000);
-        const double unit = __hiloint2double((ef - 52) << 20, 0);
-        // (the band: the fast form is within 4.7e-16 of the true angle -- measured against 300 k multi-precision values, octant
-        //  edges included --, the reference's libm within an ulp of a double of it, 7e-16 at most: 1e-14 leaves a factor of eight.
-        //  It was 1e-12 until the decision inside it became a double-double evaluation: at 1.4e-4 of the points of a scan that
-        //  cost the pass a third; at 1e-14 it is 1.4e-6 of them)
-        if (ef >= 1023 - 126 && (double)d * unit > 1e-14) return (float)v;
-        if (mn > 0.0) rare = true;  // (a point ON an axis: the library's special cases are exact)
-    }
-    return (float)(-atan2(y, x));
-}
-// (within 1e-14 of the middle between two floats: the nearest double, as the reference's libm returns it; the device library's 2-ulp atan2 rounded the other way for one point in 1.6e9, atan2_cr.h)
-__device__ __forceinline__ float neg_atan2_exact(float yf, float xf) { return (float)(-mml_cr::atan2_cr((double)yf, (double)xf)); }
-// the two azimuths of :1136-1139 as the doubles the reference converts to float: the device library's atan2, and the nearest
-// double instead when either result lies within 1e-12 of the middle between two floats (wave-uniform, a few times in 1e9 scans)
-__device__ __forceinline__ bool near_float_middle(double v) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const int ef = (int)((hi >> 20) & 0x7ffu);
-    const int d = abs((int)(lo & 0x1fffffffu) - 0x10000000);
-    const double unit = __hiloint2double((ef - 52) << 20, 0);
-    return !(ef >= 1023 - 126 && (double)d * unit > 1e-12);
-}
+// `-atan2(point.y, point.x)` of :1168 (:1136-1139 for the sweep's ends): the float overload, i.e. glibc's atan2f, whose bits
+// libm_f32.h reproduces -- two IEEE float divisions and 21 float multiply / adds per point.  (Rounds 1-5 took the call as the
+// DOUBLE atan2 rounded to float -- a fast double form, a guard band, a queue of undecided points and a double-double kernel
+// behind it --: one azimuth in six then differs by a float ulp from what the reference binary computes.  HISTORY.md A.000.)
+__device__ __forceinline__ float neg_atan2f(float y, float x) { return -mml_libm::atan2f_fd(y, x); }
 __device__ __forceinline__ void sweep_azimuths(const float4 p0, const float4 p1, float& startOri, float& endOri) {
-    double s = -atan2((double)p0.y, (double)p0.x);             // :1136
-    double e = -atan2((double)p1.y, (double)p1.x) + 2 * M_PI;  // :1137-1138
-    if (near_float_middle(s) || near_float_middle(e)) {
-        s = -mml_cr::atan2_cr((double)p0.y, (double)p0.x);
-        e = -mml_cr::atan2_cr((double)p1.y, (double)p1.x) + 2 * M_PI;
-    }
-    startOri = s;
-    endOri = e;
+    startOri = neg_atan2f(p0.y, p0.x);                                 // :1136
+    endOri = (float)((double)neg_atan2f(p1.y, p1.x) + 2 * M_PI);       // :1137-1139: float + double, rounded on assignment
 }
 
-constexpr int AZ_CAP = 64;  // per slot; a scan holds a handful at most (more -- an adversarial cloud -- keep the library's rounding)
-__device__ __forceinline__ void az_push(const FeatParams& P, int b, int i, int dst) {
-    const int k = atomicAdd(&P.az_cnt[b], 1);
-    if (k < AZ_CAP) {
-        P.az_queue[((size_t)b * AZ_CAP + k) * 2] = i;
-        P.az_queue[((size_t)b * AZ_CAP + k) * 2 + 1] = dst;
-    }
+__global__ void k_libm_f32(const float* y, const float* x, long n, float* o2, float* o1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (o2) o2[i] = mml_libm::atan2f_fd(y[i], x[i]);
+    if (o1) o1[i] = mml_libm::atanf_fd(y[i]);
 }
-// QUEUE: the azimuths the fast form leaves open go to k_azimuth_exact (the three-pass bucketing).  mml_launch_raw_lines runs this
-// pass for the line ids alone, with nobody behind it to take the queue: there it stays empty.
-template <int PPT, bool QUEUE>
+
+template <int PPT>
 __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     __shared__ int s_bcnt[MAX_LINES];
     __shared__ int s_valid, s_keep;
@@ -388,7 +318,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     //  trip count every round waited for its own load, one kilobyte in flight per wavefront -- and before the slot's point count
     //  is read, the index clamped to the slot's buffer: the block's first round trip to memory is the records themselves)
     float4 pv[PPT];
-    if (sensor == 0) {
+    if (sensor == 0 && P.NV > 0) {  // (a context without a Velodyne part, max_velo_points = 0, has no buffer to clamp into)
 #pragma unroll
         for (int r = 0; r < PPT; ++r)
             pv[r] = nt_load4(P.velo_in + (size_t)b * P.NV + min((int)((blockIdx.x * PPT + r) * AB_THREADS + tid), P.NV - 1));
@@ -406,7 +336,6 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     // (dense layouts: four points per thread -- a 130-entry histogram record per 1024 points instead of per 256: the records were a
     //  quarter of this pass's written bytes and all of pass B's work)
     const int ppt = sensor == 0 ? PPT : 1;
-    unsigned rare_rounds = 0;  // bit r: the azimuth of this thread's point of round r is left to k_azimuth_exact (one point in 1e6)
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
     if (r >= ppt) break;
@@ -422,9 +351,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
             if (fin) {
                 ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
                 if (ring == 255) ring = 254;
-                bool rare;
-                ori = neg_atan2_f(p.y, p.x, rare);
-                if (rare) rare_rounds |= 1u << r;
+                ori = neg_atan2f(p.y, p.x);
             }
             P.raw_line[(size_t)b * P.NT + i] = (uint8_t)ring;
             P.raw_ori[(size_t)b * P.NV + i] = ori;
@@ -447,11 +374,6 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_a(FeatParams P) {
     if (lane == 0 && vm) atomicAdd(&s_valid, __popcll(vm));
     if (lane == 0 && km) atomicAdd(&s_keep, __popcll(km));
     __builtin_amdgcn_sched_barrier(0);  // (one point at a time: the evaluations' temporaries do not overlap)
-    }
-    if (QUEUE && rare_rounds) {  // (behind the loop: the queue's atomic inside it cost the pass 6 %)
-#pragma unroll 1
-        for (int r = 0; r < PPT; ++r)
-            if ((rare_rounds >> r) & 1u) az_push(P, b, (blockIdx.x * ppt + r) * AB_THREADS + tid, -1);
     }
     __syncthreads();
     int* cnt = P.blk_cnt + ((size_t)(b * 2 + sensor) * P.nblk_max + blockIdx.x) * BLK_STRIDE;
@@ -788,7 +710,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_assign_c_staged(FeatParams P) {
     float ori[CB_TP];
     uint32_t off_time[CB_TP];
     double timeSpan = 1.0;
-    if (sensor == 0) {
+    if (sensor == 0 && P.NV > 0) {
 #pragma unroll
         for (int r = 0; r < CB_TP; ++r) {
             const int ic = min((int)(bx * CB_TILE + r * CB_THREADS + tid), P.NV - 1);
@@ -1011,65 +933,6 @@ __global__ __launch_bounds__(64) void k_assign_ends(FeatParams P, int count) {
     }
 }
 
-// The queued azimuths, decided by the nearest double (atan2_cr.h).  One wavefront per slot; nearly every slot has none.
-// ONEPASS: the point's in-sweep time is written again from the exact azimuth (the expressions of the bucketing kernel's last
-// phase; the slot's half-turn index = the minimum over its blocks' look-back words -- for a point of block k the blocks behind k
-// cannot change the comparison, their indices are larger than the point's).  Otherwise: raw_ori, which passes B and C read.
-// (Not re-decided: whether the point ITSELF is the one that sets halfPassed, :1169-1177 -- the library's float and the exact one
-//  differ by an ulp for one queued point in 1e4, and that ulp would have to straddle startOri + pi.)
-template <bool ONEPASS>
-__global__ __launch_bounds__(64) void k_azimuth_exact(FeatParams P, int count) {
-    const int t = blockIdx.x;
-    if (t >= count) return;
-    const int b = P.first + t, lane = threadIdx.x;
-    const int nq = P.az_cnt[b];
-    if (nq <= 0) return;  // (wave-uniform)
-    const int n = nq < AZ_CAP ? nq : AZ_CAP;
-    float startOri = 0.f, endOri = 0.f;
-    int trig = 0x7fffffff;
-    if constexpr (ONEPASS) {
-        if (P.ends_inline) {
-            sweep_ends(P, b, startOri, endOri);
-        } else {
-            const AssignAux* a = reinterpret_cast<const AssignAux*>(P.assign_aux) + b;
-            startOri = a->startOri;
-            endOri = a->endOri;
-        }
-        const int nbv = (P.n_in[2 * b] + MML_OP_BLK - 1) / MML_OP_BLK;
-        for (int k = lane; k < nbv; k += 64) {
-            const unsigned long long w = P.op_agg[(size_t)b * 2 * MML_SEG_MAX + k];
-            const unsigned coff = (unsigned)((w >> 26) & 0x1fffu);
-            if (coff != 0x1fffu) trig = min(trig, k * MML_OP_BLK + (int)coff);
-        }
-        for (int o = 32; o > 0; o >>= 1) trig = min(trig, __shfl_xor(trig, o));
-    }
-    for (int e = lane; e < n; e += 64) {
-        const int i = P.az_queue[((size_t)b * AZ_CAP + e) * 2], dst = P.az_queue[((size_t)b * AZ_CAP + e) * 2 + 1];
-        const float4 p = P.velo_in[(size_t)b * P.NV + i];
-        float ori = neg_atan2_exact(p.y, p.x);
-        if constexpr (ONEPASS) {
-            if (i <= trig) {  // :1169-1177
-                if (ori < startOri - M_PI / 2)
-                    ori += 2 * M_PI;
-                else if (ori > startOri + M_PI * 3 / 2)
-                    ori -= 2 * M_PI;
-            } else {  // :1178-1184
-                ori += 2 * M_PI;
-                if (ori < endOri - M_PI * 3 / 2)
-                    ori += 2 * M_PI;
-                else if (ori > endOri + M_PI / 2)
-                    ori -= 2 * M_PI;
-            }
-            const float rel = (ori - startOri) / (endOri - startOri);  // :1186
-            P.ln_rel[(size_t)b * P.NT + dst] = __float_as_int(rel);
-        } else {
-            P.raw_ori[(size_t)b * P.NV + i] = ori;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) P.az_cnt[b] = 0;  // (every lane has read the count)
-}
-
 // inclusive scan over the 64 lanes of a wavefront
 __device__ __forceinline__ int wave_incl_scan(int v) {
     const int lane = threadIdx.x & 63;
@@ -1139,6 +1002,10 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     float4 pt[OP_PPT];
     unsigned xw[OP_PPT];    // velodyne: the raw azimuth (float bits), Livox: offset_time
     unsigned info[OP_PPT];  // [0:7] line id, OPI_* flags, rank among the points of the line / among the kept points in the wavefront round
+    // (a context without this sensor -- max_velo_points / max_livox_points = 0 -- has no buffer for the clamped index to land in;
+    //  the combined launch of <= 16 scans still dispatches the sensor's z-plane.  The per-slot resets below are then the other
+    //  sensor's: n_in is 0 for this one)
+    if ((SENSOR == 0 ? P.NV : P.NL) == 0) return;
     if constexpr (SENSOR == 0) {
         const float4* in = P.velo_in + (size_t)b * P.NV;
 #pragma unroll
@@ -1195,7 +1062,6 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
     aux.endOri = S.ori[1];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int cond_min = 0x7fffffff;  // (wave-uniform) first index of this wavefront's points that sets halfPassed
-    unsigned rare_rounds = 0;   // bit r: the azimuth of this thread's point of round r is left to k_azimuth_exact (one point in 1e6)
 #pragma unroll
     for (int r = 0; r < OP_PPT; ++r) {
         const int i = i0 + r * OP_THREADS + tid;
@@ -1209,9 +1075,7 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
                     const int ring = velo_ring(p, P.pitch0, P.pitch_step, P.n_rings);
                     valid = ring != 255;                                  // outside the ring table: dropped at :1163-1166
                     key = valid ? ring : 0;
-                    bool rare;
-                    ori = neg_atan2_f(p.y, p.x, rare);
-                    if (rare) rare_rounds |= 1u << r;
+                    ori = neg_atan2f(p.y, p.x);
                 }
                 xw[r] = __float_as_uint(ori);
                 if (valid) {
@@ -1392,9 +1256,6 @@ __device__ __forceinline__ void assign_onepass_body(const FeatParams& P, Onepass
         }
         const size_t gpos = (size_t)b * P.NT + dst;
         P.ln_pts[gpos] = pt[r];
-        if constexpr (SENSOR == 0) {
-            if ((rare_rounds >> r) & 1u) az_push(P, b, i, dst);
-        }
         const bool keep = (f & OPI_KEEP) != 0;
         // the two 4-byte records of the point go through LDS, in the order the block's region is laid out, and leave it as whole
         // rows below: as scattered 4-byte stores they were what the pass waited for (0.61 -> 0.71 ms when the 8-byte record of
@@ -4100,8 +3961,6 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.sel_list = ctx->sel_list;
     P.sel_list_cnt = ctx->sel_list_cnt;
     P.st_exit = ctx->st_exit;
-    P.az_cnt = ctx->az_cnt;
-    P.az_queue = ctx->az_cnt + ctx->B;
     P.st_stride = ctx->NT / 256 + ctx->L + 8;
     P.seg_cum = ctx->seg_cum;
     P.seg_pos = ctx->seg_pos;
@@ -4123,6 +3982,35 @@ FeatParams make_params(mml_ctx* ctx, int first) {
 }
 
 }  // namespace
+
+extern "C" int mml_libm_f32(mml_ctx* ctx, const float* y, const float* x, long n, float* out_atan2, float* out_atan) {
+    if (!ctx || !y || !x || n < 0) return MML_ERR_INVALID;
+    if (n == 0) return MML_OK;
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    float *dy = nullptr, *dx = nullptr, *d2 = nullptr, *d1 = nullptr;
+    auto release = [&]() {
+        if (dy) (void)hipFree(dy);
+        if (dx) (void)hipFree(dx);
+        if (d2) (void)hipFree(d2);
+        if (d1) (void)hipFree(d1);
+    };
+    const size_t bytes = sizeof(float) * (size_t)n;
+    if (hipMalloc(&dy, bytes) != hipSuccess || hipMalloc(&dx, bytes) != hipSuccess ||
+        (out_atan2 && hipMalloc(&d2, bytes) != hipSuccess) || (out_atan && hipMalloc(&d1, bytes) != hipSuccess)) {
+        release();
+        return MML_ERR_HIP;
+    }
+    bool ok = hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_libm_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, MML_STREAM(ctx), dy, dx, n, d2, d1);
+        ok = hipStreamSynchronize(MML_STREAM(ctx)) == hipSuccess;
+    }
+    if (ok && out_atan2) ok = hipMemcpy(out_atan2, d2, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && out_atan) ok = hipMemcpy(out_atan, d1, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    release();
+    return ok ? MML_OK : MML_ERR_HIP;
+}
 
 int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) {
     for (int i = 0; i < count; ++i) ctx->raw_extracted[first + i] = 1;  // (mml_gicp_refresh re-derives line ids from the raw buffers)
@@ -4153,17 +4041,15 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
         {
             MmlStageScope t(ctx, "assign_tables");
             hipLaunchKernelGGL(k_assign_tables, dim3(count), dim3(TB_THREADS), 0, s, P, count);
-            hipLaunchKernelGGL(k_azimuth_exact<true>, dim3(count), dim3(64), 0, s, P, count);  // (the in-sweep times of the queued points)
         }
     } else {
     {
         MmlStageScope t(ctx, "assign_count");
         hipLaunchKernelGGL(k_assign_init, dim3((count + 255) / 256), dim3(256), 0, s, P, count);
         if (P.ab_ppt == 4)
-            hipLaunchKernelGGL((k_assign_a<4, true>), dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
+            hipLaunchKernelGGL((k_assign_a<4>), dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
         else
-            hipLaunchKernelGGL((k_assign_a<1, true>), dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
-        hipLaunchKernelGGL(k_azimuth_exact<false>, dim3(count), dim3(64), 0, s, P, count);  // (raw_ori of the queued points, before pass B reads it)
+            hipLaunchKernelGGL((k_assign_a<1>), dim3(P.nblk_max, count, 2), dim3(AB_THREADS), 0, s, P);
     }
     {
         MmlStageScope t(ctx, "assign_scan");
@@ -4211,18 +4097,6 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
             hipLaunchKernelGGL(k_stencil_redo, dim3(4, count), dim3(256), 0, s, P);
             hipLaunchKernelGGL(k_stencil_break, dim3(2, count), dim3(256), 0, s, P);
         }
-    }
-    if (ctx->und_fork) {
-        // mml_step: the stencil was the last reader of the raw points; the selection below touches neither them nor their times.
-        // The lane's sibling stream undistorts the slots meanwhile (mml_step joins it in front of the down-sampler).
-        const int lane = ctx->cur, side = lane + mml_ctx::MAX_LANES / 2;
-        MML_HIP(hipEventRecord(ctx->fork_ev[lane], s));
-        MML_HIP(hipStreamWaitEvent(ctx->streams[side], ctx->fork_ev[lane], 0));
-        ctx->cur = side;
-        const int r = mml_undistort(ctx, first, count, ctx->und_dR, ctx->und_dt);
-        ctx->cur = lane;
-        if (r != MML_OK) return r;
-        MML_HIP(hipEventRecord(ctx->join_ev[lane], ctx->streams[side]));
     }
     {
         MmlStageScope t(ctx, "select");
@@ -4319,9 +4193,9 @@ int mml_launch_cloud_decode(mml_ctx* ctx, int slot, const float* d_raw, int n, i
 int mml_launch_raw_lines(mml_ctx* ctx, int slot) {
     FeatParams P = make_params(ctx, slot);
     if (P.ab_ppt == 4)
-        hipLaunchKernelGGL((k_assign_a<4, false>), dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+        hipLaunchKernelGGL((k_assign_a<4>), dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
     else
-        hipLaunchKernelGGL((k_assign_a<1, false>), dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
+        hipLaunchKernelGGL((k_assign_a<1>), dim3(P.nblk_max, 1, 2), dim3(AB_THREADS), 0, MML_STREAM(ctx), P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }

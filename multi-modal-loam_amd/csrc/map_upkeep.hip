@@ -374,6 +374,8 @@ __global__ void k_seg_empty(SegParams P) {  // segments without labelled points 
 }  // namespace
 
 int mml_downsample_big(mml_ctx* ctx, int first, int count) {
+    // (new stack sizes: statistics computed on demand must not pair the counts written below with an earlier association)
+    for (int i = 0; i < count; ++i) ctx->stats_stale[first + i] = 1;
     hipStream_t s = MML_STREAM(ctx);
     const int nseg = 2 * count;
     // scratch for the worst case (every point of every slot labelled), allocated on first use

@@ -96,13 +96,6 @@ struct mml_ctx {
     // another; an entry point that touches a slot range first makes the lanes wait for the uploads still in flight on it
     hipStream_t copy_stream = nullptr;
     hipEvent_t lane_mark[MAX_LANES] = {};
-    // mml_step: the undistortion of a lane's slots runs on a sibling stream (lane + MAX_LANES / 2) next to the lane's selection
-    // kernels -- forked behind the stencil, the last reader of the raw points, joined in front of the down-sampler
-    hipEvent_t fork_ev[MAX_LANES] = {}, join_ev[MAX_LANES] = {};
-    int und_fork = 0;                  // set by mml_step around its extraction stage
-    const double* und_dR = nullptr;    // the caller's motion arrays, indexed from und_first
-    const double* und_dt = nullptr;
-    int und_first = 0;
     struct Upload {
         int first, count;
         hipEvent_t done;
@@ -169,7 +162,6 @@ struct mml_ctx {
     int* sel_list = nullptr;           // 2 * B * L * 2 ints: (slot, line) lists of the lines left to k_select (rings | Livox lines)
     int* sel_list_cnt = nullptr;       // 2 B ints
     unsigned char* st_exit = nullptr;  // B * (NT / 256 + L + 8): k_stencil segment mode, exit offsets of the stride walk per tile
-    int* az_cnt = nullptr;             // B + B * 64 * 2: per slot the count | the queue of the azimuths left to k_azimuth_exact (feature.hip)
     int* vx_big = nullptr;             // 2 B: per launch (indexed by its first slot) the slots k_voxel<512> left to the large form: count | list
 
     // combined (pre-crop) cloud, velo part at [0, NV), livox part at [NV, NT)

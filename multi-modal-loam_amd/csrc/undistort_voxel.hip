@@ -518,6 +518,8 @@ int mml_launch_undistort(mml_ctx* ctx, int first, int count, const double* d_par
 
 int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     MmlStageScope t(ctx, "voxel_downsample");
+    // (ft_n changes: the association statistics, computed lazily from ft_n as it is when somebody asks, are stale from here on)
+    for (int i = 0; i < count; ++i) ctx->stats_stale[first + i] = 1;
     if (ctx->NT > (1 << 20)) return mml_downsample_big(ctx, first, count);  // indices beyond the key layouts of k_voxel
     // `cap` labelled points per (slot, kind) fit the LDS sort; a slot with more gets ft_n = -1 here and is redone through
     // the global-sort path by mml_downsample_redo_overflow (the label lists hold every labelled point: stride VX_CAP)

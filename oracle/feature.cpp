@@ -3,13 +3,18 @@
 //
 // Floating-point conventions (the reference is x86-64 gcc -O3, SSE2, no FMA):
 //   * float expressions are evaluated in float, left to right, exactly as written there;
-//   * unqualified sqrt()/atan()/atan2() on float arguments are the double libm functions
-//     (<cmath> only adds the float overloads to namespace std), result rounded on assignment;
+//   * unqualified sqrt()/atan()/atan2() on float arguments are the FLOAT functions -- sqrtf / atanf / atan2f of glibc: the TU
+//     includes lidars_extrinsic_cali.h (:58), that <tf/tf.h> (lidars_extrinsic_cali.h:3) and tf/LinearMath/Scalar.h <math.h>,
+//     which with libstdc++ >= 6 (melodic: gcc 7.5) puts std::atan2(float, float) ... into the global namespace, where overload
+//     resolution prefers them (tests/test_oracle.py::test_libm_overloads_resolve_to_float).  atanf / atan2f are restated in
+//     libm_f32.h (glibc's fdlibm float routines, pinned against this image's libm on all 2^32 / 4e8 arguments); sqrtf is
+//     correctly rounded, std::sqrt(float) here.  The same convention as oracle/estimate.cpp (the aligner's TU);
 //   * Eigen::Vector3d dot()/norm() reduce as (x0+x1)+x2 (Eigen 3.3 SSE2 linear-vectorised redux,
 //     PacketSize 2), normalize() divides each coefficient by the norm and leaves a zero vector alone.
 // Build with -ffp-contract=off.
 #include "mml_oracle.h"
 #include "threads.h"
+#include "libm_f32.h"
 
 #include <cmath>
 #include <cstring>
@@ -77,7 +82,7 @@ extern "C" void mmlo_detect_feature_points(const float* pts_, int n, int* sharp,
         float diffY = 0;
         float diffZ = 0;
 
-        float dis = sqrt(pt[i].x * pt[i].x + pt[i].y * pt[i].y + pt[i].z * pt[i].z);
+        float dis = std::sqrt(pt[i].x * pt[i].x + pt[i].y * pt[i].y + pt[i].z * pt[i].z);
 
         V3d pt_last = v3(pt[i - 1].x, pt[i - 1].y, pt[i - 1].z);
         V3d pt_cur = v3(pt[i].x, pt[i].y, pt[i].z);
@@ -193,7 +198,7 @@ extern "C" void mmlo_detect_feature_points(const float* pts_, int n, int* sharp,
 
     // ---- :543-650 plane-intersection corners (flag 150), data-dependent stride ---------------
     for (int i = 5; i < cloudSize - 5; i += count_num) {
-        float depth = sqrt(pt[i].x * pt[i].x + pt[i].y * pt[i].y + pt[i].z * pt[i].z);
+        float depth = std::sqrt(pt[i].x * pt[i].x + pt[i].y * pt[i].y + pt[i].z * pt[i].z);
         float ldiffX = pt[i - 4].x + pt[i - 3].x - 4 * pt[i - 2].x + pt[i - 1].x + pt[i].x;
         float ldiffY = pt[i - 4].y + pt[i - 3].y - 4 * pt[i - 2].y + pt[i - 1].y + pt[i].y;
         float ldiffZ = pt[i - 4].z + pt[i - 3].z - 4 * pt[i - 2].z + pt[i - 1].z + pt[i].z;
@@ -256,16 +261,16 @@ extern "C" void mmlo_detect_feature_points(const float* pts_, int n, int* sharp,
             float diffX1 = pt[i + count].x - pt[i].x;
             float diffY1 = pt[i + count].y - pt[i].y;
             float diffZ1 = pt[i + count].z - pt[i].z;
-            diff_right[count - 1] = sqrt(diffX1 * diffX1 + diffY1 * diffY1 + diffZ1 * diffZ1);
+            diff_right[count - 1] = std::sqrt(diffX1 * diffX1 + diffY1 * diffY1 + diffZ1 * diffZ1);
 
             float diffX2 = pt[i - count].x - pt[i].x;
             float diffY2 = pt[i - count].y - pt[i].y;
             float diffZ2 = pt[i - count].z - pt[i].z;
-            diff_left[count - 1] = sqrt(diffX2 * diffX2 + diffY2 * diffY2 + diffZ2 * diffZ2);
+            diff_left[count - 1] = std::sqrt(diffX2 * diffX2 + diffY2 * diffY2 + diffZ2 * diffZ2);
         }
 
-        float depth_right = sqrt(pt[i + 1].x * pt[i + 1].x + pt[i + 1].y * pt[i + 1].y + pt[i + 1].z * pt[i + 1].z);
-        float depth_left = sqrt(pt[i - 1].x * pt[i - 1].x + pt[i - 1].y * pt[i - 1].y + pt[i - 1].z * pt[i - 1].z);
+        float depth_right = std::sqrt(pt[i + 1].x * pt[i + 1].x + pt[i + 1].y * pt[i + 1].y + pt[i + 1].z * pt[i + 1].z);
+        float depth_left = std::sqrt(pt[i - 1].x * pt[i - 1].x + pt[i - 1].y * pt[i - 1].y + pt[i - 1].z * pt[i - 1].z);
 
         if (fabs(diff_right[0] - diff_left[0]) > thBreakCornerDis) {
             if (diff_right[0] > diff_left[0]) {
@@ -298,7 +303,7 @@ extern "C" void mmlo_detect_feature_points(const float* pts_, int n, int* sharp,
             V3d norm_front = v3(0, 0, 0);
             V3d norm_back = v3(0, 0, 0);
             for (int k = 1; k < 4; k++) {
-                float temp_depth = sqrt(pt[i - k].x * pt[i - k].x + pt[i - k].y * pt[i - k].y + pt[i - k].z * pt[i - k].z);
+                float temp_depth = std::sqrt(pt[i - k].x * pt[i - k].x + pt[i - k].y * pt[i - k].y + pt[i - k].z * pt[i - k].z);
                 if (temp_depth < 1) {
                     continue;
                 }
@@ -309,7 +314,7 @@ extern "C" void mmlo_detect_feature_points(const float* pts_, int n, int* sharp,
                 norm_front.z += (k / 6.0) * tmp.z;
             }
             for (int k = 1; k < 4; k++) {
-                float temp_depth = sqrt(pt[i - k].x * pt[i - k].x + pt[i - k].y * pt[i - k].y + pt[i - k].z * pt[i - k].z);
+                float temp_depth = std::sqrt(pt[i - k].x * pt[i - k].x + pt[i - k].y * pt[i - k].y + pt[i - k].z * pt[i - k].z);
                 if (temp_depth < 1) {
                     continue;
                 }
@@ -396,6 +401,14 @@ void detect_lines_and_label(std::vector<CombPt>& cloud, int n_lines, int threads
 
 }  // namespace
 
+// the two restated libm routines on arrays (tests: against this image's libm, and as the checker of the device's copies)
+extern "C" void mmlo_atanf(const float* x, float* out, long n) {
+    for (long i = 0; i < n; ++i) out[i] = mmlo_libm::atanf_fdlibm(x[i]);
+}
+extern "C" void mmlo_atan2f(const float* y, const float* x, float* out, long n) {
+    for (long i = 0; i < n; ++i) out[i] = mmlo_libm::atan2f_fdlibm(y[i], x[i]);
+}
+
 // unionFeatureExtract.cpp:1113-1317 getVeloFeature
 extern "C" int mmlo_extract_velo(const float* in_xyzi, int n_in, int n_rings, float pitch0_deg,
                                  float pitch_step_deg, float near_th, float far_th, float* out_xyzi,
@@ -413,8 +426,8 @@ extern "C" int mmlo_extract_velo(const float* in_xyzi, int n_in, int n_rings, fl
     *n_surf = 0;
     if (cloudSize == 0) return 0;
 
-    float startOri = -atan2(in[0].y, in[0].x);
-    float endOri = -atan2(in[cloudSize - 1].y, in[cloudSize - 1].x) + 2 * M_PI;
+    float startOri = -mmlo_libm::atan2f_fdlibm(in[0].y, in[0].x);                        // :1136, float overload
+    float endOri = -mmlo_libm::atan2f_fdlibm(in[cloudSize - 1].y, in[cloudSize - 1].x) + 2 * M_PI;  // float + double, rounded on assignment
     if (endOri - startOri > 3 * M_PI)
         endOri -= 2 * M_PI;
     else if (endOri - startOri < M_PI)
@@ -429,7 +442,8 @@ extern "C" int mmlo_extract_velo(const float* in_xyzi, int n_in, int n_rings, fl
         point.y = in[i].y;
         point.z = in[i].z;
 
-        float angle = atan(point.z / sqrt(point.x * point.x + point.y * point.y)) * 180 / M_PI;
+        // :1159 with the float overloads: sqrtf, a float division, atanf, `* 180` in float (int -> float), `/ M_PI` in double
+        float angle = mmlo_libm::atanf_fdlibm(point.z / std::sqrt(point.x * point.x + point.y * point.y)) * 180 / M_PI;
         int scanID = 0;
         // :1162 scanID = int((angle + 15) / 2 + 0.5), generalised: (angle - pitch0) / step
         // A (0,0,0) record -- a no-return of some drivers -- has angle = atan(0 / 0) = NaN, and int(NaN) is undefined in C++:
@@ -443,7 +457,7 @@ extern "C" int mmlo_extract_velo(const float* in_xyzi, int n_in, int n_rings, fl
             continue;
         }
 
-        float ori = -atan2(point.y, point.x);
+        float ori = -mmlo_libm::atan2f_fdlibm(point.y, point.x);  // :1168
         if (!halfPassed) {
             if (ori < startOri - M_PI / 2)
                 ori += 2 * M_PI;

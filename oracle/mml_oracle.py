@@ -101,6 +101,23 @@ def extract_velo(xyzi, n_rings=16, pitch0=-15.0, pitch_step=2.0, near=2.0, far=5
                 n_corner=nc.value, n_surf=nsf.value)
 
 
+def atanf(x):
+    """glibc's atanf restated (oracle/libm_f32.h), element-wise on float32."""
+    x = _f32(x).ravel()
+    out = np.empty_like(x)
+    lib().mmlo_atanf(_p(x), _p(out), C.c_long(len(x)))
+    return out
+
+
+def atan2f(y, x):
+    """glibc's atan2f restated (oracle/libm_f32.h), element-wise on float32."""
+    y, x = _f32(y).ravel(), _f32(x).ravel()
+    assert len(x) == len(y)
+    out = np.empty_like(x)
+    lib().mmlo_atan2f(_p(y), _p(x), _p(out), C.c_long(len(x)))
+    return out
+
+
 def extract_livox(rec, n_lines=6, near=2.0, far=50.0):
     rec = np.ascontiguousarray(rec)
     assert rec.dtype.itemsize == 20

@@ -331,15 +331,20 @@ def test_voxel_grid_index_overflow_returns_the_labelled_cloud_unfiltered(M, O, s
         c.close()
 
 
-def test_azimuths_on_float_rounding_boundaries(M, O, synth):
-    """Points whose azimuth -atan2(y, x) lies, as a double, within 2e-15 of the middle between two floats (tests/golden/
-    azimuth_edge_xy.npy; the first is the point of campaign seed 836 on which the device library's atan2 rounded the other way).
-    The bucketing kernels queue them and k_azimuth_exact decides them with the nearest double (csrc/atan2_cr.h): in-sweep times
-    bit for bit as unionFeatureExtract.cpp:1154-1186 forms them, through the one-pass bucketing of a single scan (sweep ends
-    found inline), of a batch (k_assign_ends), and through the three-pass bucketing of a 64-ring layout (raw_ori patched before
-    pass B)."""
+def test_azimuths_where_the_float_and_the_double_arctangent_differ(M, O, synth):
+    """unionFeatureExtract.cpp:1136-1139,1168 call glibc's atan2f (the float overload, DESIGN.md section 2 convention 4): a scan
+    salted with points on which atan2f and float(atan2(double)) -- what rounds 1-5 computed -- differ by an ulp, with ratios on
+    atanf's reduction thresholds and octant edges (pairs of tests/golden/libm_f32_kat.npz, known answers of this image's libm).
+    In-sweep times bit for bit as :1154-1186 form them, through the one-pass bucketing of a single scan (sweep ends found inline),
+    of a batch (k_assign_ends), and through the three-pass bucketing of a 64-ring layout."""
     import os
-    edge = np.load(os.path.join(os.path.dirname(__file__), "golden", "azimuth_edge_xy.npy"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "libm_f32_kat.npz"))
+    y, x, want = g["atan2_y"], g["atan2_x"], g["atan2_out"]
+    r = np.hypot(x.astype(np.float64), y.astype(np.float64))
+    d64 = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)
+    pick = np.isfinite(want) & (r > 3) & (r < 40) & (d64 != want)
+    edge = np.stack([x[pick], y[pick]], 1)[:400]
+    assert len(edge) >= 300
 
     def salted(v, z_of):
         v = v.copy()
@@ -360,7 +365,7 @@ def test_azimuths_on_float_rounding_boundaries(M, O, synth):
             c.extract(0, B)
             for s in range(B):
                 _check_extraction(c.scan_download(s), o16)
-            c.extract(0, B)  # (the queue is empty again: a second extraction finds the same)
+            c.extract(0, B)  # (a second extraction finds the same)
             _check_extraction(c.scan_download(B - 1), o16)
         finally:
             c.close()
@@ -368,6 +373,58 @@ def test_azimuths_on_float_rounding_boundaries(M, O, synth):
     p0, st = -16.0, np.float32(32.0 / 63.0)
     kw = dict(n_rings=64, pitch0=p0, pitch_step=st)
     v64 = salted(synth.velo_scan(22, n_az=512, **kw), float(p0 + 30 * st))
+    o64 = oracle_pipeline(O, dict(velo=v64, livox=None, dR=np.eye(3), dt=np.zeros(3)), None, None, **kw)
+    for B in (1, 18):
+        c = M.Context(max_scans=B, max_velo_points=64 * 512, max_livox_points=24000, n_rings=64, pitch0_deg=p0, pitch_step_deg=st)
+        try:
+            for s in range(B):
+                c.scan_upload(s, v64, None)
+            c.extract(0, B)
+            for s in range(B):
+                _check_extraction(c.scan_download(s), o64)
+        finally:
+            c.close()
+
+
+def test_ring_ids_on_rounding_boundaries(M, O, synth):
+    """`int((angle + 15) / 2 + 0.5)` (unionFeatureExtract.cpp:1159-1162) for pitches within a few float ulps of a ring boundary,
+    where the ring id depends on every rounding of `atan(z / sqrt(x * x + y * y)) * 180 / M_PI` as the reference's float overloads
+    evaluate it (sqrtf, a float division, glibc's atanf, a float product, a double division).  A third of a scan's points are
+    moved onto boundaries (z chosen so that the oracle's own float pitch lands within 3 ulps of an even degree, both sides); ring
+    ids, times and labels equal the oracle's in the one-pass and the three-pass bucketing.  The device decides such points with the
+    reference expression (csrc/libm_f32.h), everything else from a fast estimate."""
+    rng = np.random.default_rng(5)
+
+    def on_boundaries(v, p0, step, n_rings):
+        v = v.copy()
+        idx = rng.choice(len(v), len(v) // 3, replace=False)
+        x, y = v[idx, 0].astype(np.float64), v[idx, 1].astype(np.float64)
+        k = rng.integers(0, n_rings + 1, len(idx))
+        ang = np.deg2rad(float(p0) + (k - 0.5) * float(step))          # the boundary below ring k
+        z = (np.hypot(x, y) * np.tan(ang)).astype(np.float32)
+        z = (z.view(np.int32) + rng.integers(-3, 4, len(idx)).astype(np.int32)).view(np.float32)
+        v[idx, 2] = z
+        return v
+
+    v16 = on_boundaries(synth.velo_scan(23), -15.0, 2.0, 16)
+    l16 = synth.livox_scan(23)
+    o16 = oracle_pipeline(O, dict(velo=v16, livox=l16, dR=np.eye(3), dt=np.zeros(3)), None, None)
+    # (the salted points really sit on both sides of boundaries: drops at the table's two ends occur, not all of them)
+    e16 = O.extract_velo(v16, near=0.0, far=1e9)
+    assert len(v16) - len(v16) // 3 // 8 < len(e16["xyzi"]) < len(v16) - len(v16) // 3 // 64
+    for B in (1, 20):
+        c = M.Context(max_scans=B)
+        try:
+            for s in range(B):
+                c.scan_upload(s, v16, l16)
+            c.extract(0, B)
+            for s in range(B):
+                _check_extraction(c.scan_download(s), o16)
+        finally:
+            c.close()
+    p0, st = -16.0, np.float32(32.0 / 63.0)
+    kw = dict(n_rings=64, pitch0=p0, pitch_step=st)
+    v64 = on_boundaries(synth.velo_scan(24, n_az=512, **kw), p0, st, 64)
     o64 = oracle_pipeline(O, dict(velo=v64, livox=None, dR=np.eye(3), dt=np.zeros(3)), None, None, **kw)
     for B in (1, 18):
         c = M.Context(max_scans=B, max_velo_points=64 * 512, max_livox_points=24000, n_rings=64, pitch0_deg=p0, pitch_step_deg=st)

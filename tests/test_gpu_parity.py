@@ -43,6 +43,37 @@ def assert_fused_equal(g, o):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def test_device_atan2f_atanf_bits(ctx, O):
+    """The device's copies of the libm routines behind the ring / azimuth assignment (csrc/libm_f32.h, glibc's atanf / atan2f:
+    unionFeatureExtract.cpp:1136-1139,1159,1168) produce the bits of the binary functions: the known answers of
+    tests/golden/libm_f32_kat.npz (this image's libm through ctypes) and, on 3e7 further pairs -- random bit patterns, lidar-like
+    coordinates, denormals, ratios within ulps of the reduction thresholds --, the oracle's restatement, which the CPU suite
+    compares with libm on all 2^32 / 4e8 arguments."""
+    g = load("libm_f32_kat.npz")
+    a2, _ = ctx.libm_f32(g["atan2_y"], g["atan2_x"])
+    _, a1 = ctx.libm_f32(g["atan_in"], g["atan_in"])
+    nan = np.isnan(g["atan2_out"])
+    assert np.array_equal(np.isnan(a2), nan) and np.array_equal(a2[~nan].view(np.int32), g["atan2_out"][~nan].view(np.int32))
+    nan = np.isnan(g["atan_out"])
+    assert np.array_equal(np.isnan(a1), nan) and np.array_equal(a1[~nan].view(np.int32), g["atan_out"][~nan].view(np.int32))
+    rng = np.random.default_rng(99)
+    n = 10_000_000
+    sets = [(rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),
+             rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)),
+            (rng.uniform(-200, 200, n).astype(np.float32), rng.uniform(-200, 200, n).astype(np.float32))]
+    x = rng.uniform(-100, 100, n).astype(np.float32)
+    thr = np.array([1.0, 0.4375, 0.6875, 1.1875, 2.4375], np.float32)[rng.integers(0, 5, n)]
+    y = ((x * thr).view(np.int32) + rng.integers(-8, 9, n).astype(np.int32)).view(np.float32)
+    sets.append((np.where(rng.random(n) < 0.5, y, -y).astype(np.float32), x))
+    for y, x in sets:
+        a2, a1 = ctx.libm_f32(y, x)
+        w2, w1 = O.atan2f(y, x), O.atanf(y)
+        for got, want in ((a2, w2), (a1, w1)):
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan)
+            assert np.array_equal(got[~nan].view(np.int32), want[~nan].view(np.int32))
+
+
 def test_detect_line_golden_and_oracle(ctx, O, synth):
     g = load("detect_lines.npz")
     for pre in ("ring", "livox"):
@@ -199,6 +230,32 @@ def test_extract_velodyne_only_context(M, O, synth):
             assert np.array_equal(c.features_download(1, 1), O.voxel_downsample(xyz[o["label"] == 2], 0.2))
         finally:
             c.close()
+
+
+def test_extract_livox_only_context(M, O, synth):
+    """A context without a Velodyne region (max_velo_points = 0): the combined bucketing launch of <= 16 scans still dispatches
+    the Velodyne plane of blocks, which used to request records at index min(i, NV - 1) = -1; one scan and a batch of 20 (the
+    per-sensor launches), and the three-pass form ($MML_ASSIGN_ONEPASS=0 is read per context)."""
+    import os
+    l = synth.livox_scan(78)
+    o = O.extract_livox(l)
+    for onepass in ("1", "0"):
+        os.environ["MML_ASSIGN_ONEPASS"] = onepass
+        try:
+            for B in (1, 20):
+                c = M.Context(max_scans=B, max_velo_points=0, max_livox_points=len(l))
+                try:
+                    for s in range(B):
+                        c.scan_upload(s, None, l)
+                    c.extract(0, B)
+                    for s in (0, B - 1):
+                        d = c.scan_download(s)
+                        assert np.array_equal(d["xyzi"], o["xyzi"]) and np.array_equal(d["label"], o["label"])
+                        assert np.array_equal(d["ring"], o["ring"]) and np.array_equal(d["reltime"], o["reltime"])
+                finally:
+                    c.close()
+        finally:
+            del os.environ["MML_ASSIGN_ONEPASS"]
 
 
 def test_extract_livox_extrinsic_and_far_labels(M, O, synth):

@@ -80,21 +80,17 @@ def test_bench_launch_shapes_replicas_match_oracle(M, O, synth, scene):
         x1 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
         dg1 = c.slot_digest(0, B)
         assert np.array_equal(x1, x) and np.array_equal(dg1, dg)
-        # (3) the undistortion on the lane's sibling stream next to the selection kernels ($MML_UND_FORK=1; off by default):
-        #     same results, slot for slot, on one lane and on two
-        import os
-        if os.environ.get("MML_TEST_UND_FORK", "0") != "1":   # (an experimental schedule, off in the library: compared on request)
-            print("launch shapes: %d slots, %d distinct scans, 0 mismatching replicas, %.1f s" % (B, ND, time.time() - t0))
-            return
-        os.environ["MML_UND_FORK"] = "1"
-        try:
-            x2 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
-            assert np.array_equal(x2, x) and np.array_equal(c.slot_digest(0, B), dg)
-            c.set_lanes(2)
-            x3 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
-            assert np.array_equal(x3, x) and np.array_equal(c.slot_digest(0, B), dg)
-        finally:
-            del os.environ["MML_UND_FORK"]
         print("launch shapes: %d slots, %d distinct scans, 0 mismatching replicas, %.1f s" % (B, ND, time.time() - t0))
     finally:
         c.close()
+
+
+def test_replica_stress(M, O, synth):
+    """The 4096-slot step repeated: 30 rounds on the library's default lanes, then 10 alternating between one lane and two --
+    every replica equal to the first slot of its scan in all ten digest words and in its pose, every round equal to the first
+    (tests/replica_stress.py; round 5's suite ran the step twice and one run of it met a slot whose surf stack did not match,
+    with the since-removed undistortion fork on -- HISTORY.md A.000)."""
+    import replica_stress
+    bad, per = replica_stress.run(M, O, synth, 40, lanes=[None] * 30 + [1, 2] * 5)
+    assert bad == 0
+    print("replica stress: %.3f s per round" % per)

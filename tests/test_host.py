@@ -311,37 +311,22 @@ def test_one_hip_runtime_and_one_rccl_whatever_the_import_order(tmp_path, order)
     assert int(probe[3]) >= 20000
 
 
-def test_atan2_cr_is_the_nearest_double(tmp_path):
-    """csrc/atan2_cr.h (host and device source): atan2 of two floats rounded to the nearest double, the value the bucketing's
-    k_azimuth_exact converts to float where the fast form cannot decide -- against mpmath on random pairs, octant and table edges,
-    and the (x, y) pairs of tests/golden/azimuth_edge_xy.npy (angles within 2e-15 of the middle between two floats; the first of
-    them is the point of the campaign's seed 836 on which the device math library's 2-ulp atan2 rounded the other way)."""
-    mp = pytest.importorskip("mpmath")
-    import ctypes
-    import math
-    src = tmp_path / "cr.cpp"
-    src.write_text('#include "atan2_cr.h"\nextern "C" double cr_atan2(double y, double x) { return mml_cr::atan2_cr(y, x); }\n')
-    so = tmp_path / "libcr.so"
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "multi-modal-loam_amd", "csrc"), str(src), "-o", str(so)],
+def _libm_check(tmp_path, include_dir, ns, f1, f2, pairs=400_000_000):
+    """Compile tests/cpp/libm_f32_check.cpp around one libm_f32.h and run it: atanf on all 2^32 arguments and atan2f on `pairs`
+    pairs against this machine's libm, bit for bit."""
+    exe = tmp_path / "libm_f32_check"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", '-DIMPL_HEADER="libm_f32.h"', "-DIMPL_NS=" + ns, "-DIMPL_ATAN=" + f1,
+                    "-DIMPL_ATAN2=" + f2, "-I", include_dir, os.path.join(ROOT, "tests", "cpp", "libm_f32_check.cpp"), "-o", str(exe), "-lpthread"],
                    check=True)
-    L = ctypes.CDLL(str(so))
-    L.cr_atan2.restype = ctypes.c_double
-    L.cr_atan2.argtypes = [ctypes.c_double, ctypes.c_double]
-    mp.mp.prec = 300
-    rng = np.random.default_rng(7)
-    pairs = [(np.float32(rng.normal() * 10 ** rng.uniform(-3, 3)), np.float32(rng.normal() * 10 ** rng.uniform(-3, 3))) for _ in range(3000)]
-    pairs += [(np.float32(a), np.float32(b)) for a, b in ((1, 1), (1, -1), (-1, -1), (-1, 1), (1e-20, 1), (1, 1e-20), (3, 4), (0.41421357, 1),
-                                                           (0.41421354, 1), (0.0625, 1), (0.1875, 1), (0.3125, 1), (0.125, 1), (0.25, 1), (0.375, 1))]
-    edge = np.load(os.path.join(ROOT, "tests", "golden", "azimuth_edge_xy.npy"))
-    pairs += [(xy[1], xy[0]) for xy in edge]
-    n_libm = 0
-    for y, x in pairs:
-        if x == 0 or y == 0:
-            continue
-        want = float(mp.atan2(mp.mpf(float(y)), mp.mpf(float(x))))
-        assert L.cr_atan2(float(y), float(x)) == want, (float(y), float(x))
-        n_libm += int(math.atan2(float(y), float(x)) != want)
-    # (this box's libm is the nearest double nearly always, not always: what the oracle -- and the reference -- round is libm's)
-    assert n_libm < len(pairs) // 100
-    # the special cases stay the library's
-    assert L.cr_atan2(0.0, -1.0) == np.pi and L.cr_atan2(1.0, 0.0) == np.pi / 2 and L.cr_atan2(0.0, 1.0) == 0.0
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    out = subprocess.run([str(exe), str(pairs), str(threads)], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "atanf 0" in out.stdout and "atan2f 0" in out.stdout, out.stdout[-2000:]
+
+
+def test_libm_f32_equals_glibc(tmp_path):
+    """csrc/libm_f32.h (host and device source; the bucketing kernels' azimuth and ring pitch) computes the bits of glibc's atanf /
+    atan2f -- the float overloads unionFeatureExtract.cpp:1136-1139,1159,1168 resolve to (convention 4).
+    Compiled for the host and compared with THIS image's libm (2.35: the same fdlibm float routines as melodic's 2.27) on all 2^32
+    arguments of atanf and 4e8 pairs of atan2f (random patterns, lidar-like coordinates, ratios on the reduction thresholds,
+    zeros / denormals / infinities)."""
+    _libm_check(tmp_path, os.path.join(ROOT, "multi-modal-loam_amd", "csrc"), "mml_libm", "atanf_fd", "atan2f_fd")

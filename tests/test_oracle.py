@@ -807,37 +807,87 @@ def test_sensor_faithful_golden_and_no_return_conventions(O, synth):
     assert np.array_equal(e2["label"], el["label"]) and np.array_equal(e2["xyzi"], el["xyzi"])
 
 
+def _glibc_f32():
+    """atanf / atan2f of THIS image's glibc through ctypes: the binary functions the reference's calls resolve to."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.atanf.restype = ctypes.c_float
+    libm.atanf.argtypes = [ctypes.c_float]
+    libm.atan2f.restype = ctypes.c_float
+    libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    return (lambda v: np.float32(libm.atanf(float(v)))), (lambda y, x: np.float32(libm.atan2f(float(y), float(x))))
+
+
+def test_libm_overloads_resolve_to_float(tmp_path):
+    """Which libm functions do unionFeatureExtract.cpp:1136-1139,1159,1168 call?  `atan2(float, float)`, `atan(float)`,
+    `sqrt(float)` written without std::.  With <cmath> alone only the C functions (double) are in the global namespace; the TU
+    includes lidars_extrinsic_cali.h (:58) -> <tf/tf.h> (lidars_extrinsic_cali.h:3) -> tf/LinearMath/Scalar.h -> <math.h>, and
+    libstdc++'s <math.h> (gcc >= 6; melodic has 7.5) adds `using std::atan2;` ... -- the float overloads win.  Compiled here both
+    ways; the oracle (feature.cpp, and estimate.cpp for the aligner's TU) and the device follow the second."""
+    src = tmp_path / "ov.cpp"
+    src.write_text("#include <cmath>\n#ifdef WITH_MATH_H\n#include <math.h>\n#endif\n#include <type_traits>\n"
+                   "static_assert(std::is_same<decltype(atan2(1.f, 1.f)), EXPECT>::value, \"atan2\");\n"
+                   "static_assert(std::is_same<decltype(atan(1.f)), EXPECT>::value, \"atan\");\n"
+                   "static_assert(std::is_same<decltype(sqrt(1.f)), EXPECT>::value, \"sqrt\");\nint main() {}\n")
+    import subprocess
+
+    def compiles(*flags):
+        return subprocess.run(["g++", "-std=c++14", "-fsyntax-only", *flags, str(src)], capture_output=True).returncode == 0
+    assert compiles("-DEXPECT=double") and not compiles("-DEXPECT=float")                              # <cmath> alone
+    assert compiles("-DWITH_MATH_H", "-DEXPECT=float") and not compiles("-DWITH_MATH_H", "-DEXPECT=double")  # the reference's TU
+
+
+def test_oracle_libm_equals_glibc(tmp_path, O):
+    """oracle/libm_f32.h restates glibc's atanf / atan2f (the fdlibm float routines, identical from melodic's 2.27 to this image's
+    2.35).  PINNED against the binary: all 2^32 arguments of atanf and 4e8 pairs of atan2f through tests/cpp/libm_f32_check.cpp,
+    and the committed known answers tests/golden/libm_f32_kat.npz (generated from this image's libm by make_libm_kat.py)."""
+    import os
+    from test_host import _libm_check
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _libm_check(tmp_path, os.path.join(root, "oracle"), "mmlo_libm", "atanf_fdlibm", "atan2f_fdlibm")
+    g = np.load(os.path.join(root, "tests", "golden", "libm_f32_kat.npz"))
+    assert np.array_equal(O.atanf(g["atan_in"]).view(np.int32), g["atan_out"].view(np.int32))
+    got, want = O.atan2f(g["atan2_y"], g["atan2_x"]), g["atan2_out"]
+    assert np.array_equal(got.view(np.int32), want.view(np.int32))
+    # what rounds 1-5 took the calls for -- the double function rounded to float -- is a different function on one pair in six
+    d = (np.arctan2(g["atan2_y"].astype(np.float64), g["atan2_x"].astype(np.float64))).astype(np.float32)
+    fin = np.isfinite(want) & (want != 0)
+    assert 0.05 < np.mean(d[fin] != want[fin]) < 0.3
+
+
 def test_velo_time_assignment_against_a_serial_loop(O, synth):
     """getVeloFeature's per-point loop (unionFeatureExtract.cpp:1133-1195: start / end azimuth with the 3 pi / pi corrections,
-    the serial halfPassed flag, relTime) written out in Python with numpy float32 scalars, on scans that overlap their own
-    start (the real driver's cut) -- the oracle's ring ids and times equal it bit for bit."""
+    the ring id, the serial halfPassed flag, relTime) written out in Python with numpy float32 scalars and THIS IMAGE'S glibc
+    atanf / atan2f called through ctypes, on scans that overlap their own start (the real driver's cut) -- the oracle's ring ids
+    and times equal it bit for bit."""
+    atanf, atan2f = _glibc_f32()
     for k, mode in ((8, "skip"), (9, "nan")):
         v = synth.velo_scan_vlp16(k, dropout=mode)
         e = O.extract_velo(v, near=0.0, far=1e9)
         p = v[np.isfinite(v[:, 0]) & np.isfinite(v[:, 1]) & np.isfinite(v[:, 2])]
         f32, pi = np.float32, np.pi
-        start = f32(-np.arctan2(np.float64(p[0, 1]), np.float64(p[0, 0])))
-        end = f32(-np.arctan2(np.float64(p[-1, 1]), np.float64(p[-1, 0])) + 2 * pi)
+        start = f32(-atan2f(p[0, 1], p[0, 0]))
+        end = f32(np.float64(f32(-atan2f(p[-1, 1], p[-1, 0]))) + 2 * pi)
         if np.float64(end) - np.float64(start) > 3 * pi:
             end = f32(np.float64(end) - 2 * pi)
         elif np.float64(end) - np.float64(start) < pi:
             end = f32(np.float64(end) + 2 * pi)
         half = False
         rel, ring = [], []
-        ang = np.arctan(p[:, 2].astype(np.float64) / np.sqrt((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]).astype(np.float64)))
-        ang = (ang * 180 / pi).astype(np.float32)
-        oris = (-np.arctan2(p[:, 1].astype(np.float64), p[:, 0].astype(np.float64))).astype(np.float32)
         for i in range(len(p)):
-            sid = int((np.float64(ang[i]) + 15) / 2 + 0.5)
+            x, y, z = p[i, 0], p[i, 1], p[i, 2]
+            # :1159 float sqrt, float division, atanf, `* 180` in float, `/ M_PI` in double, rounded to float on assignment
+            ang = f32(np.float64(f32(atanf(f32(z / np.sqrt(f32(f32(x * x) + f32(y * y))))) * f32(180))) / pi)
+            sid = int(np.float64(f32(f32(ang + f32(15)) / f32(2))) + 0.5)   # :1162
             if sid > 15 or sid < 0:
                 continue
-            ori = oris[i]
+            ori = f32(-atan2f(y, x))
             if not half:
                 if ori < np.float64(start) - pi / 2:
                     ori = f32(np.float64(ori) + 2 * pi)
                 elif ori > np.float64(start) + pi * 3 / 2:
                     ori = f32(np.float64(ori) - 2 * pi)
-                if np.float64(ori) - np.float64(start) > pi:   # float - float promoted against the double constant
+                if np.float64(f32(ori - start)) > pi:   # float - float, promoted against the double constant
                     half = True
             else:
                 ori = f32(np.float64(ori) + 2 * pi)
