@@ -110,6 +110,7 @@ def parse():
     ap.add_argument("--cell-surf", type=float, default=0.0, help="kNN grid cell edge for the surf map (0: library default)")
     ap.add_argument("--replay-scans", type=int, default=240, help="--config 2: scans replayed through the odometry loop")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: CPU plumbing test only)")
+    ap.add_argument("--skip-by-slots", action="store_true", help="skip the value_by_slots section (counter passes: only launches of one size)")
     ap.add_argument("--skip-upload", action="store_true", help="skip the PCIe-inclusive section (counter passes: only launches of one size)")
     ap.add_argument("--stub-step", action="store_true", help="CPU plumbing test: no device, a step is a short sleep")
     ap.add_argument("--strict", action="store_true", help="exit non-zero when any section of the run reported an error (the JSON line's "
@@ -423,8 +424,15 @@ def run_throughput(args, rank, local_rank, world, dist):
     # first slot of such a group to the oracle; here the equality is checked on the run that is being reported.
     dg_timed = ctx.slot_digest(0, B)
     replica = replica_check(dg_timed, x, [(s % nd, (s // nd) % len(tiles)) for s in range(B)])
-    if replica["mismatches"]:
-        raise RuntimeError("bench: replica check failed: %s" % json.dumps(replica))
+    # (every rank learns of a mismatch on any rank BEFORE anyone raises: a rank that raised alone would leave the others waiting
+    #  in the next collective)
+    any_mismatch = replica["mismatches"]
+    if dist is not None:
+        t = torch.tensor([float(any_mismatch)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        any_mismatch = int(t.item())
+    if any_mismatch:
+        raise RuntimeError("bench: replica check failed (this rank: %s)" % json.dumps(replica))
     # Per-kernel durations for the roofline object: the timed region overlaps sub-batches on the stream lanes, so kernel
     # time there is shared between concurrent kernels.  The same step is therefore repeated on ONE stream (every
     # kernel covers the whole batch and owns the device) with HIP events around each stage on that stream; these
@@ -442,13 +450,37 @@ def run_throughput(args, rank, local_rank, world, dist):
     dg_one = ctx.slot_digest(0, KB)
     replica["one_lane_vs_timed_region_slots"] = KB
     replica["one_lane_vs_timed_region_mismatches"] = int(np.any(dg_one != dg_timed[:KB], axis=1).sum())
-    if replica["one_lane_vs_timed_region_mismatches"]:
-        raise RuntimeError("bench: the single-lane pass differs from the timed region: %s" % json.dumps(replica))
     ctx.set_lanes(n_lanes)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(replica["one_lane_vs_timed_region_mismatches"])], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if t[1].item() > 0 and not replica["one_lane_vs_timed_region_mismatches"]:
+            raise RuntimeError("bench: the single-lane pass differs from the timed region on another rank")
+    if replica["one_lane_vs_timed_region_mismatches"]:
+        raise RuntimeError("bench: the single-lane pass differs from the timed region: %s" % json.dumps(replica))
+
+    # ---- where the headline comes from: the same step at other batch sizes (outside the timed region; rank 0) -----------------
+    # `value` needs thousands of resident slots; the reference registers ONE scan at a time.  Scans/s of mml_step over the first S
+    # slots, the library's lanes as in the timed region, every size run for >= 0.3 s.
+    value_by_slots = None
+    if rank == 0 and not args.skip_by_slots:
+        value_by_slots = {}
+        try:
+            for S in (1, 8, 64, 512, 4096, 8192):
+                if S > B:
+                    continue
+                ctx.step(0, S, dR[:S], dt[:S], exTlb, 25.0, gn_iters, x0[:S])
+                n_it, t1 = 0, time.perf_counter()
+                while True:
+                    ctx.step(0, S, dR[:S], dt[:S], exTlb, 25.0, gn_iters, x0[:S])
+                    n_it += 1
+                    el = time.perf_counter() - t1
+                    if el >= 0.3:
+                        break
+                value_by_slots[str(S)] = {"scans_per_s": S * n_it / el, "ms_per_call": el / n_it * 1e3}
+        except Exception as e:
+            errors.append("value_by_slots: " + repr(e)[:200])
 
     # pose sanity: the step must actually have registered the scans.  Only the slots on tile 0 count -- the original,
     # un-jittered copy of the scene, where the generating pose IS the registration optimum up to the range noise; on the
@@ -474,7 +506,7 @@ def run_throughput(args, rank, local_rank, world, dist):
     # (both files carry the hash of the library they were measured on; numbers from another build are reported as stale)
     lib_sha = lib_sha16(M)
     traffic, traffic_file, traffic_stale = None, None, None
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         tr_file = os.path.join(ROOT, "profiles", "traffic_%s%s.json" % (tag, suffix))
         if os.path.exists(tr_file):
             try:
@@ -486,19 +518,28 @@ def run_throughput(args, rank, local_rank, world, dist):
                     break
             except Exception:
                 pass
-    # Issue-bound kernels: a wave64 VALU instruction occupies a SIMD for 4 cycles, so the device issues at most
-    # CUs x 4 SIMDs x clock / 4 wave-instructions per second (6.14e11 at 256 CUs, 2.4 GHz); the fraction of that peak the
-    # dominant stage reaches says how much of its time is instruction issue -- for such a kernel THIS is the roof, not HBM.
+    # Issue-bound kernels.  The VALU issue peak is MEASURED on the box (mml_issue_rate; tools/issue_probe.hip has every class,
+    # profiles/r06_issue_probe.txt): a wave64 float / VOP3 / DPP instruction holds a SIMD for 4 cycles (v_fma_f32, v_mul_f32,
+    # v_pk_fma_f32, v_fma_f64: 6.0e11 wave-instructions/s on 256 CUs), a simple 32-bit integer VOP2 instruction for 2.2
+    # (v_add_u32: 1.12e12), v_rcp_f32 for 8.  `peak` is the v_fma_f32 rate -- the roof of a kernel made of float arithmetic --,
+    # `peak_int` the v_add_u32 rate; the fraction of `peak` the dominant stage reaches says how much of its time is instruction
+    # issue -- for such a kernel THIS is the roof, not HBM.
     issue = None
-    sq_file = next((f for f in (os.path.join(ROOT, "profiles", "sq_%s%s.json" % (tag, suffix)) for tag in ("r05", "r04", "r03"))
+    try:
+        issue_peak, issue_peak_int, peak_source = float(ctx.issue_rate(0)), float(ctx.issue_rate(1)), "measured"
+    except Exception as e:
+        issue_peak, issue_peak_int, peak_source = cus * 4 * VALU_CLOCK_HZ / 4.0, None, "assumed"
+        errors.append("issue_rate: " + repr(e)[:200])
+    sq_file = next((f for f in (os.path.join(ROOT, "profiles", "sq_%s%s.json" % (tag, suffix)) for tag in ("r06", "r05", "r04", "r03"))
                     if os.path.exists(f)), None)
     if sq_file is not None:
         try:
             sq = json.load(open(sq_file))
             if dom in sq and stage_ms[dom] > 0:
                 wi = sq[dom]["valu_wave_instr"] * KB / float(sq.get("scans_per_launch", KB))
-                peak = cus * 4 * VALU_CLOCK_HZ / 4.0
+                peak = issue_peak
                 issue = {"valu_wave_instr_per_launch": wi, "achieved": wi / (stage_ms[dom] * 1e-3), "peak": peak,
+                         "peak_int": issue_peak_int, "peak_source": peak_source,
                          "unit": "wave-instructions/s", "frac": wi / (stage_ms[dom] * 1e-3) / peak,
                          "source": os.path.relpath(sq_file, ROOT), "stale": sq.get("lib_sha16") != lib_sha}
         except Exception:
@@ -707,7 +748,7 @@ def run_throughput(args, rank, local_rank, world, dist):
             "config": {"workload": "%s, local map %d pts, 1 association pass (thres_dist 25), %d GN iterations, W=1"
                                    % (cfg["name"], map_points, gn_iters),
                        "scans_per_step_per_gpu": batch, "resident_slots": B, "passes_per_step": passes, "stream_lanes": n_lanes, "distinct_scans": nd,
-                       "map_tiles_touched": len(tiles), "parallelism": "scan-sharded x%d" % world,
+                       "map_tiles_touched": len(tiles), "map_tiles_complete": full_tiles, "parallelism": "scan-sharded x%d" % world,
                        "device": dev_name, "cus": cus, "features_per_scan": nf / KB, "points_per_scan": (n_v + n_l) / KB,
                        "algorithmic_bytes_per_scan": bytes_per_scan, "max_pose_err_vs_gt_m_tile0": gt_err,
                        "timed_region_s": elapsed},
@@ -725,6 +766,7 @@ def run_throughput(args, rank, local_rank, world, dist):
             "window_solve": window,
             "rccl": rccl_report(M),
             "replica_check": replica,
+            "value_by_slots": value_by_slots,
             "errors": errors,
         }
         return json.dumps(out), window_timed_out, errors

@@ -518,6 +518,11 @@ int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hb
 /* Device-to-device copy bandwidth probe (GB/s, read + write counted) over `bytes` bytes, `reps` repetitions: the better of a
  * grid-stride 16-byte copy and a non-temporal one with four loads in flight per lane (the practical HBM roof). */
 int mml_copy_bandwidth(mml_ctx* ctx, size_t bytes, int reps, double* gbps);
+/* Instruction-issue probe for bench.py's `issue` object: wave64 instructions per second the whole device sustains on eight
+ * independent chains per lane at eight wavefronts per SIMD.  kind 0: v_fma_f32 (every float / VOP3 instruction class measured
+ * issues at this rate, 4 cycles per wavefront: tools/issue_probe.hip, profiles/r06_issue_probe.txt); kind 1: v_add_u32 (simple
+ * 32-bit integer VOP2 instructions, about twice that). */
+int mml_issue_rate(mml_ctx* ctx, int kind, int reps, double* wave_instr_per_s);
 
 #ifdef __cplusplus
 }

@@ -623,6 +623,12 @@ class Context:
         self._ck(lib().mml_extract_queue_counts(self._h, C.c_int(slot), C.byref(r), C.byref(b)))
         return r.value, b.value
 
+    def issue_rate(self, kind=0, reps=3):
+        """wave64 instructions per second of the device on v_fma_f32 (kind 0) / v_add_u32 (kind 1) chains (mml_issue_rate)."""
+        r = C.c_double(0)
+        self._ck(lib().mml_issue_rate(self._h, C.c_int(kind), C.c_int(reps), C.byref(r)))
+        return r.value
+
     def libm_f32(self, y, x):
         """(atan2f(y, x), atanf(y)) evaluated by the device's copies of the two libm routines (mml_libm_f32, a test hook)."""
         y, x = np.ascontiguousarray(y, np.float32).ravel(), np.ascontiguousarray(x, np.float32).ravel()

@@ -1824,6 +1824,71 @@ extern "C" int mml_copy_bandwidth(mml_ctx* ctx, size_t bytes, int reps, double* 
     return MML_OK;
 }
 
+namespace {
+// tools/issue_probe.hip in small: eight independent chains per lane of one instruction class, every SIMD eight wavefronts deep
+template <int KIND>
+__global__ __launch_bounds__(256) void k_issue_rate(float* out, float a, float b, int ia) {
+    float x[8];
+    int u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = (float)(threadIdx.x + i);
+        u[i] = (int)threadIdx.x * 7 + i;
+    }
+    for (int it = 0; it < 2048; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (KIND == 0) x[i] = __builtin_fmaf(x[i], a, b);
+            if constexpr (KIND == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(ia));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i] + (float)u[i];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int mml_issue_rate(mml_ctx* ctx, int kind, int reps, double* wave_instr_per_s) {
+    if (!ctx || !wave_instr_per_s || reps <= 0 || kind < 0 || kind > 1) return MML_ERR_INVALID;
+    MML_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    MML_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * 64;  // eight workgroups of four wavefronts per CU, eight rounds of them
+    float* d = nullptr;
+    MML_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * 256 * (size_t)blocks));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto launch = [&]() {
+        if (kind == 0)
+            hipLaunchKernelGGL(k_issue_rate<0>, dim3(blocks), dim3(256), 0, MML_STREAM(ctx), d, 0.999f, 0.001f, 3);
+        else
+            hipLaunchKernelGGL(k_issue_rate<1>, dim3(blocks), dim3(256), 0, MML_STREAM(ctx), d, 0.999f, 0.001f, 3);
+    };
+    launch();
+    double best = 0.0;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < reps && e == hipSuccess; ++r) {
+        hipEventRecord(e0, MML_STREAM(ctx));
+        launch();
+        hipEventRecord(e1, MML_STREAM(ctx));
+        e = hipStreamSynchronize(MML_STREAM(ctx));
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && ms > 0) best = std::max(best, (double)blocks * 4 * 2048 * 8 / (ms * 1e-3));
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d);
+    if (e != hipSuccess) {
+        ctx->err = hipGetErrorString(e);
+        return MML_ERR_HIP;
+    }
+    *wave_instr_per_s = best;
+    return MML_OK;
+}
+
 int mml_stage_begin(mml_ctx* ctx, const char* name) {
     if (!ctx->profiling) return -1;
     int idx = -1;

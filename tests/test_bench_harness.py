@@ -87,6 +87,9 @@ class StubContext:
     def profile_get(self):
         return {"stencil": (2.4, 4), "assign_onepass": (2.0, 4), "solve": (1.2, 4), "fullwindow": (0.5, 3)}
 
+    def issue_rate(self, kind=0, reps=3):
+        return 6.0e11 if kind == 0 else 1.1e12
+
     def copy_bandwidth(self, nbytes, reps):
         return 5000.0
 

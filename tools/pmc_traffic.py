@@ -23,17 +23,20 @@ def per_stage(path, counter):
     d = d[d.stage.notna()]
     mx = d.groupby("kfull")["Grid_Size"].transform("max")
     per_variant = d[d.Grid_Size == mx].groupby(["stage", "kfull"])["Counter_Value"].mean()
-    return per_variant.groupby(level=0).sum(), sorted(set(d[d.Grid_Size == mx]["kfull"]))
+    by_kernel = {k: float(v) for (st, k), v in per_variant.items()}
+    return per_variant.groupby(level=0).sum(), sorted(set(d[d.Grid_Size == mx]["kfull"])), by_kernel
 
 
 def main(fp, wp, scans):
-    f, kf = per_stage(fp, "FETCH_SIZE")
-    w, _ = per_stage(wp, "WRITE_SIZE")
+    f, kf, fk = per_stage(fp, "FETCH_SIZE")
+    w, _, wk = per_stage(wp, "WRITE_SIZE")
     out = {}
     for st in sorted(set(f.index) | set(w.index)):
         out[st] = round(2.0 * float(f.get(st, 0.0)) * 1024.0 + float(w.get(st, 0.0)) * 1024.0)
     out["scans_per_launch"] = int(scans)
     out["kernels"] = kf
+    # per kernel variant: [bytes fetched (doubled as above), bytes written] per launch
+    out["by_kernel"] = {k: [round(2.0 * fk.get(k, 0.0) * 1024.0), round(wk.get(k, 0.0) * 1024.0)] for k in sorted(set(fk) | set(wk))}
     out["lib_sha16"] = os.environ.get("MML_LIB_SHA16")  # the library these bytes were counted on (bench.py marks a mismatch as stale)
     print(json.dumps(out, indent=1))
 

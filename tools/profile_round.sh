@@ -16,7 +16,7 @@ ARGS="--steps 4 --warmup 1 --cpu-seconds 0 --strict $*"
 # The counter passes run ONLY launches of 1024 scans on one stream (the launches bench.py times for its roofline object): the
 # summarisers average a kernel's launches of the largest grid, and the kernels with a fixed grid (k_associate, the k_select rows) look
 # the same at every batch size -- mixed with the timed region's per-lane launches their counters would describe no launch at all.
-PMCARGS="--steps 1 --warmup 0 --cpu-seconds 0 --slots ${KB:-1024} --batch ${KB:-1024} --skip-upload $*"
+PMCARGS="--steps 1 --warmup 0 --cpu-seconds 0 --slots ${KB:-1024} --batch ${KB:-1024} --skip-upload --skip-by-slots $*"
 export PMC_LANES=1
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(ls $OUT/trace/*/*.db 2>/dev/null | head -1); [ -z "$DB" ] && DB=$(ls $OUT/trace/*.db 2>/dev/null | head -1)
