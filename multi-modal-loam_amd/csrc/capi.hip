@@ -78,7 +78,7 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->ln_gidx, ctx->ln_rel, ctx->line_start, ctx->line_len, ctx->seg_cum, ctx->seg_pos, ctx->seg_n, ctx->seg_flat, ctx->seg_flat_n, ctx->op_agg, ctx->seg_rs, ctx->seg_rw, ctx->ln_curv, ctx->ln_refl,  ctx->ln_attr,
                     ctx->sel_scratch, ctx->blk_cnt, ctx->assign_aux, ctx->brk_queue, ctx->brk_cnt, ctx->redo_queue, ctx->st_exit, ctx->vx_big, ctx->sel_done, ctx->sel_list, ctx->sel_list_cnt,
                     ctx->cb_n,     ctx->queue_off, ctx->slot_flags, ctx->ln_line,  ctx->ln_label,
-                    ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->lf,
+                    ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->vx_gidx, ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
                     ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_summ, ctx->d_trace, ctx->d_rec,
@@ -212,6 +212,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->ft_xyz[1], B * MF);
     ALLOC(ctx->ft_n, B * 2);
     ALLOC(ctx->vx_keys, B * (size_t)ctx->VX_CAP);  // B*2*VX_CAP unsigned
+    ALLOC(ctx->vx_gidx, 2 * B * (size_t)ctx->VX_CAP);
     ALLOC(ctx->lf, B * MF);
     ALLOC(ctx->pf, B * MF);
     ALLOC(ctx->assoc_stats, B * 16);

@@ -68,7 +68,8 @@ struct FeatParams {
     int nblk_v, nblk_l, nblk_max, ring_bits, line_bits;
     int asb_stride;      // row stride of k_assign_b's LDS tile
     CropBlk* crop_cnt;   // [B][nblk_t] per-block counts / exclusive offsets of the crop passes
-    unsigned* label_idx; // [B][2][cap] fused-cloud indices of the corner / surf labelled points
+    unsigned* label_idx; // [B][2][cap] storage positions of the corner / surf labelled points
+    int* label_gidx;     // [B][2][cap] ... and their fused indices (k_voxel's sort key: one gather per labelled point less)
     int label_cap;       // entries per list
     int nblk_t;
     unsigned* sel_scratch;  // global-memory scratch for lines longer than sel_cap: 4 x B*NT unsigned
@@ -2524,8 +2525,9 @@ __device__ __forceinline__ void p2_acc(const uint2 o, unsigned me, unsigned mk, 
 // or beyond far_th, :925-940) | kept corner, kept surf}: words 0 .. 1 are written and 2 .. 7 zeroed by the bucketing's table kernel;
 // words 6 / 7 double as the lists' fill counters.  One 64-bit atomic per pair of counters.
 // `labs`: NW labels of this lane, 4 bits each (bit 3: Livox point beyond far_th: counted, not listed); pos[u]: storage position.
+// (gi: the fused indices of the lane's NW points where the caller holds them; nullptr: read again for the labelled ones)
 template <int NW>
-__device__ __forceinline__ void label_append(const FeatParams& P, int b, bool velo_line, unsigned labs, const int (&pos)[NW]) {
+__device__ __forceinline__ void label_append(const FeatParams& P, int b, bool velo_line, unsigned labs, const int (&pos)[NW], const int* gi = nullptr) {
     static_assert(NW <= 8, "4 bits per label");
     // per lane: how many of its NW labels are corner (nibble 1), surf (2), far corner (9), far surf (10); bit 2 is never set
     const unsigned m = 0x11111111u;
@@ -2563,14 +2565,23 @@ __device__ __forceinline__ void label_append(const FeatParams& P, int b, bool ve
     int ds = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32)) + (excl >> 16);
     unsigned* list_c = P.label_idx + ((size_t)b * 2 + 0) * P.label_cap;
     unsigned* list_s = P.label_idx + ((size_t)b * 2 + 1) * P.label_cap;
+    int* glist_c = P.label_gidx + ((size_t)b * 2 + 0) * P.label_cap;
+    int* glist_s = P.label_gidx + ((size_t)b * 2 + 1) * P.label_cap;
+    const int* gx = P.ln_gidx + (size_t)b * P.NT;
     if (mine) {
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
             if ((is1 >> (4 * u)) & 1u) {
-                if (dc < P.label_cap) list_c[dc] = (unsigned)pos[u];
+                if (dc < P.label_cap) {
+                    list_c[dc] = (unsigned)pos[u];
+                    glist_c[dc] = gi ? gi[u] : gx[pos[u]];
+                }
                 ++dc;
             } else if ((is2 >> (4 * u)) & 1u) {
-                if (ds < P.label_cap) list_s[ds] = (unsigned)pos[u];
+                if (ds < P.label_cap) {
+                    list_s[ds] = (unsigned)pos[u];
+                    glist_s[ds] = gi ? gi[u] : gx[pos[u]];
+                }
                 ++ds;
             }
         }
@@ -3663,7 +3674,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             lnlab[ps4[u]] = (uint8_t)labv;
             labs |= (unsigned)((labv & 3) | ((labv & 0x80) ? 8 : 0)) << (4 * u);
         }
-        label_append<8>(P, b, line < P.n_rings, labs, ps4);
+        label_append<8>(P, b, line < P.n_rings, labs, ps4, gi4);
     }
     SP_MARK(7);
 #undef SP_SYNC
@@ -3796,10 +3807,16 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crop(FeatParams P, int cap, in
                     const int p = position(c0 + w, q);
                     const int l = (v >> (8 * q)) & 255u;
                     if (p >= 0 && l == 1) {
-                        if (d1 < cap) P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)p;
+                        if (d1 < cap) {
+                            P.label_idx[((size_t)b * 2 + 0) * cap + d1] = (unsigned)p;
+                            P.label_gidx[((size_t)b * 2 + 0) * cap + d1] = P.ln_gidx[(size_t)b * P.NT + p];
+                        }
                         ++d1;
                     } else if (p >= 0 && l == 2) {
-                        if (d2 < cap) P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)p;
+                        if (d2 < cap) {
+                            P.label_idx[((size_t)b * 2 + 1) * cap + d2] = (unsigned)p;
+                            P.label_gidx[((size_t)b * 2 + 1) * cap + d2] = P.ln_gidx[(size_t)b * P.NT + p];
+                        }
                         ++d2;
                     }
                 }
@@ -3940,6 +3957,7 @@ FeatParams make_params(mml_ctx* ctx, int first) {
     P.asb_stride |= 1;
     P.crop_cnt = reinterpret_cast<CropBlk*>(ctx->crop_cnt);
     P.label_idx = reinterpret_cast<unsigned*>(ctx->vx_keys);
+    P.label_gidx = ctx->vx_gidx;
     P.label_cap = ctx->VX_CAP;
     P.nblk_t = (ctx->NT + 255) / 256;
     P.sel_scratch = ctx->sel_scratch;

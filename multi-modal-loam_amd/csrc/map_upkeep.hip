@@ -232,6 +232,7 @@ struct SegParams {
     const float4* ln_pts;
     const int* ln_gidx;
     const unsigned* lists;
+    const int* glists;  // the listed points' fused indices (label_append)
     int* seg_off;     // 2 * count + 1
     int* seg_bbox;    // 2 * count x 6 order-preserving int keys
     float4* cat;      // gathered points
@@ -269,11 +270,11 @@ __global__ void k_seg_gather_bbox(SegParams P) {
     const int n = P.fu_info[8 * b + 6 + kind], off = P.seg_off[g];
     const unsigned* list = P.lists + ((size_t)b * 2 + kind) * P.list_stride;
     const float4* px = P.ln_pts + (size_t)b * P.NT;
-    const int* gx = P.ln_gidx + (size_t)b * P.NT;
+    const int* glist = P.glists + ((size_t)b * 2 + kind) * P.list_stride;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 p = px[list[i]];
-        p.w = __int_as_float(gx[list[i]]);  // the fused index rides along: it orders the points of a voxel
+        p.w = __int_as_float(glist[i]);  // the fused index rides along: it orders the points of a voxel
         P.cat[off + i] = p;
         mn[0] = fminf(mn[0], p.x);
         mn[1] = fminf(mn[1], p.y);
@@ -419,6 +420,7 @@ int mml_downsample_big(mml_ctx* ctx, int first, int count) {
     P.ln_pts = ctx->ln_pts;
     P.ln_gidx = ctx->ln_gidx;
     P.lists = reinterpret_cast<const unsigned*>(ctx->vx_keys);
+    P.glists = ctx->vx_gidx;
     int* meta = ctx->seg_meta + (size_t)ctx->cur * (8 * (size_t)ctx->B * 2 + 16);
     P.seg_off = meta + 8;
     P.seg_bbox = meta + 8 + (2 * (size_t)ctx->B + 8);

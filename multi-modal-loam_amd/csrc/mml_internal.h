@@ -181,6 +181,7 @@ struct mml_ctx {
     float4* ft_xyz[2] = {nullptr, nullptr};  // B * MF
     int* ft_n = nullptr;                     // 2 * B
     unsigned long long* vx_keys = nullptr;   // voxel sort scratch: B * 2 * VX_CAP
+    int* vx_gidx = nullptr;                  // B * 2 * VX_CAP: the fused index of every listed point (label_append), parallel to the lists in vx_keys
     // batched global-sort down-sampler (map_upkeep.hip mml_downsample_big), allocated on first use
     unsigned long long* seg_keys = nullptr;
     unsigned* seg_vals = nullptr;

@@ -241,6 +241,7 @@ struct VoxelArgs {
     float4* ft1;
     int* ft_n;
     const unsigned* seq_scratch;
+    const int* seq_gidx;  // the listed points' fused indices (label_append), parallel to seq_scratch
 };
 template <int VX_THREADS>
 struct VoxelLds {
@@ -259,12 +260,13 @@ struct VoxelLds {
 // the part of k_voxel that depends on the number of keys per thread
 template <int VX_THREADS, int KPT>
 __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREADS>& S, unsigned long long* keys, int b, int kind, int cnt,
-                                           const unsigned* seq2idx, const float4* px, const int* gx, bool wide, float leaf VX_DBG_PARAMS) {
+                                           const unsigned* seq2idx, const float4* px, const int* glist, bool wide, float leaf VX_DBG_PARAMS) {
     constexpr int VX_WAVES = VX_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1. the labelled points of this (slot, kind) were listed by the selection kernels (feature.hip label_append), in no particular
-    //    order; every lane fetches its KPT points ONCE (position, coordinates, fused index stay in registers), min / max of the
-    //    coordinates (getMinMax3D)
+    //    order, position and fused index side by side; every lane fetches its KPT points ONCE (position, coordinates, fused index
+    //    stay in registers; the fused index comes from the list -- until round 6 it was a second gather, one more 64-byte line per
+    //    16-byte point), min / max of the coordinates (getMinMax3D)
     // (up to four points per lane stay in registers between the two uses; eight are fetched again for the keys -- from the L2 --:
     //  their 40 registers across the reduction would not fit the 64 the kernel is held to)
     constexpr bool KEEP = KPT <= 4;
@@ -287,7 +289,7 @@ __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREA
                 x[a] = p.x;
                 y[a] = p.y;
                 z[a] = p.z;
-                gi[a] = gx[pos[a]];
+                gi[a] = glist[min((wave * KPT + a) * 64 + lane, cnt - 1)];
             }
             mn[0] = fminf(mn[0], p.x);
             mn[1] = fminf(mn[1], p.y);
@@ -351,7 +353,7 @@ __device__ __forceinline__ void voxel_sort(const VoxelArgs& A, VoxelLds<VX_THREA
             px_ = p.x;
             py_ = p.y;
             pz_ = p.z;
-            g = gx[pos[a]];
+            g = glist[min(sidx, cnt - 1)];
         }
         const int ijk0 = static_cast<int>(floor(px_ * inv) - static_cast<float>(min_b[0]));
         const int ijk1 = static_cast<int>(floor(py_ * inv) - static_cast<float>(min_b[1]));
@@ -378,10 +380,10 @@ __device__ __forceinline__ void voxel_slot(const VoxelArgs& A, VoxelLds<VX_THREA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = A.NT, MF = A.MF;
     const float4* px = A.ln_pts + (size_t)b * NT;
-    const int* gx = A.ln_gidx + (size_t)b * NT;
     const float leaf = kind == 0 ? A.leaf_corner : A.leaf_surf;
     float4* out = (kind == 0 ? A.ft0 : A.ft1) + (size_t)b * MF;
     const unsigned* seq2idx = A.seq_scratch + ((size_t)b * 2 + kind) * A.list_stride;
+    const int* glist = A.seq_gidx + ((size_t)b * 2 + kind) * A.list_stride;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     static_assert(MML_VOXEL_LDS_CAP <= 8192, "the wide key layout carries the place in the label list in 13 bits");
     const bool wide = NT > 65536;
@@ -404,13 +406,13 @@ __device__ __forceinline__ void voxel_slot(const VoxelArgs& A, VoxelLds<VX_THREA
         return;
     }
     if (cnt <= VX_THREADS)
-        voxel_sort<VX_THREADS, 1>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
+        voxel_sort<VX_THREADS, 1>(A, S, keys, b, kind, cnt, seq2idx, px, glist, wide, leaf VX_DBG_ARGS);
     else if (cnt <= 2 * VX_THREADS)
-        voxel_sort<VX_THREADS, 2>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
+        voxel_sort<VX_THREADS, 2>(A, S, keys, b, kind, cnt, seq2idx, px, glist, wide, leaf VX_DBG_ARGS);
     else if (cnt <= 4 * VX_THREADS)
-        voxel_sort<VX_THREADS, 4>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
+        voxel_sort<VX_THREADS, 4>(A, S, keys, b, kind, cnt, seq2idx, px, glist, wide, leaf VX_DBG_ARGS);
     else
-        voxel_sort<VX_THREADS, 8>(A, S, keys, b, kind, cnt, seq2idx, px, gx, wide, leaf VX_DBG_ARGS);
+        voxel_sort<VX_THREADS, 8>(A, S, keys, b, kind, cnt, seq2idx, px, glist, wide, leaf VX_DBG_ARGS);
     VX_MARK(0);
     // 4. one lane per voxel head: centroid in input order (AccumulatorXYZ: float sum, then / n)
     if (tid == 0) {
@@ -544,6 +546,7 @@ int mml_launch_downsample(mml_ctx* ctx, int first, int count) {
     A.ft1 = ctx->ft_xyz[1];
     A.ft_n = ctx->ft_n;
     A.seq_scratch = reinterpret_cast<const unsigned*>(ctx->vx_keys);
+    A.seq_gidx = ctx->vx_gidx;
     A.skip_above = 0;
     A.only_above = 0;
     A.zero_big = 0;

@@ -18,6 +18,9 @@
  *     loss_function.cc (TRADITIONAL_DOGLEG, Jacobi scaling, HuberLoss)
  * It is cross-checked in tests/ against independent numpy/scipy implementations
  * (brute-force kNN, numpy.linalg.eigh / lstsq, finite-difference Jacobians).
+ * ONE piece IS pinned against a binary the reference links: glibc's atanf / atan2f (the float
+ * overloads unionFeatureExtract.cpp:1136-1139,1159,1168 resolve to), restated in libm_f32.h and
+ * compared with this image's libm on all 2^32 / 4e8 arguments (tests/test_oracle.py).
  */
 #ifndef MML_ORACLE_H
 #define MML_ORACLE_H
