@@ -110,6 +110,7 @@ def parse():
     ap.add_argument("--cell-surf", type=float, default=0.0, help="kNN grid cell edge for the surf map (0: library default)")
     ap.add_argument("--replay-scans", type=int, default=240, help="--config 2: scans replayed through the odometry loop")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: CPU plumbing test only)")
+    ap.add_argument("--skip-cpp-loop", action="store_true", help="--config 2: skip the C++ adapter leg (tools/live_loop.cpp)")
     ap.add_argument("--skip-by-slots", action="store_true", help="skip the value_by_slots section (counter passes: only launches of one size)")
     ap.add_argument("--skip-upload", action="store_true", help="skip the PCIe-inclusive section (counter passes: only launches of one size)")
     ap.add_argument("--stub-step", action="store_true", help="CPU plumbing test: no device, a step is a short sleep")
@@ -874,6 +875,42 @@ def perturbed(T, dt_=(0.02, -0.015, 0.01), rv=None):
     return T2
 
 
+def cpp_live_loop(scans, motions, predicted, reps=3):
+    """Builds tools/live_loop.cpp (g++, against the in-tree library) and runs it on a scene file of the replay's scans: the
+    odometry loop driven through the C++ adapter, timed with std::chrono inside the process.  -> its JSON object."""
+    import struct
+    import subprocess
+    import tempfile
+    from scipy.spatial.transform import Rotation as Rsc
+    libdir = os.path.join(ROOT, "multi-modal-loam_amd")
+    tmp = tempfile.mkdtemp(prefix="mml_live_")
+    exe, scene = os.path.join(tmp, "live_loop"), os.path.join(tmp, "scene.bin")
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "host"),
+           os.path.join(ROOT, "tools", "live_loop.cpp"), "-o", exe, "-L", libdir, "-lmmloam_hip", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("g++ tools/live_loop.cpp: " + out.stderr[-300:])
+    with open(scene, "wb") as f:   # (the scene format of tests/cpp/adapter_gpu_probe.cpp, mode 0)
+        f.write(struct.pack("<iii", 0x4d4d4c31, 0, len(scans)))
+        for (v, l), (mR, mt), Tp in zip(scans, motions, predicted):
+            v = np.ascontiguousarray(v, np.float32).reshape(-1, 4)
+            f.write(struct.pack("<i", len(v)))
+            f.write(v.tobytes())
+            f.write(struct.pack("<i", len(l)))
+            f.write(np.ascontiguousarray(l).tobytes())
+            q = Rsc.from_matrix(Tp[:3, :3]).as_quat()
+            for a in (mR.reshape(9), mt, Tp[:3, 3], q, np.zeros(3)):
+                f.write(np.ascontiguousarray(a, np.float64).tobytes())
+            f.write(struct.pack("<i", 0))
+        f.write(struct.pack("<i", 0))
+        f.write(struct.pack("<i", 0))
+    run = subprocess.run([exe, scene, str(reps)], capture_output=True, text=True, timeout=600)
+    if run.returncode != 0:
+        raise RuntimeError("live_loop rc %d: %s" % (run.returncode, (run.stderr or run.stdout)[-300:]))
+    return json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+
+
 # ---- configs[2]: replay through the whole odometry loop ----------------------------------------------------------------
 def run_replay(args, rank, local_rank, world, dist):
     import torch
@@ -1078,6 +1115,15 @@ def run_replay(args, rank, local_rank, world, dist):
             errors.append("cpu_baseline: " + repr(e)[:200])
     # <<< cpu_baseline leg
 
+    # ---- the same replay from the reference's host language: tools/live_loop.cpp drives the C++ adapter (no Python in the loop) ----
+    cpp = None
+    if rank == 0 and not args.skip_cpp_loop:
+        try:
+            cpp = cpp_live_loop(scans, motions, [perturbed(synth.pose_matrix(k0 + i)) for i in range(n)])
+        except Exception as e:
+            cpp = {"error": repr(e)[:300]}
+            errors.append("cpp_adapter_loop: " + repr(e)[:200])
+
     if rank == 0:
         out = {
             "metric": "scans/s sustained (full odometry loop incl. upload + 8-scan window solve), one scan at a time",
@@ -1093,6 +1139,7 @@ def run_replay(args, rank, local_rank, world, dist):
             "latency_ms": {"per_scan_p50": pctl(r["lat"], 50), "per_scan_p99": pctl(r["lat"], 99), "per_scan_max": float(np.max(r["lat"])),
                            "window8_part_p50": pctl(r["lat_win"], 50), "window8_part_p99": pctl(r["lat_win"], 99),
                            "configs1_step_B1_p50": pctl(lat1, 50), "configs1_step_B1_p99": pctl(lat1, 99)},
+            "latency_ms_cpp_adapter": cpp,
             "full_window_imu": fullwin,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg / (stage_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": alg / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,

@@ -326,6 +326,10 @@ class Estimator {
         }
     }
 
+    int keyScans() const { return key_scans_; }
+    int localMapCorners() const { return n_corner_map_; }
+    int localMapSurfs() const { return n_surf_map_; }
+
     // get_corner_map() / get_surf_map() (Estimator.h:221-226): the MAP_MANAGER cube store, concatenated
     PointCloud get_corner_map() { return global_map(0); }
     PointCloud get_surf_map() { return global_map(1); }
@@ -425,6 +429,7 @@ class Estimator {
             if (d2 >= 0.5 && (lidarMode == 1 || lidarMode == 2)) {
                 check(ctx_.get(), mml_map_increment_local(ctx_.get(), front.slot, T, &n_corner_map_, &n_surf_map_),
                       "MapIncrementLocal");
+                ++key_scans_;
                 double* last = lidarMode == 2 ? last_velo_update_pose_ : last_hori_update_pose_;
                 last[0] = T[3];
                 last[1] = T[7];
@@ -636,6 +641,7 @@ class Estimator {
     mml_prior prior_;
     bool have_prior_ = false;
     int n_corner_map_ = 0, n_surf_map_ = 0;
+    int key_scans_ = 0;  // scans that entered the local map (the key-scan rule of :1121-1135)
     double last_velo_update_pose_[3] = {-1.0, -1.0, -1.0};  // Estimator.h:339-340
     double last_hori_update_pose_[3] = {-1.0, -1.0, -1.0};
     bool _fail_detected = false;

@@ -138,6 +138,8 @@ def stubbed(bench, monkeypatch):
     import torch
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    # (the C++ adapter leg of --config 2 builds and runs a real binary against the library: stubbed like the context)
+    monkeypatch.setattr(bench, "cpp_live_loop", lambda scans, motions, predicted, reps=3: {"host": "stub", "per_scan_p50_ms": 0.5, "scans": len(scans)})
     return bench
 
 
@@ -173,6 +175,7 @@ def test_run_replay_on_a_stub_context(stubbed, monkeypatch):
     for k, v in fw.items():
         assert "error" not in v and v["evaluations"] == 7 and isinstance(v["estimate_ms"], float), (k, v)
     assert r["latency_ms"]["per_scan_p50"] is not None and r["config"]["key_scans"] == 10
+    assert r["latency_ms_cpp_adapter"]["scans"] == 10
 
 
 def test_strict_turns_errors_into_a_nonzero_exit(tmp_path):
