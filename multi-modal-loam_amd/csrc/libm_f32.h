@@ -23,14 +23,9 @@ namespace mml_libm {
 MML_LIBM_HD int f2i(float f) { return __builtin_bit_cast(int, f); }
 MML_LIBM_HD float i2f(int i) { return __builtin_bit_cast(float, i); }
 
-MML_LIBM_HD float atanf_fd(float x) {
-    const int hx = f2i(x), ix = hx & 0x7fffffff;
-    if (ix >= 0x4c000000) {  // |x| >= 2^25 (inf, NaN)
-        if (ix > 0x7f800000) return x + x;
-        const float r = 1.5707962513e+00f + 7.5497894159e-08f;  // atanhi[3] + atanlo[3]
-        return hx > 0 ? r : -r;
-    }
-    if (ix < 0x31000000) return x;  // |x| < 2^-29
+// s_atanf.c behind its two early returns: 2^-29 <= |x| < 2^25 (hx = the bits of x)
+MML_LIBM_HD float atanf_core(float x, int hx) {
+    const int ix = hx & 0x7fffffff;
     const float ax = i2f(ix);
     const bool small = ix < 0x3ee00000;  // |x| < 7/16: no reduction
     const bool c0 = ix < 0x3f300000;     // < 11/16: (2x - 1) / (2 + x)
@@ -47,9 +42,19 @@ MML_LIBM_HD float atanf_fd(float x) {
     const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
     const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
     const float ts = t * (s1 + s2);
-    if (small) return t - ts;
     const float r = hi - ((ts - lo) - t);
-    return hx < 0 ? -r : r;
+    return small ? t - ts : (hx < 0 ? -r : r);
+}
+
+MML_LIBM_HD float atanf_fd(float x) {
+    const int hx = f2i(x), ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25 (inf, NaN)
+        if (ix > 0x7f800000) return x + x;
+        const float r = 1.5707962513e+00f + 7.5497894159e-08f;  // atanhi[3] + atanlo[3]
+        return hx > 0 ? r : -r;
+    }
+    if (ix < 0x31000000) return x;  // |x| < 2^-29
+    return atanf_core(x, hx);
 }
 
 MML_LIBM_HD float atan2f_fd(float y, float x) {
@@ -57,6 +62,18 @@ MML_LIBM_HD float atan2f_fd(float y, float x) {
     const float pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
     const int hx = f2i(x), ix = hx & 0x7fffffff;
     const int hy = f2i(y), iy = hy & 0x7fffffff;
+    // The common case in ONE test (every coordinate pair of a scan but a handful): both arguments normal numbers, x != 1, exponents
+    // within 2^24 of each other -- none of the routine's special cases applies and the quotient lies inside atanf's general range
+    // [2^-25, 2^25], so what is left is a division, atanf's reduction + polynomial and the quadrant.  Same operations, same order.
+    {
+        const unsigned dk = (unsigned)(((iy - ix) >> 23) + 24);
+        if ((unsigned)(ix - 0x00800000) < 0x7f000000u && (unsigned)(iy - 0x00800000) < 0x7f000000u && hx != 0x3f800000 && dk <= 48u) {
+            const int hq = f2i(y / x) & 0x7fffffff;
+            const float z = atanf_core(i2f(hq), hq);
+            const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+            return m == 0 ? z : m == 1 ? i2f(f2i(z) ^ (int)0x80000000) : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+        }
+    }
     if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
     if (hx == 0x3f800000) return atanf_fd(y);
     const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
