@@ -80,6 +80,15 @@ def test_bench_launch_shapes_replicas_match_oracle(M, O, synth, scene):
         x1 = c.step(0, B, dR, dt, np.eye(4), 25.0, 10, x0)
         dg1 = c.slot_digest(0, B)
         assert np.array_equal(x1, x) and np.array_equal(dg1, dg)
+        # (3) ONE slot at a time -- the live path's kernel variants (workgroup-per-line k_select, tile-per-wavefront k_stencil, the
+        #     combined bucketing launch with the sweep's ends found inline, the 16-lane group search of <= 8 slots, the single
+        #     1024-thread k_voxel launch): every distinct scan's first slot and three far slots stepped alone must come out
+        #     bit-identical, digest word for digest word and pose for pose, to what the 4096-slot launches left there
+        for s in list(first) + [B - 1, B // 2, 1023]:
+            xs = c.step(int(s), 1, dR[s:s + 1], dt[s:s + 1], np.eye(4), 25.0, 10, x0[s:s + 1])
+            d1 = c.slot_digest(int(s), 1)[0]
+            assert np.array_equal(d1, dg[s]), (int(s), int(assign[s]), [PIECES[w] for w in range(10) if d1[w] != dg[s][w]])
+            assert np.array_equal(xs[0], x[s]), (int(s), xs[0] - x[s])
         print("launch shapes: %d slots, %d distinct scans, 0 mismatching replicas, %.1f s" % (B, ND, time.time() - t0))
     finally:
         c.close()
