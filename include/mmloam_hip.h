@@ -513,6 +513,10 @@ int mml_extract_queue_counts(mml_ctx* ctx, int slot, int* redo, int* brk);
  * atan2f, the float overloads unionFeatureExtract.cpp:1136-1139,1159,1168 resolve to), evaluated on n host values on the
  * context's device.  out_atan2[i] = atan2f(y[i], x[i]), out_atan[i] = atanf(y[i]); either output may be NULL. */
 int mml_libm_f32(mml_ctx* ctx, const float* y, const float* x, long n, float* out_atan2, float* out_atan);
+/* How many 5-NN queries of the context's last association call (mml_associate / mml_step's association on the lane that ran
+ * last) went beyond rings 0-1 of the grid into the far-query kernels (k_associate_hard): the share to watch when the map's density
+ * and the configured cell edge do not fit each other. */
+int mml_associate_far_count(mml_ctx* ctx, int* n);
 /* Device facts for bench.py: name, CU count, total HBM bytes. */
 int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes);
 /* Device-to-device copy bandwidth probe (GB/s, read + write counted) over `bytes` bytes, `reps` repetitions: the better of a

@@ -637,6 +637,12 @@ class Context:
         self._ck(lib().mml_libm_f32(self._h, _p(y), _p(x), C.c_long(len(x)), _p(o2), _p(o1)))
         return o2, o1
 
+    def associate_far_count(self):
+        """5-NN queries of the last association that went to the far-query kernels (summed over the stream lanes)."""
+        n = C.c_int(0)
+        self._ck(lib().mml_associate_far_count(self._h, C.byref(n)))
+        return n.value
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus = C.c_int(0)

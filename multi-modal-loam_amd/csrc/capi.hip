@@ -1745,6 +1745,17 @@ int mml_extract_queue_counts(mml_ctx* ctx, int slot, int* redo, int* brk) {
     return MML_OK;
 }
 
+int mml_associate_far_count(mml_ctx* ctx, int* n) {
+    if (!ctx || !n) return MML_ERR_INVALID;
+    int rc = mml_sync_all(ctx);
+    if (rc != MML_OK) return rc;
+    int h[mml_ctx::MAX_LANES];
+    MML_HIP(hipMemcpy(h, ctx->d_misc + 32, sizeof(h), hipMemcpyDeviceToHost));  // (one counter per stream lane: map_assoc.hip hard_count)
+    *n = 0;
+    for (int l = 0; l < mml_ctx::MAX_LANES; ++l) *n += h[l];
+    return MML_OK;
+}
+
 int mml_device_info(mml_ctx* ctx, char* name, int name_cap, int* cus, size_t* hbm_bytes) {
     if (!ctx) return MML_ERR_INVALID;
     hipDeviceProp_t prop;

@@ -3,7 +3,7 @@ python tools/stage_table.py profiles/r03f_bench.json profiles/sq_r03.json profil
 import json
 import sys
 
-PEAK = 256 * 4 * 2.4e9 / 4  # VALU wave-instructions / s
+PEAK = 256 * 4 * 2.4e9 / 4  # VALU wave-instructions / s (fall-back: the bench line's measured v_fma_f32 rate is used when it has one)
 
 GROUPS = [("assign", ["assign_count", "assign_scan", "assign_scatter", "assign_ends", "assign_onepass", "assign_tables"]),
           ("stencil (3 kernels)", ["stencil"]),
@@ -15,6 +15,11 @@ GROUPS = [("assign", ["assign_count", "assign_scan", "assign_scatter", "assign_e
 def main(bench, sq, traffic):
     b = json.loads(open(bench).read().strip().splitlines()[-1])
     st = b["roofline"]["stage_ms_per_launch"]
+    global PEAK
+    iss = b["roofline"].get("issue") or {}
+    if iss.get("peak_source") == "measured":
+        PEAK = iss["peak"]
+        print("(issue peak: measured v_fma_f32 rate of the box, %.3g wave-instructions/s; v_add_u32: %.3g)\n" % (iss["peak"], iss.get("peak_int") or 0))
     sq = json.load(open(sq))
     tr = json.load(open(traffic))
     print("| stage | ms | VALU (M wave-instructions, % of issue peak in the stage's own time) | HBM (GB, TB/s) |")
