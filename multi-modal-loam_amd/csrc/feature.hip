@@ -672,7 +672,10 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_c_direct(FeatParams P) {
 // bytes per lane (1.6 TB/s at BASELINE configs[3]); out of the staged order consecutive lanes write consecutive records of a
 // line -- runs of (points per line per workgroup) x 16 bytes.  A workgroup stages 2048 points, two per thread (round 3: 1024 --
 // 8-point runs of 128 / 32 / 32 bytes per line and array; now 16-point runs), and the workgroups of one scan run on ONE XCD.
-constexpr int CB_TP = 2;                        // points per thread
+#ifndef MML_CB_TP
+#define MML_CB_TP 2
+#endif
+constexpr int CB_TP = MML_CB_TP;                // points per thread (measurement switch: 4 = 4096-point tiles, one workgroup per CU)
 constexpr int CB_THREADS = 1024;
 constexpr int CB_TILE = CB_THREADS * CB_TP;     // points per workgroup
 constexpr int CB_SUB = CB_TILE / AB_THREADS;    // pass-A blocks per workgroup at most (256-point blocks)
