@@ -4,7 +4,7 @@ import re
 
 PREFIX = [
     ("k_assign_ends", "assign_ends"), ("k_assign_onepass", "assign_onepass"), ("k_assign_tables", "assign_tables"),
-    ("k_seg_records", "assign_tables"), ("k_azimuth_exact", "assign_tables"),
+    ("k_seg_records", "assign_tables"),
     ("k_assign_init", "assign_count"), ("k_assign_a", "assign_count"), ("k_assign_b", "assign_scan"),
     ("k_assign_c_direct", "assign_scatter"), ("k_assign_c_staged", "assign_scatter"), ("k_assign_c", "assign_scatter"),
     ("k_stencil_break", "stencil"), ("k_stencil_redo", "stencil"), ("k_stencil", "stencil"), ("k_queue_prefix", "stencil"),
