@@ -1579,3 +1579,24 @@ def test_config0_single_vlp16_scan_five_iterations(M, O, synth):
         assert np.abs(Pg[0] - synth.pose_matrix(9)[:3, 3]).max() < 0.03
     finally:
         c.close()
+
+
+def test_measurement_hooks(ctx, O, scene, synth):
+    """The three measurement entry points bench.py and the documentation lean on: the VALU issue probe (v_fma_f32 slower than
+    v_add_u32, both within a factor of three of CUs x 4 SIMDs x 2.4 GHz / 4 and / 2), the copy roof, and the far-query count of
+    the last association (a few per cent of the queries on the test scene, never more than the features of the slot)."""
+    name, cus, hbm = ctx.device_info()
+    f32, i32 = ctx.issue_rate(0, 2), ctx.issue_rate(1, 2)
+    assert 0.3 * cus * 2.4e9 < f32 < 1.5 * cus * 2.4e9 and f32 < i32 < 3.0 * cus * 2.4e9, (f32, i32)
+    assert 1000.0 < ctx.copy_bandwidth(1 << 28, 3) < 8000.0
+    v, l = synth.velo_scan(7), synth.livox_scan(7)
+    ctx.scan_upload(0, v, l)
+    ctx.extract(0, 1)
+    ctx.undistort(0, 1, np.eye(3).reshape(1, 9), np.zeros((1, 3)))
+    ctx.downsample(0, 1)
+    ctx.map_set_local(0, scene["corner_map"])
+    ctx.map_set_local(1, scene["surf_map"])
+    ctx.associate(0, 1, synth.pose_matrix(7)[None], 25.0)
+    nf = len(ctx.features_download(0, 0)) + len(ctx.features_download(0, 1))
+    far = ctx.associate_far_count()
+    assert 0 <= far <= nf
