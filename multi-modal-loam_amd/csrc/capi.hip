@@ -18,6 +18,7 @@ hipError_t dalloc(T** p, size_t n) {
     return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1));
 }
 
+constexpr int kPackMaxSlots = 16;  // calls of up to this many slots move their parameter blocks / results in one copy each way
 // pinned staging ring for small host<->device parameter blocks
 constexpr size_t kStageDoubles = 1u << 22;  // 32 MiB: a 1024-scan step stages ~45 k doubles; a wrap synchronises the device
 
@@ -81,7 +82,7 @@ void mml_destroy(mml_ctx* ctx) {
                     ctx->fu_info,  ctx->ft_xyz[0], ctx->ft_xyz[1], ctx->ft_n,   ctx->vx_keys,  ctx->vx_gidx, ctx->lf,
                     ctx->pf,       ctx->assoc_stats, ctx->hard_list, ctx->work_off, ctx->grid[0].pts, ctx->grid[1].pts, ctx->grid[0].cell_start,
                     ctx->grid[1].cell_start, ctx->map_tmp, ctx->map_keys, ctx->map_keys2, ctx->map_vals,
-                    ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_summ, ctx->d_trace, ctx->d_rec,
+                    ctx->map_vals2, ctx->sort_tmp, ctx->d_x, ctx->d_pose_in, ctx->d_result, ctx->d_summ, ctx->d_trace, ctx->d_rec,
                     ctx->d_extr,   ctx->d_misc,   ctx->ggrid[0].pts, ctx->ggrid[1].pts, ctx->ggrid[0].cell_start,
                     ctx->ggrid[1].cell_start, ctx->ggrid[0].tags, ctx->ggrid[1].tags, ctx->gmap_orig[0],
                     ctx->gmap_orig[1], ctx->gtag_orig[0], ctx->gtag_orig[1], ctx->cube_cnt[0], ctx->cube_cnt[1],
@@ -231,6 +232,7 @@ int mml_create(const mml_config* cfg, int device, mml_ctx** out) {
     ALLOC(ctx->map_vals2, MM);
     ALLOC(ctx->d_x, B * 6);
     ALLOC(ctx->d_pose_in, B * 64);
+    ALLOC(ctx->d_result, B * MML_SOLVE_RESULT);
     ALLOC(ctx->d_summ, B * 8);
     ALLOC(ctx->d_trace, B * 6 * 64);
     ALLOC(ctx->d_rec, B * 32);
@@ -1387,6 +1389,8 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
     std::vector<int> done(count, 0), outer(count, 0), degen(count, 0);
     std::vector<double> x(6 * (size_t)count), Twl(16 * (size_t)count);
     std::vector<mml_assoc_stats> st(count);
+    std::vector<int> last_fn(2 * (size_t)count, 0);  // the slots' stack sizes as the last result records reported them
+    bool have_fn = false;
     double thres = 25.0;  // Estimator.cpp:1207
     mml_solve_opts so;
     so.max_num_iterations = inner_iters;
@@ -1407,10 +1411,38 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
         }
         // association and solve are enqueued back to back and read back together: one host synchronisation per outer
         // iteration (the statistics of the association only feed the degeneracy flag, nothing the solve waits for)
-        int rc = mml_associate(ctx, first_slot, count, Twl.data(), thres, nullptr);
+        std::vector<double> xs = x;
+        int rc;
+        if (count <= kPackMaxSlots) {
+            // (the live path: one copy down -- T_wl | x | T_bl --, one record per slot up -- pose, stack sizes, statistics; see mml_step)
+            const size_t c = (size_t)count, n = 22 * c + 16;
+            double* hp = stage_alloc(ctx, n);
+            double* dp = ctx->d_pose_in + 64 * (size_t)first_slot;
+            memcpy(hp, Twl.data(), sizeof(double) * 16 * c);
+            memcpy(hp + 16 * c, x.data(), sizeof(double) * 6 * c);
+            memcpy(hp + 22 * c, T_bl, sizeof(double) * 16);
+            MML_HIP(hipMemcpyAsync(dp, hp, sizeof(double) * n, hipMemcpyHostToDevice, MML_STREAM(ctx)));
+            rc = mml_launch_associate(ctx, first_slot, count, dp, thres, true);
+            if (rc != MML_OK) return rc;
+            thres = (it == 0) ? 10.0 : 1.0;  // :1377-1381
+            double* d_res = ctx->d_result + MML_SOLVE_RESULT * (size_t)first_slot;
+            rc = mml_launch_solve(ctx, first_slot, count, 1, dp + 22 * c, so, false, dp + 16 * c, d_res);
+            if (rc != MML_OK) return rc;
+            double* h_res = stage_alloc(ctx, MML_SOLVE_RESULT * c);
+            MML_HIP(hipMemcpyAsync(h_res, d_res, sizeof(double) * MML_SOLVE_RESULT * c, hipMemcpyDeviceToHost, MML_STREAM(ctx)));
+            MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
+            for (int i = 0; i < count; ++i) {
+                const double* r = h_res + MML_SOLVE_RESULT * (size_t)i;
+                finish_stats(r + 8, &st[i]);
+                memcpy(&xs[6 * (size_t)i], r, sizeof(double) * 6);
+                last_fn[2 * i] = (int)r[6];
+                last_fn[2 * i + 1] = (int)r[7];
+            }
+            have_fn = true;
+        } else {
+        rc = mml_associate(ctx, first_slot, count, Twl.data(), thres, nullptr);
         if (rc != MML_OK) return rc;
         thres = (it == 0) ? 10.0 : 1.0;  // :1377-1381
-        std::vector<double> xs = x;
         rc = solve_enqueue(ctx, first_slot, count, 1, T_bl, &so, xs.data(), false);
         if (rc != MML_OK) return rc;
         double* h_back = stage_alloc(ctx, 22 * (size_t)count);  // pinned: stats (16 per slot), then poses (6 per slot)
@@ -1421,6 +1453,7 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
         MML_HIP(hipStreamSynchronize(MML_STREAM(ctx)));
         for (int i = 0; i < count; ++i) finish_stats(h_back + 16 * (size_t)i, &st[i]);
         memcpy(xs.data(), h_back + 16 * (size_t)count, sizeof(double) * 6 * count);
+        }
         for (int i = 0; i < count; ++i) {
             if (done[i]) continue;
             if (st[i].is_degenerate) degen[i] = 1;
@@ -1442,7 +1475,14 @@ int mml_estimate(mml_ctx* ctx, int first_slot, int count, const double* exTlb, d
             if ((deltaR < 0.05 && deltaT < 0.05) || (it + 1) == max_outer) done[i] = 1;  // :1448
         }
     }
-    if (info) {
+    if (info && have_fn) {
+        for (int i = 0; i < count; ++i) {
+            info[i].outer_iterations = outer[i];
+            info[i].is_degenerate = degen[i];
+            info[i].n_corner_feat = last_fn[2 * i];
+            info[i].n_surf_feat = last_fn[2 * i + 1];
+        }
+    } else if (info) {
         std::vector<int> fn(2 * (size_t)ctx->B);
         MML_HIP(hipMemcpy(fn.data(), ctx->ft_n, sizeof(int) * fn.size(), hipMemcpyDeviceToHost));
         for (int i = 0; i < count; ++i) {
@@ -1490,6 +1530,28 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     double* h_x = stage_alloc(ctx, 7 * (size_t)count + 1);  // pinned read-back area: poses, then the two stack-size arrays
     int* h_ftn = reinterpret_cast<int*>(h_x + 6 * (size_t)count);
     int rc = MML_OK;
+    // A handful of slots (the live path): every small transfer is a launch of its own in the dependency chain (a blit kernel of
+    // ~4 us plus the gap in front of it), and a one-scan step made eight of them.  All parameter blocks of the call -- sweep
+    // motions, association poses, start poses, T_bl -- go down in ONE copy into the call's slice of d_pose_in, and everything read
+    // back afterwards (poses, stack sizes) comes up in ONE record per slot that k_solve leaves (MML_SOLVE_RESULT doubles).
+    const bool packed = count <= kPackMaxSlots;
+    double *dp = nullptr, *h_res = nullptr;
+    if (packed) {
+        const size_t c = (size_t)count, n = 34 * c + 16;  // und [0, 12c) | T_wl [12c, 28c) | x [28c, 34c) | T_bl [34c, 34c + 16)
+        double* hp = stage_alloc(ctx, n);
+        dp = ctx->d_pose_in + 64 * (size_t)first_slot;
+        for (size_t i = 0; i < c; ++i) {
+            memcpy(hp + 12 * i, dR + 9 * i, sizeof(double) * 9);
+            memcpy(hp + 12 * i + 9, dt + 3 * i, sizeof(double) * 3);
+            double q[4];
+            so3_exp_h(x_inout + 6 * i + 3, q);
+            pose_to_Twl(q, x_inout + 6 * i, T_bl, hp + 12 * c + 16 * i);
+        }
+        memcpy(hp + 28 * c, x_inout, sizeof(double) * 6 * c);
+        memcpy(hp + 34 * c, T_bl, sizeof(double) * 16);
+        if (hipMemcpyAsync(dp, hp, sizeof(double) * n, hipMemcpyHostToDevice, MML_STREAM(ctx)) != hipSuccess) return MML_ERR_HIP;
+        h_res = stage_alloc(ctx, MML_SOLVE_RESULT * c);
+    }
     // Entry points outside mml_step enqueue on stream 0 (mml_scan_upload's copies, a staged mml_extract ...): the other streams
     // start behind whatever stream 0 holds at this point.  (Found by running 80 slots on the default two lanes straight
     // after their uploads: the last slot's copy was still in flight when lane 1 began to bucket it.)
@@ -1507,9 +1569,12 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
         const int off = f - first_slot;
         switch (stage) {
             case 0: return mml_launch_extract(ctx, f, c, false);
-            case 1: return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
+            case 1:
+                if (packed) return mml_launch_undistort(ctx, f, c, dp);
+                return mml_undistort(ctx, f, c, dR + 9 * (size_t)off, dt + 3 * (size_t)off);
             case 2: return mml_launch_downsample(ctx, f, c);
             case 3:
+                if (packed) return mml_launch_associate(ctx, f, c, dp + 12 * (size_t)count, thres_dist, false);
                 for (int i = 0; i < c; ++i) {
                     double q[4];
                     so3_exp_h(x_inout + 6 * (size_t)(off + i) + 3, q);
@@ -1517,6 +1582,15 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
                 }
                 return associate_enqueue(ctx, f, c, Twl.data(), thres_dist, false);  // (nobody reads the statistics of a step)
             default: {
+                if (packed) {
+                    int r = mml_launch_solve(ctx, f, c, 1, dp + 34 * (size_t)count, so, false, dp + 28 * (size_t)count,
+                                             ctx->d_result + MML_SOLVE_RESULT * (size_t)f);
+                    if (r != MML_OK) return r;
+                    if (hipMemcpyAsync(h_res, ctx->d_result + MML_SOLVE_RESULT * (size_t)f, sizeof(double) * MML_SOLVE_RESULT * c,
+                                       hipMemcpyDeviceToHost, MML_STREAM(ctx)) != hipSuccess)
+                        return MML_ERR_HIP;
+                    return MML_OK;
+                }
                 int r = solve_enqueue(ctx, f, c, 1, T_bl, &so, x_inout + 6 * (size_t)off, false);
                 if (r != MML_OK) return r;
                 hipError_t e = hipMemcpyAsync(h_x + 6 * (size_t)off, ctx->d_x + 6 * (size_t)f, sizeof(double) * 6 * c, hipMemcpyDeviceToHost,
@@ -1547,7 +1621,7 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
         ctx->cur = 0;
         for (int l = 1; l < mml_ctx::MAX_LANES && rc == MML_OK; ++l)
             if (hipStreamSynchronize(ctx->streams[l]) != hipSuccess) rc = MML_ERR_HIP;
-        for (int kind = 0; kind < 2 && rc == MML_OK; ++kind)
+        for (int kind = 0; kind < 2 && rc == MML_OK && !packed; ++kind)
             if (hipMemcpyAsync(h_ftn + (size_t)kind * count, ctx->ft_n + kind * ctx->B + first_slot, sizeof(int) * count,
                                hipMemcpyDeviceToHost, MML_STREAM(ctx)) != hipSuccess)
                 rc = MML_ERR_HIP;
@@ -1556,6 +1630,12 @@ int mml_step(mml_ctx* ctx, int first_slot, int count, const double* dR, const do
     int rs = mml_sync_all(ctx);
     if (rc != MML_OK) return rc;
     if (rs != MML_OK) return rs;
+    if (packed)  // the result records: pose (6), the two stack sizes, (association statistics: nobody reads them here)
+        for (int i = 0; i < count; ++i) {
+            memcpy(h_x + 6 * (size_t)i, h_res + MML_SOLVE_RESULT * (size_t)i, sizeof(double) * 6);
+            h_ftn[i] = (int)h_res[MML_SOLVE_RESULT * (size_t)i + 6];
+            h_ftn[count + i] = (int)h_res[MML_SOLVE_RESULT * (size_t)i + 7];
+        }
     // A negative stack size is the down-sampler's overflow mark.  Slots whose labelled cloud is merely too dense for the
     // LDS sort are redone through the global-sort filter and re-registered one by one (rare: > 8192 corner- or
     // surf-labelled points in one scan); a slot that exceeds max_features stays failed.  Either way every other slot of

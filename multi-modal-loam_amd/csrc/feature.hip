@@ -4147,6 +4147,13 @@ int mml_launch_extract(mml_ctx* ctx, int first, int count, bool have_extrinsic) 
             hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(rows_v), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap_velo), s, Pv, 0);
             if (rows_l > 0)
                 hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(rows_l), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, Pl, 1);
+        } else if (count <= ST_SEGMENT_MAX_SLOTS && ctx->L > ctx->cfg.n_rings && ctx->sel_cap >= ctx->sel_cap_velo) {
+            // a handful of scans: rings and Livox lines in ONE launch of the long-line variant -- its larger LDS block costs a
+            // device this empty nothing, and the rings' 25 us run under the Livox lines' 42 instead of in front of them (the
+            // variant only sets how many points a thread holds: the same flags come out, tests/test_gpu_shapes.py (3))
+            FeatParams Pa = P;
+            Pa.sel_done = nullptr;
+            hipLaunchKernelGGL(select_variant(ctx->sel_cap), dim3(ctx->L, count), dim3(SELP_THREADS), select_lds_bytes(ctx->sel_cap), s, Pa, -1);
         } else {
             hipLaunchKernelGGL(select_variant(ctx->sel_cap_velo), dim3(ctx->cfg.n_rings, count), dim3(SELP_THREADS),
                                select_lds_bytes(ctx->sel_cap_velo), s, Pv, -1);

@@ -246,6 +246,7 @@ struct mml_ctx {
     // solver state
     double* d_x = nullptr;        // B * 6
     double* d_pose_in = nullptr;  // B * 32 generic double params (T_wl, dR/dt ...)
+    double* d_result = nullptr;      // B * MML_SOLVE_RESULT: k_solve's result records (pose, stack sizes, association statistics) for small calls
     double* d_summ = nullptr;     // B * 8
     double* d_trace = nullptr;    // B * 6 * MAX_ITERS
     double* d_und = nullptr;      // B * 8 per-scan undistortion constants
@@ -335,8 +336,9 @@ int mml_launch_knn5(mml_ctx* ctx, int kind, const float* d_q, int nq, float max_
 // computed by mml_ensure_assoc_stats when a consumer asks (mml_linearize*, the next mml_associate with statistics)
 int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl, double thres_dist, bool with_stats = true);
 int mml_ensure_assoc_stats(mml_ctx* ctx, int first, int count);
+#define MML_SOLVE_RESULT 24  // doubles per problem of k_solve's result record: x (6), stack sizes (2), association statistics (16)
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
-                     bool want_trace);
+                     bool want_trace, const double* d_x_in = nullptr, double* d_result = nullptr);
 int mml_window_solve_continue(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts);
 int mml_feature_init(mml_ctx* ctx);
 void mml_fullwindow_dev_release(mml_ctx* ctx);

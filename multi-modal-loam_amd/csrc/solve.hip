@@ -50,6 +50,12 @@ struct SolveParams {
     double* x;          // B * 6
     double* summ;       // per problem 8 doubles
     double* trace;      // per problem max_iters * 6 * window, or nullptr
+    // a handful of slots (the live path): every small transfer is a launch of its own in the chain, so the start poses come in one
+    // copy with the call's other parameter blocks and everything the host reads back afterwards leaves in ONE record per problem
+    const double* x_in;     // start poses of THIS launch's problems (6 * window each), nullptr: x holds them
+    double* result;         // per problem MML_SOLVE_RESULT doubles, or nullptr: x (6 * window <= 48 ... window 1 only), the two stack
+                            // sizes of slot b0, the 16 association statistics of slot b0
+    const double* stats;    // assoc_stats (16 doubles per slot) or nullptr
 };
 
 // Trust-region state kept in LDS, manipulated by lane 0 (restates ceres 2.1.0 trust_region_minimizer.cc +
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     unsigned long long sv_prev = clock64();
     if (sv_dbg) g_sv_dbg[7] += 1;
 #endif
-    if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x[(size_t)b0 * 6 + tid];
+    if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x_in ? P.x_in[(size_t)prob * 6 * W + tid] : P.x[(size_t)b0 * 6 + tid];
     __syncthreads();
 
     double acc[28];
@@ -853,6 +859,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         __syncthreads();
     }
     if (tid < 6 * W) P.x[(size_t)b0 * 6 + tid] = S.x[tid];
+    if (P.result && W == 1) {  // (W = 1: the callers that ask for it)
+        double* r = P.result + (size_t)prob * MML_SOLVE_RESULT;
+        if (tid < 6) r[tid] = S.x[tid];
+        if (tid == 6) r[6] = (double)P.ft_n[b0];
+        if (tid == 7) r[7] = (double)P.ft_n[P.B + b0];
+        if (tid >= 8 && tid < 24) r[tid] = P.stats ? P.stats[16 * (size_t)b0 + (tid - 8)] : 0.0;
+    }
     // rows of the trace beyond the last iteration that ran repeat the final point
     if (P.trace && tid < 6 * W)
         for (int it = S.iter; it < P.max_iters; ++it) P.trace[((size_t)prob * P.max_iters + it) * 6 * W + tid] = S.x[tid];
@@ -1214,7 +1227,7 @@ int mml_window_state_read(mml_ctx* ctx, const void* d_state, int W, double* x_wi
 }
 
 int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const double* d_Tbl, mml_solve_opts opts,
-                     bool want_trace) {
+                     bool want_trace, const double* d_x_in, double* d_result) {
     MML_REQUIRE(window >= 1 && window <= MAXW && count % window == 0, MML_ERR_INVALID,
                 "window must be in [1,8] and divide count");
     if (window > 1 && !want_trace && ctx->window_frame_parallel) return launch_solve_frame_parallel(ctx, first, count, window, d_Tbl, opts, false);
@@ -1234,6 +1247,10 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
     P.x = ctx->d_x;
     P.summ = ctx->d_summ + 8 * (size_t)first;
     P.trace = want_trace ? ctx->d_trace + (size_t)first * 6 * 64 : nullptr;
+    P.x_in = d_x_in;
+    P.result = d_result;
+    P.stats = ctx->assoc_stats;
+    MML_REQUIRE((!d_x_in && !d_result) || window == 1, MML_ERR_INVALID, "packed start poses / result records: one-frame problems only");
     MmlStageScope t(ctx, "solve");
     hipLaunchKernelGGL(k_solve, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
     MML_HIP(hipGetLastError());
