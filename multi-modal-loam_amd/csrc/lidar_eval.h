@@ -270,6 +270,70 @@ __device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFacto
     }
 }
 
+// ---- the same evaluation with TWO plane factors of a thread in flight (the live path's launches: k_solve<true>) -----------------
+// One problem per CU leaves one wavefront per SIMD, and a factor is a chain of ~350 dependent double-precision instructions: the
+// SIMD waits out every one of them.  Here a thread forms the rows of its factors i and i + SOLVE_THREADS side by side -- two
+// independent chains the scheduler interleaves -- and then adds them to its 28 sums in the order eval_frame adds them (i first).
+// Every factor goes through the same operations in the same order as in eval_frame (plane_row restates its loop body; the two
+// are held bit-identical by tests/test_gpu_shapes.py: a slot solved alone against the same slot in a 4096-slot launch).
+// (for plan_weight_tan = 0 -- the one-frame mode's only setting, Estimator.cpp:1206 --: a plane factor is ONE residual row, and
+//  everything below is straight-line code on registers; with the tangential rows the callers keep eval_frame)
+struct PlaneRow {
+    double J[6], rr, rho0, rho1;
+    bool valid;  // false: the factor is skipped (no record, or |error| <= 1e-5)
+};
+__device__ __forceinline__ void plane_row(const MmlPlaneFactor& f, const Pose& P, double ka, double huber_delta, PlaneRow& o) {
+    o.valid = !(f.src < 0 || !(fabs(f.error) > 1e-5));  // Estimator.cpp:1396
+    const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
+    double Pw[3];
+    Pw[0] = __builtin_fma(P.R[2], cz, __builtin_fma(P.R[1], cy, __builtin_fma(P.R[0], cx, P.t[0])));
+    Pw[1] = __builtin_fma(P.R[5], cz, __builtin_fma(P.R[4], cy, __builtin_fma(P.R[3], cx, P.t[1])));
+    Pw[2] = __builtin_fma(P.R[8], cz, __builtin_fma(P.R[7], cy, __builtin_fma(P.R[6], cx, P.t[2])));
+    const double d[3] = {Pw[0] - f.proj[0], Pw[1] - f.proj[1], Pw[2] - f.proj[2]};
+    double nd, ind, s12, is12, rs, sm14;
+    sqrt_pair(__builtin_fma(d[2], d[2], __builtin_fma(d[1], d[1], d[0] * d[0])), nd, ind);
+    const double s = __builtin_fma(Pw[2], Pw[2], __builtin_fma(Pw[1], Pw[1], Pw[0] * Pw[0]));
+    sqrt_pair(s, s12, is12);
+    sqrt_pair(s12, rs, sm14);
+    const double weight = 1.0 - 0.9 * nd * sm14;
+    const double sm54 = sm14 * (is12 * is12);
+    double gw[3];
+    const double gwa = sm14 * ind, gwb = nd * (-0.5) * sm54;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gw[c] = (-0.9) * __builtin_fma(gwb, Pw[c], gwa * d[c]);
+    const double row[3] = {ka * (double)f.omega[0], ka * (double)f.omega[1], ka * (double)f.omega[2]};
+    o.rr = weight * __builtin_fma(row[2], d[2], __builtin_fma(row[1], d[1], row[0] * d[0]));
+    double sq = 0;
+    sq = __builtin_fma(o.rr, o.rr, sq);
+    huber(sq, huber_delta, o.rho0, o.rho1);
+    const double rd = __builtin_fma(row[2], d[2], __builtin_fma(row[1], d[1], row[0] * d[0]));
+    double gr[3] = {__builtin_fma(rd, gw[0], weight * row[0]), __builtin_fma(rd, gw[1], weight * row[1]), __builtin_fma(rd, gw[2], weight * row[2])};
+    row_jacobian(P, Pw, gr, o.J);
+}
+// plan_weight_tan must be 0 (one residual row per plane factor)
+__device__ void eval_frame_pairs(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
+                                 double huber_delta, double* acc) {
+    // the line factors (a fifth of the records) as eval_frame takes them: its loop runs with zero plane factors
+    eval_frame(lf, nlf, pf, 0, P, 0.0, huber_delta, acc);
+    const double ka = 1.0 / kLidarM;
+    for (int i = threadIdx.x; i < npf; i += 2 * SOLVE_THREADS) {
+        const bool hb = i + SOLVE_THREADS < npf;
+        const MmlPlaneFactor fa = pf[i];
+        const MmlPlaneFactor fb = pf[hb ? i + SOLVE_THREADS : i];
+        PlaneRow a, b;
+        plane_row(fa, P, ka, huber_delta, a);
+        plane_row(fb, P, ka, huber_delta, b);
+        if (a.valid) {
+            acc[27] += 0.5 * a.rho0;
+            accum(acc, a.J, a.rr, a.rho1);
+        }
+        if (hb && b.valid) {
+            acc[27] += 0.5 * b.rho0;
+            accum(acc, b.J, b.rr, b.rho1);
+        }
+    }
+}
+
 // block reduction of acc[28] into out[28] (LDS or global); result valid for thread 0 after the trailing barrier.
 // Inside a wavefront the 28 sums are reduced as a butterfly that halves the number of values a lane carries at every
 // step (at offset o the lanes with bit o set keep the upper half of their values and hand over the lower half): 16 + 8 +

@@ -762,6 +762,9 @@ __device__ void tr_decide_wave(TRState& S, double* w, int W, int fixed) {
 #undef WSYNC
 
 // (256 registers, two wavefronts per SIMD.  Held to 168 for three it spills 400 bytes per lane: 0.32 -> 0.93 ms per 1024 problems.)
+// PAIRS: launches of at most one problem per CU (the live path) evaluate two plane factors of a thread side by side
+// (lidar_eval.h eval_frame_pairs): same sums in the same order, half the exposed latency of the factor passes.
+template <bool PAIRS>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     __shared__ TRState S;
     __shared__ double s_part[SOLVE_WAVES * 28];
@@ -785,8 +788,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         Pose pose;
         make_pose(S.x + 6 * f, P.Tbl, pose);
         const int b = b0 + f;
-        eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan,
-                   P.huber, acc);
+        if constexpr (PAIRS)
+            eval_frame_pairs(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.huber, acc);
+        else
+            eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan, P.huber, acc);
         block_reduce28(acc, s_part, S.rec + 28 * f);
     }
     if (tid == 0) {
@@ -844,8 +849,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
                 Pose pose;
                 make_pose(S.xc + 6 * f, P.Tbl, pose);
                 const int b = b0 + f;
-                eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose,
-                           P.w_tan, P.huber, acc);
+                if constexpr (PAIRS)
+                    eval_frame_pairs(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.huber, acc);
+                else
+                    eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan, P.huber, acc);
                 SV_MARK(2);  // factor pass of this thread
                 block_reduce28(acc, s_part, S.recc + 28 * f);
                 SV_MARK(3);  // block reduction (waits for the slowest wavefront's factor pass)
@@ -1252,7 +1259,16 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
     P.stats = ctx->assoc_stats;
     MML_REQUIRE((!d_x_in && !d_result) || window == 1, MML_ERR_INVALID, "packed start poses / result records: one-frame problems only");
     MmlStageScope t(ctx, "solve");
-    hipLaunchKernelGGL(k_solve, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
+    static int pairs_max = -1;  // problems per launch up to which k_solve<true> runs (measurement switch: $MML_SOLVE_PAIRS=0 -> never)
+    if (pairs_max < 0) {
+        const char* e = getenv("MML_SOLVE_PAIRS");
+        hipDeviceProp_t prop;
+        pairs_max = (e && atoi(e) == 0) ? 0 : (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 0);
+    }
+    if (count / window <= pairs_max && opts.plan_weight_tan == 0.0)
+        hipLaunchKernelGGL(k_solve<true>, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
+    else
+        hipLaunchKernelGGL(k_solve<false>, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
     MML_HIP(hipGetLastError());
     return MML_OK;
 }
