@@ -330,3 +330,17 @@ def test_libm_f32_equals_glibc(tmp_path):
     arguments of atanf and 4e8 pairs of atan2f (random patterns, lidar-like coordinates, ratios on the reduction thresholds,
     zeros / denormals / infinities)."""
     _libm_check(tmp_path, os.path.join(ROOT, "multi-modal-loam_amd", "csrc"), "mml_libm", "atanf_fd", "atan2f_fd")
+
+
+def test_live_loop_builds_against_the_library(tmp_path):
+    """tools/live_loop.cpp (the configs[2] replay driven through the C++ adapter: bench.py --config 2 builds and runs it on the GPU
+    box) compiles and links against the in-tree library and the adapter header as they are now; without a scene file it exits 2."""
+    libdir = os.path.join(ROOT, "multi-modal-loam_amd")
+    exe = tmp_path / "live_loop"
+    out = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "host"),
+                          os.path.join(ROOT, "tools", "live_loop.cpp"), "-o", str(exe), "-L", libdir, "-lmmloam_hip", "-Wl,-rpath," + libdir,
+                          "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 2
