@@ -1481,12 +1481,26 @@ int mml_launch_associate(mml_ctx* ctx, int first, int count, const double* d_Twl
         MmlStageScope t(ctx, "associate_far");
         // (a whole / half a wavefront per query while all queries of the call -- every feature of up to 4 / 8 scans -- are resident
         //  at once: 2048 workgroups hold 8192 / 16384 of them)
-        const int span = !P.fresh_all ? 16 : (count <= 4 ? 64 : 32);
+        // lanes per far query of a batch: FOUR.  A batch has tens of thousands of far queries -- throughput, not the slowest query,
+        // is what its kernel lasts -- and the lanes of a group split the (y, z) rows of a shell: 25 rows at ring 2 leave a 16-lane
+        // group's second turn half empty.  Per 1024 scans (configs[1] / configs[3]): 64 lanes 0.331, 32: 0.224, 16: 0.164 / 0.118,
+        // 8: 0.153, 4: 0.147 / 0.113, 2: 0.142 / 0.153, 1: 0.185 ms ($MML_HARD_SPAN: measurement switch).
+        static int span_batch = -1;
+        if (span_batch < 0) span_batch = getenv("MML_HARD_SPAN") ? atoi(getenv("MML_HARD_SPAN")) : 4;
+        const int span = !P.fresh_all ? span_batch : (count <= 4 ? 64 : 32);
         auto launch_hard = [&](int round) {
             if (span == 64)
                 hipLaunchKernelGGL(k_associate_hard<64>, dim3(2048), dim3(256), 0, MML_STREAM(ctx), P, round);
             else if (span == 32)
                 hipLaunchKernelGGL(k_associate_hard<32>, dim3(2048), dim3(256), 0, MML_STREAM(ctx), P, round);
+            else if (span == 8)
+                hipLaunchKernelGGL(k_associate_hard<8>, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, round);
+            else if (span == 4)
+                hipLaunchKernelGGL(k_associate_hard<4>, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, round);
+            else if (span == 2)
+                hipLaunchKernelGGL(k_associate_hard<2>, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, round);
+            else if (span == 1)
+                hipLaunchKernelGGL(k_associate_hard<1>, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, round);
             else
                 hipLaunchKernelGGL(k_associate_hard<16>, dim3(1024), dim3(256), 0, MML_STREAM(ctx), P, round);
         };
