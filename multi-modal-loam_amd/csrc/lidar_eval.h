@@ -153,7 +153,9 @@ __device__ __forceinline__ void accum(double* acc, const double* J, double r, do
 }
 
 // Evaluate one frame at pose P: thread-strided over the factors; acc[28] per thread.
-__device__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
+// (forced inline: with a third caller in this header -- eval_frame_pairs -- the compiler stopped inlining it into k_solve, and the
+//  batch solve paid 10 % for two real calls per pass)
+__device__ __forceinline__ void eval_frame(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
                            double w_tan, double huber_delta, double* acc) {
     for (int k = 0; k < 28; ++k) acc[k] = 0;
     const double ka = 1.0 / kLidarM;
@@ -311,7 +313,7 @@ __device__ __forceinline__ void plane_row(const MmlPlaneFactor& f, const Pose& P
     row_jacobian(P, Pw, gr, o.J);
 }
 // plan_weight_tan must be 0 (one residual row per plane factor)
-__device__ void eval_frame_pairs(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
+__device__ __forceinline__ void eval_frame_pairs(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
                                  double huber_delta, double* acc) {
     // the line factors (a fifth of the records) as eval_frame takes them: its loop runs with zero plane factors
     eval_frame(lf, nlf, pf, 0, P, 0.0, huber_delta, acc);

@@ -56,6 +56,7 @@ struct SolveParams {
     double* result;         // per problem MML_SOLVE_RESULT doubles, or nullptr: x (6 * window <= 48 ... window 1 only), the two stack
                             // sizes of slot b0, the 16 association statistics of slot b0
     const double* stats;    // assoc_stats (16 doubles per slot) or nullptr
+    int pairs;              // k_solve<true>: two plane factors of a thread side by side (measurement switch $MML_SOLVE_PAIRS=0: off)
 };
 
 // Trust-region state kept in LDS, manipulated by lane 0 (restates ceres 2.1.0 trust_region_minimizer.cc +
@@ -78,7 +79,7 @@ __host__ __device__ double quad_form(const TRState& S, int W, const double* v) {
     return q;
 }
 
-__host__ __device__ void tr_propose(TRState& S, int W, int max_iters) {
+__host__ __device__ inline __attribute__((always_inline)) void tr_propose(TRState& S, int W, int max_iters) {
     const int n = 6 * W;
     S.evaluate = 0;
     if (S.iter >= max_iters || S.radius < 1e-32) {
@@ -243,7 +244,9 @@ extern "C" int mml_debug_sv_timing(unsigned long long* out, int reset) {
 #else
 #define PV_MARK(id)
 #endif
-__device__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
+// (forced inline, as tr_propose and tr_decide_wave: with two instantiations of k_solve calling them the compiler made them real
+//  functions -- a call inside the iteration loop of a kernel with 256 live registers: the batch solve 0.251 -> 0.28 ms per 1024 problems)
+__device__ __forceinline__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
     const int lane = threadIdx.x;  // 0..63
     double* T = w;         // 36 terms of a quadratic form
     double* A = w + 36;    // 36: the damped matrix, then its Cholesky factor (lower triangle)
@@ -697,7 +700,7 @@ __device__ void tr_propose_wave(TRState& S, double* w, int W, int max_iters) {
     }
 }
 
-__device__ void tr_decide_wave(TRState& S, double* w, int W, int fixed) {
+__device__ __forceinline__ void tr_decide_wave(TRState& S, double* w, int W, int fixed) {
     const int lane = threadIdx.x;
     const int n = 6 * W;
     double* U = w + 36 * MAXW;
@@ -762,9 +765,12 @@ __device__ void tr_decide_wave(TRState& S, double* w, int W, int fixed) {
 #undef WSYNC
 
 // (256 registers, two wavefronts per SIMD.  Held to 168 for three it spills 400 bytes per lane: 0.32 -> 0.93 ms per 1024 problems.)
-// PAIRS: launches of at most one problem per CU (the live path) evaluate two plane factors of a thread side by side
-// (lidar_eval.h eval_frame_pairs): same sums in the same order, half the exposed latency of the factor passes.
-template <bool PAIRS>
+// SMALL: the variant of launches of at most one problem per CU (the live path).  It evaluates two plane factors of a thread side by
+// side (lidar_eval.h eval_frame_pairs: same sums in the same order, half the exposed latency of the factor passes; one-row plane
+// factors only, i.e. plan_weight_tan = 0), and it is the one that takes its start poses from a packed parameter block (x_in) and
+// leaves a result record per problem (result).  The batch variant carries none of that: a pointer test and 24 conditional stores
+// in a kernel that sits on its 256-register limit cost it 10 % (0.253 -> 0.28 ms per 1024 problems) while they were in both.
+template <bool SMALL>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     __shared__ TRState S;
     __shared__ double s_part[SOLVE_WAVES * 28];
@@ -779,7 +785,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
     unsigned long long sv_prev = clock64();
     if (sv_dbg) g_sv_dbg[7] += 1;
 #endif
-    if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x_in ? P.x_in[(size_t)prob * 6 * W + tid] : P.x[(size_t)b0 * 6 + tid];
+    if constexpr (SMALL) {
+        if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x_in ? P.x_in[(size_t)prob * 6 * W + tid] : P.x[(size_t)b0 * 6 + tid];
+    } else {
+        if (tid < 6 * W) S.x[tid] = S.x_init[tid] = P.x[(size_t)b0 * 6 + tid];
+    }
+    const bool pairs = SMALL && P.pairs && P.w_tan == 0.0;  // (uniform)
     __syncthreads();
 
     double acc[28];
@@ -788,7 +799,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         Pose pose;
         make_pose(S.x + 6 * f, P.Tbl, pose);
         const int b = b0 + f;
-        if constexpr (PAIRS)
+        if (SMALL && pairs)
             eval_frame_pairs(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.huber, acc);
         else
             eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan, P.huber, acc);
@@ -849,7 +860,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
                 Pose pose;
                 make_pose(S.xc + 6 * f, P.Tbl, pose);
                 const int b = b0 + f;
-                if constexpr (PAIRS)
+                if (SMALL && pairs)
                     eval_frame_pairs(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.huber, acc);
                 else
                     eval_frame(P.lf + (size_t)b * P.MF, P.ft_n[b], P.pf + (size_t)b * P.MF, P.ft_n[P.B + b], pose, P.w_tan, P.huber, acc);
@@ -866,7 +877,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         __syncthreads();
     }
     if (tid < 6 * W) P.x[(size_t)b0 * 6 + tid] = S.x[tid];
-    if (P.result && W == 1) {  // (W = 1: the callers that ask for it)
+    if (SMALL && P.result && W == 1) {  // (W = 1: the callers that ask for it)
         double* r = P.result + (size_t)prob * MML_SOLVE_RESULT;
         if (tid < 6) r[tid] = S.x[tid];
         if (tid == 6) r[6] = (double)P.ft_n[b0];
@@ -1259,13 +1270,17 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
     P.stats = ctx->assoc_stats;
     MML_REQUIRE((!d_x_in && !d_result) || window == 1, MML_ERR_INVALID, "packed start poses / result records: one-frame problems only");
     MmlStageScope t(ctx, "solve");
-    static int pairs_max = -1;  // problems per launch up to which k_solve<true> runs (measurement switch: $MML_SOLVE_PAIRS=0 -> never)
-    if (pairs_max < 0) {
+    static int n_cus = -1, pairs_on = 1;
+    if (n_cus < 0) {
         const char* e = getenv("MML_SOLVE_PAIRS");
+        pairs_on = (e && atoi(e) == 0) ? 0 : 1;
         hipDeviceProp_t prop;
-        pairs_max = (e && atoi(e) == 0) ? 0 : (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 0);
+        n_cus = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 64;
     }
-    if (count / window <= pairs_max && opts.plan_weight_tan == 0.0)
+    const bool small = count / window <= n_cus;  // at most one problem per CU
+    MML_REQUIRE((!d_x_in && !d_result) || small, MML_ERR_INVALID, "packed start poses / result records: small launches only");
+    P.pairs = pairs_on;
+    if (small)
         hipLaunchKernelGGL(k_solve<true>, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
     else
         hipLaunchKernelGGL(k_solve<false>, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
