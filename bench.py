@@ -878,12 +878,20 @@ def perturbed(T, dt_=(0.02, -0.015, 0.01), rv=None):
 def cpp_live_loop(scans, motions, predicted, reps=3):
     """Builds tools/live_loop.cpp (g++, against the in-tree library) and runs it on a scene file of the replay's scans: the
     odometry loop driven through the C++ adapter, timed with std::chrono inside the process.  -> its JSON object."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="mml_live_")   # (the scene file is ~0.9 MB per scan: removed again below)
+    try:
+        return _cpp_live_loop_in(tmp, scans, motions, predicted, reps)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _cpp_live_loop_in(tmp, scans, motions, predicted, reps):
     import struct
     import subprocess
-    import tempfile
     from scipy.spatial.transform import Rotation as Rsc
     libdir = os.path.join(ROOT, "multi-modal-loam_amd")
-    tmp = tempfile.mkdtemp(prefix="mml_live_")
     exe, scene = os.path.join(tmp, "live_loop"), os.path.join(tmp, "scene.bin")
     cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "host"),
            os.path.join(ROOT, "tools", "live_loop.cpp"), "-o", exe, "-L", libdir, "-lmmloam_hip", "-Wl,-rpath," + libdir,
