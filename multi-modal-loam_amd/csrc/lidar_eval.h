@@ -7,6 +7,7 @@
 //   a20     J^T J / J^T r with Ceres' Huber correction (corrector.cc: rho'' <= 0 => scale by sqrt(rho'))
 #pragma once
 #include <math.h>
+#include <stddef.h>
 
 #include "mml_internal.h"
 
@@ -370,6 +371,369 @@ __device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, d
         out[threadIdx.x] = r;
     }
     __syncthreads();
+}
+
+// ---- the live path's factor pass on all FOUR SIMDs of its CU (k_solve_wide: W = 1, plan_weight_tan = 0) ---------------------------
+// A launch of at most one problem per CU runs the 128-thread pass above on two of the CU's four SIMDs, and the pass is bound by the
+// double-precision issue rate there (1013 factors of configs[1] x ~350 instructions = 2 800 wave-instructions per SIMD at 4.1 cycles).
+// Here the workgroup has 4 x 128 threads: thread (vt, sub) stands for a quarter of the work of thread vt of the 128-thread pass.
+//   rows:  the factors of "virtual thread" vt, in the order eval_frame takes them (lines vt, vt + 128, ..., then planes vt, vt + 128,
+//          ...), are its SLOTS 0, 1, 2, ...; thread (vt, sub) forms the rows (J, r, rho) of slots sub, sub + 4, sub + 8 of a round of
+//          twelve -- line_row / plane_row: the operations of eval_frame's loop bodies in their order -- two plane rows side by side
+//          where it can, and leaves them in LDS (9 doubles a row).
+//   sums:  every one of the 28 sums of virtual thread vt is its own chain of fma(w J_a, J_b, acc) over the slots in order; the
+//          chains are dealt to the four sub-threads by Jacobian row (a = 0 + cost | a = 1, 5 | a = 2, 4 | a = 3: 10, 10, 10, 5
+//          instructions a slot), each walks the round's rows in slot order: every sum sees the same operands in the same order as
+//          acc[k] of thread vt in eval_frame.
+//   tree:  the 128 partial sums of a value meet in block_reduce28's order (xor 32, 16, 8, 4, 2, 1 inside the wavefront, then
+//          wavefront 0 + wavefront 1), eight values a lane instead of 28.
+// The results are bit-identical to eval_frame + block_reduce28 (tests/test_gpu_shapes.py (3): slots solved alone and in launches of
+// <= 256 against the 4096-slot launches).
+constexpr int WIDE_SUBS = 4;
+constexpr int WIDE_THREADS = WIDE_SUBS * SOLVE_THREADS;
+constexpr int WIDE_ROUND = 3 * WIDE_SUBS;  // slots (rows per virtual thread) per round
+constexpr int ROW_DOUBLES = 9;             // J[6], r, rho0, rho1 (-1: no row)
+constexpr int WIDE_ROW_LDS = WIDE_ROUND * ROW_DOUBLES * SOLVE_THREADS;  // doubles
+static_assert(SOLVE_WAVES == 2, "eval_frame_wide restates block_reduce28 for two wavefronts");
+
+__device__ __forceinline__ void line_row(const MmlLineFactor& f, const Pose& P, double ka, double huber_delta, PlaneRow& o) {
+    o.valid = !(f.src < 0 || !(fabs(f.error) > 1e-5));  // Estimator.cpp:1385
+    const double cx = f.ori[0], cy = f.ori[1], cz = f.ori[2];
+    const double ax = f.p1[0], ay = f.p1[1], az = f.p1[2], bx = f.p2[0], by = f.p2[1], bz = f.p2[2];
+    double Pw[3];
+    Pw[0] = __builtin_fma(P.R[2], cz, __builtin_fma(P.R[1], cy, __builtin_fma(P.R[0], cx, P.t[0])));
+    Pw[1] = __builtin_fma(P.R[5], cz, __builtin_fma(P.R[4], cy, __builtin_fma(P.R[3], cx, P.t[1])));
+    Pw[2] = __builtin_fma(P.R[8], cz, __builtin_fma(P.R[7], cy, __builtin_fma(P.R[6], cx, P.t[2])));
+    double l12, il12, a012, ia012, s12, is12, rs, sm14;
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    sqrt_pair(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), l12, il12);
+    const double pax = Pw[0] - ax, pay = Pw[1] - ay, paz = Pw[2] - az, pbx = Pw[0] - bx, pby = Pw[1] - by, pbz = Pw[2] - bz;
+    const double c0 = __builtin_fma(pax, pby, -(pbx * pay));
+    const double c1 = __builtin_fma(pax, pbz, -(pbx * paz));
+    const double c2 = __builtin_fma(pay, pbz, -(pby * paz));
+    sqrt_pair(__builtin_fma(c2, c2, __builtin_fma(c1, c1, c0 * c0)), a012, ia012);
+    const double ld2 = a012 * il12;
+    const double s = __builtin_fma(Pw[2], Pw[2], __builtin_fma(Pw[1], Pw[1], Pw[0] * Pw[0]));
+    sqrt_pair(s, s12, is12);
+    sqrt_pair(s12, rs, sm14);
+    const double weight = 1.0 - 0.9 * fabs(ld2) * sm14;
+    const double r = ka * weight * ld2;
+    const double ux = c2 * ia012, uy = -c1 * ia012, uz = c0 * ia012;
+    double gl[3] = {__builtin_fma(dy, uz, -(dz * uy)) * il12, __builtin_fma(dz, ux, -(dx * uz)) * il12, __builtin_fma(dx, uy, -(dy * ux)) * il12};
+    const double sm54 = sm14 * (is12 * is12);
+    double gr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double gw = (-0.9) * __builtin_fma(fabs(ld2) * (-0.5) * sm54, Pw[c], sm14 * gl[c]);
+        gr[c] = ka * __builtin_fma(ld2, gw, weight * gl[c]);
+    }
+    row_jacobian(P, Pw, gr, o.J);
+    huber(r * r, huber_delta, o.rho0, o.rho1);
+    o.rr = r;
+}
+
+struct WideRec {
+    uint4 q[4];
+};
+static_assert(sizeof(MmlLineFactor) == 48 && sizeof(MmlPlaneFactor) == 64, "WideRec holds either record");
+__device__ __forceinline__ void wide_load(WideRec& r, bool is_line, const MmlLineFactor* lf, int il, const MmlPlaneFactor* pf, int ip) {
+    if (is_line) {
+        const uint4* p = reinterpret_cast<const uint4*>(lf + il);
+        r.q[0] = p[0];
+        r.q[1] = p[1];
+        r.q[2] = p[2];
+    } else {
+        const uint4* p = reinterpret_cast<const uint4*>(pf + ip);
+        r.q[0] = p[0];
+        r.q[1] = p[1];
+        r.q[2] = p[2];
+        r.q[3] = p[3];
+    }
+}
+// (field by field: a memcpy of the record makes a private copy that the compiler then keeps in LDS)
+__device__ __forceinline__ MmlLineFactor wide_line(const WideRec& r) {
+    MmlLineFactor f;
+    f.ori[0] = __uint_as_float(r.q[0].x);
+    f.ori[1] = __uint_as_float(r.q[0].y);
+    f.ori[2] = __uint_as_float(r.q[0].z);
+    f.p1[0] = __uint_as_float(r.q[0].w);
+    f.p1[1] = __uint_as_float(r.q[1].x);
+    f.p1[2] = __uint_as_float(r.q[1].y);
+    f.p2[0] = __uint_as_float(r.q[1].z);
+    f.p2[1] = __uint_as_float(r.q[1].w);
+    f.p2[2] = __uint_as_float(r.q[2].x);
+    f.src = (int)r.q[2].y;
+    f.error = __hiloint2double((int)r.q[2].w, (int)r.q[2].z);
+    return f;
+}
+__device__ __forceinline__ MmlPlaneFactor wide_plane(const WideRec& r) {
+    MmlPlaneFactor f;
+    f.ori[0] = __uint_as_float(r.q[0].x);
+    f.ori[1] = __uint_as_float(r.q[0].y);
+    f.ori[2] = __uint_as_float(r.q[0].z);
+    f.omega[0] = __uint_as_float(r.q[0].w);
+    f.omega[1] = __uint_as_float(r.q[1].x);
+    f.omega[2] = __uint_as_float(r.q[1].y);
+    f.proj[0] = __hiloint2double((int)r.q[1].w, (int)r.q[1].z);
+    f.proj[1] = __hiloint2double((int)r.q[2].y, (int)r.q[2].x);
+    f.proj[2] = __hiloint2double((int)r.q[2].w, (int)r.q[2].z);
+    f.error = __hiloint2double((int)r.q[3].y, (int)r.q[3].x);
+    f.src = (int)r.q[3].z;
+    f._pad = 0;
+    return f;
+}
+static_assert(offsetof(MmlLineFactor, src) == 36 && offsetof(MmlLineFactor, error) == 40 && offsetof(MmlPlaneFactor, proj) == 24 &&
+                  offsetof(MmlPlaneFactor, error) == 48 && offsetof(MmlPlaneFactor, src) == 56,
+              "wide_line / wide_plane unpack the records by offset");
+
+__device__ __forceinline__ void row_store(double* s_rows, int j, int vt, const PlaneRow& o, bool in_range) {
+    double* p = s_rows + (size_t)j * ROW_DOUBLES * SOLVE_THREADS + vt;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p[k * SOLVE_THREADS] = o.J[k];
+    p[6 * SOLVE_THREADS] = o.rr;
+    p[7 * SOLVE_THREADS] = o.rho0;
+    p[8 * SOLVE_THREADS] = (o.valid && in_range) ? o.rho1 : -1.0;  // rho' > 0 for every row (huber: >= DBL_MIN); -1: the factor is skipped
+}
+
+// value of lane (l ^ O) without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap (halves of the wavefront, rows of
+// 16 lanes) and DPP moves inside a row (xor 8 = half-mirror o mirror, xor 4 = quad-reverse o half-mirror, xor 2 / 1 = quad_perm).
+// A ds_bpermute round trip is ~300 cycles and block_reduce28's tree has six of them one after the other; these are a few VALU
+// instructions each.
+template <int O>
+__device__ __forceinline__ unsigned lane_xor_u32(unsigned x, int lane) {
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0]: both halves = the lower, r[1]: = the upper
+        return lane < 32 ? r[1] : r[0];
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0]: odd rows = the even row below, r[1]: even rows = the odd row above
+        return (lane & 16) ? r[0] : r[1];
+    } else if constexpr (O == 8) {
+        const int m = __builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false);        // row_mirror: i -> 15 - i
+        return (unsigned)__builtin_amdgcn_update_dpp(0, m, 0x141, 0xf, 0xf, false);          // row_half_mirror: -> 8 (i / 8) + 7 - i % 8
+    } else if constexpr (O == 4) {
+        const int m = __builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(0, m, 0x1B, 0xf, 0xf, false);           // quad_perm [3, 2, 1, 0]
+    } else if constexpr (O == 2) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
+    } else {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+    }
+}
+template <int O>
+__device__ __forceinline__ double lane_xor_f64(double v, int lane) {
+    const unsigned lo = lane_xor_u32<O>((unsigned)__double2loint(v), lane), hi = lane_xor_u32<O>((unsigned)__double2hiint(v), lane);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// the chains of sub-thread SUB over the ns rows of a round, in slot order: six slots a turn, their values requested together (an
+// LDS round trip is ~300 cycles: two of them per pass instead of two per slot), straight-line code (a skipped factor leaves the
+// sums as they were by a select, not a branch)
+template <int SUB>
+__device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, double* v) {
+    constexpr int T = 5;
+    for (int j0 = 0; j0 < ns; j0 += T) {
+        double J0[T], J1[T], J2[T], J3[T], J4[T], J5[T], rr[T], rho0[T], w[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+            const double* p = s_rows + (size_t)min(j0 + u, ns - 1) * ROW_DOUBLES * SOLVE_THREADS + vt;
+            if constexpr (SUB == 0) J0[u] = p[0];
+            if constexpr (SUB <= 1) J1[u] = p[SOLVE_THREADS];
+            if constexpr (SUB <= 2) J2[u] = p[2 * SOLVE_THREADS];
+            J3[u] = p[3 * SOLVE_THREADS];
+            J4[u] = p[4 * SOLVE_THREADS];
+            J5[u] = p[5 * SOLVE_THREADS];
+            rr[u] = p[6 * SOLVE_THREADS];
+            if constexpr (SUB == 0) rho0[u] = p[7 * SOLVE_THREADS];
+            w[u] = p[8 * SOLVE_THREADS];
+        }
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+            const bool ok = j0 + u < ns && w[u] > 0.0;  // no row: the factor is skipped (rho' of a row is > 0)
+            double n[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) n[k] = v[k];
+            if constexpr (SUB == 0) {  // row a = 0 (sums 0 .. 5, 21) and the cost (27)
+                n[7] = v[7] + 0.5 * rho0[u];
+                const double wj = w[u] * J0[u];
+                n[0] = __builtin_fma(wj, J0[u], v[0]);
+                n[1] = __builtin_fma(wj, J1[u], v[1]);
+                n[2] = __builtin_fma(wj, J2[u], v[2]);
+                n[3] = __builtin_fma(wj, J3[u], v[3]);
+                n[4] = __builtin_fma(wj, J4[u], v[4]);
+                n[5] = __builtin_fma(wj, J5[u], v[5]);
+                n[6] = __builtin_fma(wj, rr[u], v[6]);
+            } else if constexpr (SUB == 1) {  // rows a = 1 (sums 6 .. 10, 22) and a = 5 (20, 26)
+                const double wj = w[u] * J1[u];
+                n[0] = __builtin_fma(wj, J1[u], v[0]);
+                n[1] = __builtin_fma(wj, J2[u], v[1]);
+                n[2] = __builtin_fma(wj, J3[u], v[2]);
+                n[3] = __builtin_fma(wj, J4[u], v[3]);
+                n[4] = __builtin_fma(wj, J5[u], v[4]);
+                n[5] = __builtin_fma(wj, rr[u], v[5]);
+                const double wj5 = w[u] * J5[u];
+                n[6] = __builtin_fma(wj5, J5[u], v[6]);
+                n[7] = __builtin_fma(wj5, rr[u], v[7]);
+            } else if constexpr (SUB == 2) {  // rows a = 2 (sums 11 .. 14, 23) and a = 4 (18, 19, 25)
+                const double wj = w[u] * J2[u];
+                n[0] = __builtin_fma(wj, J2[u], v[0]);
+                n[1] = __builtin_fma(wj, J3[u], v[1]);
+                n[2] = __builtin_fma(wj, J4[u], v[2]);
+                n[3] = __builtin_fma(wj, J5[u], v[3]);
+                n[4] = __builtin_fma(wj, rr[u], v[4]);
+                const double wj4 = w[u] * J4[u];
+                n[5] = __builtin_fma(wj4, J4[u], v[5]);
+                n[6] = __builtin_fma(wj4, J5[u], v[6]);
+                n[7] = __builtin_fma(wj4, rr[u], v[7]);
+            } else {  // row a = 3 (sums 15 .. 17, 24)
+                const double wj = w[u] * J3[u];
+                n[0] = __builtin_fma(wj, J3[u], v[0]);
+                n[1] = __builtin_fma(wj, J4[u], v[1]);
+                n[2] = __builtin_fma(wj, J5[u], v[2]);
+                n[3] = __builtin_fma(wj, rr[u], v[3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = ok ? n[k] : v[k];
+        }
+    }
+}
+
+#ifdef MML_SV_TIMING
+// phase clocks of eval_frame_wide, thread 0 of problem MML_SV_TIMING: rows, wait at the barrier, sums, tree; [4] passes
+__device__ unsigned long long g_svw_dbg[8];
+#define SVW_MARK(id)                                   \
+    do {                                               \
+        if (svw_dbg) {                                 \
+            const unsigned long long now_ = clock64(); \
+            g_svw_dbg[id] += now_ - svw_prev;          \
+            svw_prev = now_;                           \
+        }                                              \
+    } while (0)
+#else
+#define SVW_MARK(id)
+#endif
+// workgroup of WIDE_THREADS; s_rows: WIDE_ROW_LDS doubles, s_part: SOLVE_WAVES * 28; out[28] valid after the trailing barrier
+__device__ __forceinline__ void eval_frame_wide(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
+                                                double huber_delta, double* s_rows, double* s_part, double* out) {
+    const int vt = threadIdx.x & (SOLVE_THREADS - 1);
+    const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SOLVE_THREADS));  // (uniform in a wavefront)
+    const int lane = threadIdx.x & 63, wv = vt >> 6;
+    const int SL = (nlf + SOLVE_THREADS - 1) / SOLVE_THREADS, SP = (npf + SOLVE_THREADS - 1) / SOLVE_THREADS, NS = SL + SP;
+    const double ka = 1.0 / kLidarM;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0;
+#ifdef MML_SV_TIMING
+    const bool svw_dbg = threadIdx.x == 0 && blockIdx.x == MML_SV_TIMING;
+    unsigned long long svw_prev = clock64();
+    if (svw_dbg) g_svw_dbg[4] += 1;
+#endif
+    for (int s0 = 0; s0 < NS; s0 += WIDE_ROUND) {
+        // ---- rows: slots s0 + sub, + 4, + 8 of this round ----
+        const int sA = s0 + sub, sB = sA + WIDE_SUBS, sC = sB + WIDE_SUBS;
+        const bool hA = sA < NS, hB = sB < NS, hC = sC < NS;            // the slot exists
+        const bool lA = sA < SL, lB = sB < SL, lC = sC < SL;            // ... and is a line slot
+        const int iA = vt + SOLVE_THREADS * (lA ? sA : sA - SL), iB = vt + SOLVE_THREADS * (lB ? sB : sB - SL),
+                  iC = vt + SOLVE_THREADS * (lC ? sC : sC - SL);
+        // (all records of the round requested before the first row is formed: one exposed round trip per pass; a slot's record,
+        //  48 bytes of a line factor or 64 of a plane factor, lands in the same registers)
+        WideRec qa, qb, qc;
+        if (hA) wide_load(qa, lA, lf, min(iA, nlf - 1), pf, min(iA, npf - 1));
+        if (hB) wide_load(qb, lB, lf, min(iB, nlf - 1), pf, min(iB, npf - 1));
+        if (hC) wide_load(qc, lC, lf, min(iC, nlf - 1), pf, min(iC, npf - 1));
+        const bool inA = iA < (lA ? nlf : npf), inB = iB < (lB ? nlf : npf), inC = iC < (lC ? nlf : npf);
+        PlaneRow ra, rb, rc;
+        if (hA && hB && !lA && !lB) {  // two plane rows side by side, then the third slot
+            plane_row(wide_plane(qa), P, ka, huber_delta, ra);
+            plane_row(wide_plane(qb), P, ka, huber_delta, rb);
+            row_store(s_rows, sub, vt, ra, inA);
+            row_store(s_rows, sub + WIDE_SUBS, vt, rb, inB);
+            if (hC) {
+                plane_row(wide_plane(qc), P, ka, huber_delta, rc);  // (slots ascend: behind a plane slot there are only plane slots)
+                row_store(s_rows, sub + 2 * WIDE_SUBS, vt, rc, inC);
+            }
+        } else {
+            if (hA) {
+                if (lA)
+                    line_row(wide_line(qa), P, ka, huber_delta, ra);
+                else
+                    plane_row(wide_plane(qa), P, ka, huber_delta, ra);
+                row_store(s_rows, sub, vt, ra, inA);
+            }
+            if (hB && hC && !lB && !lC) {
+                plane_row(wide_plane(qb), P, ka, huber_delta, rb);
+                plane_row(wide_plane(qc), P, ka, huber_delta, rc);
+                row_store(s_rows, sub + WIDE_SUBS, vt, rb, inB);
+                row_store(s_rows, sub + 2 * WIDE_SUBS, vt, rc, inC);
+            } else {
+                if (hB) {
+                    if (lB)
+                        line_row(wide_line(qb), P, ka, huber_delta, rb);
+                    else
+                        plane_row(wide_plane(qb), P, ka, huber_delta, rb);
+                    row_store(s_rows, sub + WIDE_SUBS, vt, rb, inB);
+                }
+                if (hC) {
+                    if (lC)
+                        line_row(wide_line(qc), P, ka, huber_delta, rc);
+                    else
+                        plane_row(wide_plane(qc), P, ka, huber_delta, rc);
+                    row_store(s_rows, sub + 2 * WIDE_SUBS, vt, rc, inC);
+                }
+            }
+        }
+        SVW_MARK(0);
+        __syncthreads();
+        SVW_MARK(1);
+        // ---- sums: this sub-thread's chains over the round's rows, in slot order ----
+        const int ns = min(WIDE_ROUND, NS - s0);
+        if (sub == 0)
+            wide_sums<0>(s_rows, vt, ns, v);
+        else if (sub == 1)
+            wide_sums<1>(s_rows, vt, ns, v);
+        else if (sub == 2)
+            wide_sums<2>(s_rows, vt, ns, v);
+        else
+            wide_sums<3>(s_rows, vt, ns, v);
+        SVW_MARK(2);
+        if (s0 + WIDE_ROUND < NS) __syncthreads();  // (the next round overwrites the rows)
+    }
+    // ---- tree: block_reduce28's, eight values a lane (the halving butterfly for xor 32, 16, 8; then the one value left); the
+    //      partner's value by lane_xor_f64, not through the LDS crossbar ----
+    int idx = 0;
+    {
+        const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double keep = u32 ? v[j + 4] : v[j], send = u32 ? v[j] : v[j + 4];
+            v[j] = keep + lane_xor_f64<32>(send, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double keep = u16 ? v[j + 2] : v[j], send = u16 ? v[j] : v[j + 2];
+            v[j] = keep + lane_xor_f64<16>(send, lane);
+        }
+        {
+            const double keep = u8 ? v[1] : v[0], send = u8 ? v[0] : v[1];
+            v[0] = keep + lane_xor_f64<8>(send, lane);
+        }
+        idx = (u32 ? 4 : 0) + (u16 ? 2 : 0) + (u8 ? 1 : 0);
+    }
+    double tot = v[0] + lane_xor_f64<4>(v[0], lane);
+    tot = tot + lane_xor_f64<2>(tot, lane);
+    tot = tot + lane_xor_f64<1>(tot, lane);
+    // which of the 28 sums value idx of this sub-thread is (one byte each; 0xff: none)
+    const unsigned long long kmap = sub == 0 ? 0x1B15050403020100ull
+                                             : (sub == 1 ? 0x1A14160A09080706ull : (sub == 2 ? 0x191312170E0D0C0Bull : 0xFFFFFFFF1811100Full));
+    const int k = (int)((kmap >> (8 * idx)) & 0xffull);
+    if (!(lane & 7) && k < 28) s_part[wv * 28 + k] = tot;
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double r = s_part[threadIdx.x];
+        r += s_part[28 + threadIdx.x];
+        out[threadIdx.x] = r;
+    }
+    __syncthreads();
+    SVW_MARK(3);
 }
 
 __host__ __device__ __forceinline__ int tri(int a, int b) {  // index into 21-entry upper triangle, a <= b

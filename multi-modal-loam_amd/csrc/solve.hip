@@ -229,6 +229,13 @@ extern "C" int mml_debug_sv_timing(unsigned long long* out, int reset) {
     }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sv_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
+extern "C" int mml_debug_svw_timing(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_svw_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_svw_dbg), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
 #else
 #define SV_MARK(id)
 #endif
@@ -246,8 +253,8 @@ extern "C" int mml_debug_sv_timing(unsigned long long* out, int reset) {
 #endif
 // (forced inline, as tr_propose and tr_decide_wave: with two instantiations of k_solve calling them the compiler made them real
 //  functions -- a call inside the iteration loop of a kernel with 256 live registers: the batch solve 0.251 -> 0.28 ms per 1024 problems)
-__device__ __forceinline__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters) {
-    const int lane = threadIdx.x;  // 0..63
+// (lane: threadIdx.x of the first wavefront; k_solve_wide hands over an opaque copy per iteration, see there)
+__device__ __forceinline__ void tr_propose_w1_wave(TRState& S, double* w, int max_iters, const int lane = threadIdx.x) {
     double* T = w;         // 36 terms of a quadratic form
     double* A = w + 36;    // 36: the damped matrix, then its Cholesky factor (lower triangle)
     double* bv = w + 72;   // 6
@@ -496,8 +503,7 @@ constexpr int TRW_DOUBLES = 36 * MAXW + 3 * 64 + 8;
         asm volatile("" ::: "memory");   \
     } while (0)
 // lane l < nsum returns t[64 l + 0] + t[64 l + 1] + ... + t[64 l + m - 1], added in that order
-__device__ __forceinline__ double ordered_sums(const double* t, int m, int nsum) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ double ordered_sums(const double* t, int m, int nsum, const int lane = threadIdx.x) {
     const double* p = t + 64 * (lane < nsum ? lane : 0);
     double s = 0;
     int k = 0;
@@ -700,15 +706,14 @@ __device__ void tr_propose_wave(TRState& S, double* w, int W, int max_iters) {
     }
 }
 
-__device__ __forceinline__ void tr_decide_wave(TRState& S, double* w, int W, int fixed) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void tr_decide_wave(TRState& S, double* w, int W, int fixed, const int lane = threadIdx.x) {
     const int n = 6 * W;
     double* U = w + 36 * MAXW;
     double* fl = U + 3 * 64;
     WSYNC();
     if (lane < W) U[lane] = S.recc[28 * lane + 27];
     WSYNC();
-    const double cand_l = ordered_sums(U, W, 1);
+    const double cand_l = ordered_sums(U, W, 1, lane);
     if (lane == 0) fl[4] = cand_l;
     WSYNC();
     const double cand = fl[4], cost = S.cost;
@@ -740,7 +745,7 @@ __device__ __forceinline__ void tr_decide_wave(TRState& S, double* w, int W, int
         }
         for (int i = lane; i < 28 * W; i += 64) S.rec[i] = S.recc[i];
         WSYNC();
-        const double xn = ordered_sums(U, n, 1);
+        const double xn = ordered_sums(U, n, 1, lane);
         double gm = gabs;  // a maximum does not depend on the order
         for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
         if (lane == 0) {
@@ -894,6 +899,120 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         o[3] = S.cost;
         o[4] = S.termination;
         o[5] = 0;  // (finished: see k_window_export)
+    }
+}
+
+// k_solve<true> for one-frame problems with one-row plane factors (the live path's only setting), on all four SIMDs of the problem's
+// CU: 4 x 128 threads, the factor passes through eval_frame_wide (lidar_eval.h: rows formed by 512 threads, sums and reduction tree of
+// the 128-thread pass -- bit-identical), the trust-region code between the passes on the first wavefront as in k_solve.  123 KB of
+// LDS for the rows of a round: one workgroup per CU, which is what these launches (at most one problem per CU) have anyway.
+__global__ __launch_bounds__(WIDE_THREADS) void k_solve_wide(SolveParams P) {
+    __shared__ TRState S;
+    __shared__ double s_part[SOLVE_WAVES * 28];
+    __shared__ double s_work[92];
+    __shared__ double s_wd[TRW_DOUBLES];
+    __shared__ double s_rows[WIDE_ROW_LDS];
+    const int prob = blockIdx.x;
+    const int b0 = P.first + prob;
+    const int tid = threadIdx.x;
+#ifdef MML_SV_TIMING
+    const unsigned long long svk_t0 = clock64();
+    const bool sv_dbg = tid == 0 && prob == MML_SV_TIMING;
+    unsigned long long sv_prev = svk_t0;
+#endif
+    if (tid < 6) S.x[tid] = S.x_init[tid] = P.x_in ? P.x_in[(size_t)prob * 6 + tid] : P.x[(size_t)b0 * 6 + tid];
+    __syncthreads();
+    const MmlLineFactor* lf = P.lf + (size_t)b0 * P.MF;
+    const MmlPlaneFactor* pf = P.pf + (size_t)b0 * P.MF;
+    const int nlf = P.ft_n[b0], npf = P.ft_n[P.B + b0];
+    {
+        Pose pose;
+        make_pose(S.x, P.Tbl, pose);
+        eval_frame_wide(lf, nlf, pf, npf, pose, P.huber, s_rows, s_part, S.rec);
+    }
+    if (tid == 0) {
+        S.cost = 0;
+        double xn = 0;
+        S.cost += S.rec[27];
+        for (int i = 0; i < 6; ++i) {
+            S.scale[i] = 1.0 / (1.0 + sqrt(Hget(S.rec, i, i)));
+            xn += S.x[i] * S.x[i];
+        }
+        S.x_norm = sqrt(xn);
+        S.radius = 1e4;
+        S.mu = 1e-8;
+        S.reuse = 0;
+        S.num_invalid = 0;
+        S.iter = 0;
+        S.successful = 0;
+        S.termination = 0;
+        S.go = 1;
+        S.alpha = 0;
+        S.dogleg_norm = 0;
+        P.summ[8 * prob + 2] = S.cost;  // initial cost
+        if (!P.fixed) {
+            double gm = 0;
+            for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(S.rec[21 + i]));
+            if (gm <= 1e-10) {
+                S.termination = 1;
+                S.go = 0;
+            }
+        }
+    }
+    __syncthreads();
+    int go = S.go;
+    __syncthreads();
+    while (go) {
+        // (the lane number is made opaque to the compiler in every iteration: with it a known function of threadIdx.x the dozens of
+        //  LDS addresses of the trust-region code are formed once in front of the loop and held -- across the factor pass, which needs
+        //  the 256 registers two wavefronts per SIMD leave: they were spilled, and every reload is a memory round trip on the ONE
+        //  wavefront everybody waits for: +35 k cycles per solve)
+        int lane_op = tid;
+        asm volatile("" : "+v"(lane_op));
+        SV_MARK(0);  // (everything outside the two trust-region phases: set-up, factor passes, the loop's barriers)
+        if (tid < 64) tr_propose_w1_wave(S, s_work, P.max_iters, lane_op);
+        __syncthreads();
+        SV_MARK(1);  // trust-region proposal (first wavefront) + barrier
+        go = S.go;
+        const int ev = S.evaluate;
+        if (!go) break;
+        if (ev) {
+            Pose pose;
+            make_pose(S.xc, P.Tbl, pose);
+            eval_frame_wide(lf, nlf, pf, npf, pose, P.huber, s_rows, s_part, S.recc);
+            asm volatile("" : "+v"(lane_op));
+            SV_MARK(0);
+            if (tid < 64) tr_decide_wave(S, s_wd, 1, P.fixed, lane_op);
+        }
+        __syncthreads();
+        SV_MARK(4);  // accept / reject (first wavefront) + barrier
+        go = S.go;
+        if (P.trace && tid < 6) P.trace[((size_t)prob * P.max_iters + (S.iter - 1)) * 6 + tid] = S.x[tid];
+        __syncthreads();
+    }
+    if (tid < 6) P.x[(size_t)b0 * 6 + tid] = S.x[tid];
+    if (P.result) {
+        double* r = P.result + (size_t)prob * MML_SOLVE_RESULT;
+        if (tid < 6) r[tid] = S.x[tid];
+        if (tid == 6) r[6] = (double)nlf;
+        if (tid == 7) r[7] = (double)npf;
+        if (tid >= 8 && tid < 24) r[tid] = P.stats ? P.stats[16 * (size_t)b0 + (tid - 8)] : 0.0;
+    }
+    if (P.trace && tid < 6)
+        for (int it = S.iter; it < P.max_iters; ++it) P.trace[((size_t)prob * P.max_iters + it) * 6 + tid] = S.x[tid];
+    if (tid == 0) {
+        double* o = P.summ + 8 * prob;
+        o[0] = S.iter;
+        o[1] = S.successful;
+        o[3] = S.cost;
+        o[4] = S.termination;
+        o[5] = 0;  // (finished: see k_window_export)
+#ifdef MML_SV_TIMING
+        if (prob == MML_SV_TIMING) {
+            g_svw_dbg[5] += clock64() - svk_t0;
+            g_svw_dbg[6] += 1;
+        }
+#endif
     }
 }
 
@@ -1280,7 +1399,11 @@ int mml_launch_solve(mml_ctx* ctx, int first, int count, int window, const doubl
     const bool small = count / window <= n_cus;  // at most one problem per CU
     MML_REQUIRE((!d_x_in && !d_result) || small, MML_ERR_INVALID, "packed start poses / result records: small launches only");
     P.pairs = pairs_on;
-    if (small)
+    // one-frame problems with one-row plane factors (the live path): the 512-thread form ($MML_SOLVE_WIDE=0: measurement switch)
+    static const bool wide_on = !(getenv("MML_SOLVE_WIDE") && atoi(getenv("MML_SOLVE_WIDE")) == 0);
+    if (small && wide_on && window == 1 && opts.plan_weight_tan == 0.0)
+        hipLaunchKernelGGL(k_solve_wide, dim3(count), dim3(WIDE_THREADS), 0, MML_STREAM(ctx), P);
+    else if (small)
         hipLaunchKernelGGL(k_solve<true>, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);
     else
         hipLaunchKernelGGL(k_solve<false>, dim3(count / window), dim3(SOLVE_THREADS), 0, MML_STREAM(ctx), P);

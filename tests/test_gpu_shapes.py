@@ -89,6 +89,13 @@ def test_bench_launch_shapes_replicas_match_oracle(M, O, synth, scene):
             d1 = c.slot_digest(int(s), 1)[0]
             assert np.array_equal(d1, dg[s]), (int(s), int(assign[s]), [PIECES[w] for w in range(10) if d1[w] != dg[s][w]])
             assert np.array_equal(xs[0], x[s]), (int(s), xs[0] - x[s])
+        # (4) launches of at most one problem per CU (k_solve_wide: the factor pass on 4 x 128 threads, the sums and the reduction
+        #     tree of the 128-thread pass): 200 and 17 slots at once, same bits as the 4096-slot launches
+        for s0, n in ((1000, 200), (B - 17, 17)):
+            xs = c.step(s0, n, dR[s0:s0 + n], dt[s0:s0 + n], np.eye(4), 25.0, 10, x0[s0:s0 + n])
+            dn = c.slot_digest(s0, n)
+            assert np.array_equal(dn, dg[s0:s0 + n]), (s0, n, np.argwhere(dn != dg[s0:s0 + n])[:5])
+            assert np.array_equal(xs, x[s0:s0 + n]), (s0, n)
         print("launch shapes: %d slots, %d distinct scans, 0 mismatching replicas, %.1f s" % (B, ND, time.time() - t0))
     finally:
         c.close()
