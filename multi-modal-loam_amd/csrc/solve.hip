@@ -441,6 +441,229 @@ __device__ __forceinline__ void tr_propose_w1_wave(TRState& S, double* w, int ma
 }
 #undef WSYNC
 
+// tr_propose for W = 1 once more, for k_solve_wide: the scalar algorithm of tr_propose on REGISTER copies of the state, every lane of
+// the first wavefront computing the same values (lane 0 stores them).  tr_propose_w1_wave spreads the independent entries over lanes
+// and exchanges them through LDS: ~120 dependent LDS round trips of ~130 cycles per call -- 15.7 k cycles, 45 % of the live path's
+// solve.  With no exchange at all the ~1 700 double-precision instructions of the scalar form run back to back out of registers.
+// Every value comes from the expression tr_propose (and tr_propose_w1_wave) forms it with, every sum is added in their order.
+// (w: 36 doubles of LDS: the matrix S H S is formed once, parked there by lane 0 and read back -- one broadcast round trip -- where the
+//  damped system and the second quadratic form need it, instead of being held in 72 registers across the Cholesky factorisation)
+#define RSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__device__ __forceinline__ void tr_propose_w1_regs(TRState& S, double* w, int max_iters, const int lane) {
+    const int iter = S.iter, num_invalid = S.num_invalid, reuse = S.reuse;
+    const double radius = S.radius;
+    if (lane == 0) S.evaluate = 0;
+    if (iter >= max_iters || radius < 1e-32) {
+        if (lane == 0) S.go = 0;
+        return;
+    }
+    if (lane == 0) S.iter = iter + 1;
+    double rec[28], scale[6];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) rec[k] = S.rec[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) scale[k] = S.scale[k];
+    double diag[6], grad[6], gn[6], alpha = S.alpha, mu = S.mu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // (what a call with reuse = 1 finds from the call before)
+        diag[k] = S.diag[k];
+        grad[k] = S.grad[k];
+        gn[k] = S.gn[k];
+    }
+    // entry (a, b) of S H S as quad_form and the matrix build compute it
+    double M[36];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) M[6 * a + b] = Hget(rec, a, b) * scale[a] * scale[b];
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) w[k] = M[k];
+    }
+    bool solve_ok = true;
+    int reuse_out = reuse;
+    if (!reuse) {
+        reuse_out = 1;
+        double sg[6], gg = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double d = M[7 * i];  // (= Hget(rec, i, i) * scale[i] * scale[i])
+            d = fmin(fmax(d, 1e-6), 1e32);
+            diag[i] = sqrt(d);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            grad[i] = rec[21 + i] * scale[i] / diag[i];
+            sg[i] = grad[i] / diag[i];
+            gg += grad[i] * grad[i];
+        }
+        double q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) q += sg[a] * M[6 * a + b] * sg[b];
+        alpha = gg / q;
+        solve_ok = false;
+        while (mu < 1.0) {
+            double A[36], bv[6];
+            RSYNC();
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = 0; b <= a; ++b) A[6 * a + b] = w[6 * a + b];  // (chol6 reads the lower triangle only)
+                A[7 * a] += mu * diag[a] * diag[a];
+                bv[a] = rec[21 + a] * scale[a];
+            }
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {  // chol6, the lower triangle
+                double d = A[7 * j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+                ok = ok && d > 0.0;
+                d = sqrt(d);
+                A[7 * j] = d;
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) {
+                    double t = A[i * 6 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) t -= A[i * 6 + k] * A[j * 6 + k];
+                    A[i * 6 + j] = t / d;
+                }
+            }
+            if (ok) {  // (a pivot that is not positive ends chol6 there: nothing behind it is used)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double t = bv[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= A[i * 6 + k] * bv[k];
+                    bv[i] = t / A[i * 6 + i];
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double t = bv[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) t -= A[k * 6 + i] * bv[k];
+                    bv[i] = t / A[i * 6 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ok = ok && isfinite(bv[i]);
+            }
+            if (!ok) {
+                mu *= 10.0;
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gn[i] = bv[i] * -diag[i];
+            solve_ok = true;
+            break;
+        }
+    }
+    double mu_out = mu;
+    bool step_valid = solve_ok;
+    double st[6] = {0, 0, 0, 0, 0, 0}, dogleg_norm = 0, model_change = 0;
+    if (solve_ok) {
+        double gradient_norm = 0, gn_norm = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            gradient_norm += grad[i] * grad[i];
+            gn_norm += gn[i] * gn[i];
+        }
+        gradient_norm = sqrt(gradient_norm);
+        gn_norm = sqrt(gn_norm);
+        if (gn_norm <= radius) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st[i] = gn[i];
+            dogleg_norm = gn_norm;
+        } else if (gradient_norm * alpha >= radius) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st[i] = -(radius / gradient_norm) * grad[i];
+            dogleg_norm = radius;
+        } else {
+            double gdot = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gdot += grad[i] * gn[i];
+            const double b_dot_a = -alpha * gdot;
+            const double a_sq = (alpha * gradient_norm) * (alpha * gradient_norm);
+            const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+            const double c = b_dot_a - a_sq;
+            const double d = sqrt(c * c + bma_sq * (radius * radius - a_sq));
+            const double beta = (c <= 0) ? (d - c) / bma_sq : (radius * radius - a_sq) / (d + c);
+            double sn = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                st[i] = (-alpha * (1.0 - beta)) * grad[i] + beta * gn[i];
+                sn += st[i] * st[i];
+            }
+            dogleg_norm = sqrt(sn);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st[i] /= diag[i];
+        double sgd = 0, q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sgd += st[i] * rec[21 + i] * scale[i];
+        RSYNC();
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) q += st[a] * w[6 * a + b] * st[b];
+        model_change = -(sgd + 0.5 * q);
+        step_valid = model_change > 0.0;
+    }
+    if (lane == 0) {
+        if (!reuse) {
+            S.alpha = alpha;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                S.diag[i] = diag[i];
+                S.grad[i] = grad[i];
+                if (solve_ok) S.gn[i] = gn[i];
+            }
+        }
+        if (solve_ok) {
+            S.dogleg_norm = dogleg_norm;
+            S.model_change = model_change;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) S.step[i] = st[i];
+        }
+    }
+    if (!step_valid) {
+        if (lane == 0) {
+            if (num_invalid + 1 >= 5) {  // HandleInvalidStep: FAILURE, parameters as on entry (see tr_propose)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) S.x[i] = S.x_init[i];
+                S.termination = 4;
+                S.go = 0;
+                S.mu = mu_out;
+                S.reuse = reuse_out;
+            } else {
+                S.mu = mu_out * 10.0;
+                S.reuse = 0;
+            }
+            S.num_invalid = num_invalid + 1;
+        }
+        return;  // go stays 1 unless failed, evaluate 0: next round proposes again
+    }
+    if (lane == 0) {
+        // (the small integers below formed HERE: left to itself the compiler forms them in front of the solve's loop, runs out of
+        //  registers for them across the factor pass and reloads them from scratch memory -- a memory round trip at this point)
+        int zero = 0, one = 1;
+        asm volatile("" : "+v"(zero), "+v"(one));
+        S.mu = mu_out;
+        S.reuse = reuse_out;
+        S.num_invalid = zero;
+        double sn = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double delta = st[i] * scale[i];
+            S.xc[i] = S.x[i] + delta;
+            sn += delta * delta;
+        }
+        S.step_norm = sqrt(sn);
+        S.evaluate = one;
+    }
+}
+
 __host__ __device__ void tr_decide(TRState& S, int W, int fixed) {
     const int n = 6 * W;
     double cand = 0;
@@ -970,7 +1193,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_wide(SolveParams P) {
         int lane_op = tid;
         asm volatile("" : "+v"(lane_op));
         SV_MARK(0);  // (everything outside the two trust-region phases: set-up, factor passes, the loop's barriers)
+#ifdef MML_WIDE_PROPOSE_WAVE
         if (tid < 64) tr_propose_w1_wave(S, s_work, P.max_iters, lane_op);
+#else
+        if (tid < 64) tr_propose_w1_regs(S, s_work, P.max_iters, lane_op);
+#endif
         __syncthreads();
         SV_MARK(1);  // trust-region proposal (first wavefront) + barrier
         go = S.go;
