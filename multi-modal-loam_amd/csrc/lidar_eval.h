@@ -346,12 +346,62 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int o) {
     const unsigned lo = __shfl_xor((unsigned)__double2loint(v), o), hi = __shfl_xor((unsigned)__double2hiint(v), o);
     return __hiloint2double((int)hi, (int)lo);
 }
+// value of lane (l ^ O) without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap (halves of the wavefront, rows of
+// 16 lanes) and DPP moves inside a row (xor 8 = half-mirror o mirror, xor 4 = quad-reverse o half-mirror, xor 2 / 1 = quad_perm).
+// A ds_bpermute round trip is ~300 cycles and block_reduce28's tree has six of them one after the other; these are a few VALU
+// instructions each.
+template <int O>
+__device__ __forceinline__ unsigned lane_xor_u32(unsigned x, int lane) {
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0]: both halves = the lower, r[1]: = the upper
+        return lane < 32 ? r[1] : r[0];
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0]: odd rows = the even row below, r[1]: even rows = the odd row above
+        return (lane & 16) ? r[0] : r[1];
+    } else if constexpr (O == 8) {
+        const int m = __builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false);        // row_mirror: i -> 15 - i
+        return (unsigned)__builtin_amdgcn_update_dpp(0, m, 0x141, 0xf, 0xf, false);          // row_half_mirror: -> 8 (i / 8) + 7 - i % 8
+    } else if constexpr (O == 4) {
+        const int m = __builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(0, m, 0x1B, 0xf, 0xf, false);           // quad_perm [3, 2, 1, 0]
+    } else if constexpr (O == 2) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
+    } else {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+    }
+}
+template <int O>
+__device__ __forceinline__ double lane_xor_f64(double v, int lane) {
+    const unsigned lo = lane_xor_u32<O>((unsigned)__double2loint(v), lane), hi = lane_xor_u32<O>((unsigned)__double2hiint(v), lane);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+#ifdef MML_REDUCE_DPP
+template <int C, int O>
+__device__ __forceinline__ void halve_step(double* v, int lane, int& idx) {
+    const bool up = (lane & O) != 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const double keep = up ? v[j + C] : v[j], send = up ? v[j] : v[j + C];
+        v[j] = keep + lane_xor_f64<O>(send, lane);
+    }
+    idx += up ? C : 0;
+}
+#endif
 __device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, double* out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double v[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) v[k] = k < 28 ? acc[k] : 0.0;
     int idx = 0;  // which of the 32 sums this lane ends up holding
+#ifdef MML_REDUCE_DPP
+    halve_step<16, 32>(v, lane, idx);
+    halve_step<8, 16>(v, lane, idx);
+    halve_step<4, 8>(v, lane, idx);
+    halve_step<2, 4>(v, lane, idx);
+    halve_step<1, 2>(v, lane, idx);
+    const double tot = v[0] + lane_xor_f64<1>(v[0], lane);
+#else
 #pragma unroll
     for (int c = 16, o = 32; c >= 1; c >>= 1, o >>= 1) {
         const bool up = (lane & o) != 0;
@@ -363,6 +413,7 @@ __device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, d
         idx += up ? c : 0;
     }
     const double tot = v[0] + shfl_xor_f64(v[0], 1);
+#endif
     if (!(lane & 1) && idx < 28) s_part[wave * 28 + idx] = tot;
     __syncthreads();
     if (threadIdx.x < 28) {
@@ -382,11 +433,11 @@ __device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, d
 //          twelve -- line_row / plane_row: the operations of eval_frame's loop bodies in their order -- two plane rows side by side
 //          where it can, and leaves them in LDS (9 doubles a row).
 //   sums:  every one of the 28 sums of virtual thread vt is its own chain of fma(w J_a, J_b, acc) over the slots in order; the
-//          chains are dealt to the four sub-threads by Jacobian row (a = 0 + cost | a = 1, 5 | a = 2, 4 | a = 3: 10, 10, 10, 5
-//          instructions a slot), each walks the round's rows in slot order: every sum sees the same operands in the same order as
-//          acc[k] of thread vt in eval_frame.
+//          chains are dealt to TWO of the four sub-threads by Jacobian row (wide_sums: a = 0, 3, 5 + cost | a = 1, 2, 4: 14 chains
+//          each), each walks the round's rows in slot order: every sum sees the same operands in the same order as acc[k] of thread
+//          vt in eval_frame.
 //   tree:  the 128 partial sums of a value meet in block_reduce28's order (xor 32, 16, 8, 4, 2, 1 inside the wavefront, then
-//          wavefront 0 + wavefront 1), eight values a lane instead of 28.
+//          wavefront 0 + wavefront 1), sixteen values a lane instead of 32, the partner's value by v_permlane*_swap / DPP.
 // The results are bit-identical to eval_frame + block_reduce28 (tests/test_gpu_shapes.py (3): slots solved alone and in launches of
 // <= 256 against the 4096-slot launches).
 constexpr int WIDE_SUBS = 4;
@@ -394,6 +445,7 @@ constexpr int WIDE_THREADS = WIDE_SUBS * SOLVE_THREADS;
 constexpr int WIDE_ROUND = 3 * WIDE_SUBS;  // slots (rows per virtual thread) per round
 constexpr int ROW_DOUBLES = 9;             // J[6], r, rho0, rho1 (-1: no row)
 constexpr int WIDE_ROW_LDS = WIDE_ROUND * ROW_DOUBLES * SOLVE_THREADS;  // doubles
+constexpr int WIDE_SAVE_LDS = 14 * 2 * SOLVE_THREADS;                   // doubles: the sums between the rounds of a long scan
 static_assert(SOLVE_WAVES == 2, "eval_frame_wide restates block_reduce28 for two wavefronts");
 
 __device__ __forceinline__ void line_row(const MmlLineFactor& f, const Pose& P, double ka, double huber_delta, PlaneRow& o) {
@@ -495,50 +547,24 @@ __device__ __forceinline__ void row_store(double* s_rows, int j, int vt, const P
     p[8 * SOLVE_THREADS] = (o.valid && in_range) ? o.rho1 : -1.0;  // rho' > 0 for every row (huber: >= DBL_MIN); -1: the factor is skipped
 }
 
-// value of lane (l ^ O) without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap (halves of the wavefront, rows of
-// 16 lanes) and DPP moves inside a row (xor 8 = half-mirror o mirror, xor 4 = quad-reverse o half-mirror, xor 2 / 1 = quad_perm).
-// A ds_bpermute round trip is ~300 cycles and block_reduce28's tree has six of them one after the other; these are a few VALU
-// instructions each.
-template <int O>
-__device__ __forceinline__ unsigned lane_xor_u32(unsigned x, int lane) {
-    if constexpr (O == 32) {
-        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0]: both halves = the lower, r[1]: = the upper
-        return lane < 32 ? r[1] : r[0];
-    } else if constexpr (O == 16) {
-        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0]: odd rows = the even row below, r[1]: even rows = the odd row above
-        return (lane & 16) ? r[0] : r[1];
-    } else if constexpr (O == 8) {
-        const int m = __builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false);        // row_mirror: i -> 15 - i
-        return (unsigned)__builtin_amdgcn_update_dpp(0, m, 0x141, 0xf, 0xf, false);          // row_half_mirror: -> 8 (i / 8) + 7 - i % 8
-    } else if constexpr (O == 4) {
-        const int m = __builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false);
-        return (unsigned)__builtin_amdgcn_update_dpp(0, m, 0x1B, 0xf, 0xf, false);           // quad_perm [3, 2, 1, 0]
-    } else if constexpr (O == 2) {
-        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
-    } else {
-        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
-    }
-}
-template <int O>
-__device__ __forceinline__ double lane_xor_f64(double v, int lane) {
-    const unsigned lo = lane_xor_u32<O>((unsigned)__double2loint(v), lane), hi = lane_xor_u32<O>((unsigned)__double2hiint(v), lane);
-    return __hiloint2double((int)hi, (int)lo);
-}
-
-// the chains of sub-thread SUB over the ns rows of a round, in slot order: six slots a turn, their values requested together (an
-// LDS round trip is ~300 cycles: two of them per pass instead of two per slot), straight-line code (a skipped factor leaves the
-// sums as they were by a select, not a branch)
+// the chains of summing sub-thread SUB (0 / 1) over the ns rows of a round, in slot order: five slots a turn, their values requested
+// together (an LDS round trip is ~130 - 300 cycles: two per pass instead of two per slot), straight-line code (a skipped factor
+// leaves the sums as they were by a select, not a branch).  TWO of the four sub-threads sum, 14 chains each: the phase is bound by
+// the LDS reads (every summing wavefront reads most of a row's nine values), and with four summing sub-threads of 8 / 8 / 8 / 4
+// chains the CU read 27 values per row and slot instead of 16 (2 980 cycles per pass against the 1 150 the reads of two take).
+//   SUB 0: Jacobian rows a = 0 (sums 0 .. 5, 21), a = 3 (15 .. 17, 24), a = 5 (20, 26) and the cost (27)
+//   SUB 1: rows a = 1 (6 .. 10, 22), a = 2 (11 .. 14, 23), a = 4 (18, 19, 25)
 template <int SUB>
 __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, double* v) {
-    constexpr int T = 5;
+    constexpr int T = 3;
     for (int j0 = 0; j0 < ns; j0 += T) {
         double J0[T], J1[T], J2[T], J3[T], J4[T], J5[T], rr[T], rho0[T], w[T];
 #pragma unroll
         for (int u = 0; u < T; ++u) {
             const double* p = s_rows + (size_t)min(j0 + u, ns - 1) * ROW_DOUBLES * SOLVE_THREADS + vt;
             if constexpr (SUB == 0) J0[u] = p[0];
-            if constexpr (SUB <= 1) J1[u] = p[SOLVE_THREADS];
-            if constexpr (SUB <= 2) J2[u] = p[2 * SOLVE_THREADS];
+            J1[u] = p[SOLVE_THREADS];
+            J2[u] = p[2 * SOLVE_THREADS];
             J3[u] = p[3 * SOLVE_THREADS];
             J4[u] = p[4 * SOLVE_THREADS];
             J5[u] = p[5 * SOLVE_THREADS];
@@ -549,11 +575,8 @@ __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, 
 #pragma unroll
         for (int u = 0; u < T; ++u) {
             const bool ok = j0 + u < ns && w[u] > 0.0;  // no row: the factor is skipped (rho' of a row is > 0)
-            double n[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) n[k] = v[k];
-            if constexpr (SUB == 0) {  // row a = 0 (sums 0 .. 5, 21) and the cost (27)
-                n[7] = v[7] + 0.5 * rho0[u];
+            double n[14];
+            if constexpr (SUB == 0) {
                 const double wj = w[u] * J0[u];
                 n[0] = __builtin_fma(wj, J0[u], v[0]);
                 n[1] = __builtin_fma(wj, J1[u], v[1]);
@@ -562,7 +585,16 @@ __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, 
                 n[4] = __builtin_fma(wj, J4[u], v[4]);
                 n[5] = __builtin_fma(wj, J5[u], v[5]);
                 n[6] = __builtin_fma(wj, rr[u], v[6]);
-            } else if constexpr (SUB == 1) {  // rows a = 1 (sums 6 .. 10, 22) and a = 5 (20, 26)
+                const double wj3 = w[u] * J3[u];
+                n[7] = __builtin_fma(wj3, J3[u], v[7]);
+                n[8] = __builtin_fma(wj3, J4[u], v[8]);
+                n[9] = __builtin_fma(wj3, J5[u], v[9]);
+                n[10] = __builtin_fma(wj3, rr[u], v[10]);
+                const double wj5 = w[u] * J5[u];
+                n[11] = __builtin_fma(wj5, J5[u], v[11]);
+                n[12] = __builtin_fma(wj5, rr[u], v[12]);
+                n[13] = v[13] + 0.5 * rho0[u];
+            } else {
                 const double wj = w[u] * J1[u];
                 n[0] = __builtin_fma(wj, J1[u], v[0]);
                 n[1] = __builtin_fma(wj, J2[u], v[1]);
@@ -570,29 +602,26 @@ __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, 
                 n[3] = __builtin_fma(wj, J4[u], v[3]);
                 n[4] = __builtin_fma(wj, J5[u], v[4]);
                 n[5] = __builtin_fma(wj, rr[u], v[5]);
-                const double wj5 = w[u] * J5[u];
-                n[6] = __builtin_fma(wj5, J5[u], v[6]);
-                n[7] = __builtin_fma(wj5, rr[u], v[7]);
-            } else if constexpr (SUB == 2) {  // rows a = 2 (sums 11 .. 14, 23) and a = 4 (18, 19, 25)
-                const double wj = w[u] * J2[u];
-                n[0] = __builtin_fma(wj, J2[u], v[0]);
-                n[1] = __builtin_fma(wj, J3[u], v[1]);
-                n[2] = __builtin_fma(wj, J4[u], v[2]);
-                n[3] = __builtin_fma(wj, J5[u], v[3]);
-                n[4] = __builtin_fma(wj, rr[u], v[4]);
+                const double wj2 = w[u] * J2[u];
+                n[6] = __builtin_fma(wj2, J2[u], v[6]);
+                n[7] = __builtin_fma(wj2, J3[u], v[7]);
+                n[8] = __builtin_fma(wj2, J4[u], v[8]);
+                n[9] = __builtin_fma(wj2, J5[u], v[9]);
+                n[10] = __builtin_fma(wj2, rr[u], v[10]);
                 const double wj4 = w[u] * J4[u];
-                n[5] = __builtin_fma(wj4, J4[u], v[5]);
-                n[6] = __builtin_fma(wj4, J5[u], v[6]);
-                n[7] = __builtin_fma(wj4, rr[u], v[7]);
-            } else {  // row a = 3 (sums 15 .. 17, 24)
-                const double wj = w[u] * J3[u];
-                n[0] = __builtin_fma(wj, J3[u], v[0]);
-                n[1] = __builtin_fma(wj, J4[u], v[1]);
-                n[2] = __builtin_fma(wj, J5[u], v[2]);
-                n[3] = __builtin_fma(wj, rr[u], v[3]);
+                n[11] = __builtin_fma(wj4, J4[u], v[11]);
+                n[12] = __builtin_fma(wj4, J5[u], v[12]);
+                n[13] = __builtin_fma(wj4, rr[u], v[13]);
             }
+            // (a slot whose 64 factors of this wavefront all have a row -- nearly every one -- takes the sums as they come: the 28
+            //  selects per slot of the general case were half of this phase's instructions)
+            if (__all(ok)) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = ok ? n[k] : v[k];
+                for (int k = 0; k < 14; ++k) v[k] = n[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 14; ++k) v[k] = ok ? n[k] : v[k];
+            }
         }
     }
 }
@@ -611,17 +640,19 @@ __device__ unsigned long long g_svw_dbg[8];
 #else
 #define SVW_MARK(id)
 #endif
-// workgroup of WIDE_THREADS; s_rows: WIDE_ROW_LDS doubles, s_part: SOLVE_WAVES * 28; out[28] valid after the trailing barrier
+// workgroup of WIDE_THREADS; s_rows: WIDE_ROW_LDS doubles, s_vsave: WIDE_SAVE_LDS, s_part: SOLVE_WAVES * 28; out[28] is valid for the FIRST WAVEFRONT on return
 __device__ __forceinline__ void eval_frame_wide(const MmlLineFactor* lf, int nlf, const MmlPlaneFactor* pf, int npf, const Pose& P,
-                                                double huber_delta, double* s_rows, double* s_part, double* out) {
-    const int vt = threadIdx.x & (SOLVE_THREADS - 1);
-    const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SOLVE_THREADS));  // (uniform in a wavefront)
-    const int lane = threadIdx.x & 63, wv = vt >> 6;
+                                                double huber_delta, double* s_rows, double* s_vsave, double* s_part, double* out) {
+    // (the thread number is made opaque to the compiler at every call: as a known function of threadIdx.x every address below is formed
+    //  once in front of the solve's loop and held across the trust-region code and the rows phase -- the registers for that are not
+    //  there, and a spilled address is a memory round trip when it is needed; see k_solve_wide)
+    int tx = threadIdx.x;
+    asm volatile("" : "+v"(tx));
+    const int vt = tx & (SOLVE_THREADS - 1);
+    const int sub = __builtin_amdgcn_readfirstlane(tx / SOLVE_THREADS);  // (uniform in a wavefront)
+    const int lane = tx & 63, wv = vt >> 6;
     const int SL = (nlf + SOLVE_THREADS - 1) / SOLVE_THREADS, SP = (npf + SOLVE_THREADS - 1) / SOLVE_THREADS, NS = SL + SP;
     const double ka = 1.0 / kLidarM;
-    double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 0;
 #ifdef MML_SV_TIMING
     const bool svw_dbg = threadIdx.x == 0 && blockIdx.x == MML_SV_TIMING;
     unsigned long long svw_prev = clock64();
@@ -684,55 +715,72 @@ __device__ __forceinline__ void eval_frame_wide(const MmlLineFactor* lf, int nlf
         SVW_MARK(0);
         __syncthreads();
         SVW_MARK(1);
-        // ---- sums: this sub-thread's chains over the round's rows, in slot order ----
+        // ---- sums: the summing sub-threads' chains over the round's rows, in slot order; behind the last round the tree ----
+        // (the sums live in registers only from here to the end of the round: a scan with more than WIDE_ROUND slots per thread parks
+        //  them in LDS between its rounds -- held across the rows phase they cost it the registers it needs)
         const int ns = min(WIDE_ROUND, NS - s0);
-        if (sub == 0)
-            wide_sums<0>(s_rows, vt, ns, v);
-        else if (sub == 1)
-            wide_sums<1>(s_rows, vt, ns, v);
-        else if (sub == 2)
-            wide_sums<2>(s_rows, vt, ns, v);
-        else
-            wide_sums<3>(s_rows, vt, ns, v);
-        SVW_MARK(2);
-        if (s0 + WIDE_ROUND < NS) __syncthreads();  // (the next round overwrites the rows)
-    }
-    // ---- tree: block_reduce28's, eight values a lane (the halving butterfly for xor 32, 16, 8; then the one value left); the
-    //      partner's value by lane_xor_f64, not through the LDS crossbar ----
-    int idx = 0;
-    {
-        const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
+        const bool last = s0 + WIDE_ROUND >= NS;
+        if (sub < 2) {
+            double v[16];  // 14 chains, two zeros
+            double* sv = s_vsave + (size_t)sub * SOLVE_THREADS + vt;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double keep = u32 ? v[j + 4] : v[j], send = u32 ? v[j] : v[j + 4];
-            v[j] = keep + lane_xor_f64<32>(send, lane);
-        }
+            for (int k = 0; k < 16; ++k) v[k] = 0;
+            if (s0 > 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const double keep = u16 ? v[j + 2] : v[j], send = u16 ? v[j] : v[j + 2];
-            v[j] = keep + lane_xor_f64<16>(send, lane);
+                for (int k = 0; k < 14; ++k) v[k] = sv[(size_t)k * 2 * SOLVE_THREADS];
+            }
+            if (sub == 0)
+                wide_sums<0>(s_rows, vt, ns, v);
+            else
+                wide_sums<1>(s_rows, vt, ns, v);
+            SVW_MARK(2);
+            if (!last) {
+#pragma unroll
+                for (int k = 0; k < 14; ++k) sv[(size_t)k * 2 * SOLVE_THREADS] = v[k];
+            } else {
+                // ---- tree: block_reduce28's, sixteen values a lane (the halving butterfly for xor 32, 16, 8, 4; then the one value
+                //      left); the partner's value by lane_xor_f64, not through the LDS crossbar ----
+                const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double keep = u32 ? v[j + 8] : v[j], send = u32 ? v[j] : v[j + 8];
+                    v[j] = keep + lane_xor_f64<32>(send, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double keep = u16 ? v[j + 4] : v[j], send = u16 ? v[j] : v[j + 4];
+                    v[j] = keep + lane_xor_f64<16>(send, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double keep = u8 ? v[j + 2] : v[j], send = u8 ? v[j] : v[j + 2];
+                    v[j] = keep + lane_xor_f64<8>(send, lane);
+                }
+                {
+                    const double keep = u4 ? v[1] : v[0], send = u4 ? v[0] : v[1];
+                    v[0] = keep + lane_xor_f64<4>(send, lane);
+                }
+                const int idx = (u32 ? 8 : 0) + (u16 ? 4 : 0) + (u8 ? 2 : 0) + (u4 ? 1 : 0);
+                double tot = v[0] + lane_xor_f64<2>(v[0], lane);
+                tot = tot + lane_xor_f64<1>(tot, lane);
+                // which of the 28 sums value idx of this sub-thread is (one byte each, wide_sums' order; 0xff: none)
+                const unsigned long long km = idx < 8 ? (sub == 0 ? 0x0F15050403020100ull : 0x0C0B160A09080706ull)
+                                                      : (sub == 0 ? 0xFFFF1B1A14181110ull : 0xFFFF191312170E0Dull);
+                const int k = (int)((km >> (8 * (idx & 7))) & 0xffull);
+                if (!(lane & 3) && k < 28) s_part[wv * 28 + k] = tot;
+            }
         }
-        {
-            const double keep = u8 ? v[1] : v[0], send = u8 ? v[0] : v[1];
-            v[0] = keep + lane_xor_f64<8>(send, lane);
-        }
-        idx = (u32 ? 4 : 0) + (u16 ? 2 : 0) + (u8 ? 1 : 0);
+        if (!last) __syncthreads();  // (the next round overwrites the rows)
     }
-    double tot = v[0] + lane_xor_f64<4>(v[0], lane);
-    tot = tot + lane_xor_f64<2>(tot, lane);
-    tot = tot + lane_xor_f64<1>(tot, lane);
-    // which of the 28 sums value idx of this sub-thread is (one byte each; 0xff: none)
-    const unsigned long long kmap = sub == 0 ? 0x1B15050403020100ull
-                                             : (sub == 1 ? 0x1A14160A09080706ull : (sub == 2 ? 0x191312170E0D0C0Bull : 0xFFFFFFFF1811100Full));
-    const int k = (int)((kmap >> (8 * idx)) & 0xffull);
-    if (!(lane & 7) && k < 28) s_part[wv * 28 + k] = tot;
+    if (NS == 0 && tx < SOLVE_WAVES * 28) s_part[tx] = 0.0;  // (no factor at all: the sums of nothing)
     __syncthreads();
-    if (threadIdx.x < 28) {
-        double r = s_part[threadIdx.x];
-        r += s_part[28 + threadIdx.x];
-        out[threadIdx.x] = r;
+    if (tx < 28) {
+        double r = s_part[tx];
+        r += s_part[28 + tx];
+        out[tx] = r;
     }
-    __syncthreads();
+    // (no barrier behind this: out[] is read by the first wavefront, which has just written it -- k_solve_wide's trust-region code --
+    //  and everybody else meets that wavefront at the caller's next barrier before s_rows / s_part are written again)
     SVW_MARK(3);
 }
 

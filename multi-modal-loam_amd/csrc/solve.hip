@@ -992,6 +992,62 @@ __device__ __forceinline__ void tr_decide_wave(TRState& S, double* w, int W, int
 }
 #undef WSYNC
 
+// tr_decide for W = 1 on register copies (k_solve_wide; see tr_propose_w1_regs): every lane of the first wavefront forms the same
+// values -- tr_decide's expressions in its order --, lane 0 stores them, the 28 values of the accepted record are copied by 28 lanes.
+__device__ __forceinline__ void tr_decide_w1_regs(TRState& S, int fixed, const int lane) {
+    double cand = 0;
+    cand += S.recc[27];
+    const double cost = S.cost;
+    int zero = 0, one = 1;  // (formed here: see tr_propose_w1_regs)
+    asm volatile("" : "+v"(zero), "+v"(one));
+    if (!fixed) {
+        if (S.step_norm <= 1e-8 * (S.x_norm + 1e-8)) {
+            if (lane == 0) {
+                S.termination = one + one;
+                S.go = zero;
+            }
+            return;
+        }
+        if (fabs(cost - cand) <= 1e-6 * cost) {
+            if (lane == 0) {
+                S.termination = one + one + one;
+                S.go = zero;
+            }
+            return;
+        }
+    }
+    const double rel = (cost - cand) / S.model_change;
+    if (rel > 1e-3) {
+        double xc[6], xn = 0, gm = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            xc[i] = S.xc[i];
+            xn += xc[i] * xc[i];
+            gm = fmax(gm, fabs(S.recc[21 + i]));  // (a maximum does not depend on the order)
+        }
+        if (lane < 28) S.rec[lane] = S.recc[lane];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) S.x[i] = xc[i];
+            S.x_norm = sqrt(xn);
+            S.cost = cand;
+            S.successful++;
+            if (!fixed && gm <= 1e-10) {
+                S.termination = one;
+                S.go = zero;
+            } else {
+                if (rel < 0.25) S.radius *= 0.5;
+                if (rel > 0.75) S.radius = fmax(S.radius, 3.0 * S.dogleg_norm);
+                S.mu = fmax(1e-8, 2.0 * S.mu / 10.0);
+                S.reuse = zero;
+            }
+        }
+    } else if (lane == 0) {
+        S.radius *= 0.5;
+        S.reuse = one;
+    }
+}
+
 // (256 registers, two wavefronts per SIMD.  Held to 168 for three it spills 400 bytes per lane: 0.32 -> 0.93 ms per 1024 problems.)
 // SMALL: the variant of launches of at most one problem per CU (the live path).  It evaluates two plane factors of a thread side by
 // side (lidar_eval.h eval_frame_pairs: same sums in the same order, half the exposed latency of the factor passes; one-row plane
@@ -1074,7 +1130,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(SolveParams P) {
         // lane 0 owns the trust-region state between the barriers; every other lane only reads it after one
         // lane 0 (first wavefront for W = 1) owns the trust-region state between the barriers
         if (W == 1) {
+#ifdef MML_BATCH_PROPOSE_REGS
+            if (tid < 64) tr_propose_w1_regs(S, s_work, P.max_iters, tid);
+#else
             if (tid < 64) tr_propose_w1_wave(S, s_work, P.max_iters);
+#endif
         } else if (tid == 0) {
             tr_propose(S, W, P.max_iters);
         }
@@ -1133,8 +1193,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_wide(SolveParams P) {
     __shared__ TRState S;
     __shared__ double s_part[SOLVE_WAVES * 28];
     __shared__ double s_work[92];
+#ifdef MML_WIDE_PROPOSE_WAVE
     __shared__ double s_wd[TRW_DOUBLES];
+#endif
     __shared__ double s_rows[WIDE_ROW_LDS];
+    __shared__ double s_vsave[WIDE_SAVE_LDS];
     const int prob = blockIdx.x;
     const int b0 = P.first + prob;
     const int tid = threadIdx.x;
@@ -1151,7 +1214,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_wide(SolveParams P) {
     {
         Pose pose;
         make_pose(S.x, P.Tbl, pose);
-        eval_frame_wide(lf, nlf, pf, npf, pose, P.huber, s_rows, s_part, S.rec);
+        eval_frame_wide(lf, nlf, pf, npf, pose, P.huber, s_rows, s_vsave, s_part, S.rec);
     }
     if (tid == 0) {
         S.cost = 0;
@@ -1206,10 +1269,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_wide(SolveParams P) {
         if (ev) {
             Pose pose;
             make_pose(S.xc, P.Tbl, pose);
-            eval_frame_wide(lf, nlf, pf, npf, pose, P.huber, s_rows, s_part, S.recc);
+            eval_frame_wide(lf, nlf, pf, npf, pose, P.huber, s_rows, s_vsave, s_part, S.recc);
             asm volatile("" : "+v"(lane_op));
             SV_MARK(0);
+#ifdef MML_WIDE_PROPOSE_WAVE
             if (tid < 64) tr_decide_wave(S, s_wd, 1, P.fixed, lane_op);
+#else
+            if (tid < 64) tr_decide_w1_regs(S, P.fixed, lane_op);
+#endif
         }
         __syncthreads();
         SV_MARK(4);  // accept / reject (first wavefront) + barrier
