@@ -433,11 +433,11 @@ __device__ void block_reduce28(double* acc, double* s_part /*SOLVE_WAVES*28*/, d
 //          twelve -- line_row / plane_row: the operations of eval_frame's loop bodies in their order -- two plane rows side by side
 //          where it can, and leaves them in LDS (9 doubles a row).
 //   sums:  every one of the 28 sums of virtual thread vt is its own chain of fma(w J_a, J_b, acc) over the slots in order; the
-//          chains are dealt to TWO of the four sub-threads by Jacobian row (wide_sums: a = 0, 3, 5 + cost | a = 1, 2, 4: 14 chains
-//          each), each walks the round's rows in slot order: every sum sees the same operands in the same order as acc[k] of thread
-//          vt in eval_frame.
+//          chains are dealt to the four sub-threads by Jacobian row (wide_sums: a = 0 + cost | a = 1, 5 | a = 2, 4 | a = 3), each
+//          walks the round's rows in slot order: every sum sees the same operands in the same order as acc[k] of thread vt in
+//          eval_frame.
 //   tree:  the 128 partial sums of a value meet in block_reduce28's order (xor 32, 16, 8, 4, 2, 1 inside the wavefront, then
-//          wavefront 0 + wavefront 1), sixteen values a lane instead of 32, the partner's value by v_permlane*_swap / DPP.
+//          wavefront 0 + wavefront 1), eight values a lane instead of 32, the partner's value by v_permlane*_swap / DPP.
 // The results are bit-identical to eval_frame + block_reduce28 (tests/test_gpu_shapes.py (3): slots solved alone and in launches of
 // <= 256 against the 4096-slot launches).
 constexpr int WIDE_SUBS = 4;
@@ -445,7 +445,7 @@ constexpr int WIDE_THREADS = WIDE_SUBS * SOLVE_THREADS;
 constexpr int WIDE_ROUND = 3 * WIDE_SUBS;  // slots (rows per virtual thread) per round
 constexpr int ROW_DOUBLES = 9;             // J[6], r, rho0, rho1 (-1: no row)
 constexpr int WIDE_ROW_LDS = WIDE_ROUND * ROW_DOUBLES * SOLVE_THREADS;  // doubles
-constexpr int WIDE_SAVE_LDS = 14 * 2 * SOLVE_THREADS;                   // doubles: the sums between the rounds of a long scan
+constexpr int WIDE_SAVE_LDS = 8 * WIDE_THREADS;                          // doubles: the sums between the rounds of a long scan
 static_assert(SOLVE_WAVES == 2, "eval_frame_wide restates block_reduce28 for two wavefronts");
 
 __device__ __forceinline__ void line_row(const MmlLineFactor& f, const Pose& P, double ka, double huber_delta, PlaneRow& o) {
@@ -547,24 +547,25 @@ __device__ __forceinline__ void row_store(double* s_rows, int j, int vt, const P
     p[8 * SOLVE_THREADS] = (o.valid && in_range) ? o.rho1 : -1.0;  // rho' > 0 for every row (huber: >= DBL_MIN); -1: the factor is skipped
 }
 
-// the chains of summing sub-thread SUB (0 / 1) over the ns rows of a round, in slot order: five slots a turn, their values requested
-// together (an LDS round trip is ~130 - 300 cycles: two per pass instead of two per slot), straight-line code (a skipped factor
-// leaves the sums as they were by a select, not a branch).  TWO of the four sub-threads sum, 14 chains each: the phase is bound by
-// the LDS reads (every summing wavefront reads most of a row's nine values), and with four summing sub-threads of 8 / 8 / 8 / 4
-// chains the CU read 27 values per row and slot instead of 16 (2 980 cycles per pass against the 1 150 the reads of two take).
-//   SUB 0: Jacobian rows a = 0 (sums 0 .. 5, 21), a = 3 (15 .. 17, 24), a = 5 (20, 26) and the cost (27)
-//   SUB 1: rows a = 1 (6 .. 10, 22), a = 2 (11 .. 14, 23), a = 4 (18, 19, 25)
+// the chains of sub-thread SUB over the ns rows of a round, in slot order: T slots a turn, their values requested together (an LDS
+// round trip is a few hundred cycles with every wavefront of the workgroup reading: one per turn instead of two per slot), straight-
+// line code.  The 28 chains are dealt to the four sub-threads by Jacobian row:
+//   SUB 0: a = 0 (sums 0 .. 5, 21) + cost (27) | SUB 1: a = 1 (6 .. 10, 22), a = 5 (20, 26) | SUB 2: a = 2 (11 .. 14, 23), a = 4 (18, 19, 25)
+//   | SUB 3: a = 3 (15 .. 17, 24)
+// (measured, cycles per pass of configs[1]'s 187 + 826 factors: four summing sub-threads with a select per sum and slot 2 980; two
+//  sub-threads of 14 chains 4 120 -- fewer LDS reads, but 18 dependent-free instructions per slot and thread on two SIMDs instead of
+//  10 on four, and two or three slots a turn is all the registers allow there)
 template <int SUB>
 __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, double* v) {
-    constexpr int T = 3;
+    constexpr int T = 5;
     for (int j0 = 0; j0 < ns; j0 += T) {
         double J0[T], J1[T], J2[T], J3[T], J4[T], J5[T], rr[T], rho0[T], w[T];
 #pragma unroll
         for (int u = 0; u < T; ++u) {
             const double* p = s_rows + (size_t)min(j0 + u, ns - 1) * ROW_DOUBLES * SOLVE_THREADS + vt;
             if constexpr (SUB == 0) J0[u] = p[0];
-            J1[u] = p[SOLVE_THREADS];
-            J2[u] = p[2 * SOLVE_THREADS];
+            if constexpr (SUB <= 1) J1[u] = p[SOLVE_THREADS];
+            if constexpr (SUB <= 2) J2[u] = p[2 * SOLVE_THREADS];
             J3[u] = p[3 * SOLVE_THREADS];
             J4[u] = p[4 * SOLVE_THREADS];
             J5[u] = p[5 * SOLVE_THREADS];
@@ -575,8 +576,11 @@ __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, 
 #pragma unroll
         for (int u = 0; u < T; ++u) {
             const bool ok = j0 + u < ns && w[u] > 0.0;  // no row: the factor is skipped (rho' of a row is > 0)
-            double n[14];
+            double n[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) n[k] = v[k];
             if constexpr (SUB == 0) {
+                n[7] = v[7] + 0.5 * rho0[u];
                 const double wj = w[u] * J0[u];
                 n[0] = __builtin_fma(wj, J0[u], v[0]);
                 n[1] = __builtin_fma(wj, J1[u], v[1]);
@@ -585,16 +589,7 @@ __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, 
                 n[4] = __builtin_fma(wj, J4[u], v[4]);
                 n[5] = __builtin_fma(wj, J5[u], v[5]);
                 n[6] = __builtin_fma(wj, rr[u], v[6]);
-                const double wj3 = w[u] * J3[u];
-                n[7] = __builtin_fma(wj3, J3[u], v[7]);
-                n[8] = __builtin_fma(wj3, J4[u], v[8]);
-                n[9] = __builtin_fma(wj3, J5[u], v[9]);
-                n[10] = __builtin_fma(wj3, rr[u], v[10]);
-                const double wj5 = w[u] * J5[u];
-                n[11] = __builtin_fma(wj5, J5[u], v[11]);
-                n[12] = __builtin_fma(wj5, rr[u], v[12]);
-                n[13] = v[13] + 0.5 * rho0[u];
-            } else {
+            } else if constexpr (SUB == 1) {
                 const double wj = w[u] * J1[u];
                 n[0] = __builtin_fma(wj, J1[u], v[0]);
                 n[1] = __builtin_fma(wj, J2[u], v[1]);
@@ -602,25 +597,35 @@ __device__ __forceinline__ void wide_sums(const double* s_rows, int vt, int ns, 
                 n[3] = __builtin_fma(wj, J4[u], v[3]);
                 n[4] = __builtin_fma(wj, J5[u], v[4]);
                 n[5] = __builtin_fma(wj, rr[u], v[5]);
-                const double wj2 = w[u] * J2[u];
-                n[6] = __builtin_fma(wj2, J2[u], v[6]);
-                n[7] = __builtin_fma(wj2, J3[u], v[7]);
-                n[8] = __builtin_fma(wj2, J4[u], v[8]);
-                n[9] = __builtin_fma(wj2, J5[u], v[9]);
-                n[10] = __builtin_fma(wj2, rr[u], v[10]);
+                const double wj5 = w[u] * J5[u];
+                n[6] = __builtin_fma(wj5, J5[u], v[6]);
+                n[7] = __builtin_fma(wj5, rr[u], v[7]);
+            } else if constexpr (SUB == 2) {
+                const double wj = w[u] * J2[u];
+                n[0] = __builtin_fma(wj, J2[u], v[0]);
+                n[1] = __builtin_fma(wj, J3[u], v[1]);
+                n[2] = __builtin_fma(wj, J4[u], v[2]);
+                n[3] = __builtin_fma(wj, J5[u], v[3]);
+                n[4] = __builtin_fma(wj, rr[u], v[4]);
                 const double wj4 = w[u] * J4[u];
-                n[11] = __builtin_fma(wj4, J4[u], v[11]);
-                n[12] = __builtin_fma(wj4, J5[u], v[12]);
-                n[13] = __builtin_fma(wj4, rr[u], v[13]);
+                n[5] = __builtin_fma(wj4, J4[u], v[5]);
+                n[6] = __builtin_fma(wj4, J5[u], v[6]);
+                n[7] = __builtin_fma(wj4, rr[u], v[7]);
+            } else {
+                const double wj = w[u] * J3[u];
+                n[0] = __builtin_fma(wj, J3[u], v[0]);
+                n[1] = __builtin_fma(wj, J4[u], v[1]);
+                n[2] = __builtin_fma(wj, J5[u], v[2]);
+                n[3] = __builtin_fma(wj, rr[u], v[3]);
             }
-            // (a slot whose 64 factors of this wavefront all have a row -- nearly every one -- takes the sums as they come: the 28
-            //  selects per slot of the general case were half of this phase's instructions)
+            // (a slot whose 64 factors of this wavefront all have a row -- nearly every one -- takes the sums as they come: the
+            //  selects of the general case were half of this phase's instructions)
             if (__all(ok)) {
 #pragma unroll
-                for (int k = 0; k < 14; ++k) v[k] = n[k];
+                for (int k = 0; k < 8; ++k) v[k] = n[k];
             } else {
 #pragma unroll
-                for (int k = 0; k < 14; ++k) v[k] = ok ? n[k] : v[k];
+                for (int k = 0; k < 8; ++k) v[k] = ok ? n[k] : v[k];
             }
         }
     }
@@ -720,54 +725,54 @@ __device__ __forceinline__ void eval_frame_wide(const MmlLineFactor* lf, int nlf
         //  them in LDS between its rounds -- held across the rows phase they cost it the registers it needs)
         const int ns = min(WIDE_ROUND, NS - s0);
         const bool last = s0 + WIDE_ROUND >= NS;
-        if (sub < 2) {
-            double v[16];  // 14 chains, two zeros
+        {
+            double v[8];
             double* sv = s_vsave + (size_t)sub * SOLVE_THREADS + vt;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0;
+            for (int k = 0; k < 8; ++k) v[k] = 0;
             if (s0 > 0) {
 #pragma unroll
-                for (int k = 0; k < 14; ++k) v[k] = sv[(size_t)k * 2 * SOLVE_THREADS];
+                for (int k = 0; k < 8; ++k) v[k] = sv[(size_t)k * WIDE_THREADS];
             }
             if (sub == 0)
                 wide_sums<0>(s_rows, vt, ns, v);
-            else
+            else if (sub == 1)
                 wide_sums<1>(s_rows, vt, ns, v);
+            else if (sub == 2)
+                wide_sums<2>(s_rows, vt, ns, v);
+            else
+                wide_sums<3>(s_rows, vt, ns, v);
             SVW_MARK(2);
             if (!last) {
 #pragma unroll
-                for (int k = 0; k < 14; ++k) sv[(size_t)k * 2 * SOLVE_THREADS] = v[k];
+                for (int k = 0; k < 8; ++k) sv[(size_t)k * WIDE_THREADS] = v[k];
             } else {
-                // ---- tree: block_reduce28's, sixteen values a lane (the halving butterfly for xor 32, 16, 8, 4; then the one value
+                // ---- tree: block_reduce28's, eight values a lane (the halving butterfly for xor 32, 16, 8; then the one value
                 //      left); the partner's value by lane_xor_f64, not through the LDS crossbar ----
-                const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
+                const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double keep = u32 ? v[j + 8] : v[j], send = u32 ? v[j] : v[j + 8];
+                for (int j = 0; j < 4; ++j) {
+                    const double keep = u32 ? v[j + 4] : v[j], send = u32 ? v[j] : v[j + 4];
                     v[j] = keep + lane_xor_f64<32>(send, lane);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double keep = u16 ? v[j + 4] : v[j], send = u16 ? v[j] : v[j + 4];
+                for (int j = 0; j < 2; ++j) {
+                    const double keep = u16 ? v[j + 2] : v[j], send = u16 ? v[j] : v[j + 2];
                     v[j] = keep + lane_xor_f64<16>(send, lane);
                 }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const double keep = u8 ? v[j + 2] : v[j], send = u8 ? v[j] : v[j + 2];
-                    v[j] = keep + lane_xor_f64<8>(send, lane);
-                }
                 {
-                    const double keep = u4 ? v[1] : v[0], send = u4 ? v[0] : v[1];
-                    v[0] = keep + lane_xor_f64<4>(send, lane);
+                    const double keep = u8 ? v[1] : v[0], send = u8 ? v[0] : v[1];
+                    v[0] = keep + lane_xor_f64<8>(send, lane);
                 }
-                const int idx = (u32 ? 8 : 0) + (u16 ? 4 : 0) + (u8 ? 2 : 0) + (u4 ? 1 : 0);
-                double tot = v[0] + lane_xor_f64<2>(v[0], lane);
+                const int idx = (u32 ? 4 : 0) + (u16 ? 2 : 0) + (u8 ? 1 : 0);
+                double tot = v[0] + lane_xor_f64<4>(v[0], lane);
+                tot = tot + lane_xor_f64<2>(tot, lane);
                 tot = tot + lane_xor_f64<1>(tot, lane);
                 // which of the 28 sums value idx of this sub-thread is (one byte each, wide_sums' order; 0xff: none)
-                const unsigned long long km = idx < 8 ? (sub == 0 ? 0x0F15050403020100ull : 0x0C0B160A09080706ull)
-                                                      : (sub == 0 ? 0xFFFF1B1A14181110ull : 0xFFFF191312170E0Dull);
-                const int k = (int)((km >> (8 * (idx & 7))) & 0xffull);
-                if (!(lane & 3) && k < 28) s_part[wv * 28 + k] = tot;
+                const unsigned long long km = sub == 0 ? 0x1B15050403020100ull
+                                                       : (sub == 1 ? 0x1A14160A09080706ull : (sub == 2 ? 0x191312170E0D0C0Bull : 0xFFFFFFFF1811100Full));
+                const int k = (int)((km >> (8 * idx)) & 0xffull);
+                if (!(lane & 7) && k < 28) s_part[wv * 28 + k] = tot;
             }
         }
         if (!last) __syncthreads();  // (the next round overwrites the rows)
