@@ -49,6 +49,25 @@ def random_dirt(rng, v, l):
     return v, l
 
 
+def plane_records_close(g, o):
+    """Plane factor records (point_ori, point_proj, omega, error) against the oracle's: <= 1e-9 in every field -- or, for a record whose
+    omega is one FLOAT ulp off in some component, <= 1e-6 in the fields computed from it.  omega is `float pa = X[0]` of the plane fit's
+    double solution (Estimator.cpp:722-738) normalised in float: the oracle's and the device's QR agree on X to ~1e-16 relative, so the
+    cast rounds the other way for about one value in 1e8 -- campaign seed 930 met the first one in 1.3e8 plane records (round 6,
+    identical on the libraries before and after that round's changes: pose difference 8.5e-14).  Returns (ok, flipped records)."""
+    if len(g) != len(o):
+        return False, 0
+    if len(g) == 0:
+        return True, 0
+    d = np.abs(g - o)
+    bad = np.flatnonzero(d.max(axis=1) > 1e-9)
+    if len(bad) == 0:
+        return True, 0
+    og, oo = g[bad, 6:9].astype(np.float32), o[bad, 6:9].astype(np.float32)
+    one_ulp = np.abs(og - oo) <= np.spacing(np.maximum(np.abs(og), np.abs(oo)))
+    return bool(np.all(one_ulp) and np.all(d[bad] <= 1e-6)), len(bad)
+
+
 def batch_section(args, M, O, synth, rng):
     """Large batches -- the kernels bench.py runs: k_stencil<0>, batch k_select_part + k_select_list, k_voxel<256> / <1024>, the
     lane-per-feature search, mml_step on 4 / 1 / 2 stream lanes by turns -- on 96 slots of 24 fresh random scans per round: ideal-grid scans with
@@ -74,6 +93,7 @@ def batch_section(args, M, O, synth, rng):
     c.map_set_local(1, sm)
     n_pts = n_fac = redo = 0
     worst_pose = 0.0
+    flips = 0  # plane records (slots) whose omega is one float ulp off the oracle's (plane_records_close)
     for rnd in range(args.batch):
         cases = []
         for j in range(ND):
@@ -127,16 +147,30 @@ def batch_section(args, M, O, synth, rng):
             ok = (np.array_equal(d["label"], o["label"]) and np.array_equal(d["xyzi"][:, :3], o["und"]) and np.all(d["reltime"] == 1.0)
                   and c.features_download(s, 0).tobytes() == o["corner"].tobytes() and c.features_download(s, 1).tobytes() == o["surf"].tobytes()
                   and np.array_equal(glsrc, o["lsrc"]) and np.array_equal(gpsrc, o["psrc"])
-                  and np.allclose(gl, o["lf_arr"], rtol=0, atol=1e-9) and np.allclose(gp, o["pf_arr"], rtol=0, atol=1e-9))
+                  and np.allclose(gl, o["lf_arr"], rtol=0, atol=1e-9))
+            pok, nflip = plane_records_close(gp, o["pf_arr"])
+            ok = ok and pok
+            flips += nflip
             dd = float(np.abs(x[s] - o["x"]).max())
             worst_pose = max(worst_pose, dd)
             if not ok or not dd < 1e-6:
-                print("BATCH STEP MISMATCH seed %d round %d slot %d (scan %d): records ok %s, pose diff %.3g" % (args.seed, rnd, s, perm[s], ok, dd))
+                pieces = dict(label=np.array_equal(d["label"], o["label"]), und=np.array_equal(d["xyzi"][:, :3], o["und"]), reltime=bool(np.all(d["reltime"] == 1.0)),
+                              corner=c.features_download(s, 0).tobytes() == o["corner"].tobytes(), surf=c.features_download(s, 1).tobytes() == o["surf"].tobytes(),
+                              lsrc=np.array_equal(glsrc, o["lsrc"]), psrc=np.array_equal(gpsrc, o["psrc"]))
+                if pieces["lsrc"]: pieces["lf |d|"] = float(np.abs(gl - o["lf_arr"]).max()) if len(gl) else 0.0
+                else: pieces["lsrc diff"] = sorted(set(glsrc.tolist()) ^ set(o["lsrc"].tolist()))[:8]
+                if pieces["psrc"]: pieces["pf |d|"] = float(np.abs(gp - o["pf_arr"]).max()) if len(gp) else 0.0
+                else: pieces["psrc diff"] = sorted(set(gpsrc.tolist()) ^ set(o["psrc"].tolist()))[:8]
+                print("BATCH STEP MISMATCH seed %d round %d slot %d (scan %d): records ok %s, pose diff %.3g; %s" % (args.seed, rnd, s, perm[s], ok, dd, pieces))
                 return 1
             n_pts += len(o["xyzi"])
             n_fac += len(glsrc) + len(gpsrc)
-    print("batch: %d rounds x %d slots ok (%d points, %d factor records, redo-queue share %.3f %%, worst pose difference %.2e) %.0f s"
-          % (args.batch, B, n_pts, n_fac, 100.0 * redo / max(n_pts, 1), worst_pose, time.time() - t0), flush=True)
+    if flips > 16:
+        print("BATCH: %d plane records with a float-ulp omega -- more than the cast's rounding explains" % flips)
+        return 1
+    print("batch: %d rounds x %d slots ok (%d points, %d factor records%s, redo-queue share %.3f %%, worst pose difference %.2e) %.0f s"
+          % (args.batch, B, n_pts, n_fac, ", %d of them with omega one float ulp off" % flips if flips else "", 100.0 * redo / max(n_pts, 1), worst_pose,
+             time.time() - t0), flush=True)
     c.close()
     return 0
 

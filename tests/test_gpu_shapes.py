@@ -110,3 +110,62 @@ def test_replica_stress(M, O, synth):
     bad, per = replica_stress.run(M, O, synth, 40, lanes=[None] * 30 + [1, 2] * 5)
     assert bad == 0
     print("replica stress: %.3f s per round" % per)
+
+
+def test_wide_solve_long_factor_lists_equal_batch_kernel(M, O, scene):
+    """k_solve_wide (launches of at most one one-frame problem per CU) against the batch kernel k_solve<false> (more problems than
+    CUs) on factor lists LONGER than one round of its row exchange (12 x 128 factors per round: 2 300 line + 3 700 plane records
+    are four rounds, the sums parked in LDS between them), with skipped records (|error| <= 1e-5, Estimator.cpp:1385,1396) spread
+    through both lists, ragged ends, an empty line list, an empty problem, and with / without the Huber loss, fixed and free
+    iteration counts: poses, iteration counts and terminations bit for bit; one problem of each setting against the oracle."""
+    from conftest import perturbed, pose_to_x
+    B = 320
+    c = M.Context(max_scans=B, max_features=4096)
+    try:
+        tc, ts = O.KdTree(scene["corner_map"]), O.KdTree(scene["surf_map"])
+        fr = scene["frames"][1]
+        T = perturbed(fr["T_gt"])
+        lf, _ = O.associate_lines(fr["corner"], tc, T, 25.0)
+        pf, _ = O.associate_planes(fr["surf"], ts, T, 25.0)
+        rng = np.random.default_rng(77)
+
+        def long_list(a, n):
+            out = np.concatenate([a] * (n // len(a) + 1))[:n].copy()
+            out["point_ori"] = (out["point_ori"] + rng.normal(0, 0.02, out["point_ori"].shape)).astype(np.float32)  # distinct rows (floats, as the feature clouds)
+            out["error"] = np.where(np.abs(out["error"]) > 1e-5, out["error"], 0.25)
+            out["error"][rng.integers(0, n, n // 9)] = 0.0                                                  # skipped records
+            return out
+
+        arr_l = lambda a: np.concatenate([a["point_ori"], a["p1"], a["p2"], a["error"][:, None]], axis=1)
+        arr_p = lambda a: np.concatenate([a["point_ori"], a["point_proj"], a["omega"], a["error"][:, None]], axis=1)
+        x0 = pose_to_x(T)
+        cases = [(long_list(lf, 2300), long_list(pf, 3700)),      # 18 + 29 slots a thread: four rounds
+                 (lf[:0], long_list(pf, 1537)),                   # no line factor; 13 slots: two rounds, the second nearly empty
+                 (long_list(lf, 129), long_list(pf, 1)),          # ragged: a second line slot of one factor, one plane factor
+                 (lf, pf),                                        # the association's own lists (one round)
+                 (lf[:0], pf[:0])]                                # nothing at all: the pose stays where it is
+        for huber, fixed in ((0.1 / 1.5e-3, True), (0.0, False), (0.1 / 1.5e-3, False)):
+            for ci, (l2, p2) in enumerate(cases):
+                for s in range(B):
+                    if s < 3 or ci == 0 and s < 40 or s == B - 1:   # (the slots compared below; the rest keep what they hold)
+                        c.factors_upload(s, 0, arr_l(l2))
+                        c.factors_upload(s, 1, arr_p(p2))
+                xs = np.tile(x0, (B, 1))
+                xb, sb, _ = c.solve(0, B, xs, np.eye(4), max_iters=10, fixed=fixed, huber=huber)          # k_solve<false>
+                x1, s1, _ = c.solve(0, 1, xs[:1], np.eye(4), max_iters=10, fixed=fixed, huber=huber)      # k_solve_wide, one problem
+                x3, s3, _ = c.solve(0, 3, xs[:3], np.eye(4), max_iters=10, fixed=fixed, huber=huber)      # ... three
+                xl, sl, _ = c.solve(B - 1, 1, xs[:1], np.eye(4), max_iters=10, fixed=fixed, huber=huber)
+                key = lambda q: (q.iterations, q.successful, q.termination, q.initial_cost, q.final_cost)
+                assert np.array_equal(x1[0], xb[0]) and key(s1[0]) == key(sb[0]), (ci, huber, fixed, x1[0] - xb[0])
+                assert np.array_equal(x3, xb[:3]) and [key(q) for q in s3] == [key(q) for q in sb[:3]], (ci, huber, fixed)
+                assert np.array_equal(xl[0], xb[B - 1]) and key(sl[0]) == key(sb[B - 1]), (ci, huber, fixed)
+                if ci == 0:
+                    x40, s40, _ = c.solve(0, 40, xs[:40], np.eye(4), max_iters=10, fixed=fixed, huber=huber)
+                    assert np.array_equal(x40, xb[:40]) and [key(q) for q in s40] == [key(q) for q in sb[:40]], (huber, fixed)
+                if len(l2) + len(p2) == 0:
+                    assert np.array_equal(x1[0], x0)
+                elif ci in (0, 3):
+                    xo, so, _ = O.solve_window([l2], [p2], x0[None], np.eye(4), 10, fixed=fixed, huber=huber, w_tan=0.0)
+                    assert np.abs(x1 - xo).max() < 1e-9 and s1[0].iterations == so["iterations"], (ci, huber, fixed, np.abs(x1 - xo).max())
+    finally:
+        c.close()
