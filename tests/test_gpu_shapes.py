@@ -96,6 +96,17 @@ def test_bench_launch_shapes_replicas_match_oracle(M, O, synth, scene):
             dn = c.slot_digest(s0, n)
             assert np.array_equal(dn, dg[s0:s0 + n]), (s0, n, np.argwhere(dn != dg[s0:s0 + n])[:5])
             assert np.array_equal(xs, x[s0:s0 + n]), (s0, n)
+        # (5) the small launches repeated: 150 times 200 slots and 150 times one slot -- every repetition the bits of the first (the
+        #     wide solve keeps its rows, sums and trust-region state in LDS across barriers that were cut to the minimum: a race
+        #     there would show as a result that moves)
+        s0, n = 1000, 200
+        for rep in range(150):
+            xs = c.step(s0, n, dR[s0:s0 + n], dt[s0:s0 + n], np.eye(4), 25.0, 10, x0[s0:s0 + n])
+            assert np.array_equal(xs, x[s0:s0 + n]), (rep, np.argwhere(xs != x[s0:s0 + n])[:4])
+            s1 = int(first[rep % ND])
+            x1s = c.step(s1, 1, dR[s1:s1 + 1], dt[s1:s1 + 1], np.eye(4), 25.0, 10, x0[s1:s1 + 1])
+            assert np.array_equal(x1s[0], x[s1]), (rep, s1)
+        assert np.array_equal(c.slot_digest(s0, n), dg[s0:s0 + n])
         print("launch shapes: %d slots, %d distinct scans, 0 mismatching replicas, %.1f s" % (B, ND, time.time() - t0))
     finally:
         c.close()
